@@ -1,0 +1,149 @@
+"""ORACLE — golden-vector generator (build container only; needs /root/reference).
+
+Runs the REAL reference (`model/trainer.py::Trainer.update_bcd`, `model/utils.py::
+BCEDiceLoss`/`adjust_learning_rate`, `utils/metric_tool.py::get_confuse_matrix`/`cm2score`,
+Adam as in `scripts/train_BCD.py:284-290`) on PyTorch-CPU fp32 with seeded synthetic
+weights/inputs from `oracle/synth.py`, first asserting that the repo's restatement
+(`oracle/model.py`) reproduces it bit-for-bit, then writes small fixtures:
+
+    tests/golden/bcd_s{S}_b{B}.npz
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden [--sizes 64 256]
+The fixtures are DATA (inputs are regenerated from seeds; expected outputs are stored).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import model as om
+from . import ref_import, synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+WEIGHT_SEED = 16
+DATA_SEED = 0
+MASK_MARGIN = 0.25
+N_STEPS = 3
+BASE_LR = 2e-4
+MAX_ITER = 80000
+
+
+def probe_idx(numel, n=64, seed=7):
+    return np.random.default_rng(seed).integers(0, numel, size=n)
+
+
+def summarize(t):
+    t = t.detach().double().contiguous().view(-1)
+    idx = probe_idx(t.numel())
+    return np.concatenate([[t.mean().item(), t.std().item(), t.norm().item()], t[idx].numpy()])
+
+
+def run(size, batch, check_restatement=True):
+    tr, mu, met = ref_import.import_reference()
+    args = om.make_args(size=size)
+    args.lr_mode, args.lr, args.max_epochs, args.step_loss = "poly", BASE_LR, 1, 100
+    ref = tr.Trainer(args)
+    sd = synth.synth_state_dict(ref, seed=WEIGHT_SEED, mask_margin=MASK_MARGIN)
+    ref.load_state_dict(sd, strict=True)
+    pre, post, tgt = synth.synth_batch(batch, size, seed=DATA_SEED)
+    out = {"meta": np.array([size, batch, WEIGHT_SEED, DATA_SEED, N_STEPS], dtype=np.int64),
+           "mask_margin": np.array(MASK_MARGIN), "base_lr": np.array(BASE_LR),
+           "max_iter": np.array(MAX_ITER)}
+
+    # ---- eval-mode forward (BN running stats), reference scripts/train_BCD.py:92-154
+    ref.eval()
+    with torch.no_grad():
+        p_eval = ref.update_bcd(pre, post)
+        loss_eval = mu.BCEDiceLoss(p_eval, tgt)
+    stride = max(1, size // 32)
+    out["eval_prob_lattice"] = p_eval[:, :, ::stride, ::stride].numpy()
+    out["eval_prob_full"] = p_eval.numpy().astype(np.float32) if size <= 64 else np.zeros(0, np.float32)
+    out["eval_mask_bits"] = np.packbits((p_eval > 0.5).numpy().astype(np.uint8).reshape(-1))
+    out["eval_band"] = np.array(int(((p_eval - 0.5).abs() < 1e-4).sum()))
+    out["eval_loss"] = np.array(loss_eval.item())
+
+    # ---- train-mode forward + backward (fresh module so BN buffers are untouched)
+    ref.train()
+    feats = ref.encoder(pre, post)
+    for i, f in enumerate(feats):
+        out[f"train_feat_c{i + 1}"] = summarize(f[0])
+    opt = torch.optim.Adam(ref.parameters(), BASE_LR, (0.9, 0.99), eps=1e-08, weight_decay=1e-4)
+    ref.load_state_dict(sd, strict=True)  # undo the BN running-stat update of the probe forward
+    losses, lrs = [], []
+    cm_total = np.zeros((2, 2))
+    for it in range(N_STEPS):
+        lr = mu.adjust_learning_rate(args, opt, 0, it, MAX_ITER, lr_factor=1.0)
+        prob = ref.update_bcd(pre, post)
+        loss = mu.BCEDiceLoss(prob, tgt)
+        pred = torch.where(prob > 0.5, torch.ones_like(prob), torch.zeros_like(prob)).long()
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            out["train_prob_lattice"] = prob.detach()[:, :, ::stride, ::stride].numpy()
+            out["train_prob_full"] = (prob.detach().numpy().astype(np.float32) if size <= 64
+                                      else np.zeros(0, np.float32))
+            out["train_mask_bits"] = np.packbits(pred.numpy().astype(np.uint8).reshape(-1))
+            out["train_band"] = np.array(int(((prob - 0.5).abs() < 1e-4).sum()))
+            names, norms, probes = [], [], []
+            for n, p in ref.named_parameters():
+                if p.grad is None:
+                    continue
+                names.append(n)
+                norms.append(p.grad.double().norm().item())
+                g = p.grad.detach().double().view(-1)
+                probes.append(g[probe_idx(g.numel(), 4, seed=11)].numpy())
+            out["grad_names"] = np.array(names)
+            out["grad_norms"] = np.array(norms)
+            out["grad_probes"] = np.stack(probes)
+            unused = [n for n, p in ref.named_parameters() if p.grad is None]
+            out["unused_param_count"] = np.array(sum(dict(ref.named_parameters())[n].numel() for n in unused))
+        opt.step()
+        losses.append(loss.item())
+        lrs.append(lr)
+        cm_total += met.get_confuse_matrix(2, tgt.numpy(), pred.numpy())
+    out["loss_curve"] = np.array(losses)
+    out["lr_curve"] = np.array(lrs)
+    out["cm_total"] = cm_total
+    sc = met.cm2score(cm_total)
+    out["scores"] = np.array([sc["Kappa"], sc["IoU"], sc["F1"], sc["OA"], sc["recall"], sc["precision"]])
+    fin = ref.state_dict()
+    out["final_param_l2"] = np.array([fin[n].double().norm().item() for n in out["grad_names"]])
+    rm = [v.double().sum().item() for k, v in fin.items() if k.endswith("running_mean") and ".blocks.4." not in k and ".blocks.5." not in k]
+    rv = [v.double().sum().item() for k, v in fin.items() if k.endswith("running_var") and ".blocks.4." not in k and ".blocks.5." not in k]
+    out["final_running_mean_sums"] = np.array(rm)
+    out["final_running_var_sums"] = np.array(rv)
+    out["final_nbt"] = np.array([int(v) for k, v in fin.items() if k.endswith("num_batches_tracked")])
+
+    if check_restatement:
+        ora = om.Trainer(om.make_args(size=size))
+        ora.load_state_dict(sd, strict=True)
+        ora.train()
+        o = ora.update_bcd(pre, post)
+        lo = om.bce_dice_loss(o, tgt)
+        assert abs(lo.item() - losses[0]) == 0.0, (lo.item(), losses[0])
+        assert np.array_equal(np.packbits(om.binarize(o).numpy().astype(np.uint8).reshape(-1)),
+                              out["train_mask_bits"])
+        assert abs(om.poly_lr(BASE_LR, 1, MAX_ITER, 0) - lrs[1]) < 1e-18
+        print(f"[gen_golden] restatement == reference at size {size} (loss {losses[0]:.6f})")
+
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(GOLDEN_DIR, f"bcd_s{size}_b{batch}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[gen_golden] wrote {path} ({os.path.getsize(path) / 1024:.1f} kB); losses {losses}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sizes", type=int, nargs="+", default=[64, 256])
+    ap.add_argument("--batch", type=int, default=2)
+    a = ap.parse_args()
+    sys.dont_write_bytecode = True
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    for s in a.sizes:
+        run(s, a.batch)
+
+
+if __name__ == "__main__":
+    main()

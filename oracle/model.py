@@ -1,0 +1,331 @@
+"""ORACLE — test infrastructure only (never imported by the product path).
+
+Torch-CPU fp32 restatement (logical NCDHW, eager) of the reference's hot path:
+
+  X3D-L builder        reference model/x3d.py:23-106 (stem), :109-232 (bottleneck),
+                        :235-328 (res block), :331-412 (stage), :415-540 (head),
+                        :543-744 (create_x3d), :747-811 (ProjectedPool)
+  Encoder / Trainer    reference model/trainer.py:20-167, :170-241
+  ChangeDecoder        reference model/change_decoder.py:10-81
+  BCEDiceLoss, lr, init reference model/utils.py:20-82, :84-152, :154-169
+  confusion matrix/IoU reference utils/metric_tool.py:87-128
+
+State-dict keys are identical to the reference's (1 141 backbone tensors, 1 156 for the
+BCD ``Trainer``); ``oracle/gen_golden.py`` verifies, in the build container, that this
+restatement and the imported reference produce bit-identical outputs and gradients on the
+same weights/inputs.  The third-party layer classes come from ``oracle/pv.py`` (parity
+unpinned there — see its header).
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pv
+
+BN_EPS = 1e-5
+BN_MOM = 0.1
+
+
+# --------------------------------------------------------------------------- X3D-L
+def _bn(c):
+    return nn.BatchNorm3d(num_features=c, eps=BN_EPS, momentum=BN_MOM)
+
+
+def build_stem(cin, cout, ksize=(5, 3, 3), stride=(1, 1, 1)):
+    """reference model/x3d.py:70-106.  `conv_t` is the SPATIAL conv, `conv_xy` the
+    TEMPORAL depthwise conv (names swapped upstream, kept for key compatibility)."""
+    spatial = nn.Conv3d(cin, cout, (1, ksize[1], ksize[2]), stride=(1, stride[1], stride[2]),
+                        padding=(0, ksize[1] // 2, ksize[2] // 2), bias=False)
+    temporal = nn.Conv3d(cout, cout, (ksize[0], 1, 1), stride=(stride[0], 1, 1),
+                         padding=(ksize[0] // 2, 0, 0), bias=False, groups=cout)
+    conv = pv.Conv2plus1d(conv_t=spatial, norm=None, activation=None, conv_xy=temporal)
+    return pv.ResNetBasicStem(conv=conv, norm=_bn(cout), activation=nn.ReLU(), pool=None)
+
+
+def build_bottleneck(cin, cinner, cout, stride, use_se, se_ratio=0.0625):
+    """reference model/x3d.py:173-232."""
+    conv_a = nn.Conv3d(cin, cinner, (1, 1, 1), bias=False)
+    conv_b = nn.Conv3d(cinner, cinner, (3, 3, 3), stride=stride, padding=[1, 1, 1], bias=False,
+                       groups=cinner, dilation=(1, 1, 1))
+    se = (pv.SqueezeExcitation(num_channels=cinner,
+                               num_channels_reduced=pv.round_width(cinner, se_ratio), is_3d=True)
+          if use_se else nn.Identity())
+    norm_b = nn.Sequential(_bn(cinner), se)
+    conv_c = nn.Conv3d(cinner, cout, (1, 1, 1), bias=False)
+    return pv.BottleneckBlock(conv_a=conv_a, norm_a=_bn(cinner), act_a=nn.ReLU(),
+                              conv_b=conv_b, norm_b=norm_b, act_b=pv.Swish(),
+                              conv_c=conv_c, norm_c=_bn(cout))
+
+
+def build_res_block(cin, cinner, cout, stride, use_se):
+    """reference model/x3d.py:296-328: shortcut conv iff channel change or stride>1;
+    shortcut BN (default eps/momentum) iff channel change."""
+    need_conv = cin != cout or int(np.prod(stride)) > 1
+    b1c = nn.Conv3d(cin, cout, kernel_size=(1, 1, 1), stride=stride, bias=False) if need_conv else None
+    b1n = nn.BatchNorm3d(num_features=cout) if cin != cout else None
+    return pv.ResBlock(branch1_conv=b1c, branch1_norm=b1n,
+                       branch2=build_bottleneck(cin, cinner, cout, stride, use_se),
+                       activation=nn.ReLU(), branch_fusion=lambda x, y: x + y)
+
+
+def build_stage(depth, cin, cinner, cout, stride):
+    """reference model/x3d.py:393-412: only block 0 strided / takes cin; SE on even idx."""
+    blocks = [build_res_block(cin if i == 0 else cout, cinner, cout,
+                              stride if i == 0 else (1, 1, 1), use_se=bool((i + 1) % 2))
+              for i in range(depth)]
+    return pv.ResStage(res_blocks=nn.ModuleList(blocks))
+
+
+class ProjectedPool(nn.Module):
+    """reference model/x3d.py:747-811."""
+
+    def __init__(self, *, pre_conv=None, pre_norm=None, pre_act=None, pool=None,
+                 post_conv=None, post_norm=None, post_act=None):
+        super().__init__()
+        pv.set_attributes(self, locals())
+
+    def forward(self, x):
+        x = self.pre_conv(x)
+        if self.pre_norm is not None:
+            x = self.pre_norm(x)
+        if self.pre_act is not None:
+            x = self.pre_act(x)
+        x = self.pool(x)
+        x = self.post_conv(x)
+        if self.post_norm is not None:
+            x = self.post_norm(x)
+        if self.post_act is not None:
+            x = self.post_act(x)
+        return x
+
+
+def build_head(cin, cinner, cout, num_classes, pool_kernel, dropout_rate=0.5):
+    """reference model/x3d.py:472-540 with head_activation=None, bn_lin5_on=False."""
+    pool = ProjectedPool(pre_conv=nn.Conv3d(cin, cinner, (1, 1, 1), bias=False),
+                         pre_norm=_bn(cinner), pre_act=nn.ReLU(),
+                         pool=nn.AvgPool3d(pool_kernel, stride=1),
+                         post_conv=nn.Conv3d(cinner, cout, (1, 1, 1), bias=False),
+                         post_norm=None, post_act=nn.ReLU())
+    return pv.ResNetBasicHead(proj=nn.Linear(cout, num_classes, bias=True), activation=None,
+                              pool=pool, dropout=nn.Dropout(dropout_rate),
+                              output_pool=nn.AdaptiveAvgPool3d(1))
+
+
+def x3d_config(input_clip_length=13, input_crop_size=160, width_factor=2.0, depth_factor=2.2,
+               stem_dim_in=12, bottleneck_factor=2.25):
+    """Derived widths/depths, reference model/x3d.py:657-691,720-726."""
+    stem_out = pv.round_width(stem_dim_in, width_factor)
+    dims = [stem_dim_in]
+    for _ in range(3):
+        dims.append(pv.round_width(dims[-1], 2.0, divisor=8))
+    dim_out = [pv.round_width(d, width_factor) for d in dims]
+    dim_inner = [int(bottleneck_factor * d) for d in dim_out]
+    depths = [pv.round_repeats(d, depth_factor) for d in (1, 2, 5, 3)]
+    tot_spatial = 1 * 2 ** 4
+    pool_kernel = (input_clip_length // 1, int(math.ceil(input_crop_size / tot_spatial)),
+                   int(math.ceil(input_crop_size / tot_spatial)))
+    return SimpleNamespace(stem_out=stem_out, dim_out=dim_out, dim_inner=dim_inner,
+                           depths=depths, pool_kernel=pool_kernel)
+
+
+def create_x3d(*, input_clip_length=13, depth_factor=2.2, input_channel=3, input_crop_size=160,
+               model_num_class=400, head_dim_out=2048):
+    """reference model/x3d.py:543-744 with every other keyword at its default
+    (stem stride (1,1,1), stage stride (1,2,2))."""
+    cfg = x3d_config(input_clip_length, input_crop_size, depth_factor=depth_factor)
+    blocks = [build_stem(input_channel, cfg.stem_out)]
+    cin = cfg.stem_out
+    for i in range(4):
+        blocks.append(build_stage(cfg.depths[i], cin, cfg.dim_inner[i], cfg.dim_out[i], (1, 2, 2)))
+        cin = cfg.dim_out[i]
+    blocks.append(build_head(cin, cfg.dim_inner[3], head_dim_out, model_num_class, cfg.pool_kernel))
+    return pv.Net(blocks=nn.ModuleList(blocks))
+
+
+# ------------------------------------------------------------------- change decoder
+class ChangeDecoder(nn.Module):
+    """reference model/change_decoder.py:15-81."""
+
+    def __init__(self, args, in_dim=(64, 128, 256, 384), has_sigmoid=False):
+        super().__init__()
+        self.has_sigmoid = has_sigmoid
+        c1, c2, c3, c4 = in_dim
+
+        def up(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=False),
+                                 nn.ConvTranspose2d(cout, cout, kernel_size=4, stride=2, padding=1))
+
+        self.up_c4, self.up_c3, self.up_c2 = up(c4, c3), up(c3, c2), up(c2, c1)
+        nc = 1 if has_sigmoid else args.num_class
+        self.up_c1 = nn.Sequential(nn.Conv2d(c1, nc, kernel_size=3, stride=1, padding=1, bias=False))
+
+    def forward(self, f):
+        c1, c2, c3, c4 = f
+        c3f = c3 + self.up_c4(c4)
+        c2f = c2 + self.up_c3(c3f)
+        c1f = c1 + self.up_c2(c2f)
+        pred = self.up_c1(c1f)
+        return torch.sigmoid(pred) if self.has_sigmoid else pred
+
+
+def weight_init(module):
+    """reference model/utils.py:20-82 restricted to what a ChangeDecoder contains:
+    Conv2d (directly or inside Sequential) -> kaiming-normal fan_in/relu;
+    ConvTranspose2d is NOT matched (keeps torch default init)."""
+    for _, child in module.named_children():
+        if isinstance(child, nn.Conv2d):
+            nn.init.kaiming_normal_(child.weight, mode="fan_in", nonlinearity="relu")
+            if child.bias is not None:
+                nn.init.zeros_(child.bias)
+        elif isinstance(child, nn.Sequential):
+            for _, sub in child.named_children():
+                if isinstance(sub, nn.Conv2d):
+                    nn.init.kaiming_normal_(sub.weight, mode="fan_in", nonlinearity="relu")
+                    if sub.bias is not None:
+                        nn.init.zeros_(sub.bias)
+                else:
+                    weight_init(sub)
+        elif len(list(child.children())) > 0:
+            weight_init(child)
+
+
+# ------------------------------------------------------------------ encoder/trainer
+class Encoder(nn.Module):
+    """reference model/trainer.py:20-167."""
+
+    def __init__(self, args, embed_dims):
+        super().__init__()
+        self.args = args
+        self.x3d = create_x3d(input_clip_length=3, depth_factor=5.0)
+        self.perception_frames = nn.Parameter(
+            torch.randn(1, 3, args.num_perception_frame, args.in_height, args.in_width))
+        self.fc = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(d, d, kernel_size=1, stride=1, padding=0, bias=False), nn.ReLU())
+            for d in embed_dims])
+
+    def enhance(self, x, fc):
+        mid = x.shape[2] // 2
+        diff = torch.abs(x[:, :, 0] - x[:, :, self.args.num_perception_frame + 1])
+        out = x.clone()
+        out[:, :, mid] = x[:, :, mid] + fc(diff)
+        return out
+
+    def base_forward(self, x, output_final=False):
+        if output_final:
+            for i in range(5):
+                x = self.x3d.blocks[i](x)
+            return x[:, :, self.args.num_perception_frame]
+        out = []
+        for i in range(4):
+            x = self.enhance(self.x3d.blocks[i](x), self.fc[i])
+            out.append([x[:, :, k + 1] for k in range(self.args.num_perception_frame)])
+        return out
+
+    def forward(self, x, y, output_final=False):
+        p = self.perception_frames.expand(x.shape[0], -1, -1, -1, -1)
+        frames = torch.cat([x.unsqueeze(2), p, y.unsqueeze(2)], dim=2)
+        return self.base_forward(frames, output_final)
+
+
+class Trainer(nn.Module):
+    """reference model/trainer.py:170-306 (BCD / SCD / BDA heads; CC head is 'next')."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.embed_dims = [24, 24, 48, 96]
+        self.encoder = Encoder(args, self.embed_dims)
+        k = args.num_perception_frame
+        if k == 1 and "CD" in args.dataset:
+            self.decoder = ChangeDecoder(args, in_dim=self.embed_dims, has_sigmoid=True)
+            weight_init(self.decoder)
+        elif k == 3:
+            self.decoder_pre = ChangeDecoder(args, in_dim=self.embed_dims)
+            self.decoder_post = ChangeDecoder(args, in_dim=self.embed_dims)
+            self.decoder_change = ChangeDecoder(args, in_dim=self.embed_dims, has_sigmoid=True)
+            for d in (self.decoder_pre, self.decoder_post, self.decoder_change):
+                weight_init(d)
+        elif k == 2:
+            self.decoder_cls = ChangeDecoder(args, in_dim=self.embed_dims)
+            self.decoder_loc = ChangeDecoder(args, in_dim=self.embed_dims, has_sigmoid=True)
+            weight_init(self.decoder_cls)
+            weight_init(self.decoder_loc)
+        else:
+            raise AssertionError("CC head not part of this oracle yet")
+
+    def update_bcd(self, x, y):
+        feats = self.encoder(x, y)
+        return self.decoder([f[0] for f in feats])
+
+    def update_scd(self, x, y):
+        feats = self.encoder(x, y)
+        return (self.decoder_pre([f[0] for f in feats]),
+                self.decoder_post([f[2] for f in feats]),
+                self.decoder_change([f[1] for f in feats]))
+
+    def update_bda(self, x, y):
+        feats = self.encoder(x, y)
+        return self.decoder_cls([f[0] for f in feats]), self.decoder_loc([f[1] for f in feats])
+
+
+# --------------------------------------------------------------- loss / lr / metrics
+def bce_dice_loss(inputs, targets):
+    """reference model/utils.py:154-169 (Dice sums run over the whole batch)."""
+    bce = F.binary_cross_entropy(inputs, targets)
+    inter = (inputs * targets).sum()
+    eps = 1e-5
+    dice = (2 * inter + eps) / (inputs.sum() + targets.sum() + eps)
+    return bce + 1 - dice
+
+
+def poly_lr(base_lr, it, max_iter, epoch):
+    """reference model/utils.py:130-143 (lr_mode='poly' + epoch-0 warm-up)."""
+    lr = base_lr * (1 - it * 1.0 / max_iter) ** 0.9
+    if epoch == 0 and it < 200:
+        lr = base_lr * 0.9 * (it + 1) / 200 + 0.1 * base_lr
+    return lr
+
+
+def binarize(prob):
+    """reference scripts/train_BCD.py:204-208 — strict '>' 0.5."""
+    return torch.where(prob > 0.5, torch.ones_like(prob), torch.zeros_like(prob)).long()
+
+
+def confusion_matrix(num_classes, label_gts, label_preds):
+    """reference utils/metric_tool.py:111-128."""
+    cm = np.zeros((num_classes, num_classes))
+    for gt, pr in zip(label_gts, label_preds):
+        gt, pr = gt.flatten(), pr.flatten()
+        mask = (gt >= 0) & (gt < num_classes)
+        cm += np.bincount(num_classes * gt[mask].astype(int) + pr[mask],
+                          minlength=num_classes ** 2).reshape(num_classes, num_classes)
+    return cm
+
+
+def cm2score(cm):
+    """reference utils/metric_tool.py:87-108."""
+    tp, fn, fp, tn = cm[1, 1], cm[1, 0], cm[0, 1], cm[0, 0]
+    e = np.finfo(np.float32).eps
+    oa = (tp + tn) / (tp + fn + fp + tn + e)
+    recall = tp / (tp + fn + e)
+    precision = tp / (tp + fp + e)
+    f1 = 2 * recall * precision / (recall + precision + e)
+    iou = tp / (tp + fp + fn + e)
+    pre = ((tp + fn) * (tp + fp) + (tn + fp) * (tn + fn)) / (tp + fp + tn + fn) ** 2
+    kappa = (oa - pre) / (1 - pre)
+    return {"Kappa": kappa, "IoU": iou, "F1": f1, "OA": oa, "recall": recall,
+            "precision": precision, "Pre": pre}
+
+
+def make_args(num_perception_frame=1, size=256, dataset="LEVIR-CD", num_class=1):
+    return SimpleNamespace(pretrained="/nonexistent", num_perception_frame=num_perception_frame,
+                           in_height=size, in_width=size, dataset=dataset, num_class=num_class)
+
+
+def make_adam(model, lr=2e-4):
+    """reference scripts/train_BCD.py:284-290."""
+    return torch.optim.Adam(model.parameters(), lr, (0.9, 0.99), eps=1e-08, weight_decay=1e-4)
