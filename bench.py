@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py — BCD X3D-L train throughput (images/s) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one full training iteration of the reference loop (reference
+scripts/train_BCD.py:179-225) on one synthetic LEVIR-CD-shaped batch already resident in HBM:
+poly-LR update, Trainer.update_bcd forward (train-mode BN), BCE+Dice, zero_grad, backward,
+gradient all-reduce (N>1), Adam, thresholded confusion-matrix update.  Workload = BASELINE.json
+configs[1]: BCD X3D-L, bf16 activations, B=32 per GPU, 256x256 pairs, T=3.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed, algorithmic
+bytes) and `cpu_baseline` (the CPU oracle = port of the reference path, timed on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+A_BCD_ELEMS = 159_784_960        # materialised activation elements per sample
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--kernel-table", default="", help="write the per-kernel HIP-event table (JSON) here")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, batch=2, timed=2):
+    """Reference arithmetic (oracle = torch-CPU fp32 eager NCDHW port of the reference path),
+    same loss / Adam, on all host cores.  Bounded sample: 1 warm-up + `timed` steps of B=`batch`."""
+    from oracle import model as om, synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = om.Trainer(om.make_args(size=size))
+    net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25))
+    net.train()
+    opt = om.make_adam(net)
+    pre, post, tgt = synth.synth_batch(batch, size, seed=0)
+
+    def one():
+        prob = net.update_bcd(pre, post)
+        loss = om.bce_dice_loss(prob, tgt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    one()
+    t0 = time.time()
+    for _ in range(timed):
+        one()
+    dt = time.time() - t0
+    return {"value": round(batch * timed / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{timed} timed steps (+1 warm-up) of B={batch} {size}x{size} pairs, fp32, torch-CPU eager, "
+                      f"{cores} threads"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from oracle import synth  # deterministic synthetic weights / batches only (not the checker here)
+    from oracle.model import make_args
+    from change3d_amd import ops
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.utils import BCEDiceLoss, FusedAdam, adjust_learning_rate
+    from change3d_amd.parallel import broadcast_module_state, setup_data_parallel
+    from change3d_amd.utils.metric_tool import ConfuseMatrixMeter
+
+    act = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    margs = make_args(size=a.size)
+    margs.act_dtype = act
+    margs.lr_mode, margs.lr, margs.max_epochs, margs.step_loss = "poly", 2e-4, 1, 100
+    net = Trainer(margs)
+    net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25))
+    net = net.to(dev).train()
+    broadcast_module_state(net)
+    arena, sync = setup_data_parallel(net, dev, overlap=True)
+    opt = FusedAdam(arena, lr=margs.lr, capturable=True)
+    meter = ConfuseMatrixMeter(2)
+    pre, post, tgt = (t.to(dev) for t in synth.synth_batch(a.batch, a.size, seed=rank))
+    MAX_ITER = 80000
+    state = {"it": 0, "loss": None, "prob": None}
+
+    def fwd_bwd():
+        opt.zero_grad()
+        prob = net.update_bcd(pre, post)
+        loss = BCEDiceLoss(prob, tgt)
+        loss.backward()
+        meter.update_cm_device(prob, tgt)
+        return loss.detach(), prob.detach()
+
+    graph = None
+    use_graph = not a.no_graph and world == 1  # N>1: the overlapped all-reduce is issued from inside backward
+    # eager warm-up (also instantiates workspaces / function attributes before any capture)
+    adjust_learning_rate(margs, opt, 0, 0, MAX_ITER)
+    opt.prepare_step()
+    state["loss"], state["prob"] = fwd_bwd()
+    sync.finish()
+    opt.launch()
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fwd_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                state["loss"], state["prob"] = fwd_bwd()
+                opt.launch()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        adjust_learning_rate(margs, opt, 0, state["it"], MAX_ITER)
+        opt.prepare_step()
+        if graph is not None:
+            graph.replay()
+        else:
+            state["loss"], state["prob"] = fwd_bwd()
+            sync.finish()
+            opt.launch()
+        state["it"] += 1
+        if state["it"] % 5 == 0:  # reference prints (and syncs on) the loss every 5 iterations
+            state["last_loss"] = float(state["loss"])
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(state["loss"])
+    if not (final_loss == final_loss):
+        raise SystemExit("loss is NaN")
+
+    ms_per_step = elapsed / a.steps * 1e3
+    value = a.batch * world * a.steps / elapsed
+    es = 2 if a.dtype == "bf16" else 4
+    bytes_per_sample = 5 * A_BCD_ELEMS * es * (a.size / 256.0) ** 2
+    out = {
+        "metric": "train images/sec (256x256 pairs, X3D-L BCD)", "value": round(value, 2), "unit": "images/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"BCD X3D-L {a.dtype}, B={a.batch}/GPU, {a.size}x{a.size} synthetic LEVIR-CD-shaped "
+                               f"pairs, T=3, train step (fwd+BCE/Dice+bwd+Adam)",
+                   "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                   "hip_graph": graph is not None, "final_loss": round(final_loss, 5)},
+        "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_sample": bytes_per_sample,
+                          "achieved": round(value / world * bytes_per_sample / 1e9, 1), "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": round(value / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+
+    # ---- dominant kernel, timed live with HIP events on the launch stream (one extra eager step)
+    if rank == 0 and not a.no_kernel_profile:
+        net.encoder.x3d.blocks[3].post_backward = None
+        ops.profile_begin()
+        fwd_bwd()
+        opt.launch()
+        prof = ops.profile_end()
+        tot = sum(v["ms_total"] for v in prof.values())
+        table = sorted(prof.items(), key=lambda kv: -kv[1]["ms_total"])
+        name, d = table[0]
+        ach = d["bytes_total"] / max(d["ms_total"], 1e-9) / 1e6
+        out["roofline"] = {"bound": "hbm", "kernel": name, "launches_per_step": d["launches"],
+                           "avg_us_per_launch": round(d["ms_total"] / d["launches"] * 1e3, 2),
+                           "algorithmic_bytes_per_launch": round(d["bytes_total"] / d["launches"]),
+                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "share_of_kernel_time": round(d["ms_total"] / max(tot, 1e-9), 3)}
+        rows = [{"kernel": k, "launches": v["launches"], "ms_total": round(v["ms_total"], 3),
+                 "GBps": round(v["bytes_total"] / max(v["ms_total"], 1e-9) / 1e6, 1)} for k, v in table]
+        out["kernel_time_ms_eager_step"] = round(tot, 3)
+        if a.kernel_table:
+            with open(a.kernel_table, "w") as f:
+                json.dump({"ms_per_step": ms_per_step, "kernels": rows}, f, indent=1)
+        for r in rows:
+            print(f"[kernels] {r['kernel']:24s} x{r['launches']:4d} {r['ms_total']:9.3f} ms {r['GBps']:8.1f} GB/s",
+                  file=sys.stderr)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.size)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

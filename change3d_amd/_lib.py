@@ -1,0 +1,115 @@
+"""ctypes binding of libchange3d_hip.so (the C ABI declared in include/change3d_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc, gfx950).  There is NO
+fallback: if the shared object is missing or a symbol is absent, import-time use raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libchange3d_hip.so")
+
+DT_F32, DT_BF16 = 0, 1
+PRO_NONE, PRO_BN_SE_SWISH, PRO_AFFINE2 = 0, 1, 2
+EPI_STORE, EPI_STATS, EPI_SWISH_SE_BWD, EPI_ADD = 0, 1, 2, 3
+ROWS_DENSE, ROWS_FRAME, ROWS_STRIDE2, ROWS_S2SHIFT = 0, 1, 2, 3
+SC_NONE, SC_IDENTITY, SC_BN, SC_RAW = 0, 1, 2, 3
+
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+
+class PwArgs(C.Structure):
+    _fields_ = [("x", vp), ("x2", vp), ("y", vp), ("e1", vp), ("w", vp), ("pro_p", vp), ("pro_gate", vp),
+                ("epi_p", vp), ("epi_gate", vp), ("stats", vp),
+                ("M", i64), ("gstride", i64), ("rows_per_sample", i64),
+                ("K", i32), ("Kp", i32), ("N", i32), ("Np", i32), ("w_sn", i32), ("w_sk", i32),
+                ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32),
+                ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32)]
+
+
+class PwWgradArgs(C.Structure):
+    _fields_ = [("p", vp), ("p2", vp), ("q", vp), ("dw", vp), ("ws", vp), ("p_coef", vp), ("q_ss", vp),
+                ("q_gate", vp),
+                ("M", i64), ("gstride", i64), ("rows_per_sample", i64),
+                ("K", i32), ("Kp", i32), ("N", i32), ("Np", i32), ("dw_sn", i32), ("dw_sk", i32),
+                ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32), ("dy", i32), ("dx", i32),
+                ("q_mode", i32), ("dtype", i32)]
+
+
+# name -> (restype, argtypes); every function declared in include/change3d_hip.h
+SIGNATURES = {
+    "c3d_abi_version": (i32, []),
+    "c3d_build_info": (C.c_char_p, []),
+    "c3d_device_cus": (i32, []),
+    "c3d_pw_gemm": (i32, [C.POINTER(PwArgs), vp]),
+    "c3d_pw_wgrad_ws_floats": (i64, [i32, i32]),
+    "c3d_pw_wgrad": (i32, [C.POINTER(PwWgradArgs), vp]),
+    "c3d_bn_finalize": (i32, [vp, f64, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp]),
+    "c3d_bn_se_finalize": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp, vp,
+                                 i32, vp, vp, vp, vp, vp]),
+    "c3d_bn_bwd_coef": (i32, [vp, f64, vp, vp, i32, i32, vp, vp, vp, vp]),
+    "c3d_se_bn_bwd_coef": (i32, [vp, vp, i32, f64, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp,
+                                 vp, vp, vp, vp, vp, vp]),
+    "c3d_dw333_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "c3d_dw333_bwd_data": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
+                                 i32, vp]),
+    "c3d_dw333_wgrad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "c3d_block_out_fwd": (i32, [vp, vp, vp, vp, i32, vp, i64, i32, i32, vp]),
+    "c3d_block_out_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "c3d_frame_absdiff": (i32, [vp, vp, i32, i32, i64, i32, i32, i32, i32, vp]),
+    "c3d_enhance_apply": (i32, [vp, vp, vp, i32, i32, i64, i32, i32, i32, vp]),
+    "c3d_enhance_bwd_mask": (i32, [vp, vp, vp, i32, i32, i64, i32, i32, i32, vp]),
+    "c3d_enhance_bwd_apply": (i32, [vp, vp, vp, vp, i32, i32, i64, i32, i32, i32, i32, vp]),
+    "c3d_frame_scatter": (i32, [vp, vp, i32, i32, i64, i32, i32, i32, i32, vp]),
+    "c3d_stem_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "c3d_stem_bwd_dv": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "c3d_stem_bwd_wx": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "c3d_convT4s2_fwd": (i32, [vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, vp]),
+    "c3d_convT4s2_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "c3d_col_sum": (i32, [vp, vp, i64, i32, i32, i32, vp]),
+    "c3d_head3x3_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "c3d_head3x3_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "c3d_bce_dice_fwd": (i32, [vp, vp, i64, vp, vp, vp]),
+    "c3d_bce_dice_bwd": (i32, [vp, vp, vp, vp, i64, vp, vp]),
+    "c3d_adam_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
+    "c3d_confusion2": (i32, [vp, vp, i64, vp, vp]),
+}
+
+_lib = None
+
+
+class Change3DHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the bound library.  Raises loudly when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise Change3DHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` at the repo root. "
+                f"There is no CPU/PyTorch fallback for the Change3D hot path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise Change3DHipError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check_exports():
+    """Used by build() and the CPU test-suite: every declared symbol must be exported."""
+    handle = lib()
+    assert handle.c3d_abi_version() == 1
+    return sorted(SIGNATURES)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise Change3DHipError(f"{what} failed with code {rc}")

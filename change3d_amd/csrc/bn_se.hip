@@ -1,0 +1,293 @@
+// BatchNorm3d statistics finalisation, SqueezeExcitation FCs and the matching backward
+// coefficient kernels.  All of these touch only O(B*C) numbers: one small workgroup each,
+// f64 arithmetic for the statistics (torch-CPU accumulates BN statistics in double too).
+//
+// Train-mode BN is split three ways in this framework:
+//   producer epilogue  : per-channel (or per-sample-per-channel) sum / sum-of-squares
+//   c3d_bn_finalize    : -> scale/shift (+ running-stat update, saved mean/rstd)
+//   consumer prologue  : y = x*scale + shift applied on operand load
+// and backward mirrors it (sums in a producer epilogue -> coefficients here -> affine
+// dx = A*g + B + C*x applied on operand load of the next kernel).
+#include "common.h"
+#include "../../include/change3d_hip.h"
+
+namespace {
+
+// -------------------------------------------------------------------------------------------
+// sums: [2][C] (sum, sumsq) per channel.
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var,
+                                   int64_t* nbt, float momentum, float eps, int C, int Cp, int training,
+                                   float* __restrict__ ss, float* __restrict__ mr) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && nbt) *nbt += 1;
+  if (c >= Cp) return;
+  if (c >= C) { ss[c] = 0.f; ss[Cp + c] = 0.f; return; }
+  double mean, var;
+  if (training) {
+    mean = sums[c] / count;
+    var = sums[C + c] / count - mean * mean;
+    if (var < 0) var = 0;
+    if (running_mean) {
+      const double unb = count > 1 ? var * count / (count - 1) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  const float sc = gamma[c] * rstd;
+  ss[c] = sc;
+  ss[Cp + c] = beta[c] - meanf * sc;
+  if (mr) { mr[c] = meanf; mr[C + c] = rstd; }
+}
+
+// -------------------------------------------------------------------------------------------
+// Depthwise-conv output statistics arrive per (sample, channel): nc[B][Cp][2].
+// Produces BN_b scale/shift (+running stats), and the SE gate[B][Cp].
+__global__ __launch_bounds__(256) void bn_se_finalize_kernel(
+    const double* __restrict__ nc, int B, double cnt_per_sample, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
+    float eps, int C, int Cp, int training, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, int Cr, float* __restrict__ ss,
+    float* __restrict__ mr, float* __restrict__ gate, float* __restrict__ hid) {
+  extern __shared__ float sm[];  // z[B][C] then h[B][Cr]
+  float* z = sm;
+  float* h = sm + (size_t)B * C;
+  const int tid = threadIdx.x;
+  const double count = cnt_per_sample * B;
+  if (tid == 0 && training && nbt) *nbt += 1;
+  for (int c = tid; c < Cp; c += blockDim.x) {
+    if (c >= C) { ss[c] = 0.f; ss[Cp + c] = 0.f; continue; }
+    double mean, var;
+    if (training) {
+      double s1 = 0, s2 = 0;
+      for (int n = 0; n < B; ++n) { s1 += nc[((size_t)n * Cp + c) * 2]; s2 += nc[((size_t)n * Cp + c) * 2 + 1]; }
+      mean = s1 / count;
+      var = s2 / count - mean * mean;
+      if (var < 0) var = 0;
+      if (running_mean) {
+        const double unb = count > 1 ? var * count / (count - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+      }
+    } else {
+      mean = running_mean[c];
+      var = running_var[c];
+    }
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    const float sc = gamma[c] * rstd;
+    const float sh = beta[c] - meanf * sc;
+    ss[c] = sc;
+    ss[Cp + c] = sh;
+    if (mr) { mr[c] = meanf; mr[C + c] = rstd; }
+    if (w1) {
+      for (int n = 0; n < B; ++n)
+        z[(size_t)n * C + c] = fmaf(sc, (float)(nc[((size_t)n * Cp + c) * 2] / cnt_per_sample), sh);
+    }
+  }
+  if (!w1) return;  // no SE in this block: consumers take gate = 1 (NULL)
+  __syncthreads();
+  for (int i = tid; i < B * Cr; i += blockDim.x) {
+    const int n = i / Cr, r = i - n * Cr;
+    float a = b1[r];
+    for (int c = 0; c < C; ++c) a = fmaf(w1[(size_t)r * C + c], z[(size_t)n * C + c], a);
+    a = a > 0.f ? a : 0.f;
+    h[i] = a;
+    if (hid) hid[i] = a;
+  }
+  __syncthreads();
+  for (int i = tid; i < B * Cp; i += blockDim.x) {
+    const int n = i / Cp, c = i - n * Cp;
+    float g = 0.f;
+    if (c < C) {
+      float a = b2[c];
+      for (int r = 0; r < Cr; ++r) a = fmaf(w2[(size_t)c * Cr + r], h[(size_t)n * Cr + r], a);
+      g = 1.0f / (1.0f + expf(-a));
+    }
+    gate[i] = g;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// BN backward coefficients: dsums [2][C] = (sum g, sum g*x).  dx = A*g + B + C*x.
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ dsums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ mr, int C, int Cp, float* __restrict__ coef,
+                                   float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  if (c >= C) { coef[c] = 0.f; coef[Cp + c] = 0.f; coef[2 * Cp + c] = 0.f; return; }
+  const double mean = mr[c], rstd = mr[C + c];
+  const double s1 = dsums[c], sgx = dsums[C + c];
+  const double s2 = rstd * (sgx - mean * s1);  // sum g * xhat
+  const double A = (double)gamma[c] * rstd;
+  const double Cc = -A * rstd * s2 / count;
+  const double Bc = -A * s1 / count - Cc * mean;
+  coef[c] = (float)A;
+  coef[Cp + c] = (float)Bc;
+  coef[2 * Cp + c] = (float)Cc;
+  if (dgamma) dgamma[c] += (float)s2;
+  if (dbeta) dbeta[c] += (float)s1;
+}
+
+// -------------------------------------------------------------------------------------------
+// SE backward + BN_b backward coefficients.
+//   nc3 [B][Cp][3] = per (n,c): sum dq*pb (d gate), sum t1, sum t1*b
+//   ncf [B][Cp][2] = forward per (n,c): sum b, sum b^2
+//   db = A[c]*t1 + Bnc[n][c] + Cc[c]*b
+__global__ __launch_bounds__(256) void se_bn_bwd_coef_kernel(
+    const double* __restrict__ nc3, const double* __restrict__ ncf, int B, double cnt_per_sample,
+    const float* __restrict__ gamma, const float* __restrict__ mr, const float* __restrict__ ss, int C, int Cp,
+    const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ gate,
+    const float* __restrict__ hid, int Cr, float* __restrict__ coefA, float* __restrict__ coefC,
+    float* __restrict__ coefB, float* dgamma, float* dbeta, float* dw1, float* db1, float* dw2, float* db2) {
+  extern __shared__ float sm[];
+  float* du = sm;                      // [B][C]
+  float* dh = du + (size_t)B * C;      // [B][Cr]
+  float* dz = dh + (size_t)B * Cr;     // [B][C]
+  float* zz = dz + (size_t)B * C;      // [B][C]  forward z (input of the SE FCs)
+  const int tid = threadIdx.x;
+  const double count = cnt_per_sample * B;
+  const bool se = w1 != nullptr;
+  if (se) {
+    for (int i = tid; i < B * C; i += blockDim.x) {
+      const int n = i / C, c = i - n * C;
+      const float g = gate[(size_t)n * Cp + c];
+      du[i] = (float)nc3[((size_t)n * Cp + c) * 3] * g * (1.f - g);
+      zz[i] = fmaf(ss[c], (float)(ncf[((size_t)n * Cp + c) * 2] / cnt_per_sample), ss[Cp + c]);
+    }
+    __syncthreads();
+    for (int i = tid; i < B * Cr; i += blockDim.x) {
+      const int n = i / Cr, r = i - n * Cr;
+      float a = 0.f;
+      for (int c = 0; c < C; ++c) a = fmaf(w2[(size_t)c * Cr + r], du[(size_t)n * C + c], a);
+      dh[i] = hid[i] > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < B * C; i += blockDim.x) {
+      const int n = i / C, c = i - n * C;
+      float a = 0.f;
+      for (int r = 0; r < Cr; ++r) a = fmaf(w1[(size_t)r * C + c], dh[(size_t)n * Cr + r], a);
+      dz[i] = a;
+    }
+    // parameter gradients of the two FCs
+    for (int i = tid; i < C * Cr; i += blockDim.x) {
+      const int c = i / Cr, r = i - c * Cr;  // w2[c][r]
+      float a = 0.f, b = 0.f;
+      for (int n = 0; n < B; ++n) {
+        a = fmaf(du[(size_t)n * C + c], hid[(size_t)n * Cr + r], a);
+        b = fmaf(dh[(size_t)n * Cr + r], zz[(size_t)n * C + c], b);
+      }
+      dw2[(size_t)c * Cr + r] += a;
+      dw1[(size_t)r * C + c] += b;
+    }
+    for (int c = tid; c < C; c += blockDim.x) {
+      float a = 0.f;
+      for (int n = 0; n < B; ++n) a += du[(size_t)n * C + c];
+      db2[c] += a;
+    }
+    for (int r = tid; r < Cr; r += blockDim.x) {
+      float a = 0.f;
+      for (int n = 0; n < B; ++n) a += dh[(size_t)n * Cr + r];
+      db1[r] += a;
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < Cp; c += blockDim.x) {
+    if (c >= C) {
+      coefA[c] = 0.f; coefC[c] = 0.f;
+      for (int n = 0; n < B; ++n) coefB[(size_t)n * Cp + c] = 0.f;
+      continue;
+    }
+    const double mean = mr[c], rstd = mr[C + c];
+    double s1 = 0, sgb = 0;
+    for (int n = 0; n < B; ++n) {
+      const double dzn = se ? (double)dz[(size_t)n * C + c] : 0.0;
+      s1 += nc3[((size_t)n * Cp + c) * 3 + 1] + dzn;
+      sgb += nc3[((size_t)n * Cp + c) * 3 + 2] + dzn / cnt_per_sample * ncf[((size_t)n * Cp + c) * 2];
+    }
+    const double s2 = rstd * (sgb - mean * s1);
+    const double A = (double)gamma[c] * rstd;
+    const double Cc = -A * rstd * s2 / count;
+    coefA[c] = (float)A;
+    coefC[c] = (float)Cc;
+    for (int n = 0; n < B; ++n) {
+      const double dzn = se ? (double)dz[(size_t)n * C + c] : 0.0;
+      coefB[(size_t)n * Cp + c] = (float)(A * dzn / cnt_per_sample - A * s1 / count - Cc * mean);
+    }
+    if (dgamma) dgamma[c] += (float)s2;
+    if (dbeta) dbeta[c] += (float)s1;
+  }
+}
+
+}  // namespace
+
+extern "C" int c3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float momentum, float eps, int32_t C, int32_t Cp, int32_t training, float* ss,
+                               float* mr, void* stream) {
+  if (!gamma || !beta || !ss || C <= 0 || Cp < C) return C3D_E_BADARG;
+  if (training && !sums) return C3D_E_BADARG;
+  if (!training && (!running_mean || !running_var)) return C3D_E_BADARG;
+  bn_finalize_kernel<<<dim3((Cp + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+      sums, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, C, Cp, training, ss,
+      mr);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bn_se_finalize(const double* nc, int32_t B, double cnt_per_sample, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var,
+                                  int64_t* num_batches_tracked, float momentum, float eps, int32_t C, int32_t Cp,
+                                  int32_t training, const float* w1, const float* b1, const float* w2,
+                                  const float* b2, int32_t Cr, float* ss, float* mr, float* gate, float* hid,
+                                  void* stream) {
+  if (!nc || !gamma || !beta || !ss || C <= 0 || Cp < C || B <= 0) return C3D_E_BADARG;
+  if (w1 && (!b1 || !w2 || !b2 || !gate || Cr <= 0)) return C3D_E_BADARG;
+  const size_t lds = w1 ? ((size_t)B * C + (size_t)B * Cr) * sizeof(float) : 0;
+  if (lds > 64 * 1024) return C3D_E_UNSUPPORTED;
+  bn_se_finalize_kernel<<<dim3(1), dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(
+      nc, B, cnt_per_sample, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, C, Cp,
+      training, w1, b1, w2, b2, Cr, ss, mr, gate, hid);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bn_bwd_coef(const double* dsums, double count, const float* gamma, const float* mr, int32_t C,
+                               int32_t Cp, float* coef, float* dgamma, float* dbeta, void* stream) {
+  if (!dsums || !gamma || !mr || !coef || C <= 0 || Cp < C) return C3D_E_BADARG;
+  bn_bwd_coef_kernel<<<dim3((Cp + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+      dsums, count, gamma, mr, C, Cp, coef, dgamma, dbeta);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_se_bn_bwd_coef(const double* nc3, const double* ncf, int32_t B, double cnt_per_sample,
+                                  const float* gamma, const float* mr, const float* ss, int32_t C, int32_t Cp,
+                                  const float* w1, const float* w2, const float* gate, const float* hid, int32_t Cr,
+                                  float* coefA, float* coefC, float* coefB, float* dgamma, float* dbeta,
+                                  float* dw1, float* db1, float* dw2, float* db2, void* stream) {
+  if (!nc3 || !ncf || !gamma || !mr || !ss || !coefA || !coefC || !coefB || C <= 0 || Cp < C || B <= 0)
+    return C3D_E_BADARG;
+  if (w1 && (!w2 || !gate || !hid || !dw1 || !db1 || !dw2 || !db2 || Cr <= 0)) return C3D_E_BADARG;
+  const size_t lds = w1 ? ((size_t)3 * B * C + (size_t)B * Cr) * sizeof(float) : 0;
+  if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&se_bn_bwd_coef_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+  }
+  se_bn_bwd_coef_kernel<<<dim3(1), dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(
+      nc3, ncf, B, cnt_per_sample, gamma, mr, ss, C, Cp, w1, w2, gate, hid, Cr, coefA, coefC, coefB, dgamma, dbeta,
+      dw1, db1, dw2, db2);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

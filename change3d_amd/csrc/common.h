@@ -1,0 +1,94 @@
+// Shared device helpers for the Change3D gfx950 kernels.
+//
+// Layout convention for every activation tensor handled here: channels-last,
+// [B][T][H][W][Cp] with Cp = round_up(C, 8) so that each pixel's channel row is a whole
+// number of 8-element vectors (16 B in bf16, 32 B in f32).  Pad channels hold zeros.
+// Storage type T is float (parity path) or bf16 (throughput path); all arithmetic is f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define C3D_WAVE 64
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+enum { C3D_F32 = 0, C3D_BF16 = 1 };
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- 8-element vector load / store (global or LDS), converting to/from f32 ---------------
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&f)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&f)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+  }
+};
+template <> struct Vec8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&f)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&f)[8]) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+};
+
+// Round a value the way it will be stored (so statistics describe what consumers read).
+template <typename T> __device__ __forceinline__ float round_as(float f);
+template <> __device__ __forceinline__ float round_as<float>(float f) { return f; }
+template <> __device__ __forceinline__ float round_as<bf16_t>(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float f);
+template <> __device__ __forceinline__ void st1<float>(float* p, float f) { *p = f; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float f) { *p = f32_to_bf16(f); }
+
+// sigmoid: accurate expf on the f32 (parity) path, hardware v_exp on the bf16 (throughput) path
+template <typename T> __device__ __forceinline__ float sigmoid_t(float x);
+template <> __device__ __forceinline__ float sigmoid_t<float>(float x) { return 1.0f / (1.0f + expf(-x)); }
+template <> __device__ __forceinline__ float sigmoid_t<bf16_t>(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---- wave / block reductions -----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
+
+// Host-side helpers -----------------------------------------------------------------------
+#define C3D_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e_ = hipGetLastError();                       \
+    if (e_ != hipSuccess) return (int)e_;                    \
+  } while (0)

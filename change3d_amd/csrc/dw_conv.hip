@@ -1,0 +1,591 @@
+// Depthwise 3x3x3 Conv3d (groups = C, padding 1, stride (1,s,s), s in {1,2}) on the VALU with
+// LDS-tiled inputs; replaces conv_b of the X3D bottleneck (reference model/x3d.py:184-193)
+// forward, data-gradient and weight-gradient, with the neighbouring BatchNorm arithmetic fused:
+//
+//   fwd      : in  = relu(a*scale_a + shift_a) applied once per element while staging the tile
+//              (zero padding is applied AFTER the activation, as in the reference graph);
+//              out = raw conv output b; epilogue = per-(sample,channel) sum / sum-of-squares
+//              (feeds BN_b statistics and the SE squeeze).
+//   bwd_data : in  = db = A[c]*t1 + B[n][c] + C[c]*b applied while staging (BN_b/SE backward);
+//              out = t2 = dconv * (a*scale_a+shift_a > 0); epilogue = per-channel sum t2, sum t2*a
+//   wgrad    : dW[c][kt][ky][kx] += sum db[out] * relu(bn(a))[in]
+//
+// All T frames of a spatial tile are resident in LDS (T = 3 for BCD, 5 for SCD).  A thread
+// owns one output pixel and one 8-channel vector for all T frames.
+#include "common.h"
+#include "../../include/change3d_hip.h"
+
+namespace {
+
+constexpr int DW_CV = 4;    // channel vectors (of 8) per workgroup pass = 32 channels
+constexpr int DW_MAXT = 5;
+
+template <typename T> struct LdsStore;  // tile element type in LDS
+template <> struct LdsStore<float> { typedef float type; };
+template <> struct LdsStore<bf16_t> { typedef bf16_t type; };
+
+struct DwGeom {
+  int B, T, H, W, Ho, Wo, C, Cp, stride;
+};
+
+// ----------------------------------------------------------------------------------------------
+// Forward.  grid = (tiles_x*tiles_y, channel chunks, B); block = TH*TW*DW_CV threads.
+template <typename T, int S, int TH, int TW>
+__global__ __launch_bounds__(TH * TW * DW_CV) void dw_fwd_kernel(
+    const T* __restrict__ x, const float* __restrict__ ss, const float* __restrict__ w, T* __restrict__ y,
+    double* __restrict__ nc, const DwGeom g) {
+  typedef typename LdsStore<T>::type L;
+  constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+  constexpr int NTHR = TH * TW * DW_CV;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);                         // [27][32]
+  float* red = wl + 27 * 32;                                          // [NTHR/64][DW_CV][16]
+  L* tile = reinterpret_cast<L*>(red + (NTHR / 64) * DW_CV * 16);     // [T][IH][IW][32]
+
+  const int tid = threadIdx.x;
+  const int tiles_x = (g.Wo + TW - 1) / TW;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int c0 = chunk * DW_CV * 8;
+  const int cv = tid % DW_CV;
+  const int cbase = c0 + cv * 8;
+  const bool c_ok = cbase < g.Cp;
+
+  // weights -> LDS as [tap][32 channels] (zero for channels >= C)
+  for (int i = tid; i < 27 * 32; i += NTHR) {
+    const int tap = i / 32, c = c0 + (i & 31);
+    wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
+  }
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = c_ok ? ss[cbase + j] : 0.f; sh[j] = c_ok ? ss[g.Cp + cbase + j] : 0.f; }
+
+  // input tile (all T frames) with the BN+ReLU prologue; zero outside the image
+  const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
+  const int items = g.T * IH * IW * DW_CV;
+  for (int i = tid; i < items; i += NTHR) {  // NTHR % DW_CV == 0 -> cv fixed per thread
+    const int p = i / DW_CV;
+    const int ix = p % IW;
+    const int q = p / IW;
+    const int iy = q % IH, t = q / IH;
+    const int gy = iy0 + iy, gx = ix0 + ix;
+    float f[8];
+    if (c_ok && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+      Vec8<T>::load(x + ((((size_t)b * g.T + t) * g.H + gy) * g.W + gx) * g.Cp + cbase, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = 0.f;
+    }
+    Vec8<L>::store(tile + (size_t)p * 32 + cv * 8, f);
+  }
+  __syncthreads();
+
+  const int pix = tid / DW_CV;
+  const int px = pix % TW, py = pix / TW;
+  const int oy = ty * TH + py, ox = tx * TW + px;
+  const bool p_ok = c_ok && oy < g.Ho && ox < g.Wo;
+
+  float acc[DW_MAXT][8];
+#pragma unroll
+  for (int t = 0; t < DW_MAXT; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      float wk[3][8];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + (kt * 9 + ky * 3 + kx) * 32 + cv * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(wl + (kt * 9 + ky * 3 + kx) * 32 + cv * 8 + 4);
+        wk[kt][0] = w0.x; wk[kt][1] = w0.y; wk[kt][2] = w0.z; wk[kt][3] = w0.w;
+        wk[kt][4] = w1.x; wk[kt][5] = w1.y; wk[kt][6] = w1.z; wk[kt][7] = w1.w;
+      }
+#pragma unroll
+      for (int ti = 0; ti < DW_MAXT; ++ti) {
+        if (ti < g.T) {
+          float v[8];
+          Vec8<L>::load(tile + ((size_t)(ti * IH + py * S + ky) * IW + px * S + kx) * 32 + cv * 8, v);
+#pragma unroll
+          for (int kt = 0; kt < 3; ++kt) {
+            const int to = ti - kt + 1;  // out[to] += in[to + kt - 1] * w[kt]
+            if (to >= 0 && to < DW_MAXT && to < g.T) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[to][j] = fmaf(v[j], wk[kt][j], acc[to][j]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (p_ok) {
+#pragma unroll
+    for (int t = 0; t < DW_MAXT; ++t) {
+      if (t < g.T) {
+        Vec8<T>::store(y + ((((size_t)b * g.T + t) * g.Ho + oy) * g.Wo + ox) * g.Cp + cbase, acc[t]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float r = round_as<T>(acc[t][j]);
+          s1[j] += r; s2[j] += r * r;
+        }
+      }
+    }
+  }
+  if (nc == nullptr) return;
+  // reduce over the pixels of the workgroup: lanes with equal cv inside a wave, then across waves
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int o = DW_CV; o < 64; o <<= 1) {
+      s1[j] += __shfl_xor(s1[j], o, 64);
+      s2[j] += __shfl_xor(s2[j], o, 64);
+    }
+  }
+  if (lane < DW_CV) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[(wave * DW_CV + lane) * 16 + j] = s1[j];
+      red[(wave * DW_CV + lane) * 16 + 8 + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  if (tid < DW_CV * 16) {
+    const int v = tid / 16, k = tid & 15;
+    float s = 0.f;
+    for (int wv = 0; wv < NTHR / 64; ++wv) s += red[(wv * DW_CV + v) * 16 + k];
+    const int c = c0 + v * 8 + (k & 7);
+    if (c < g.C) atomicAdd(nc + ((size_t)b * g.Cp + c) * 2 + (k >> 3), (double)s);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Data gradient.  Output positions are INPUT-resolution pixels; the staged tile is db at
+// output resolution (+halo), built on load from (t1, b, coefA, coefB[n], coefC).
+template <typename T, int S, int TH, int TW>
+__global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
+    const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
+    const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
+    const T* __restrict__ a, const float* __restrict__ ss_a, T* __restrict__ t2, double* __restrict__ dsums,
+    const DwGeom g) {
+  typedef typename LdsStore<T>::type L;
+  // dra[iy] gathers db[(iy + 1 - ky)/S]; for a TH-row tile starting at y0 (multiple of S*... ) the
+  // db rows needed span floor((y0-1)/S) .. floor((y0+TH)/S)
+  constexpr int DH = (S == 1) ? TH + 2 : TH / 2 + 2;
+  constexpr int DW_ = (S == 1) ? TW + 2 : TW / 2 + 2;
+  constexpr int NTHR = TH * TW * DW_CV;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);
+  float* red = wl + 27 * 32;
+  L* tile = reinterpret_cast<L*>(red + (NTHR / 64) * DW_CV * 16);  // [T][DH][DW_][32]
+
+  const int tid = threadIdx.x;
+  const int tiles_x = (g.W + TW - 1) / TW;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int c0 = chunk * DW_CV * 8;
+  const int cv = tid % DW_CV;
+  const int cbase = c0 + cv * 8;
+  const bool c_ok = cbase < g.Cp;
+
+  for (int i = tid; i < 27 * 32; i += NTHR) {
+    const int tap = i / 32, c = c0 + (i & 31);
+    wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
+  }
+  float cA[8], cB[8], cC[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cA[j] = c_ok ? coefA[cbase + j] : 0.f;
+    cB[j] = c_ok ? coefB[(size_t)b * g.Cp + cbase + j] : 0.f;
+    cC[j] = c_ok ? coefC[cbase + j] : 0.f;
+  }
+  const int y0 = ty * TH, x0 = tx * TW;
+  // first db row/col held in the tile
+  const int dy0 = (S == 1) ? y0 - 1 : (y0 >> 1) - 1;
+  const int dx0 = (S == 1) ? x0 - 1 : (x0 >> 1) - 1;
+  const int items = g.T * DH * DW_ * DW_CV;
+  for (int i = tid; i < items; i += NTHR) {
+    const int p = i / DW_CV;
+    const int ix = p % DW_;
+    const int q = p / DW_;
+    const int iy = q % DH, t = q / DH;
+    const int gy = dy0 + iy, gx = dx0 + ix;
+    float f[8];
+    if (c_ok && gy >= 0 && gy < g.Ho && gx >= 0 && gx < g.Wo) {
+      const size_t off = ((((size_t)b * g.T + t) * g.Ho + gy) * g.Wo + gx) * g.Cp + cbase;
+      float f2[8];
+      Vec8<T>::load(t1 + off, f);
+      Vec8<T>::load(bb + off, f2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = 0.f;
+    }
+    Vec8<L>::store(tile + (size_t)p * 32 + cv * 8, f);
+  }
+  __syncthreads();
+
+  const int pix = tid / DW_CV;
+  const int px = pix % TW, py = pix / TW;
+  const int iy = y0 + py, ix = x0 + px;
+  const bool p_ok = c_ok && iy < g.H && ix < g.W;
+
+  float acc[DW_MAXT][8];
+#pragma unroll
+  for (int t = 0; t < DW_MAXT; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ny = iy + 1 - ky;  // = S * oy
+    if (S == 2 && (ny & 1)) continue;
+    const int ly = ((S == 1) ? ny : (ny >> 1)) - dy0;  // arithmetic shift: ny >= -1... ny even here
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int nx = ix + 1 - kx;
+      if (S == 2 && (nx & 1)) continue;
+      const int lx = ((S == 1) ? nx : (nx >> 1)) - dx0;
+      float wk[3][8];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + (kt * 9 + ky * 3 + kx) * 32 + cv * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(wl + (kt * 9 + ky * 3 + kx) * 32 + cv * 8 + 4);
+        wk[kt][0] = w0.x; wk[kt][1] = w0.y; wk[kt][2] = w0.z; wk[kt][3] = w0.w;
+        wk[kt][4] = w1.x; wk[kt][5] = w1.y; wk[kt][6] = w1.z; wk[kt][7] = w1.w;
+      }
+#pragma unroll
+      for (int to = 0; to < DW_MAXT; ++to) {
+        if (to < g.T) {
+          float v[8];
+          Vec8<L>::load(tile + ((size_t)(to * DH + ly) * DW_ + lx) * 32 + cv * 8, v);
+#pragma unroll
+          for (int kt = 0; kt < 3; ++kt) {
+            const int ti = to + kt - 1;  // d in[ti] += d out[to] * w[kt]
+            if (ti >= 0 && ti < DW_MAXT && ti < g.T) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[ti][j] = fmaf(v[j], wk[kt][j], acc[ti][j]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  float sa[8], sb[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sa[j] = c_ok ? ss_a[cbase + j] : 0.f; sb[j] = c_ok ? ss_a[g.Cp + cbase + j] : 0.f;
+    s1[j] = 0.f; s2[j] = 0.f;
+  }
+  if (p_ok) {
+#pragma unroll
+    for (int t = 0; t < DW_MAXT; ++t) {
+      if (t < g.T) {
+        const size_t off = ((((size_t)b * g.T + t) * g.H + iy) * g.W + ix) * g.Cp + cbase;
+        float av[8], o[8];
+        Vec8<T>::load(a + off, av);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pa = fmaf(av[j], sa[j], sb[j]);
+          const float d = round_as<T>(pa > 0.f ? acc[t][j] : 0.f);
+          o[j] = d;
+          s1[j] += d; s2[j] += d * av[j];
+        }
+        Vec8<T>::store(t2 + off, o);
+      }
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int o = DW_CV; o < 64; o <<= 1) {
+      s1[j] += __shfl_xor(s1[j], o, 64);
+      s2[j] += __shfl_xor(s2[j], o, 64);
+    }
+  }
+  if (lane < DW_CV) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[(wave * DW_CV + lane) * 16 + j] = s1[j];
+      red[(wave * DW_CV + lane) * 16 + 8 + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  if (tid < DW_CV * 16) {
+    const int v = tid / 16, k = tid & 15;
+    float s = 0.f;
+    for (int wv = 0; wv < NTHR / 64; ++wv) s += red[(wv * DW_CV + v) * 16 + k];
+    const int c = c0 + v * 8 + (k & 7);
+    if (c < g.C) atomicAdd(dsums + (size_t)(k >> 3) * g.C + c, (double)s);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Weight gradient.  block = 64 pixels x DW_CV vectors x 3 temporal taps = 768 threads; a
+// workgroup walks `tiles_per_wg` spatial tiles of one (sample, channel chunk) keeping its
+// 9x8 partial sums in registers, then reduces across pixels once.
+template <typename T, int S, int TH, int TW>
+__global__ __launch_bounds__(TH * TW * DW_CV * 3) void dw_wgrad_kernel(
+    const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
+    const float* __restrict__ coefB, const float* __restrict__ coefC, const T* __restrict__ a,
+    const float* __restrict__ ss_a, float* __restrict__ dw, const DwGeom g, const int tiles_per_wg) {
+  typedef typename LdsStore<T>::type L;
+  constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+  constexpr int NPIX = TH * TW;
+  constexpr int NTHR = NPIX * DW_CV * 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                 // [27][32] workgroup accumulator
+  L* atile = reinterpret_cast<L*>(red + 27 * 32);              // [T][IH][IW][32]  relu(bn(a))
+  L* dtile = atile + (size_t)g.T * IH * IW * 32;               // [T][TH][TW][32]  db
+
+  const int tid = threadIdx.x;
+  const int tiles_x = (g.Wo + TW - 1) / TW, tiles_y = (g.Ho + TH - 1) / TH;
+  const int ntiles = tiles_x * tiles_y;
+  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int c0 = chunk * DW_CV * 8;
+  const int cv = tid % DW_CV;
+  const int cbase = c0 + cv * 8;
+  const bool c_ok = cbase < g.Cp;
+  const int pix = (tid / DW_CV) % NPIX;
+  const int kt = tid / (DW_CV * NPIX);
+  const int px = pix % TW, py = pix / TW;
+
+  for (int i = tid; i < 27 * 32; i += NTHR) red[i] = 0.f;
+  float sa[8], sb[8], cA[8], cB[8], cC[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sa[j] = c_ok ? ss_a[cbase + j] : 0.f; sb[j] = c_ok ? ss_a[g.Cp + cbase + j] : 0.f;
+    cA[j] = c_ok ? coefA[cbase + j] : 0.f;
+    cB[j] = c_ok ? coefB[(size_t)b * g.Cp + cbase + j] : 0.f;
+    cC[j] = c_ok ? coefC[cbase + j] : 0.f;
+  }
+  float acc[9][8];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+
+  int tile0 = blockIdx.x * tiles_per_wg, tile1 = tile0 + tiles_per_wg;
+  if (tile1 > ntiles) tile1 = ntiles;
+  for (int tl = tile0; tl < tile1; ++tl) {
+    const int tx = tl % tiles_x, ty = tl / tiles_x;
+    const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
+    __syncthreads();
+    for (int i = tid; i < g.T * IH * IW * DW_CV; i += NTHR) {  // NTHR % DW_CV == 0
+      const int p = i / DW_CV;
+      const int ix = p % IW;
+      const int q = p / IW;
+      const int iy = q % IH, t = q / IH;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      float f[8];
+      if (c_ok && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+        Vec8<T>::load(a + ((((size_t)b * g.T + t) * g.H + gy) * g.W + gx) * g.Cp + cbase, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sa[j], sb[j]), 0.f);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      }
+      Vec8<L>::store(atile + (size_t)p * 32 + cv * 8, f);
+    }
+    for (int i = tid; i < g.T * NPIX * DW_CV; i += NTHR) {
+      const int p = i / DW_CV;
+      const int ox = p % TW;
+      const int q = p / TW;
+      const int oy = q % TH, t = q / TH;
+      const int gy = ty * TH + oy, gx = tx * TW + ox;
+      float f[8];
+      if (c_ok && gy < g.Ho && gx < g.Wo) {
+        const size_t off = ((((size_t)b * g.T + t) * g.Ho + gy) * g.Wo + gx) * g.Cp + cbase;
+        float f2[8];
+        Vec8<T>::load(t1 + off, f);
+        Vec8<T>::load(bb + off, f2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      }
+      Vec8<L>::store(dtile + (size_t)p * 32 + cv * 8, f);
+    }
+    __syncthreads();
+    for (int to = 0; to < g.T; ++to) {
+      const int ti = to + kt - 1;
+      if (ti < 0 || ti >= g.T) continue;
+      float d[8];
+      Vec8<L>::load(dtile + ((size_t)(to * TH + py) * TW + px) * 32 + cv * 8, d);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          float r[8];
+          Vec8<L>::load(atile + ((size_t)(ti * IH + py * S + ky) * IW + px * S + kx) * 32 + cv * 8, r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] = fmaf(d[j], r[j], acc[ky * 3 + kx][j]);
+        }
+      }
+    }
+  }
+  // reduce across the pixels of each wave (lanes with equal cv; kt is wave-uniform: 256 | pix*cv)
+  const int lane = tid & 63;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = acc[k][j];
+#pragma unroll
+      for (int o = DW_CV; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (lane < DW_CV) atomicAdd(&red[(kt * 9 + k) * 32 + lane * 8 + j], v);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 27 * 32; i += NTHR) {
+    const int tap = i / 32, c = c0 + (i & 31);
+    if (c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, red[i]);
+  }
+}
+
+template <typename T, int S> struct DwTile;  // forward / wgrad output tile per workgroup
+template <typename T> struct DwTile<T, 1> { static constexpr int TH = 8, TW = 8; };
+template <typename T> struct DwTile<T, 2> { static constexpr int TH = 4, TW = 8; };
+
+template <typename T, int S>
+int launch_fwd(const void* x, const float* ss, const float* w, void* y, double* nc, const DwGeom& g,
+               hipStream_t stream) {
+  constexpr int TH = DwTile<T, S>::TH, TW = DwTile<T, S>::TW;
+  constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, NTHR = TH * TW * DW_CV;
+  const size_t lds = (27 * 32 + (NTHR / 64) * DW_CV * 16) * sizeof(float) +
+                     (size_t)g.T * IH * IW * 32 * sizeof(typename LdsStore<T>::type);
+  if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_kernel<T, S, TH, TW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH), (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), g.B);
+  dw_fwd_kernel<T, S, TH, TW><<<grid, dim3(NTHR), lds, stream>>>(
+      reinterpret_cast<const T*>(x), ss, w, reinterpret_cast<T*>(y), nc, g);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int S>
+int launch_bwd_data(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC,
+                    const float* w, const void* a, const float* ss_a, void* t2, double* dsums, const DwGeom& g,
+                    hipStream_t stream) {
+  constexpr int TH = 8, TW = 8;
+  constexpr int DH = (S == 1) ? TH + 2 : TH / 2 + 2, DW_ = (S == 1) ? TW + 2 : TW / 2 + 2;
+  constexpr int NTHR = TH * TW * DW_CV;
+  const size_t lds = (27 * 32 + (NTHR / 64) * DW_CV * 16) * sizeof(float) +
+                     (size_t)g.T * DH * DW_ * 32 * sizeof(typename LdsStore<T>::type);
+  if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_data_kernel<T, S, TH, TW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(((g.W + TW - 1) / TW) * ((g.H + TH - 1) / TH), (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), g.B);
+  dw_bwd_data_kernel<T, S, TH, TW><<<grid, dim3(NTHR), lds, stream>>>(
+      reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, w, reinterpret_cast<const T*>(a),
+      ss_a, reinterpret_cast<T*>(t2), dsums, g);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int S>
+int launch_wgrad(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const void* a,
+                 const float* ss_a, float* dw, const DwGeom& g, hipStream_t stream) {
+  constexpr int TH = DwTile<T, S>::TH, TW = DwTile<T, S>::TW;
+  constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, NTHR = TH * TW * DW_CV * 3;
+  typedef typename LdsStore<T>::type L;
+  const size_t lds = 27 * 32 * sizeof(float) + (size_t)g.T * (IH * IW + TH * TW) * 32 * sizeof(L);
+  if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_kernel<T, S, TH, TW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int ntiles = ((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH);
+  int tpw = 8;
+  if (tpw > ntiles) tpw = ntiles;
+  dim3 grid((ntiles + tpw - 1) / tpw, (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), g.B);
+  dw_wgrad_kernel<T, S, TH, TW><<<grid, dim3(NTHR), lds, stream>>>(
+      reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, reinterpret_cast<const T*>(a),
+      ss_a, dw, g, tpw);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+bool geom_ok(const DwGeom& g) {
+  if (g.B <= 0 || g.T <= 0 || g.T > DW_MAXT || g.H <= 0 || g.W <= 0 || g.C <= 0 || g.Cp < g.C || (g.Cp & 7))
+    return false;
+  if (g.stride != 1 && g.stride != 2) return false;
+  if (g.Ho != (g.H - 1) / g.stride + 1 || g.Wo != (g.W - 1) / g.stride + 1) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int c3d_dw333_fwd(const void* x, const float* ss, const float* w, void* y, double* nc_sums, int32_t B,
+                             int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
+                             void* stream) {
+  DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
+  if (!x || !ss || !w || !y || !geom_ok(g)) return C3D_E_BADARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == C3D_DT_F32) return stride == 1 ? launch_fwd<float, 1>(x, ss, w, y, nc_sums, g, s)
+                                              : launch_fwd<float, 2>(x, ss, w, y, nc_sums, g, s);
+  if (dtype == C3D_DT_BF16) return stride == 1 ? launch_fwd<bf16_t, 1>(x, ss, w, y, nc_sums, g, s)
+                                               : launch_fwd<bf16_t, 2>(x, ss, w, y, nc_sums, g, s);
+  return C3D_E_BADARG;
+}
+
+extern "C" int c3d_dw333_bwd_data(const void* t1, const void* b, const float* coefA, const float* coefB,
+                                  const float* coefC, const float* w, const void* a, const float* ss_a, void* t2,
+                                  double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
+                                  int32_t stride, int32_t dtype, void* stream) {
+  DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
+  if (!t1 || !b || !coefA || !coefB || !coefC || !w || !a || !ss_a || !t2 || !dsums || !geom_ok(g))
+    return C3D_E_BADARG;
+  if (stride == 2 && ((H | W) & 1)) return C3D_E_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == C3D_DT_F32)
+    return stride == 1 ? launch_bwd_data<float, 1>(t1, b, coefA, coefB, coefC, w, a, ss_a, t2, dsums, g, s)
+                       : launch_bwd_data<float, 2>(t1, b, coefA, coefB, coefC, w, a, ss_a, t2, dsums, g, s);
+  if (dtype == C3D_DT_BF16)
+    return stride == 1 ? launch_bwd_data<bf16_t, 1>(t1, b, coefA, coefB, coefC, w, a, ss_a, t2, dsums, g, s)
+                       : launch_bwd_data<bf16_t, 2>(t1, b, coefA, coefB, coefC, w, a, ss_a, t2, dsums, g, s);
+  return C3D_E_BADARG;
+}
+
+extern "C" int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const float* coefB,
+                               const float* coefC, const void* a, const float* ss_a, float* dw, int32_t B,
+                               int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride,
+                               int32_t dtype, void* stream) {
+  DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
+  if (!t1 || !b || !coefA || !coefB || !coefC || !a || !ss_a || !dw || !geom_ok(g)) return C3D_E_BADARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == C3D_DT_F32)
+    return stride == 1 ? launch_wgrad<float, 1>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s)
+                       : launch_wgrad<float, 2>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
+  if (dtype == C3D_DT_BF16)
+    return stride == 1 ? launch_wgrad<bf16_t, 1>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s)
+                       : launch_wgrad<bf16_t, 2>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
+  return C3D_E_BADARG;
+}

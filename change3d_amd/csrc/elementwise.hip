@@ -1,0 +1,319 @@
+// Elementwise / reduction kernels on channels-last tensors, 8-channel vectors per thread:
+//   * res-block output: y = relu(bn_c(c) + shortcut)      (reference model/x3d.py:326-327 and the
+//     stem's BN+ReLU, model/x3d.py:94-106) and its backward g = dy*(y>0) with the BN-backward sums
+//   * the pieces of Encoder.enhance (reference model/trainer.py:71-108)
+// Threads keep a FIXED channel vector (blockDim is a multiple of Cp/8 and so is the grid stride),
+// so per-channel parameters and partial sums stay in registers.
+#include "common.h"
+#include "../../include/change3d_hip.h"
+
+namespace {
+
+__host__ __device__ inline int ew_block(int G) { return G * (256 / G); }
+
+// shortcut modes
+enum { SC_NONE = 0, SC_IDENTITY = 1, SC_BN = 2, SC_RAW = 3 };
+
+template <typename T>
+__global__ void block_out_fwd_kernel(const T* __restrict__ c, const float* __restrict__ ss_c,
+                                     const T* __restrict__ sc, const float* __restrict__ ss_1, int sc_mode,
+                                     T* __restrict__ y, int64_t nvec, int G) {
+  const int v = threadIdx.x % G;
+  const int Cp = G * 8;
+  float a[8], b[8], a1[8], b1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = ss_c[v * 8 + j]; b[j] = ss_c[Cp + v * 8 + j];
+    a1[j] = (sc_mode == SC_BN) ? ss_1[v * 8 + j] : 1.f;
+    b1[j] = (sc_mode == SC_BN) ? ss_1[Cp + v * 8 + j] : 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float f[8], s[8];
+    Vec8<T>::load(c + i * 8, f);
+    if (sc_mode != SC_NONE) Vec8<T>::load(sc + i * 8, s);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float r = fmaf(f[j], a[j], b[j]);
+      if (sc_mode != SC_NONE) r += fmaf(s[j], a1[j], b1[j]);
+      f[j] = fmaxf(r, 0.f);
+    }
+    Vec8<T>::store(y + i * 8, f);
+  }
+}
+
+// g = dy * (y > 0); dsums_c += (sum g, sum g*c); dsums_1 += (sum g, sum g*s) when the shortcut has BN
+template <typename T>
+__global__ void block_out_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ c,
+                                     const T* __restrict__ s, T* __restrict__ g, double* __restrict__ dsums_c,
+                                     double* __restrict__ dsums_1, int64_t nvec, int G, int C) {
+  extern __shared__ float red[];  // [blockDim][24]
+  const int v = threadIdx.x % G;
+  float s1[8], s2[8], s3[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; s3[j] = 0.f; }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float d[8], yv[8], cv[8], sv[8];
+    Vec8<T>::load(dy + i * 8, d);
+    Vec8<T>::load(y + i * 8, yv);
+    Vec8<T>::load(c + i * 8, cv);
+    if (s) Vec8<T>::load(s + i * 8, sv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gg = yv[j] > 0.f ? d[j] : 0.f;
+      d[j] = gg;
+      s1[j] += gg; s2[j] += gg * cv[j];
+      if (s) s3[j] += gg * sv[j];
+    }
+    Vec8<T>::store(g + i * 8, d);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[threadIdx.x * 24 + j] = s1[j]; red[threadIdx.x * 24 + 8 + j] = s2[j]; red[threadIdx.x * 24 + 16 + j] = s3[j];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < G * 24; idx += blockDim.x) {
+    const int vv = idx / 24, k = idx % 24;
+    double acc = 0;
+    for (int t = vv; t < (int)blockDim.x; t += G) acc += red[t * 24 + k];
+    const int ch = vv * 8 + (k & 7);
+    const int which = k >> 3;
+    if (ch < C) {
+      if (which == 0) { atomicAdd(dsums_c + ch, acc); if (dsums_1) atomicAdd(dsums_1 + ch, acc); }
+      else if (which == 1) atomicAdd(dsums_c + C + ch, acc);
+      else if (dsums_1) atomicAdd(dsums_1 + C + ch, acc);
+    }
+  }
+}
+
+// ---- enhance pieces -----------------------------------------------------------------------
+// d[m][c] = | y[b, t_pre, p, c] - y[b, t_post, p, c] |   (dense [B*HW][Cp])
+template <typename T>
+__global__ void frame_absdiff_kernel(const T* __restrict__ y, T* __restrict__ d, int64_t nvec, int64_t hwv,
+                                     int Tn, int t_pre, int t_post) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int64_t b = i / hwv, r = i - b * hwv;
+    float p[8], q[8];
+    Vec8<T>::load(y + ((b * Tn + t_pre) * hwv + r) * 8, p);
+    Vec8<T>::load(y + ((b * Tn + t_post) * hwv + r) * 8, q);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = fabsf(p[j] - q[j]);
+    Vec8<T>::store(d + i * 8, p);
+  }
+}
+
+// out = copy(y); out[:, t_mid] += relu(e)      (e dense [B*HW][Cp])
+template <typename T>
+__global__ void enhance_apply_kernel(const T* __restrict__ y, const T* __restrict__ e, T* __restrict__ out,
+                                     int64_t nvec_all, int64_t hwv, int Tn, int t_mid) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec_all; i += stride) {
+    const int64_t bt = i / hwv, r = i - bt * hwv;
+    const int64_t b = bt / Tn;
+    const int t = (int)(bt - b * Tn);
+    float f[8];
+    Vec8<T>::load(y + i * 8, f);
+    if (t == t_mid) {
+      float ev[8];
+      Vec8<T>::load(e + (b * hwv + r) * 8, ev);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += fmaxf(ev[j], 0.f);
+    }
+    Vec8<T>::store(out + i * 8, f);
+  }
+}
+
+// de[m][c] = dout[b, t_mid, p, c] * (e[m][c] > 0)
+template <typename T>
+__global__ void enhance_bwd_mask_kernel(const T* __restrict__ dout, const T* __restrict__ e, T* __restrict__ de,
+                                        int64_t nvec, int64_t hwv, int Tn, int t_mid) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int64_t b = i / hwv, r = i - b * hwv;
+    float g[8], ev[8];
+    Vec8<T>::load(dout + ((b * Tn + t_mid) * hwv + r) * 8, g);
+    Vec8<T>::load(e + i * 8, ev);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = ev[j] > 0.f ? g[j] : 0.f;
+    Vec8<T>::store(de + i * 8, g);
+  }
+}
+
+// dy = copy(dout); dy[:, t_pre] += dd*sign(pre-post); dy[:, t_post] -= dd*sign(pre-post)
+template <typename T>
+__global__ void enhance_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
+                                         const T* __restrict__ dd, T* __restrict__ dy, int64_t nvec_all,
+                                         int64_t hwv, int Tn, int t_pre, int t_post) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec_all; i += stride) {
+    const int64_t bt = i / hwv, r = i - bt * hwv;
+    const int64_t b = bt / Tn;
+    const int t = (int)(bt - b * Tn);
+    float f[8];
+    Vec8<T>::load(dout + i * 8, f);
+    if (t == t_pre || t == t_post) {
+      float p[8], q[8], dv[8];
+      Vec8<T>::load(y + ((b * Tn + t_pre) * hwv + r) * 8, p);
+      Vec8<T>::load(y + ((b * Tn + t_post) * hwv + r) * 8, q);
+      Vec8<T>::load(dd + (b * hwv + r) * 8, dv);
+      const float sgn_self = (t == t_pre) ? 1.f : -1.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float df = p[j] - q[j];
+        const float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+        f[j] += sgn_self * sg * dv[j];
+      }
+    }
+    Vec8<T>::store(dy + i * 8, f);
+  }
+}
+
+// Generic helpers ------------------------------------------------------------------------------
+// dst[b, t, p, :] (frame of an NDHWC tensor) += / = src dense [B*HW][Cp]
+template <typename T>
+__global__ void frame_scatter_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t nvec, int64_t hwv,
+                                     int Tn, int t_dst, int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int64_t b = i / hwv, r = i - b * hwv;
+    float f[8];
+    Vec8<T>::load(src + i * 8, f);
+    T* p = dst + ((b * Tn + t_dst) * hwv + r) * 8;
+    if (accumulate) {
+      float o[8];
+      Vec8<T>::load(p, o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += o[j];
+    }
+    Vec8<T>::store(p, f);
+  }
+}
+
+inline int ew_grid(int64_t nvec, int block) {
+  int64_t g = (nvec + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define EW_DISPATCH(dtype, CALL_F32, CALL_BF16) \
+  if ((dtype) == C3D_DT_F32) { CALL_F32; }      \
+  else if ((dtype) == C3D_DT_BF16) { CALL_BF16; } \
+  else return C3D_E_BADARG;
+
+extern "C" int c3d_block_out_fwd(const void* c, const float* ss_c, const void* shortcut, const float* ss_1,
+                                 int32_t sc_mode, void* y, int64_t M, int32_t Cp, int32_t dtype, void* stream) {
+  if (!c || !ss_c || !y || M <= 0 || (Cp & 7) || Cp > 256) return C3D_E_BADARG;
+  if (sc_mode != SC_NONE && !shortcut) return C3D_E_BADARG;
+  if (sc_mode == SC_BN && !ss_1) return C3D_E_BADARG;
+  const int G = Cp / 8, blk = ew_block(G);
+  const int64_t nvec = M * G;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // grid stride must stay a multiple of G: blk is, so any grid works
+  EW_DISPATCH(dtype,
+              (block_out_fwd_kernel<float><<<ew_grid(nvec, blk), blk, 0, s>>>(
+                  (const float*)c, ss_c, (const float*)shortcut, ss_1, sc_mode, (float*)y, nvec, G)),
+              (block_out_fwd_kernel<bf16_t><<<ew_grid(nvec, blk), blk, 0, s>>>(
+                  (const bf16_t*)c, ss_c, (const bf16_t*)shortcut, ss_1, sc_mode, (bf16_t*)y, nvec, G)));
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_block_out_bwd(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
+                                 double* dsums_c, double* dsums_1, int64_t M, int32_t C, int32_t Cp,
+                                 int32_t dtype, void* stream) {
+  if (!dy || !y || !c || !g || !dsums_c || M <= 0 || (Cp & 7) || Cp > 256) return C3D_E_BADARG;
+  if ((s_bn == nullptr) != (dsums_1 == nullptr)) return C3D_E_BADARG;
+  const int G = Cp / 8, blk = ew_block(G);
+  const int64_t nvec = M * G;
+  int grid = ew_grid(nvec, blk);
+  if (grid > 1024) grid = 1024;
+  const size_t lds = (size_t)blk * 24 * sizeof(float);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  EW_DISPATCH(dtype,
+              (block_out_bwd_kernel<float><<<grid, blk, lds, st>>>((const float*)dy, (const float*)y,
+                                                                    (const float*)c, (const float*)s_bn, (float*)g,
+                                                                    dsums_c, dsums_1, nvec, G, C)),
+              (block_out_bwd_kernel<bf16_t><<<grid, blk, lds, st>>>((const bf16_t*)dy, (const bf16_t*)y,
+                                                                     (const bf16_t*)c, (const bf16_t*)s_bn,
+                                                                     (bf16_t*)g, dsums_c, dsums_1, nvec, G, C)));
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_frame_absdiff(const void* y, void* d, int32_t B, int32_t T, int64_t HW, int32_t Cp,
+                                 int32_t t_pre, int32_t t_post, int32_t dtype, void* stream) {
+  if (!y || !d || B <= 0 || T <= 0 || HW <= 0 || (Cp & 7) || t_pre < 0 || t_pre >= T || t_post < 0 || t_post >= T)
+    return C3D_E_BADARG;
+  const int64_t hwv = HW * (Cp / 8), nvec = (int64_t)B * hwv;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EW_DISPATCH(dtype,
+              (frame_absdiff_kernel<float><<<ew_grid(nvec, 256), 256, 0, s>>>((const float*)y, (float*)d, nvec, hwv,
+                                                                               T, t_pre, t_post)),
+              (frame_absdiff_kernel<bf16_t><<<ew_grid(nvec, 256), 256, 0, s>>>((const bf16_t*)y, (bf16_t*)d, nvec,
+                                                                                hwv, T, t_pre, t_post)));
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_enhance_apply(const void* y, const void* e, void* out, int32_t B, int32_t T, int64_t HW,
+                                 int32_t Cp, int32_t t_mid, int32_t dtype, void* stream) {
+  if (!y || !e || !out || B <= 0 || T <= 0 || HW <= 0 || (Cp & 7) || t_mid < 0 || t_mid >= T) return C3D_E_BADARG;
+  const int64_t hwv = HW * (Cp / 8), nvec = (int64_t)B * T * hwv;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EW_DISPATCH(dtype,
+              (enhance_apply_kernel<float><<<ew_grid(nvec, 256), 256, 0, s>>>((const float*)y, (const float*)e,
+                                                                               (float*)out, nvec, hwv, T, t_mid)),
+              (enhance_apply_kernel<bf16_t><<<ew_grid(nvec, 256), 256, 0, s>>>((const bf16_t*)y, (const bf16_t*)e,
+                                                                                (bf16_t*)out, nvec, hwv, T, t_mid)));
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_enhance_bwd_mask(const void* dout, const void* e, void* de, int32_t B, int32_t T, int64_t HW,
+                                    int32_t Cp, int32_t t_mid, int32_t dtype, void* stream) {
+  if (!dout || !e || !de || B <= 0 || T <= 0 || HW <= 0 || (Cp & 7) || t_mid < 0 || t_mid >= T) return C3D_E_BADARG;
+  const int64_t hwv = HW * (Cp / 8), nvec = (int64_t)B * hwv;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EW_DISPATCH(dtype,
+              (enhance_bwd_mask_kernel<float><<<ew_grid(nvec, 256), 256, 0, s>>>((const float*)dout, (const float*)e,
+                                                                                  (float*)de, nvec, hwv, T, t_mid)),
+              (enhance_bwd_mask_kernel<bf16_t><<<ew_grid(nvec, 256), 256, 0, s>>>(
+                  (const bf16_t*)dout, (const bf16_t*)e, (bf16_t*)de, nvec, hwv, T, t_mid)));
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_enhance_bwd_apply(const void* dout, const void* y, const void* dd, void* dy, int32_t B,
+                                     int32_t T, int64_t HW, int32_t Cp, int32_t t_pre, int32_t t_post,
+                                     int32_t dtype, void* stream) {
+  if (!dout || !y || !dd || !dy || B <= 0 || T <= 0 || HW <= 0 || (Cp & 7)) return C3D_E_BADARG;
+  const int64_t hwv = HW * (Cp / 8), nvec = (int64_t)B * T * hwv;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EW_DISPATCH(dtype,
+              (enhance_bwd_apply_kernel<float><<<ew_grid(nvec, 256), 256, 0, s>>>(
+                  (const float*)dout, (const float*)y, (const float*)dd, (float*)dy, nvec, hwv, T, t_pre, t_post)),
+              (enhance_bwd_apply_kernel<bf16_t><<<ew_grid(nvec, 256), 256, 0, s>>>(
+                  (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)dd, (bf16_t*)dy, nvec, hwv, T, t_pre,
+                  t_post)));
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_frame_scatter(const void* src, void* dst, int32_t B, int32_t T, int64_t HW, int32_t Cp,
+                                 int32_t t_dst, int32_t accumulate, int32_t dtype, void* stream) {
+  if (!src || !dst || B <= 0 || T <= 0 || HW <= 0 || (Cp & 7) || t_dst < 0 || t_dst >= T) return C3D_E_BADARG;
+  const int64_t hwv = HW * (Cp / 8), nvec = (int64_t)B * hwv;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EW_DISPATCH(dtype,
+              (frame_scatter_kernel<float><<<ew_grid(nvec, 256), 256, 0, s>>>((const float*)src, (float*)dst, nvec,
+                                                                               hwv, T, t_dst, accumulate)),
+              (frame_scatter_kernel<bf16_t><<<ew_grid(nvec, 256), 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dst,
+                                                                                nvec, hwv, T, t_dst, accumulate)));
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

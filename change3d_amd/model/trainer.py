@@ -1,0 +1,151 @@
+"""MI355X-native mirror of the reference's `model/trainer.py` (reference model/trainer.py:20-306):
+`Encoder(args, embed_dims)` and `Trainer(args)` with the same attributes, state-dict keys
+(`encoder.x3d.*`, `encoder.perception_frames`, `encoder.fc.{i}.0.weight`, `decoder.*`) and
+`update_bcd / update_scd / update_bda` methods, so a `scripts/train_BCD.py`-shaped driver
+calls it unchanged.  Every tensor op on the path is a HIP kernel (x3d.py, change_decoder.py,
+ops.py); `args.act_dtype` (optional, default float32) selects the activation storage type.
+"""
+from typing import Any, List
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import cpad
+from .change_decoder import ChangeDecoder
+from .utils import weight_init
+from .x3d import create_x3d, to_logical, to_ndhwc
+
+
+class _EnhanceFn(torch.autograd.Function):
+    """Encoder.enhance (reference model/trainer.py:71-108):
+    out = x.clone(); out[:, :, T//2] += relu(conv1x1(|x[:, :, 0] - x[:, :, K+1]|))."""
+
+    @staticmethod
+    def forward(ctx, x, weight, t_post):
+        ops.require_gpu(x, "enhance input")
+        B, C, T, H, W = x.shape
+        act = x.dtype
+        dt = ops.dt_code(act)
+        dev = x.device
+        xc = to_ndhwc(x.detach())
+        t_mid = T // 2
+        M2 = B * H * W
+        d = torch.empty((M2, cpad(C)), dtype=act, device=dev)
+        ops.frame_absdiff(xc, d, B, T, H * W, cpad(C), 0, t_post, dt)
+        e = torch.empty_like(d)
+        ops.pw_gemm(d, weight, e, M=M2, K=C, N=C, w_sn=C, w_sk=1, dtype=dt)
+        out = torch.empty_like(xc)
+        ops.enhance_apply(xc, e, out, B, T, H * W, cpad(C), t_mid, dt)
+        ctx.saved = (xc, d, e, weight)
+        ctx.meta = (B, C, T, H, W, t_post, t_mid)
+        return to_logical(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, d, e, weight = ctx.saved
+        B, C, T, H, W, t_post, t_mid = ctx.meta
+        act = xc.dtype
+        dt = ops.dt_code(act)
+        doc = to_ndhwc(dout).to(act)
+        M2 = B * H * W
+        de = torch.empty_like(d)
+        ops.enhance_bwd_mask(doc, e, de, B, T, H * W, cpad(C), t_mid, dt)
+        dd = torch.empty_like(d)
+        ops.pw_gemm(de, weight, dd, M=M2, K=C, N=C, w_sn=1, w_sk=C, dtype=dt)
+        ops.pw_wgrad(de, d, ops.grad_of(weight), M=M2, K=C, N=C, dw_sn=C, dw_sk=1, dtype=dt)
+        dx = torch.empty_like(xc)
+        ops.enhance_bwd_apply(doc, xc, dd, dx, B, T, H * W, cpad(C), 0, t_post, dt)
+        return to_logical(dx), None, None
+
+
+class Encoder(nn.Module):
+    """Encoder model based on X3D architecture with feature enhancement capabilities."""
+
+    def __init__(self, args: Any, embed_dims: List[int]) -> None:
+        super().__init__()
+        self.args = args
+        act_dtype = getattr(args, "act_dtype", torch.float32)
+        self.x3d = create_x3d(input_clip_length=3, depth_factor=5.0, act_dtype=act_dtype)
+        try:  # reference model/trainer.py:43-48 (failure is reported and training continues)
+            state_dict = torch.load(args.pretrained, map_location="cpu")["model_state"]
+            msg = self.x3d.load_state_dict(state_dict, strict=True)
+            print(f"Load pretrained weight: {args.pretrained}, {msg}.")
+        except Exception as e:
+            print(f"Failed to load pretrained weights: {e}")
+        self.perception_frames = nn.Parameter(
+            torch.randn(1, 3, args.num_perception_frame, args.in_height, args.in_width), requires_grad=True)
+        self.fc = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(dim, dim, kernel_size=1, stride=1, padding=0, bias=False), nn.ReLU())
+            for dim in embed_dims])
+        # the stem only needs the input gradient of the perception frames
+        self.x3d.blocks[0].grad_frames = (1, args.num_perception_frame)
+
+    def enhance(self, x: torch.Tensor, fc: nn.Module) -> torch.Tensor:
+        return _EnhanceFn.apply(x, fc[0].weight, self.args.num_perception_frame + 1)
+
+    def base_forward(self, x: torch.Tensor, output_final: bool = False):
+        if output_final:
+            for i in range(5):
+                x = self.x3d.blocks[i](x)
+            return x[:, :, self.args.num_perception_frame]
+        out = []
+        for i in range(4):
+            x = self.x3d.blocks[i](x)
+            x = self.enhance(x, self.fc[i])
+            out.append([x[:, :, idx + 1] for idx in range(self.args.num_perception_frame)])
+        return out
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor, output_final: bool = False):
+        expand = self.perception_frames.expand(x.shape[0], -1, -1, -1, -1)
+        frames = torch.cat([x.unsqueeze(2), expand, y.unsqueeze(2)], dim=2)
+        return self.base_forward(frames, output_final)
+
+
+class Trainer(nn.Module):
+    """Complete model with encoder and decoder(s)."""
+
+    def __init__(self, args: Any) -> None:
+        super().__init__()
+        self.args = args
+        self.embed_dims = [24, 24, 48, 96]
+        self.encoder = Encoder(args, self.embed_dims)
+        k = args.num_perception_frame
+        if k == 1 and "CD" in args.dataset:
+            self.decoder = ChangeDecoder(args, in_dim=self.embed_dims, has_sigmoid=True)
+            weight_init(self.decoder)
+        elif k == 3:
+            self.decoder_pre = ChangeDecoder(args, in_dim=self.embed_dims)
+            self.decoder_post = ChangeDecoder(args, in_dim=self.embed_dims)
+            self.decoder_change = ChangeDecoder(args, in_dim=self.embed_dims, has_sigmoid=True)
+            weight_init(self.decoder_pre)
+            weight_init(self.decoder_post)
+            weight_init(self.decoder_change)
+        elif k == 2:
+            self.decoder_cls = ChangeDecoder(args, in_dim=self.embed_dims)
+            self.decoder_loc = ChangeDecoder(args, in_dim=self.embed_dims, has_sigmoid=True)
+            weight_init(self.decoder_cls)
+            weight_init(self.decoder_loc)
+        elif k == 1 and "CC" in args.dataset:
+            raise NotImplementedError("change-captioning head is not built yet (SURVEY.md §8f item 2)")
+        else:
+            assert False
+
+    def set_act_dtype(self, dtype):
+        self.encoder.x3d.set_act_dtype(dtype)
+        return self
+
+    def update_bcd(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        features = self.encoder(x, y)
+        return self.decoder([f[0] for f in features])
+
+    def update_scd(self, x: torch.Tensor, y: torch.Tensor):
+        features = self.encoder(x, y)
+        pre_mask = self.decoder_pre([f[0] for f in features])
+        post_mask = self.decoder_post([f[2] for f in features])
+        change_mask = self.decoder_change([f[1] for f in features])
+        return pre_mask, post_mask, change_mask
+
+    def update_bda(self, x: torch.Tensor, y: torch.Tensor):
+        features = self.encoder(x, y)
+        return self.decoder_cls([f[0] for f in features]), self.decoder_loc([f[1] for f in features])

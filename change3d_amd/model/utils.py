@@ -1,0 +1,191 @@
+"""MI355X-native mirror of the hot-path pieces of the reference's `model/utils.py`:
+`weight_init` (reference model/utils.py:20-82), `adjust_learning_rate` (:84-152),
+`BCEDiceLoss` (:154-169) — the loss runs as HIP reduction kernels — plus the pieces the
+data-parallel train step needs that the reference gets from torch.optim: a flat parameter /
+gradient arena and a fused Adam (`scripts/train_BCD.py:284-290` hyper-parameters).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def weight_init(module):
+    """Conv2d (direct child or inside a Sequential) -> kaiming-normal fan_in/relu, norm layers
+    -> 1/0, Linear -> kaiming-normal; ConvTranspose2d is not matched and keeps torch's default
+    init (reference quirk)."""
+    for _, child in module.named_children():
+        if isinstance(child, (nn.AdaptiveAvgPool2d, nn.AdaptiveMaxPool2d, nn.ModuleList, nn.BCELoss)):
+            continue
+        if isinstance(child, (nn.Conv2d, nn.Linear)):
+            nn.init.kaiming_normal_(child.weight, mode="fan_in", nonlinearity="relu")
+            if child.bias is not None:
+                nn.init.zeros_(child.bias)
+        elif isinstance(child, (nn.BatchNorm2d, nn.GroupNorm)):
+            nn.init.ones_(child.weight)
+            if child.bias is not None:
+                nn.init.zeros_(child.bias)
+        elif isinstance(child, nn.Sequential):
+            for _, sub in child.named_children():
+                if isinstance(sub, (nn.Conv2d, nn.Linear)):
+                    nn.init.kaiming_normal_(sub.weight, mode="fan_in", nonlinearity="relu")
+                    if sub.bias is not None:
+                        nn.init.zeros_(sub.bias)
+                elif isinstance(sub, (nn.BatchNorm2d, nn.GroupNorm)):
+                    nn.init.ones_(sub.weight)
+                    if sub.bias is not None:
+                        nn.init.zeros_(sub.bias)
+                else:
+                    weight_init(sub)
+        elif len(list(child.children())) > 0:
+            weight_init(child)
+
+
+def adjust_learning_rate(args, optimizer, epoch=None, iter=None, max_batches=None, lr_factor=1.0,
+                         shrink_factor=None, verbose=True):
+    """Same schedule and argument meaning as reference model/utils.py:84-152."""
+    if shrink_factor is not None:
+        if not 0 < shrink_factor < 1:
+            raise ValueError(f"Shrink factor must be between 0 and 1, got {shrink_factor}")
+        for group in optimizer.param_groups:
+            group["lr"] = group["lr"] * shrink_factor
+        return optimizer.param_groups[0]["lr"]
+    if args.lr_mode == "step":
+        if epoch is None:
+            raise ValueError("Epoch must be provided for step lr_mode")
+        lr = args.lr * (0.1 ** (epoch // args.step_loss))
+    elif args.lr_mode == "poly":
+        if any(p is None for p in [epoch, iter, max_batches]):
+            raise ValueError("Epoch, iter, and max_batches must be provided for poly lr_mode")
+        max_iter = max_batches * args.max_epochs
+        lr = args.lr * (1 - iter * 1.0 / max_iter) ** 0.9
+    else:
+        raise ValueError(f"Unknown lr mode {args.lr_mode}")
+    if epoch == 0 and iter is not None and iter < 200:
+        lr = args.lr * 0.9 * (iter + 1) / 200 + 0.1 * args.lr
+    lr *= lr_factor
+    for group in optimizer.param_groups:
+        group["lr"] = lr
+    return lr
+
+
+class _BCEDiceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, targets):
+        ops.require_gpu(inputs, "loss input")
+        p = inputs.detach().contiguous().float()
+        t = targets.detach().contiguous().float()
+        sums = torch.empty(4, dtype=torch.float64, device=p.device)
+        loss = torch.empty(1, dtype=torch.float32, device=p.device)
+        ops.bce_dice_fwd(p, t, sums, loss)
+        ctx.saved = (p, t, sums)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        p, t, sums = ctx.saved
+        dp = torch.empty_like(p)
+        dl = dloss.detach().reshape(1).contiguous().float()
+        ops.bce_dice_bwd(p, t, sums, dl, dp)
+        return dp, None
+
+
+def BCEDiceLoss(inputs, targets):
+    """bce(mean) + 1 - (2*sum(p*t)+1e-5)/(sum(p)+sum(t)+1e-5), sums over the whole batch."""
+    return _BCEDiceFn.apply(inputs, targets)
+
+
+# ----------------------------------------------------------------------------- arenas + Adam
+class ParamArena:
+    """One flat f32 buffer for parameters and one for their gradients.
+
+    Parameters keep their identity (names, shapes, state-dict behaviour) but their storage
+    becomes a view into `flat_param`, `p.grad` a view into `flat_grad`: kernels accumulate
+    gradients in place, Adam is one launch, and data-parallel training all-reduces ONE
+    contiguous buffer.  Only parameters that take part in the hot path are
+    placed here (the never-executed res5/head of BCD are left alone, their grad stays None,
+    exactly like the reference where Adam skips them)."""
+
+    def __init__(self, named_params, device):
+        self.names, self.params, self.offsets = [], [], []
+        off = 0
+        for name, p in named_params:
+            self.names.append(name)
+            self.params.append(p)
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.numel = off
+        self.flat_param = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat_param[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = view
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def attach_grads(self):
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        self.attach_grads()
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (coupled L2 weight decay) over a ParamArena, one HIP kernel
+    per step.  `param_groups` exists so `adjust_learning_rate` works unchanged."""
+
+    def __init__(self, arena, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4, capturable=False):
+        self.arena = arena
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=arena.params)]
+        dev = arena.flat_param.device
+        self.exp_avg = torch.zeros_like(arena.flat_param)
+        self.exp_avg_sq = torch.zeros_like(arena.flat_param)
+        self.step_count = 0
+        self.capturable = capturable
+        self.hp_dev = torch.zeros(3, dtype=torch.float32, device=dev) if capturable else None
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    def hparams(self, step):
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        bc1 = 1.0 - b1 ** step
+        bc2 = 1.0 - b2 ** step
+        return float(g["lr"]), float(bc1), float(math.sqrt(bc2))
+
+    def prepare_step(self):
+        """Host-side part of a step (call OUTSIDE a captured graph, before replay)."""
+        self.step_count += 1
+        lr, bc1, bc2s = self.hparams(self.step_count)
+        if self.capturable:
+            self.hp_dev.copy_(torch.tensor([lr, bc1, bc2s], dtype=torch.float32), non_blocking=True)
+        return lr, bc1, bc2s
+
+    def launch(self, lr=0.0, bc1=1.0, bc2s=1.0):
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        a = self.arena
+        ops.adam_step(a.flat_param, a.flat_grad, self.exp_avg, self.exp_avg_sq, a.numel, self.hp_dev, lr, bc1, bc2s,
+                      b1, b2, g["eps"], g["weight_decay"])
+
+    def step(self):
+        lr, bc1, bc2s = self.prepare_step()
+        self.launch(lr, bc1, bc2s)
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+
+def hot_path_named_params(trainer):
+    """Parameters that receive gradients on the BCD/SCD/BDA path: everything except the
+    never-executed `encoder.x3d.blocks.4` (res5) and `.blocks.5` (head)."""
+    skip = ("encoder.x3d.blocks.4.", "encoder.x3d.blocks.5.")
+    return [(n, p) for n, p in trainer.named_parameters() if not n.startswith(skip)]

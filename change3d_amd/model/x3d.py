@@ -1,0 +1,424 @@
+"""MI355X-native mirror of the reference's `model/x3d.py` (reference model/x3d.py:543-744).
+
+`create_x3d(**kw)` keeps the reference's keyword-only signature and returns an `nn.Module`
+whose `.blocks` is an indexable list of 6 callables on logical-NCDHW tensors
+(`blocks[i](x)` is how reference model/trainer.py:122,130 drives it) and whose state-dict
+keys are exactly the reference's 1 141 keys (`blocks.0.conv.conv_t.weight`, ...,
+`blocks.S.res_blocks.J.branch2.norm_b.1.block.0.weight`, `blocks.5.proj.bias`), so
+`X3D_L.pyth['model_state']` still strict-loads (reference model/trainer.py:43-45).
+
+The nn.Conv3d / nn.BatchNorm3d children are PARAMETER HOLDERS only: every forward/backward
+below is a sequence of hand-written gfx950 kernels from libchange3d_hip.so (via ../ops.py).
+Only the X3D-L configuration Change3D instantiates is supported (reference
+model/trainer.py:40: `create_x3d(input_clip_length=3, depth_factor=5.0)`); other widths
+raise NotImplementedError.  Activations between kernels are channels-last
+[B][T][H][W][C] in `act_dtype` (float32 = parity path, bfloat16 = throughput path).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import cpad
+
+BN_EPS, BN_MOM = 1e-5, 0.1
+
+
+# ------------------------------------------------------------------ helpers (restated utils)
+def round_width(width, multiplier, min_width=8, divisor=8, ceil=False):
+    """pytorchvideo.layers.utils.round_width as used at reference model/x3d.py:197,657,675-683."""
+    if not multiplier:
+        return width
+    width *= multiplier
+    min_width = min_width or divisor
+    if ceil:
+        out = max(min_width, int(math.ceil(width / divisor)) * divisor)
+    else:
+        out = max(min_width, int(width + divisor / 2) // divisor * divisor)
+    if out < 0.9 * width:
+        out += divisor
+    return int(out)
+
+
+def round_repeats(repeats, multiplier):
+    return repeats if not multiplier else int(math.ceil(multiplier * repeats))
+
+
+def to_ndhwc(x):
+    """logical NCDHW (any strides) -> contiguous [B,T,H,W,C] tensor (no copy if channels_last_3d)."""
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def to_logical(y):
+    """[B,T,H,W,C] contiguous -> logical NCDHW view (channels_last_3d strides)."""
+    return y.permute(0, 4, 1, 2, 3)
+
+
+class _Holder(nn.Module):
+    """Plain container; keeps attribute names identical to the reference module tree."""
+
+
+def _f32(n, dev):
+    return torch.empty(n, dtype=torch.float32, device=dev)
+
+
+# ---------------------------------------------------------------------------------- stem
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, stem):
+        ops.require_gpu(x, "stem input")
+        B, Ci, T, H, W = x.shape
+        if Ci != 3:
+            raise NotImplementedError("stem kernel is specialised for 3 input channels")
+        dev, dt = x.device, ops.dt_code(stem.act_dtype)
+        xin = x.detach().contiguous().float()
+        training = stem.training
+        conv_s, conv_t = stem.conv.conv_t, stem.conv.conv_xy  # names swapped upstream (x3d.py:87-92)
+        C = conv_s.weight.shape[0]
+        sums = torch.zeros(2 * C, dtype=torch.float64, device=dev) if training else None
+        u = torch.empty((B, T, H, W, C), dtype=stem.act_dtype, device=dev)
+        ops.stem_fwd(xin, conv_s.weight, conv_t.weight, u, sums, B, T, H, W, dt)
+        ss, mr = _f32(2 * cpad(C), dev), _f32(2 * C, dev)
+        ops.bn_finalize(sums, B * T * H * W, stem.norm, C, ss, mr, training)
+        y = torch.empty_like(u)
+        ops.block_out_fwd(u, ss, None, None, ops.SC_NONE, y, B * T * H * W, cpad(C), dt)
+        ctx.stem, ctx.saved = stem, (xin, u, y, mr)
+        ctx.x_needs_grad = x.requires_grad
+        return to_logical(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        stem = ctx.stem
+        xin, u, y, mr = ctx.saved
+        B, _, T, H, W = xin.shape
+        dev, dt = xin.device, ops.dt_code(stem.act_dtype)
+        conv_s, conv_t = stem.conv.conv_t, stem.conv.conv_xy
+        C = conv_s.weight.shape[0]
+        M = B * T * H * W
+        dyc = to_ndhwc(dy).to(stem.act_dtype)
+        g = torch.empty_like(u)
+        dsums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        ops.block_out_bwd(dyc, y, u, None, g, dsums, None, M, C, dt)
+        coef = _f32(3 * cpad(C), dev)
+        ops.bn_bwd_coef(dsums, M, stem.norm, mr, C, coef)
+        dv = torch.empty_like(u)
+        ops.stem_bwd_dv(xin, conv_s.weight, conv_t.weight, g, u, coef, dv, ops.grad_of(conv_t.weight), B, T, H, W, dt)
+        dx = None
+        if ctx.x_needs_grad:
+            t0, nf = stem.grad_frames if stem.grad_frames is not None else (0, T)
+            dx = torch.zeros_like(xin)
+            ops.stem_bwd_wx(xin, conv_s.weight, dv, ops.grad_of(conv_s.weight), dx, B, T, H, W, t0, nf, True, dt)
+        else:
+            ops.stem_bwd_wx(xin, conv_s.weight, dv, ops.grad_of(conv_s.weight), None, B, T, H, W, 0, 0, False, dt)
+        return dx, None, None
+
+
+class X3DStem(nn.Module):
+    """`blocks[0]`: Conv2plus1d(conv_t = spatial 1x3x3, conv_xy = temporal 5x1x1 dw) -> BN -> ReLU
+    (reference model/x3d.py:23-106).  `grad_frames=(t_first, n)` limits the input gradient to
+    those frames (Change3D only needs the perception frames)."""
+
+    def __init__(self, cin, cout, ksize, stride, act_dtype):
+        super().__init__()
+        if tuple(ksize) != (5, 3, 3) or tuple(stride) != (1, 1, 1) or cout != 24:
+            raise NotImplementedError("stem kernels are specialised for k=(5,3,3), stride 1, 24 channels")
+        self.conv = _Holder()
+        self.conv.conv_t = nn.Conv3d(cin, cout, (1, 3, 3), stride=(1, 1, 1), padding=(0, 1, 1), bias=False)
+        self.conv.conv_xy = nn.Conv3d(cout, cout, (5, 1, 1), stride=(1, 1, 1), padding=(2, 0, 0), bias=False,
+                                      groups=cout)
+        self.norm = nn.BatchNorm3d(cout, eps=BN_EPS, momentum=BN_MOM)
+        self.act_dtype = act_dtype
+        self.grad_frames = None
+
+    def forward(self, x):
+        return _StemFn.apply(x, self.norm.weight, self)
+
+
+# ------------------------------------------------------------------------------ res stage
+class X3DBottleneck(_Holder):
+    pass
+
+
+class X3DResBlock(nn.Module):
+    """Parameter holder for one residual block (reference model/x3d.py:235-328, 109-232)."""
+
+    def __init__(self, cin, cinner, cout, stride, use_se, se_ratio):
+        super().__init__()
+        self.cin, self.cinner, self.cout, self.stride, self.use_se = cin, cinner, cout, stride, use_se
+        need_conv = cin != cout or stride > 1
+        self.branch1_conv = (nn.Conv3d(cin, cout, (1, 1, 1), stride=(1, stride, stride), bias=False)
+                             if need_conv else None)
+        self.branch1_norm = nn.BatchNorm3d(cout) if cin != cout else None
+        b2 = X3DBottleneck()
+        b2.conv_a = nn.Conv3d(cin, cinner, (1, 1, 1), bias=False)
+        b2.norm_a = nn.BatchNorm3d(cinner, eps=BN_EPS, momentum=BN_MOM)
+        b2.conv_b = nn.Conv3d(cinner, cinner, (3, 3, 3), stride=(1, stride, stride), padding=(1, 1, 1),
+                              bias=False, groups=cinner)
+        if use_se:
+            se = _Holder()
+            cr = round_width(cinner, se_ratio)
+            se.block = nn.Sequential(nn.Conv3d(cinner, cr, 1, bias=True), nn.ReLU(),
+                                     nn.Conv3d(cr, cinner, 1, bias=True), nn.Sigmoid())
+        else:
+            se = nn.Identity()
+        b2.norm_b = nn.Sequential(nn.BatchNorm3d(cinner, eps=BN_EPS, momentum=BN_MOM), se)
+        b2.conv_c = nn.Conv3d(cinner, cout, (1, 1, 1), bias=False)
+        b2.norm_c = nn.BatchNorm3d(cout, eps=BN_EPS, momentum=BN_MOM)
+        self.branch2 = b2
+
+
+def _block_forward(blk, x, B, T, H, W, training, act_dtype):
+    """x: [B,T,H,W,Cin] contiguous.  Returns (y, saved-for-backward dict)."""
+    dev, dt = x.device, ops.dt_code(act_dtype)
+    b2 = blk.branch2
+    Cin, Ci, Co, s = blk.cin, blk.cinner, blk.cout, blk.stride
+    Cip, Cop = cpad(Ci), cpad(Co)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    M, Mo = B * T * H * W, B * T * Ho * Wo
+    se = b2.norm_b[1] if blk.use_se else None
+    has_bn1 = blk.branch1_norm is not None
+    # f64 accumulators in one zeroed buffer
+    n_acc = 2 * Ci + B * Cip * 2 + 2 * Co + (2 * Co if has_bn1 else 0)
+    acc = torch.zeros(n_acc, dtype=torch.float64, device=dev)
+    sums_a, o = acc[:2 * Ci], 2 * Ci
+    nc_b, o = acc[o:o + B * Cip * 2], o + B * Cip * 2
+    sums_c, o = acc[o:o + 2 * Co], o + 2 * Co
+    sums_1 = acc[o:o + 2 * Co] if has_bn1 else None
+    epi = ops.EPI_STATS if training else ops.EPI_STORE
+
+    a = torch.empty((M, Cip), dtype=act_dtype, device=dev)
+    ops.pw_gemm(x, b2.conv_a.weight, a, M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt, epi_mode=epi, stats=sums_a)
+    ss_a, mr_a = _f32(2 * Cip, dev), _f32(2 * Ci, dev)
+    ops.bn_finalize(sums_a, M, b2.norm_a, Ci, ss_a, mr_a, training)
+
+    b = torch.empty((Mo, Cip), dtype=act_dtype, device=dev)
+    ops.dw_fwd(a, ss_a, b2.conv_b.weight, b, nc_b, B, T, H, W, Ci, s, dt)
+    ss_b, mr_b = _f32(2 * Cip, dev), _f32(2 * Ci, dev)
+    gate = _f32(B * Cip, dev) if se is not None else None
+    hid = _f32(B * se.block[0].weight.shape[0], dev) if se is not None else None
+    ops.bn_se_finalize(nc_b, B, T * Ho * Wo, b2.norm_b[0], se, Ci, ss_b, mr_b, gate, hid, training)
+
+    c = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
+    ops.pw_gemm(b, b2.conv_c.weight, c, M=Mo, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH,
+                pro_p=ss_b, pro_gate=gate, rows_per_sample=T * Ho * Wo, epi_mode=epi, stats=sums_c)
+    ss_c, mr_c = _f32(2 * Cop, dev), _f32(2 * Co, dev)
+    ops.bn_finalize(sums_c, Mo, b2.norm_c, Co, ss_c, mr_c, training)
+
+    ss_1 = mr_1 = None
+    if blk.branch1_conv is not None:
+        sc = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
+        ops.pw_gemm(x, blk.branch1_conv.weight, sc, M=Mo, K=Cin, N=Co, w_sn=Cin, w_sk=1, dtype=dt,
+                    row_mode=ops.ROWS_STRIDE2 if s == 2 else ops.ROWS_DENSE, H=H, W=W,
+                    epi_mode=epi if has_bn1 else ops.EPI_STORE, stats=sums_1)
+        if has_bn1:
+            ss_1, mr_1 = _f32(2 * Cop, dev), _f32(2 * Co, dev)
+            ops.bn_finalize(sums_1, Mo, blk.branch1_norm, Co, ss_1, mr_1, training)
+            mode = ops.SC_BN
+        else:
+            mode = ops.SC_RAW
+    else:
+        sc, mode = x, ops.SC_IDENTITY
+    y = torch.empty((B, T, Ho, Wo, Cop), dtype=act_dtype, device=dev)
+    ops.block_out_fwd(c, ss_c, sc, ss_1, mode, y, Mo, Cop, dt)
+    saved = dict(x=x, a=a, b=b, c=c, sc=sc if blk.branch1_conv is not None else None, y=y, ss_a=ss_a, mr_a=mr_a,
+                 ss_b=ss_b, mr_b=mr_b, gate=gate, hid=hid, mr_c=mr_c, mr_1=mr_1, nc_b=nc_b, mode=mode,
+                 dims=(B, T, H, W, Ho, Wo))
+    return y, saved
+
+
+def _block_backward(blk, dy, sv, act_dtype):
+    """dy: [B,T,Ho,Wo,Co] contiguous.  Returns dx [B,T,H,W,Cin]; parameter grads accumulate in .grad."""
+    dev, dt = dy.device, ops.dt_code(act_dtype)
+    b2 = blk.branch2
+    Cin, Ci, Co, s = blk.cin, blk.cinner, blk.cout, blk.stride
+    Cip, Cop, Cinp = cpad(Ci), cpad(Co), cpad(Cin)
+    B, T, H, W, Ho, Wo = sv["dims"]
+    M, Mo = B * T * H * W, B * T * Ho * Wo
+    se = b2.norm_b[1] if blk.use_se else None
+    mode = sv["mode"]
+    x, a, b, c, sc, y = sv["x"], sv["a"], sv["b"], sv["c"], sv["sc"], sv["y"]
+    n_acc = 2 * Co + (2 * Co if mode == ops.SC_BN else 0) + B * Cip * 3 + 2 * Ci
+    acc = torch.zeros(n_acc, dtype=torch.float64, device=dev)
+    dsums_c, o = acc[:2 * Co], 2 * Co
+    dsums_1 = None
+    if mode == ops.SC_BN:
+        dsums_1, o = acc[o:o + 2 * Co], o + 2 * Co
+    nc3, o = acc[o:o + B * Cip * 3], o + B * Cip * 3
+    dsums_a = acc[o:o + 2 * Ci]
+
+    # ---- y = relu(bn_c(c) + shortcut)
+    g = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
+    ops.block_out_bwd(dy, y, c, sc if mode == ops.SC_BN else None, g, dsums_c, dsums_1, Mo, Co, dt)
+    coef_c = _f32(3 * Cop, dev)
+    ops.bn_bwd_coef(dsums_c, Mo, b2.norm_c, sv["mr_c"], Co, coef_c)
+    # ---- conv_c (data + weight), Swish / SE backward in the epilogue
+    t1 = torch.empty((Mo, Cip), dtype=act_dtype, device=dev)
+    ops.pw_gemm(g, b2.conv_c.weight, t1, M=Mo, K=Co, N=Ci, w_sn=1, w_sk=Ci, dtype=dt, x2=c, pro_mode=ops.PRO_AFFINE2,
+                pro_p=coef_c, epi_mode=ops.EPI_SWISH_SE_BWD, e1=b, epi_p=sv["ss_b"], epi_gate=sv["gate"], stats=nc3,
+                rows_per_sample=T * Ho * Wo)
+    ops.pw_wgrad(g, b, ops.grad_of(b2.conv_c.weight), M=Mo, K=Ci, N=Co, dw_sn=Ci, dw_sk=1, dtype=dt, p2=c,
+                 p_coef=coef_c, q_mode=ops.PRO_BN_SE_SWISH, q_ss=sv["ss_b"], q_gate=sv["gate"],
+                 rows_per_sample=T * Ho * Wo)
+    cA, cC, cB = _f32(Cip, dev), _f32(Cip, dev), _f32(B * Cip, dev)
+    ops.se_bn_bwd_coef(nc3, sv["nc_b"], B, T * Ho * Wo, b2.norm_b[0], sv["mr_b"], sv["ss_b"], se, sv["gate"],
+                       sv["hid"], Ci, cA, cC, cB)
+    # ---- depthwise conv_b
+    t2 = torch.empty((M, Cip), dtype=act_dtype, device=dev)
+    ops.dw_bwd_data(t1, b, cA, cB, cC, b2.conv_b.weight, a, sv["ss_a"], t2, dsums_a, B, T, H, W, Ci, s, dt)
+    ops.dw_wgrad(t1, b, cA, cB, cC, a, sv["ss_a"], ops.grad_of(b2.conv_b.weight), B, T, H, W, Ci, s, dt)
+    coef_a = _f32(3 * Cip, dev)
+    ops.bn_bwd_coef(dsums_a, M, b2.norm_a, sv["mr_a"], Ci, coef_a)
+    # ---- shortcut branch
+    dx = torch.empty((B, T, H, W, Cinp), dtype=act_dtype, device=dev)
+    if blk.branch1_conv is not None:
+        rm = ops.ROWS_STRIDE2 if s == 2 else ops.ROWS_DENSE
+        dxs = torch.empty((Mo, Cinp), dtype=act_dtype, device=dev)
+        if mode == ops.SC_BN:
+            coef_1 = _f32(3 * Cop, dev)
+            ops.bn_bwd_coef(dsums_1, Mo, blk.branch1_norm, sv["mr_1"], Co, coef_1)
+            ops.pw_gemm(g, blk.branch1_conv.weight, dxs, M=Mo, K=Co, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=sc,
+                        pro_mode=ops.PRO_AFFINE2, pro_p=coef_1)
+            ops.pw_wgrad(g, x, ops.grad_of(blk.branch1_conv.weight), M=Mo, K=Cin, N=Co, dw_sn=Cin, dw_sk=1,
+                         dtype=dt, p2=sc, p_coef=coef_1, row_mode=rm, H=H, W=W)
+        else:
+            ops.pw_gemm(g, blk.branch1_conv.weight, dxs, M=Mo, K=Co, N=Cin, w_sn=1, w_sk=Cin, dtype=dt)
+            ops.pw_wgrad(g, x, ops.grad_of(blk.branch1_conv.weight), M=Mo, K=Cin, N=Co, dw_sn=Cin, dw_sk=1,
+                         dtype=dt, row_mode=rm, H=H, W=W)
+        res, res_mode = dxs, (1 if s == 2 else 0)
+    else:
+        res, res_mode = g, 0
+    # ---- conv_a (data + weight); the shortcut gradient is added in the epilogue
+    ops.pw_gemm(t2, b2.conv_a.weight, dx, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=a,
+                pro_mode=ops.PRO_AFFINE2, pro_p=coef_a, epi_mode=ops.EPI_ADD, e1=res, res_mode=res_mode, H=H, W=W)
+    ops.pw_wgrad(t2, x, ops.grad_of(b2.conv_a.weight), M=M, K=Cin, N=Ci, dw_sn=Cin, dw_sk=1, dtype=dt, p2=a,
+                 p_coef=coef_a)
+    return dx
+
+
+class _StageFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, stage):
+        ops.require_gpu(x, "stage input")
+        B, C, T, H, W = x.shape
+        cur = to_ndhwc(x.detach()).to(stage.act_dtype)
+        keep = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
+        saved = []
+        for blk in stage.res_blocks:
+            cur, sv = _block_forward(blk, cur, B, T, H, W, stage.training, stage.act_dtype)
+            H, W = sv["dims"][4], sv["dims"][5]
+            if keep:
+                saved.append(sv)
+        ctx.stage, ctx.saved, ctx.x_dtype = stage, saved, x.dtype
+        return to_logical(cur)
+
+    @staticmethod
+    def backward(ctx, dy):
+        stage, saved = ctx.stage, ctx.saved
+        cur = to_ndhwc(dy).to(stage.act_dtype)
+        for blk, sv in zip(reversed(list(stage.res_blocks)), reversed(saved)):
+            cur = _block_backward(blk, cur, sv, stage.act_dtype)
+            sv.clear()
+        if stage.post_backward is not None:  # data-parallel hook: this stage's grads are final
+            stage.post_backward()
+        return to_logical(cur).to(ctx.x_dtype), None, None
+
+
+class X3DResStage(nn.Module):
+    """`blocks[1..4]` (reference model/x3d.py:331-412)."""
+
+    def __init__(self, depth, cin, cinner, cout, stride, se_ratio, act_dtype):
+        super().__init__()
+        self.res_blocks = nn.ModuleList([
+            X3DResBlock(cin if i == 0 else cout, cinner, cout, stride if i == 0 else 1,
+                        use_se=bool((i + 1) % 2) and se_ratio > 0, se_ratio=se_ratio) for i in range(depth)])
+        self.act_dtype = act_dtype
+        self.post_backward = None
+
+    def forward(self, x):
+        return _StageFn.apply(x, self.res_blocks[0].branch2.conv_a.weight, self)
+
+
+class X3DHead(nn.Module):
+    """`blocks[5]`: constructed and strict-loaded by the reference, never executed by any
+    Change3D path (reference model/trainer.py:128 runs range(4), :121 range(5)); kept as a
+    parameter holder for state-dict / parameters() parity (reference model/x3d.py:415-540)."""
+
+    def __init__(self, cin, cinner, cout, num_classes, dropout_rate):
+        super().__init__()
+        self.pool = _Holder()
+        self.pool.pre_conv = nn.Conv3d(cin, cinner, (1, 1, 1), bias=False)
+        self.pool.pre_norm = nn.BatchNorm3d(cinner, eps=BN_EPS, momentum=BN_MOM)
+        self.pool.post_conv = nn.Conv3d(cinner, cout, (1, 1, 1), bias=False)
+        self.proj = nn.Linear(cout, num_classes, bias=True)
+        self.dropout_rate = dropout_rate
+
+    def forward(self, x):
+        raise NotImplementedError("the X3D classification head is never executed by Change3D; "
+                                  "it exists for state-dict compatibility only")
+
+
+class X3DNet(nn.Module):
+    def __init__(self, blocks, act_dtype):
+        super().__init__()
+        self.blocks = nn.ModuleList(blocks)
+        self.act_dtype = act_dtype
+        _init_net_weights(self)
+
+    def set_act_dtype(self, dtype):
+        self.act_dtype = dtype
+        for m in self.modules():
+            if hasattr(m, "act_dtype"):
+                m.act_dtype = dtype
+        return self
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return x
+
+
+def _init_net_weights(model, fc_init_std=0.01):
+    """pytorchvideo `init_net_weights` (called by its `Net.__init__`): kaiming-normal fan_out for
+    convs, BN weight 1 / bias 0, Linear N(0, 0.01)."""
+    for m in model.modules():
+        if isinstance(m, nn.Conv3d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.BatchNorm3d):
+            m.weight.data.fill_(1.0)
+            m.bias.data.zero_()
+        elif isinstance(m, nn.Linear):
+            m.weight.data.normal_(mean=0.0, std=fc_init_std)
+            m.bias.data.zero_()
+
+
+def create_x3d(*, input_channel=3, input_clip_length=13, input_crop_size=160, model_num_class=400,
+               dropout_rate=0.5, width_factor=2.0, depth_factor=2.2, norm=nn.BatchNorm3d, norm_eps=1e-5,
+               norm_momentum=0.1, activation=nn.ReLU, stem_dim_in=12, stem_conv_kernel_size=(5, 3, 3),
+               stem_conv_stride=(1, 1, 1), stage_conv_kernel_size=((3, 3, 3),) * 4,
+               stage_spatial_stride=(2, 2, 2, 2), stage_temporal_stride=(1, 1, 1, 1), bottleneck=None,
+               bottleneck_factor=2.25, se_ratio=0.0625, inner_act=None, head_dim_out=2048,
+               head_pool_act=nn.ReLU, head_bn_lin5_on=False, head_activation=None,
+               head_output_with_global_average=True, act_dtype=torch.float32):
+    """Same keyword surface as reference model/x3d.py:543-584 (+ `act_dtype`)."""
+    if (norm is not nn.BatchNorm3d or activation is not nn.ReLU or norm_eps != BN_EPS or norm_momentum != BN_MOM
+            or tuple(stage_spatial_stride) != (2, 2, 2, 2) or tuple(stage_temporal_stride) != (1, 1, 1, 1)
+            or any(tuple(k) != (3, 3, 3) for k in stage_conv_kernel_size) or head_bn_lin5_on
+            or head_activation is not None or bottleneck is not None or inner_act is not None):
+        raise NotImplementedError("only the X3D configuration Change3D uses is implemented as HIP kernels")
+    stem_out = round_width(stem_dim_in, width_factor)
+    blocks = [X3DStem(input_channel, stem_out, stem_conv_kernel_size, stem_conv_stride, act_dtype)]
+    dims = [stem_dim_in]
+    for _ in range(3):
+        dims.append(round_width(dims[-1], 2.0, divisor=8))
+    cin = stem_out
+    for i, d in enumerate((1, 2, 5, 3)):
+        cout = round_width(dims[i], width_factor)
+        cinner = int(bottleneck_factor * cout)
+        blocks.append(X3DResStage(round_repeats(d, depth_factor), cin, cinner, cout, stage_spatial_stride[i],
+                                  se_ratio, act_dtype))
+        cin = cout
+    blocks.append(X3DHead(cin, cinner, head_dim_out, model_num_class, dropout_rate))
+    return X3DNet(blocks, act_dtype)

@@ -1,0 +1,278 @@
+"""Thin torch-tensor wrappers over the C ABI (include/change3d_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+computation below is a hand-written gfx950 kernel in libchange3d_hip.so.  All functions
+launch on `torch.cuda.current_stream()` and never synchronise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import (DT_BF16, DT_F32, EPI_ADD, EPI_STATS, EPI_STORE, EPI_SWISH_SE_BWD, PRO_AFFINE2,  # noqa: F401
+                   PRO_BN_SE_SWISH, PRO_NONE, ROWS_DENSE, ROWS_FRAME, ROWS_S2SHIFT, ROWS_STRIDE2, SC_BN,
+                   SC_IDENTITY, SC_NONE, SC_RAW)
+
+
+def cpad(c):
+    return (c + 7) // 8 * 8
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return DT_F32
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    raise TypeError(f"unsupported activation dtype {dtype} (float32 | bfloat16)")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t, what="input"):
+    if not t.is_cuda:
+        raise L.Change3DHipError(
+            f"{what} is on {t.device}: the Change3D hot path runs only as HIP kernels on an MI355X "
+            f"(no CPU fallback). Use the oracle in oracle/ for CPU reference results.")
+
+
+PROFILE = None  # dict: kernel name -> list of (start_event, end_event, algorithmic_bytes) when enabled
+
+
+def profile_begin():
+    global PROFILE
+    PROFILE = {}
+
+
+def profile_end():
+    """Returns {name: dict(launches, ms_total, bytes_total)} and disables profiling."""
+    global PROFILE
+    prof, PROFILE = PROFILE, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in (prof or {}).items():
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+        out[name] = dict(launches=len(recs), ms_total=ms, bytes_total=float(sum(b for _, _, b in recs)))
+    return out
+
+
+def _launch(name, nbytes, fn, *args):
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        prof.setdefault(name, []).append((e0, e1, nbytes))
+    else:
+        rc = fn(*args)
+    if rc != 0:
+        raise L.Change3DHipError(f"{name} failed with code {rc}")
+
+
+def _es(dtype):
+    return 4 if dtype == DT_F32 else 2
+
+
+def grad_of(p):
+    """Accumulation target for a parameter gradient (kernels do `+=`)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+# ----------------------------------------------------------------------------- pointwise GEMM
+def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, pro_p=None,
+            pro_gate=None, epi_mode=EPI_STORE, e1=None, epi_p=None, epi_gate=None, stats=None,
+            rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, res_mode=0,
+            x_ptr=None, e1_ptr=None):
+    a = L.PwArgs()
+    a.x = x_ptr if x_ptr is not None else _p(x)
+    a.x2 = _p(x2)
+    a.y = _p(y)
+    a.e1 = e1_ptr if e1_ptr is not None else _p(e1)
+    a.w = _p(w)
+    a.pro_p, a.pro_gate, a.epi_p, a.epi_gate, a.stats = _p(pro_p), _p(pro_gate), _p(epi_p), _p(epi_gate), _p(stats)
+    a.M, a.gstride, a.rows_per_sample = M, gstride, rows_per_sample
+    a.K, a.Kp, a.N, a.Np = K, cpad(K), N, cpad(N)
+    a.w_sn, a.w_sk = w_sn, w_sk
+    a.row_mode, a.rpg, a.H, a.W = row_mode, rpg, H, W
+    a.pro_mode, a.epi_mode, a.res_mode, a.dtype = pro_mode, epi_mode, res_mode, dtype
+    _launch("c3d_pw_gemm", a.M * (a.Kp * (2 if x2 is not None else 1) + a.Np * (2 if (e1 is not None or e1_ptr is not None) else 1)) * _es(dtype), L.lib().c3d_pw_gemm, C.byref(a), _stream())
+
+
+_wgrad_ws = {}
+
+
+def _ws(device, n_floats):
+    key = (device.index,)
+    buf = _wgrad_ws.get(key)
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty(int(n_floats), dtype=torch.float32, device=device)
+        _wgrad_ws[key] = buf
+    return buf
+
+
+def pw_wgrad(p, q, dw, *, M, K, N, dw_sn, dw_sk, dtype, p2=None, p_coef=None, q_mode=PRO_NONE, q_ss=None,
+             q_gate=None, rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, dy=0, dx=0,
+             q_ptr=None, dw_ptr=None):
+    a = L.PwWgradArgs()
+    a.p, a.p2 = _p(p), _p(p2)
+    a.q = q_ptr if q_ptr is not None else _p(q)
+    a.dw = dw_ptr if dw_ptr is not None else _p(dw)
+    ws = _ws(p.device, L.lib().c3d_pw_wgrad_ws_floats(N, K))
+    a.ws = ws.data_ptr()
+    a.p_coef, a.q_ss, a.q_gate = _p(p_coef), _p(q_ss), _p(q_gate)
+    a.M, a.gstride, a.rows_per_sample = M, gstride, rows_per_sample
+    a.K, a.Kp, a.N, a.Np = K, cpad(K), N, cpad(N)
+    a.dw_sn, a.dw_sk = dw_sn, dw_sk
+    a.row_mode, a.rpg, a.H, a.W, a.dy, a.dx = row_mode, rpg, H, W, dy, dx
+    a.q_mode, a.dtype = q_mode, dtype
+    _launch("c3d_pw_wgrad", a.M * (a.Np * (2 if p2 is not None else 1) + a.Kp) * _es(dtype), L.lib().c3d_pw_wgrad, C.byref(a), _stream())
+
+
+# ------------------------------------------------------------------------------- BN / SE
+def bn_finalize(sums, count, bn, C_, ss, mr, training):
+    _launch("c3d_bn_finalize", 0, L.lib().c3d_bn_finalize, _p(sums), float(count), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+                                    _p(bn.running_var), _p(bn.num_batches_tracked) if training else None,
+                                    float(bn.momentum), float(bn.eps), C_, cpad(C_), 1 if training else 0,
+                                    _p(ss), _p(mr), _stream())
+
+
+def bn_se_finalize(nc, B, cnt, bn, se, C_, ss, mr, gate, hid, training):
+    if se is not None:
+        w1, b1, w2, b2 = se.block[0].weight, se.block[0].bias, se.block[2].weight, se.block[2].bias
+        Cr = w1.shape[0]
+    else:
+        w1 = b1 = w2 = b2 = None
+        Cr = 0
+    _launch("c3d_bn_se_finalize", 0, L.lib().c3d_bn_se_finalize, _p(nc), B, float(cnt), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+                                       _p(bn.running_var), _p(bn.num_batches_tracked) if training else None,
+                                       float(bn.momentum), float(bn.eps), C_, cpad(C_), 1 if training else 0,
+                                       _p(w1), _p(b1), _p(w2), _p(b2), Cr, _p(ss), _p(mr), _p(gate), _p(hid),
+                                       _stream())
+
+
+def bn_bwd_coef(dsums, count, bn, mr, C_, coef):
+    _launch("c3d_bn_bwd_coef", 0, L.lib().c3d_bn_bwd_coef, _p(dsums), float(count), _p(bn.weight), _p(mr), C_, cpad(C_), _p(coef),
+                                    _p(grad_of(bn.weight)), _p(grad_of(bn.bias)), _stream())
+
+
+def se_bn_bwd_coef(nc3, ncf, B, cnt, bn, mr, ss, se, gate, hid, C_, coefA, coefC, coefB):
+    if se is not None:
+        c1, c2 = se.block[0], se.block[2]
+        args = (_p(c1.weight), _p(c2.weight), _p(gate), _p(hid), c1.weight.shape[0])
+        gargs = (_p(grad_of(c1.weight)), _p(grad_of(c1.bias)), _p(grad_of(c2.weight)), _p(grad_of(c2.bias)))
+    else:
+        args = (None, None, None, None, 0)
+        gargs = (None, None, None, None)
+    _launch("c3d_se_bn_bwd_coef", 0, L.lib().c3d_se_bn_bwd_coef, _p(nc3), _p(ncf), B, float(cnt), _p(bn.weight), _p(mr), _p(ss), C_, cpad(C_),
+                                       *args, _p(coefA), _p(coefC), _p(coefB), _p(grad_of(bn.weight)),
+                                       _p(grad_of(bn.bias)), *gargs, _stream())
+
+
+# ------------------------------------------------------------------------------ depthwise
+def dw_fwd(x, ss, w, y, nc, B, T, H, W, C_, stride, dtype):
+    _launch("c3d_dw333_fwd", (x.numel() + y.numel()) * _es(dtype), L.lib().c3d_dw333_fwd, _p(x), _p(ss), _p(w), _p(y), _p(nc), B, T, H, W, C_, cpad(C_), stride, dtype,
+                                  _stream())
+
+
+def dw_bwd_data(t1, b, cA, cB, cC, w, a, ss_a, t2, dsums, B, T, H, W, C_, stride, dtype):
+    _launch("c3d_dw333_bwd_data", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_data, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(t2),
+                                       _p(dsums), B, T, H, W, C_, cpad(C_), stride, dtype, _stream())
+
+
+def dw_wgrad(t1, b, cA, cB, cC, a, ss_a, dw, B, T, H, W, C_, stride, dtype):
+    _launch("c3d_dw333_wgrad", (t1.numel() + b.numel() + a.numel()) * _es(dtype), L.lib().c3d_dw333_wgrad, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(a), _p(ss_a), _p(dw), B, T, H, W,
+                                    C_, cpad(C_), stride, dtype, _stream())
+
+
+# ----------------------------------------------------------------------------- elementwise
+def block_out_fwd(c, ss_c, shortcut, ss_1, mode, y, M, Cp, dtype):
+    _launch("c3d_block_out_fwd", M * Cp * (3 if shortcut is not None else 2) * _es(dtype), L.lib().c3d_block_out_fwd, _p(c), _p(ss_c), _p(shortcut), _p(ss_1), mode, _p(y), M, Cp, dtype,
+                                      _stream())
+
+
+def block_out_bwd(dy, y, c, s_bn, g, dsums_c, dsums_1, M, C_, dtype):
+    _launch("c3d_block_out_bwd", M * cpad(C_) * (5 if s_bn is not None else 4) * _es(dtype), L.lib().c3d_block_out_bwd, _p(dy), _p(y), _p(c), _p(s_bn), _p(g), _p(dsums_c), _p(dsums_1), M, C_,
+                                      cpad(C_), dtype, _stream())
+
+
+def frame_absdiff(y, d, B, T, HW, Cp, t_pre, t_post, dtype):
+    _launch("c3d_frame_absdiff", B * HW * Cp * 3 * _es(dtype), L.lib().c3d_frame_absdiff, _p(y), _p(d), B, T, HW, Cp, t_pre, t_post, dtype, _stream())
+
+
+def enhance_apply(y, e, out, B, T, HW, Cp, t_mid, dtype):
+    _launch("c3d_enhance_apply", B * HW * Cp * (2 * T + 1) * _es(dtype), L.lib().c3d_enhance_apply, _p(y), _p(e), _p(out), B, T, HW, Cp, t_mid, dtype, _stream())
+
+
+def enhance_bwd_mask(dout, e, de, B, T, HW, Cp, t_mid, dtype):
+    _launch("c3d_enhance_bwd_mask", B * HW * Cp * 3 * _es(dtype), L.lib().c3d_enhance_bwd_mask, _p(dout), _p(e), _p(de), B, T, HW, Cp, t_mid, dtype, _stream())
+
+
+def enhance_bwd_apply(dout, y, dd, dy, B, T, HW, Cp, t_pre, t_post, dtype):
+    _launch("c3d_enhance_bwd_apply", B * HW * Cp * (2 * T + 3) * _es(dtype), L.lib().c3d_enhance_bwd_apply, _p(dout), _p(y), _p(dd), _p(dy), B, T, HW, Cp, t_pre, t_post, dtype,
+                                          _stream())
+
+
+# ------------------------------------------------------------------------------------ stem
+def stem_fwd(x, w_t, w_xy, u, sums, B, T, H, W, dtype):
+    _launch("c3d_stem_fwd", x.numel() * 4 + u.numel() * _es(dtype), L.lib().c3d_stem_fwd, _p(x), _p(w_t), _p(w_xy), _p(u), _p(sums), B, T, H, W, dtype, _stream())
+
+
+def stem_bwd_dv(x, w_t, w_xy, g0, u, coef, dv, dw_xy, B, T, H, W, dtype):
+    _launch("c3d_stem_bwd_dv", x.numel() * 4 + 3 * u.numel() * _es(dtype), L.lib().c3d_stem_bwd_dv, _p(x), _p(w_t), _p(w_xy), _p(g0), _p(u), _p(coef), _p(dv), _p(dw_xy), B, T, H,
+                                    W, dtype, _stream())
+
+
+def stem_bwd_wx(x, w_t, dv, dw_t, dP, B, T, H, W, t_first, n_frames, per_sample, dtype):
+    _launch("c3d_stem_bwd_wx", x.numel() * 4 + dv.numel() * _es(dtype), L.lib().c3d_stem_bwd_wx, _p(x), _p(w_t), _p(dv), _p(dw_t), _p(dP), B, T, H, W, t_first, n_frames,
+                                    1 if per_sample else 0, dtype, _stream())
+
+
+# --------------------------------------------------------------------------------- decoder
+def convT_fwd(inp, w, bias, skip_ptr, skip_bstride, out, B, h, wd, C_, dtype):
+    _launch("c3d_convT4s2_fwd", (inp.numel() + 2 * out.numel()) * _es(dtype), L.lib().c3d_convT4s2_fwd, _p(inp), _p(w), _p(bias), skip_ptr, skip_bstride, _p(out), B, h, wd, C_,
+                                     dtype, _stream())
+
+
+def convT_bwd_data(dout, w, din, B, h, wd, C_, dtype):
+    _launch("c3d_convT4s2_bwd_data", (dout.numel() + din.numel()) * _es(dtype), L.lib().c3d_convT4s2_bwd_data, _p(dout), _p(w), _p(din), B, h, wd, C_, dtype, _stream())
+
+
+def col_sum(x, out, M, C_, dtype):
+    _launch("c3d_col_sum", M * cpad(C_) * _es(dtype), L.lib().c3d_col_sum, _p(x), _p(out), M, C_, cpad(C_), dtype, _stream())
+
+
+def head_fwd(x, w, out, B, H, W, C_, NC, has_sigmoid, dtype):
+    _launch("c3d_head3x3_fwd", x.numel() * _es(dtype) + out.numel() * 4, L.lib().c3d_head3x3_fwd, _p(x), _p(w), _p(out), B, H, W, C_, NC, 1 if has_sigmoid else 0, dtype,
+                                    _stream())
+
+
+def head_bwd(dout, prob, x, w, dx, dw, B, H, W, C_, NC, has_sigmoid, dtype):
+    _launch("c3d_head3x3_bwd", 2 * x.numel() * _es(dtype) + 2 * dout.numel() * 4, L.lib().c3d_head3x3_bwd, _p(dout), _p(prob), _p(x), _p(w), _p(dx), _p(dw), B, H, W, C_, NC,
+                                    1 if has_sigmoid else 0, dtype, _stream())
+
+
+# ------------------------------------------------------------------------------ train shell
+def bce_dice_fwd(prob, target, sums4, loss):
+    _launch("c3d_bce_dice_fwd", prob.numel() * 8, L.lib().c3d_bce_dice_fwd, _p(prob), _p(target), prob.numel(), _p(sums4), _p(loss), _stream())
+
+
+def bce_dice_bwd(prob, target, sums4, dloss, dprob):
+    _launch("c3d_bce_dice_bwd", prob.numel() * 12, L.lib().c3d_bce_dice_bwd, _p(prob), _p(target), _p(sums4), _p(dloss), prob.numel(), _p(dprob),
+                                     _stream())
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, n, hp_dev, lr, bc1, bc2_sqrt, beta1, beta2, eps, wd):
+    _launch("c3d_adam_step", n * 28, L.lib().c3d_adam_step, _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, _p(hp_dev), lr, bc1, bc2_sqrt,
+                                  beta1, beta2, eps, wd, _stream())
+
+
+def confusion2(prob, target, cm4):
+    _launch("c3d_confusion2", prob.numel() * 8, L.lib().c3d_confusion2, _p(prob), _p(target), prob.numel(), _p(cm4), _stream())

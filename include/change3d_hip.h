@@ -1,0 +1,241 @@
+/* change3d_hip.h — C ABI of libchange3d_hip.so (MI355X / gfx950 kernels for the Change3D
+ * BCD hot path).  Plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ * noted; `stream` is a hipStream_t passed as void*.  Every function returns 0 on success
+ * or a hipError_t / negative C3D_E* code.
+ *
+ * The reference (zhuduowang/Change3D) has no FFI: its boundary for this path is the Python
+ * module surface of model/x3d.py, model/change_decoder.py, model/trainer.py and
+ * model/utils.py.  Each entry point below therefore names the reference construct whose
+ * device work it replaces (file:line into /root/reference); the Python mirror in
+ * change3d_amd/model/ (Python) binds them with ctypes.
+ *
+ * Tensor layout: activations are channels-last [B][T][H][W][Cp], Cp = round_up(C,8), pad
+ * channels zero; `dtype` selects the storage type of activations (C3D_F32 | C3D_BF16).
+ * Parameters, BN statistics, gradients of parameters and optimizer state are always f32
+ * (reductions accumulate in f64).
+ */
+#ifndef CHANGE3D_HIP_H
+#define CHANGE3D_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C3D_DT_F32 0
+#define C3D_DT_BF16 1
+
+#define C3D_E_BADARG (-1)
+#define C3D_E_UNSUPPORTED (-2)
+
+/* library / device identification (host-only; safe to call without a GPU) */
+int c3d_abi_version(void);
+const char* c3d_build_info(void);
+/* number of compute units of the current device (needs a GPU) */
+int c3d_device_cus(void);
+
+/* ------------------------------------------------------------------------------------
+ * Pointwise (1x1x1 / 1x1) convolution family as a row GEMM on MFMA:
+ *     Y[m, n] = epilogue( sum_k prologue(X)[m, k] * Wt[n, k] )
+ * Replaces: nn.Conv3d k=1 conv_a / conv_c / branch1_conv (reference model/x3d.py:173-175,
+ * 214-216, 302-308) forward and data-gradient, nn.Conv2d k=1 of the decoder
+ * (reference model/change_decoder.py:30-45), with the neighbouring BatchNorm3d-apply,
+ * SE gate, Swish and BN-backward arithmetic fused on operand load / result store.
+ * ------------------------------------------------------------------------------------ */
+#define C3D_PRO_NONE 0
+#define C3D_PRO_BN_SE_SWISH 1 /* v = x*scale+shift; q = gate*v; out = q*sigmoid(q)            */
+#define C3D_PRO_AFFINE2 2     /* out = A*x + B + C*x2   (BatchNorm backward applied on load)  */
+
+#define C3D_EPI_STORE 0
+#define C3D_EPI_STATS 1        /* store + per-channel sum / sum-of-squares (f64 atomics)      */
+#define C3D_EPI_SWISH_SE_BWD 2 /* result*swish'(gate*bn(e1))*gate; per-(sample,channel) sums  */
+#define C3D_EPI_ADD 3          /* result + residual e1 (dense, or scattered from half res)    */
+
+#define C3D_ROWS_DENSE 0  /* row m at x + m*Kp                                               */
+#define C3D_ROWS_FRAME 1  /* row m at x + (m / rpg)*gstride + (m % rpg)*Kp (one frame of NDHWC) */
+#define C3D_ROWS_STRIDE2 2 /* row m=(bt,ho,wo) gathers input pixel (bt,2ho,2wo) of [BT][H][W] */
+#define C3D_ROWS_S2SHIFT 3 /* (wgrad only) as STRIDE2 but pixel (2ho+dy, 2wo+dx), zero outside */
+
+typedef struct c3d_pw_args {
+  const void* x;         /* A-side tensor, storage dtype, rows of Kp elements                */
+  const void* x2;        /* second A-side tensor for C3D_PRO_AFFINE2 (same addressing)       */
+  void* y;               /* output [M][Np], storage dtype                                    */
+  const void* e1;        /* epilogue tensor ([M][Np] dense; or half-res residual)            */
+  const float* w;        /* weights, element (n,k) at w[n*w_sn + k*w_sk]                     */
+  const float* pro_p;    /* BN_SE_SWISH: scale[Kp],shift[Kp]; AFFINE2: A[Kp],B[Kp],C[Kp]     */
+  const float* pro_gate; /* BN_SE_SWISH: gate[B][Kp] or NULL (=1)                            */
+  const float* epi_p;    /* SWISH_SE_BWD: scale[Np],shift[Np] of the BN applied to e1        */
+  const float* epi_gate; /* SWISH_SE_BWD: gate[B][Np] or NULL (=1)                           */
+  double* stats;         /* STATS: sum[N],sumsq[N]; SWISH_SE_BWD: [B][Np][3]                 */
+  int64_t M;             /* output rows                                                      */
+  int64_t gstride;       /* C3D_ROWS_FRAME: elements between consecutive row groups          */
+  int64_t rows_per_sample; /* output rows per batch sample (gate / per-sample sums)          */
+  int32_t K, Kp, N, Np;
+  int32_t w_sn, w_sk;
+  int32_t row_mode, rpg;
+  int32_t H, W;          /* STRIDE2: input H,W.  EPI_ADD res_mode 1: output H,W              */
+  int32_t pro_mode, epi_mode;
+  int32_t res_mode;      /* EPI_ADD: 0 dense [M][Np]; 1 e1 is [BT][H/2][W/2][Np], added where h,w even */
+  int32_t dtype;
+} c3d_pw_args;
+
+int c3d_pw_gemm(const c3d_pw_args* args, void* stream);
+
+/* Weight gradient of the same family:
+ *     dW[n, k] += sum_m P(m, n) * Q(m, k),  P = prologue_p(p, p2),  Q = prologue_q(q)
+ * (replaces the weight half of aten::convolution_backward for the k=1 convs above).
+ * `ws` is an f32 workspace of at least c3d_pw_wgrad_ws_floats(N,K) elements.             */
+typedef struct c3d_pw_wgrad_args {
+  const void* p;  const void* p2;   /* dY-side operand ([M][Np] dense) + AFFINE2 companion   */
+  const void* q;                    /* X-side operand, rows of Kp elements (row_mode applies)*/
+  float* dw;                        /* element (n,k) accumulated at dw[n*dw_sn + k*dw_sk]    */
+  float* ws;
+  const float* p_coef;              /* AFFINE2 A,B,C [Np] each, or NULL (plain p)            */
+  const float* q_ss;                /* BN_SE_SWISH scale,shift [Kp] each, or NULL            */
+  const float* q_gate;              /* gate[B][Kp] or NULL                                   */
+  int64_t M;
+  int64_t gstride;
+  int64_t rows_per_sample;
+  int32_t K, Kp, N, Np;
+  int32_t dw_sn, dw_sk;
+  int32_t row_mode, rpg, H, W;      /* addressing of q (p is always dense)                   */
+  int32_t dy, dx;                   /* C3D_ROWS_S2SHIFT: row m=(b,i,j) reads pixel (2i+dy, 2j+dx) */
+  int32_t q_mode;                   /* C3D_PRO_NONE | C3D_PRO_BN_SE_SWISH                    */
+  int32_t dtype;
+} c3d_pw_wgrad_args;
+
+int64_t c3d_pw_wgrad_ws_floats(int32_t N, int32_t K);
+int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Train-mode BatchNorm3d split (reference model/x3d.py:97,179,207,220,298): statistics are
+ * accumulated by producer epilogues, finalised here, applied by consumer prologues.
+ *   sums : f64 [2][C] (sum, sumsq);   ss : f32 scale[Cp], shift[Cp];   mr : f32 mean[C], rstd[C]
+ * training=0 builds scale/shift from the running statistics (eval mode).
+ * ------------------------------------------------------------------------------------ */
+int c3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float momentum, float eps, int32_t C, int32_t Cp, int32_t training, float* ss,
+                    float* mr, void* stream);
+/* BN_b + SqueezeExcitation (fvcore SqueezeExcitation called at reference model/x3d.py:194-202):
+ * nc is f64 [B][Cp][2] per-(sample,channel) sum / sumsq from c3d_dw333_fwd; gate is f32 [B][Cp];
+ * hid is f32 [B][Cr] (saved ReLU output of the first FC).  w1 == NULL -> block without SE.  */
+int c3d_bn_se_finalize(const double* nc, int32_t B, double cnt_per_sample, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, float momentum, float eps, int32_t C, int32_t Cp,
+                       int32_t training, const float* w1, const float* b1, const float* w2,
+                       const float* b2, int32_t Cr, float* ss, float* mr, float* gate, float* hid,
+                       void* stream);
+/* BatchNorm backward as an affine map dx = A*g + B + C*x: dsums f64 [2][C] = (sum g, sum g*x);
+ * coef f32 A[Cp],B[Cp],C[Cp]; dgamma/dbeta are accumulated (+=).                            */
+int c3d_bn_bwd_coef(const double* dsums, double count, const float* gamma, const float* mr, int32_t C,
+                    int32_t Cp, float* coef, float* dgamma, float* dbeta, void* stream);
+/* SE backward + BN_b backward: nc3 f64 [B][Cp][3] from C3D_EPI_SWISH_SE_BWD, ncf = forward nc.
+ * db = coefA[c]*t1 + coefB[n][c] + coefC[c]*b.  FC / BN parameter gradients accumulated (+=). */
+int c3d_se_bn_bwd_coef(const double* nc3, const double* ncf, int32_t B, double cnt_per_sample,
+                       const float* gamma, const float* mr, const float* ss, int32_t C, int32_t Cp,
+                       const float* w1, const float* w2, const float* gate, const float* hid, int32_t Cr,
+                       float* coefA, float* coefC, float* coefB, float* dgamma, float* dbeta,
+                       float* dw1, float* db1, float* dw2, float* db2, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Depthwise 3x3x3 Conv3d, stride (1,s,s) (conv_b, reference model/x3d.py:184-193).
+ *   fwd      : x = a (raw conv_a output) with BN_a+ReLU applied on load (ss = scale/shift);
+ *              y = b raw; nc_sums f64 [B][Cp][2] accumulated (+=).
+ *   bwd_data : db = coefA*t1 + coefB[n] + coefC*b on load -> t2 = dconv*(bn_a(a)>0);
+ *              dsums f64 [2][C] += (sum t2, sum t2*a).
+ *   wgrad    : dw f32 [C][27] += sum db * relu(bn_a(a)).
+ * ------------------------------------------------------------------------------------ */
+int c3d_dw333_fwd(const void* x, const float* ss, const float* w, void* y, double* nc_sums, int32_t B,
+                  int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
+                  void* stream);
+int c3d_dw333_bwd_data(const void* t1, const void* b, const float* coefA, const float* coefB,
+                       const float* coefC, const float* w, const void* a, const float* ss_a, void* t2,
+                       double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
+                       int32_t stride, int32_t dtype, void* stream);
+int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const float* coefB,
+                    const float* coefC, const void* a, const float* ss_a, float* dw, int32_t B, int32_t T,
+                    int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Res-block output y = relu(bn_c(c) + shortcut) (reference model/x3d.py:326-327; also the
+ * stem's BN+ReLU with sc_mode 0) and its backward g = dy*(y>0) with BN-backward sums.
+ * sc_mode: 0 none, 1 identity, 2 shortcut*scale1+shift1 (branch1_norm), 3 raw shortcut.
+ * ------------------------------------------------------------------------------------ */
+int c3d_block_out_fwd(const void* c, const float* ss_c, const void* shortcut, const float* ss_1,
+                      int32_t sc_mode, void* y, int64_t M, int32_t Cp, int32_t dtype, void* stream);
+int c3d_block_out_bwd(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
+                      double* dsums_c, double* dsums_1, int64_t M, int32_t C, int32_t Cp, int32_t dtype,
+                      void* stream);
+
+/* Encoder.enhance pieces (reference model/trainer.py:71-108); HW = H*W pixels per frame.    */
+int c3d_frame_absdiff(const void* y, void* d, int32_t B, int32_t T, int64_t HW, int32_t Cp, int32_t t_pre,
+                      int32_t t_post, int32_t dtype, void* stream);
+int c3d_enhance_apply(const void* y, const void* e, void* out, int32_t B, int32_t T, int64_t HW,
+                      int32_t Cp, int32_t t_mid, int32_t dtype, void* stream);
+int c3d_enhance_bwd_mask(const void* dout, const void* e, void* de, int32_t B, int32_t T, int64_t HW,
+                         int32_t Cp, int32_t t_mid, int32_t dtype, void* stream);
+int c3d_enhance_bwd_apply(const void* dout, const void* y, const void* dd, void* dy, int32_t B, int32_t T,
+                          int64_t HW, int32_t Cp, int32_t t_pre, int32_t t_post, int32_t dtype,
+                          void* stream);
+int c3d_frame_scatter(const void* src, void* dst, int32_t B, int32_t T, int64_t HW, int32_t Cp,
+                      int32_t t_dst, int32_t accumulate, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Stem (reference model/x3d.py:70-106): x is the logical NCDHW f32 clip [B][3][T][H][W];
+ * u is the raw channels-last output [B][T][H][W][24]; sums f64 [2][24] accumulated.
+ * Backward: dv = conv_xy^T(du) with du = A*g0+B+C*u on load (coef f32 [3][24]); then
+ * d w_t and the batch-summed input gradient of frames t_first..t_first+n_frames-1
+ * (dP f32 [3][n_frames][H][W], the learnable perception frames, model/trainer.py:51-54;
+ * with per_sample=1 dP is instead a full NCDHW gradient [B][3][T][H][W], written not summed).
+ * ------------------------------------------------------------------------------------ */
+int c3d_stem_fwd(const float* x, const float* w_t, const float* w_xy, void* u, double* sums, int32_t B,
+                 int32_t T, int32_t H, int32_t W, int32_t dtype, void* stream);
+int c3d_stem_bwd_dv(const float* x, const float* w_t, const float* w_xy, const void* g0, const void* u,
+                    const float* coef, void* dv, float* dw_xy, int32_t B, int32_t T, int32_t H, int32_t W,
+                    int32_t dtype, void* stream);
+int c3d_stem_bwd_wx(const float* x, const float* w_t, const void* dv, float* dw_t, float* dP, int32_t B,
+                    int32_t T, int32_t H, int32_t W, int32_t t_first, int32_t n_frames, int32_t per_sample,
+                    int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * ChangeDecoder (reference model/change_decoder.py:30-55, 68-81).
+ *   convT4s2_fwd : out[B][2h][2w][C] = bias + skip + ConvTranspose2d(k4,s2,p1)(in[B][h][w][C]);
+ *                  skip is one frame of an NDHWC tensor (element batch stride skip_bstride).
+ *   head3x3      : Conv2d 3x3 (24 -> NC, no bias) [+ sigmoid]; out / dout / prob are f32
+ *                  NCHW [B][NC][H][W]; dw f32 [NC][24][3][3] accumulated.
+ * ------------------------------------------------------------------------------------ */
+int c3d_convT4s2_fwd(const void* in, const float* w, const float* bias, const void* skip,
+                     int64_t skip_bstride, void* out, int32_t B, int32_t h, int32_t wd, int32_t C,
+                     int32_t dtype, void* stream);
+int c3d_convT4s2_bwd_data(const void* dout, const float* w, void* din, int32_t B, int32_t h, int32_t wd,
+                          int32_t C, int32_t dtype, void* stream);
+int c3d_col_sum(const void* x, float* out, int64_t M, int32_t C, int32_t Cp, int32_t dtype, void* stream);
+int c3d_head3x3_fwd(const void* x, const float* w, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
+                    int32_t NC, int32_t has_sigmoid, int32_t dtype, void* stream);
+int c3d_head3x3_bwd(const float* dout, const float* prob, const void* x, const float* w, void* dx,
+                    float* dw, int32_t B, int32_t H, int32_t W, int32_t C, int32_t NC, int32_t has_sigmoid,
+                    int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Train-step shell: BCEDiceLoss (reference model/utils.py:154-169), Adam
+ * (reference scripts/train_BCD.py:284-290), thresholded confusion matrix
+ * (reference scripts/train_BCD.py:204-208, utils/metric_tool.py:111-128).
+ * sums4 f64 [4] = (sum bce terms, sum p*t, sum p, sum t).  hparams_dev (optional, f32 [3] =
+ * lr, bias_correction1, sqrt(bias_correction2)) overrides the by-value scalars so a captured
+ * HIP graph can be replayed with a new learning rate.
+ * ------------------------------------------------------------------------------------ */
+int c3d_bce_dice_fwd(const float* prob, const float* target, int64_t n, double* sums4, float* loss,
+                     void* stream);
+int c3d_bce_dice_bwd(const float* prob, const float* target, const double* sums4, const float* dloss,
+                     int64_t n, float* dprob, void* stream);
+int c3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  const float* hparams_dev, float lr, float bias_correction1, float bias_correction2_sqrt,
+                  float beta1, float beta2, float eps, float weight_decay, void* stream);
+int c3d_confusion2(const float* prob, const float* target, int64_t n, unsigned long long* cm4, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHANGE3D_HIP_H */

@@ -116,6 +116,37 @@ def run(size, batch, check_restatement=True):
     out["final_running_var_sums"] = np.array(rv)
     out["final_nbt"] = np.array([int(v) for k, v in fin.items() if k.endswith("num_batches_tracked")])
 
+    # ---- float64 evaluation of the same reference modules: the yardstick for tolerances
+    # (tests require |hip - f64| <= k * |reference_f32 - f64|, see tests/test_model_gpu.py)
+    ref64 = tr.Trainer(args)
+    ref64.load_state_dict(sd, strict=True)
+    ref64 = ref64.double().train()
+    opt64 = torch.optim.Adam(ref64.parameters(), BASE_LR, (0.9, 0.99), eps=1e-08, weight_decay=1e-4)
+    pre64, post64, tgt64 = pre.double(), post.double(), tgt.double()
+    losses64 = []
+    for it in range(N_STEPS):
+        mu.adjust_learning_rate(args, opt64, 0, it, MAX_ITER, lr_factor=1.0)
+        prob64 = ref64.update_bcd(pre64, post64)
+        loss64 = mu.BCEDiceLoss(prob64, tgt64)
+        opt64.zero_grad()
+        loss64.backward()
+        if it == 0:
+            out["train_prob_lattice_f64"] = prob64.detach()[:, :, ::stride, ::stride].numpy()
+            out["train_prob_full_f64"] = prob64.detach().numpy() if size <= 64 else np.zeros(0)
+            named64 = dict(ref64.named_parameters())
+            out["grad_norms_f64"] = np.array([named64[str(n)].grad.norm().item() for n in out["grad_names"]])
+            out["grad_probes_f64"] = np.stack([named64[str(n)].grad.detach().view(-1)[probe_idx(
+                named64[str(n)].numel(), 4, seed=11)].numpy() for n in out["grad_names"]])
+        opt64.step()
+        losses64.append(loss64.item())
+    out["loss_curve_f64"] = np.array(losses64)
+    ref64.eval()
+    with torch.no_grad():
+        ref64.load_state_dict(sd, strict=True)
+        ref64 = ref64.double()
+        pe64 = ref64.update_bcd(pre64, post64)
+    out["eval_prob_lattice_f64"] = pe64[:, :, ::stride, ::stride].numpy()
+
     if check_restatement:
         ora = om.Trainer(om.make_args(size=size))
         ora.load_state_dict(sd, strict=True)

@@ -1,0 +1,221 @@
+"""CPU suite (`-m "not gpu"`): the oracle against the reference-generated golden vectors, the C-ABI
+library (loads, exports every symbol declared in include/change3d_hip.h — no compute calls), host
+logic (LR schedule, arena, module surface / state-dict keys) and the 2-rank gloo gradient sync."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ oracle vs golden vectors
+def test_oracle_matches_reference_golden_s64(golden_dir):
+    from oracle import model as om, synth
+    G = np.load(os.path.join(golden_dir, "bcd_s64_b2.npz"))
+    size, batch = int(G["meta"][0]), int(G["meta"][1])
+    net = om.Trainer(om.make_args(size=size))
+    sd = synth.synth_state_dict(net, seed=int(G["meta"][2]), mask_margin=float(G["mask_margin"]))
+    net.load_state_dict(sd)
+    pre, post, tgt = synth.synth_batch(batch, size, seed=int(G["meta"][3]))
+    net.eval()
+    with torch.no_grad():
+        pe = net.update_bcd(pre, post)
+    assert np.abs(pe.numpy() - G["eval_prob_full"]).max() < 1e-6
+    assert np.array_equal(np.packbits(om.binarize(pe).numpy().astype(np.uint8).reshape(-1)), G["eval_mask_bits"])
+    net.train()
+    opt = om.make_adam(net, float(G["base_lr"]))
+    losses = []
+    cm = np.zeros((2, 2))
+    for it in range(int(G["meta"][4])):
+        lr = om.poly_lr(float(G["base_lr"]), it, int(G["max_iter"]), 0)
+        assert abs(lr - G["lr_curve"][it]) < 1e-18
+        for g in opt.param_groups:
+            g["lr"] = lr
+        prob = net.update_bcd(pre, post)
+        loss = om.bce_dice_loss(prob, tgt)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            assert np.abs(prob.detach().numpy() - G["train_prob_full"]).max() < 2e-5
+            named = dict(net.named_parameters())
+            gn = np.array([named[str(n)].grad.double().norm().item() for n in G["grad_names"]])
+            assert np.allclose(gn, G["grad_norms"], rtol=2e-3, atol=1e-9)
+        opt.step()
+        losses.append(loss.item())
+        cm += om.confusion_matrix(2, tgt.numpy(), om.binarize(prob).numpy())
+    assert np.abs(np.array(losses) - G["loss_curve"]).max() < 1e-4
+    assert np.abs(cm - G["cm_total"]).sum() <= 4
+    sc = om.cm2score(G["cm_total"])
+    assert abs(sc["IoU"] - G["scores"][1]) < 1e-12 and abs(sc["F1"] - G["scores"][2]) < 1e-12
+
+
+def test_oracle_structure_matches_published_counts():
+    from oracle import model as om
+    net = om.Trainer(om.make_args(size=256))
+    x3d = sum(p.numel() for p in net.encoder.x3d.parameters())
+    assert x3d == 6_153_384                      # X3D-L backbone
+    assert sum(p.numel() for p in net.parameters()) == 6_424_608
+    assert len(net.state_dict()) == 1156
+    used = [p.numel() for n, p in net.named_parameters()
+            if not n.startswith(("encoder.x3d.blocks.4.", "encoder.x3d.blocks.5."))]
+    assert sum(used) - 3 * 256 * 256 == 1_542_656  # paper Table 1: 1.54 M
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model"), reason="reference tree only exists in the build container")
+def test_oracle_equals_imported_reference():
+    from oracle import model as om, ref_import, synth
+    tr, mu, _ = ref_import.import_reference()
+    args = om.make_args(size=32)
+    ref, ora = tr.Trainer(args), om.Trainer(args)
+    assert list(ref.state_dict().keys()) == list(ora.state_dict().keys())
+    sd = synth.synth_state_dict(ora, seed=3)
+    ref.load_state_dict(sd); ora.load_state_dict(sd)
+    pre, post, tgt = synth.synth_batch(2, 32, seed=1)
+    a, b = ref.update_bcd(pre, post), ora.update_bcd(pre, post)
+    assert torch.equal(a, b)
+    la, lb = mu.BCEDiceLoss(a, tgt), om.bce_dice_loss(b, tgt)
+    la.backward(); lb.backward()
+    for (n, p), (_, q) in zip(ref.named_parameters(), ora.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), n
+
+
+# ------------------------------------------------------------------------------ C ABI library
+def test_library_loads_and_exports_every_declared_symbol():
+    from change3d_amd import _lib
+    if not os.path.isfile(_lib.LIB_PATH):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g.build(verbose=False)
+    names = _lib.check_exports()
+    header = open(os.path.join(ROOT, "include", "change3d_hip.h")).read()
+    declared = set(re.findall(r"\b(c3d_[A-Za-z0-9_]+)\s*\(", header))
+    assert declared == set(names), declared ^ set(names)
+    assert b"gfx950" in _lib.lib().c3d_build_info()
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from change3d_amd import _lib
+    from change3d_amd.model.trainer import Trainer
+    from oracle import model as om, synth
+    net = Trainer(om.make_args(size=32))
+    pre, post, _ = synth.synth_batch(1, 32)
+    with pytest.raises(_lib.Change3DHipError):
+        net.update_bcd(pre, post)  # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------- host logic
+def test_module_surface_matches_reference_keys():
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.x3d import create_x3d
+    from oracle import model as om
+    mine, ora = Trainer(om.make_args(size=64)), om.Trainer(om.make_args(size=64))
+    assert list(mine.state_dict().keys()) == list(ora.state_dict().keys())
+    for (k, a), b in zip(mine.state_dict().items(), ora.state_dict().values()):
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+    net = create_x3d(input_clip_length=3, depth_factor=5.0)
+    assert len(net.blocks) == 6 and len(net.state_dict()) == 1141
+    assert [len(net.blocks[i].res_blocks) for i in (1, 2, 3, 4)] == [5, 10, 25, 15]
+    with pytest.raises(NotImplementedError):
+        create_x3d(input_clip_length=3, depth_factor=5.0, head_bn_lin5_on=True)
+    mine.load_state_dict(ora.state_dict(), strict=True)  # reference checkpoints strict-load
+
+
+def test_lr_schedule_and_weight_init_mirror():
+    from types import SimpleNamespace
+    from change3d_amd.model.utils import adjust_learning_rate
+    from oracle import model as om
+    args = SimpleNamespace(lr_mode="poly", lr=2e-4, max_epochs=3, step_loss=100)
+    opt = SimpleNamespace(param_groups=[{"lr": 0.0}])
+    for epoch, it in [(0, 0), (0, 199), (0, 200), (1, 5000), (2, 11999)]:
+        lr = adjust_learning_rate(args, opt, epoch, it, 4000)
+        assert abs(lr - om.poly_lr(2e-4, it, 12000, epoch)) < 1e-18
+        assert opt.param_groups[0]["lr"] == lr
+    with pytest.raises(ValueError):
+        adjust_learning_rate(SimpleNamespace(lr_mode="cosine", lr=1.0), opt, 0, 0, 1)
+
+
+def test_param_arena_views_and_zero_grad():
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.utils import ParamArena, hot_path_named_params
+    from change3d_amd.parallel import ordered_hot_params
+    from oracle import model as om
+    net = Trainer(om.make_args(size=32))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    named, n_late = ordered_hot_params(net)
+    assert {n for n, _ in named} == {n for n, _ in hot_path_named_params(net)}
+    assert all(not n.startswith(("encoder.x3d.blocks.3.", "encoder.fc.3.", "decoder")) for n, _ in named[:n_late])
+    arena = ParamArena(named, torch.device("cpu"))
+    assert sum(p.numel() for _, p in named) <= arena.numel
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    p = dict(net.named_parameters())["decoder.up_c1.0.weight"]
+    p.grad.add_(1.0)
+    assert arena.flat_grad.sum().item() == p.numel()
+    p.grad = None
+    arena.zero_grad()
+    assert p.grad is not None and arena.flat_grad.abs().sum().item() == 0
+    assert dict(net.named_parameters())["encoder.x3d.blocks.4.res_blocks.0.branch2.conv_a.weight"].grad is None
+
+
+# ------------------------------------------------------------------- 2-rank gloo gradient sync
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.parallel import GradSync, broadcast_module_state, setup_data_parallel
+    from oracle import model as om, synth
+    torch.manual_seed(100 + rank)               # different init per rank, fixed by the broadcast
+    net = Trainer(om.make_args(size=32))
+    broadcast_module_state(net)
+    arena, sync = setup_data_parallel(net, torch.device("cpu"), overlap=True)
+    assert isinstance(sync, GradSync) and sync.world == world
+    # rank-local gradients = oracle gradients on this rank's shard (the HIP path needs a GPU)
+    ora = om.Trainer(om.make_args(size=32))
+    ora.load_state_dict(net.state_dict())
+    ora.train()
+    pre, post, tgt = synth.synth_batch(2, 32, seed=rank)
+    om.bce_dice_loss(ora.update_bcd(pre, post), tgt).backward()
+    og = dict(ora.named_parameters())
+    arena.zero_grad()
+    for n, p in zip(arena.names, arena.params):
+        p.grad.copy_(og[n].grad)
+    hook = net.encoder.x3d.blocks[3].post_backward
+    assert hook is not None
+    hook()          # overlapped tail bucket (decoder / fc.3 / res4), as issued from stage backward
+    sync.finish()   # remaining head + average
+    flat = arena.flat_grad.clone()
+    local = torch.cat([og[n].grad.reshape(-1) for n in arena.names])
+    q.put((rank, flat.numpy(), local.numpy(), [int(o) for o in arena.offsets],
+           [int(p.numel()) for p in arena.params], float(next(net.parameters()).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce_is_mean_of_local_grads():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, f0, l0, offs, sizes, s0), (_, f1, l1, _, _, s1) = res
+    assert s0 == s1                       # parameters identical after the broadcast
+    assert np.array_equal(f0, f1)         # both ranks hold the same reduced buffer
+    mean = 0.5 * (l0 + l1)
+    pos = 0
+    for o, n in zip(offs, sizes):
+        assert np.allclose(f0[o:o + n], mean[pos:pos + n], rtol=1e-6, atol=1e-9)
+        pos += n

@@ -1,0 +1,356 @@
+"""GPU parity tests, op level: every kernel family called through the C ABI (ctypes) and
+compared with a plain PyTorch-CPU fp32 computation of the same operation.
+f32 storage: tight tolerances (parity path).  bf16 storage: tolerances sized for bf16 rounding.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def tol(dtype):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (3e-2, 3e-2)
+
+
+def close(a, b, dtype, what, scale=1.0):
+    at, rt = tol(dtype)
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    err = (a - b).abs()
+    lim = at * scale + rt * b.abs()
+    bad = (err > lim).sum().item()
+    assert bad == 0, f"{what}: {bad}/{err.numel()} out of tolerance, max err {err.max().item():.3e}, ref max {b.abs().max().item():.3e}"
+
+
+def padc(t, cp):
+    """[..., C] -> [..., Cp] zero padded."""
+    c = t.shape[-1]
+    return t if c == cp else F.pad(t, (0, cp - c))
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def q(t, dtype):
+    """quantise reference input the way the device tensor stores it."""
+    return t.to(dtype).float()
+
+
+# --------------------------------------------------------------------------- pointwise GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("K,N", [(24, 54), (54, 24), (48, 108), (108, 48), (96, 216), (216, 96), (24, 24)])
+def test_pw_gemm_plain_stats(dtype, K, N):
+    _need_gpu()
+    from change3d_amd import ops
+    M = 16 * 37 + 5
+    Kp, Np = ops.cpad(K), ops.cpad(N)
+    x = q(rnd((M, K), 1), dtype)
+    w = rnd((N, K), 2, 0.2)
+    ref = x @ w.t()
+    xd = padc(x, Kp).to(DEV, dtype).contiguous()
+    y = torch.full((M, Np), float("nan"), dtype=dtype, device=DEV)
+    stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    ops.pw_gemm(xd, w.to(DEV), y, M=M, K=K, N=N, w_sn=K, w_sk=1, dtype=ops.dt_code(dtype),
+                epi_mode=ops.EPI_STATS, stats=stats)
+    torch.cuda.synchronize()
+    close(y[:, :N], ref, dtype, "y", scale=ref.abs().max().item())
+    if Np > N:
+        assert (y[:, N:].float() == 0).all(), "pad channels must be zero"
+    yq = y[:, :N].float().cpu().double()
+    s = stats.cpu()
+    assert torch.allclose(s[:N], yq.sum(0), rtol=1e-5, atol=1e-3), "column sums"
+    assert torch.allclose(s[N:], (yq * yq).sum(0), rtol=1e-5, atol=1e-3), "column sums of squares"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pw_gemm_bn_se_swish_prologue(dtype):
+    _need_gpu()
+    from change3d_amd import ops
+    B, rows, K, N = 3, 48, 54, 24
+    M = B * rows
+    Kp = ops.cpad(K)
+    x = q(rnd((M, K), 3), dtype)
+    w = rnd((N, K), 4, 0.2)
+    scale, shift = rnd((K,), 5).abs() + 0.5, rnd((K,), 6, 0.3)
+    gate = torch.sigmoid(rnd((B, K), 7))
+    v = (x * scale + shift).view(B, rows, K) * gate[:, None, :]
+    ref = (v * torch.sigmoid(v)).view(M, K) @ w.t()
+    ss = torch.cat([padc(scale, Kp), padc(shift, Kp)]).to(DEV)
+    y = torch.empty((M, ops.cpad(N)), dtype=dtype, device=DEV)
+    ops.pw_gemm(padc(x, Kp).to(DEV, dtype).contiguous(), w.to(DEV), y, M=M, K=K, N=N, w_sn=K, w_sk=1,
+                dtype=ops.dt_code(dtype), pro_mode=ops.PRO_BN_SE_SWISH, pro_p=ss,
+                pro_gate=padc(gate, Kp).to(DEV).contiguous(), rows_per_sample=rows)
+    close(y[:, :N], ref, dtype, "y", scale=ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pw_gemm_affine2_transposed_add(dtype):
+    _need_gpu()
+    from change3d_amd import ops
+    M, K, N = 16 * 9, 54, 24      # data-gradient shape of conv_a: g[M,54] @ W[54,24]
+    Kp = ops.cpad(K)
+    g, a = q(rnd((M, K), 8), dtype), q(rnd((M, K), 9), dtype)
+    A, Bc, Cc = rnd((K,), 10), rnd((K,), 11, 0.1), rnd((K,), 12, 0.1)
+    wt = rnd((K, N), 13, 0.2)     # stored as conv weight [out=K][in=N]
+    res = q(rnd((M, N), 14), dtype)
+    ref = (A * g + Bc + Cc * a) @ wt + res
+    coef = torch.cat([padc(A, Kp), padc(Bc, Kp), padc(Cc, Kp)]).to(DEV)
+    y = torch.empty((M, ops.cpad(N)), dtype=dtype, device=DEV)
+    ops.pw_gemm(padc(g, Kp).to(DEV, dtype).contiguous(), wt.to(DEV), y, M=M, K=K, N=N, w_sn=1, w_sk=N,
+                dtype=ops.dt_code(dtype), x2=padc(a, Kp).to(DEV, dtype).contiguous(), pro_mode=ops.PRO_AFFINE2,
+                pro_p=coef, epi_mode=ops.EPI_ADD, e1=res.to(DEV, dtype).contiguous(), res_mode=0)
+    close(y[:, :N], ref, dtype, "y", scale=ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pw_gemm_stride2_gather_and_scatter_add(dtype):
+    _need_gpu()
+    from change3d_amd import ops
+    BT, H, W, K, N = 4, 8, 12, 24, 48
+    x = q(rnd((BT, H, W, K), 15), dtype)
+    w = rnd((N, K), 16, 0.2)
+    ref = x[:, ::2, ::2].reshape(-1, K) @ w.t()
+    Mo = BT * (H // 2) * (W // 2)
+    y = torch.empty((Mo, N), dtype=dtype, device=DEV)
+    ops.pw_gemm(x.to(DEV, dtype).contiguous(), w.to(DEV), y, M=Mo, K=K, N=N, w_sn=K, w_sk=1,
+                dtype=ops.dt_code(dtype), row_mode=ops.ROWS_STRIDE2, H=H, W=W)
+    close(y, ref, dtype, "gather", scale=ref.abs().max().item())
+    # scatter-add: out[M_full, K2] = z @ w2^T + (res at even pixels)
+    K2, N2 = 48, 24
+    z = q(rnd((BT * H * W, K2), 17), dtype)
+    w2 = rnd((N2, K2), 18, 0.2)
+    res = q(rnd((BT, H // 2, W // 2, N2), 19), dtype)
+    full = torch.zeros(BT, H, W, N2)
+    full[:, ::2, ::2] = res
+    ref2 = z @ w2.t() + full.view(-1, N2)
+    y2 = torch.empty((BT * H * W, N2), dtype=dtype, device=DEV)
+    ops.pw_gemm(z.to(DEV, dtype).contiguous(), w2.to(DEV), y2, M=BT * H * W, K=K2, N=N2, w_sn=K2, w_sk=1,
+                dtype=ops.dt_code(dtype), epi_mode=ops.EPI_ADD, e1=res.to(DEV, dtype).contiguous(), res_mode=1,
+                H=H, W=W)
+    close(y2, ref2, dtype, "scatter-add", scale=ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pw_gemm_swish_se_bwd_epilogue(dtype):
+    _need_gpu()
+    from change3d_amd import ops
+    B, rows, K, N = 2, 32, 24, 54
+    M = B * rows
+    Np = ops.cpad(N)
+    g = q(rnd((M, K), 20), dtype)
+    w = rnd((K, N), 21, 0.2)  # conv_c weight [out=K=24][in=N=54]; data-grad = g @ w
+    b = q(rnd((M, N), 22), dtype)
+    scale, shift = rnd((N,), 23).abs() + 0.5, rnd((N,), 24, 0.3)
+    gate = torch.sigmoid(rnd((B, N), 25))
+    dsb = g @ w
+    pb = b * scale + shift
+    gg = gate.repeat_interleave(rows, 0)
+    qv = gg * pb
+    sg = torch.sigmoid(qv)
+    dq = dsb * sg * (1 + qv * (1 - sg))
+    t1 = dq * gg
+    y = torch.empty((M, Np), dtype=dtype, device=DEV)
+    nc3 = torch.zeros(B * Np * 3, dtype=torch.float64, device=DEV)
+    ss = torch.cat([padc(scale, Np), padc(shift, Np)]).to(DEV)
+    ops.pw_gemm(g.to(DEV, dtype).contiguous(), w.to(DEV), y, M=M, K=K, N=N, w_sn=1, w_sk=N, dtype=ops.dt_code(dtype),
+                epi_mode=ops.EPI_SWISH_SE_BWD, e1=padc(b, Np).to(DEV, dtype).contiguous(), epi_p=ss,
+                epi_gate=padc(gate, Np).to(DEV).contiguous(), stats=nc3, rows_per_sample=rows)
+    close(y[:, :N], t1, dtype, "t1", scale=t1.abs().max().item())
+    s = nc3.cpu().view(B, Np, 3)[:, :N]
+    t1q = y[:, :N].float().cpu()
+    ref0 = (dq * pb).view(B, rows, N).sum(1).double()
+    ref1 = t1q.view(B, rows, N).sum(1).double()
+    ref2 = (t1q * b).view(B, rows, N).sum(1).double()
+    rt = 1e-4 if dtype == torch.float32 else 3e-2
+    assert torch.allclose(s[..., 0], ref0, rtol=rt, atol=rt * ref0.abs().max().item()), "sum dq*pb"
+    assert torch.allclose(s[..., 1], ref1, rtol=1e-4, atol=1e-3), "sum t1"
+    assert torch.allclose(s[..., 2], ref2, rtol=1e-4, atol=1e-3), "sum t1*b"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("K,N", [(24, 54), (216, 96), (96, 216), (48, 48)])
+def test_pw_wgrad(dtype, K, N):
+    _need_gpu()
+    from change3d_amd import ops
+    B, rows = 2, 200
+    M = B * rows
+    Kp, Np = ops.cpad(K), ops.cpad(N)
+    p, p2 = q(rnd((M, N), 30), dtype), q(rnd((M, N), 31), dtype)
+    A, Bc, Cc = rnd((N,), 32), rnd((N,), 33, 0.1), rnd((N,), 34, 0.1)
+    x = q(rnd((M, K), 35), dtype)
+    scale, shift = rnd((K,), 36).abs() + 0.5, rnd((K,), 37, 0.3)
+    gate = torch.sigmoid(rnd((B, K), 38))
+    P = A * p + Bc + Cc * p2
+    v = (x * scale + shift) * gate.repeat_interleave(rows, 0)
+    Q = v * torch.sigmoid(v)
+    ref = P.t() @ Q + 1.0
+    dw = torch.ones((N, K), dtype=torch.float32, device=DEV)  # accumulate semantics (+=)
+    ops.pw_wgrad(padc(p, Np).to(DEV, dtype).contiguous(), padc(x, Kp).to(DEV, dtype).contiguous(), dw, M=M, K=K, N=N,
+                 dw_sn=K, dw_sk=1, dtype=ops.dt_code(dtype), p2=padc(p2, Np).to(DEV, dtype).contiguous(),
+                 p_coef=torch.cat([padc(A, Np), padc(Bc, Np), padc(Cc, Np)]).to(DEV), q_mode=ops.PRO_BN_SE_SWISH,
+                 q_ss=torch.cat([padc(scale, Kp), padc(shift, Kp)]).to(DEV),
+                 q_gate=padc(gate, Kp).to(DEV).contiguous(), rows_per_sample=rows)
+    close(dw, ref, dtype, "dW", scale=ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pw_wgrad_row_modes(dtype):
+    _need_gpu()
+    from change3d_amd import ops
+    B, H, W, C = 2, 8, 8, 24
+    # stride-2 gather (shortcut conv): dW[n,k] = sum g[m,n] * x[b,2i,2j,k]
+    x = q(rnd((B, H, W, C), 40), dtype)
+    g = q(rnd((B * (H // 2) * (W // 2), 48), 41), dtype)
+    ref = g.t() @ x[:, ::2, ::2].reshape(-1, C)
+    dw = torch.zeros((48, C), dtype=torch.float32, device=DEV)
+    ops.pw_wgrad(g.to(DEV, dtype).contiguous(), x.to(DEV, dtype).contiguous(), dw, M=g.shape[0], K=C, N=48, dw_sn=C,
+                 dw_sk=1, dtype=ops.dt_code(dtype), row_mode=ops.ROWS_STRIDE2, H=H, W=W)
+    close(dw, ref, dtype, "stride2", scale=ref.abs().max().item())
+    # shifted stride-2 gather with zero padding (ConvTranspose weight gradient, one tap)
+    h, w = 4, 4
+    t = q(rnd((B * h * w, C), 42), dtype)
+    dout = q(rnd((B, 2 * h, 2 * w, C), 43), dtype)
+    for (ky, kx) in [(0, 0), (1, 2), (3, 3)]:
+        gath = torch.zeros(B, h, w, C)
+        for i in range(h):
+            for j in range(w):
+                yy, xx = 2 * i - 1 + ky, 2 * j - 1 + kx
+                if 0 <= yy < 2 * h and 0 <= xx < 2 * w:
+                    gath[:, i, j] = dout[:, yy, xx]
+        ref = t.t() @ gath.view(-1, C)
+        dw16 = torch.zeros((C, C, 16), dtype=torch.float32, device=DEV)
+        ops.pw_wgrad(t.to(DEV, dtype).contiguous(), dout.to(DEV, dtype).contiguous(), None, M=B * h * w, K=C, N=C,
+                     dw_sn=C * 16, dw_sk=16, dtype=ops.dt_code(dtype), row_mode=ops.ROWS_S2SHIFT, H=2 * h, W=2 * w,
+                     dy=ky - 1, dx=kx - 1, dw_ptr=dw16.data_ptr() + (ky * 4 + kx) * 4)
+        close(dw16[:, :, ky * 4 + kx], ref, dtype, f"s2shift tap {ky},{kx}", scale=ref.abs().max().item())
+        other = dw16.clone()
+        other[:, :, ky * 4 + kx] = 0
+        assert other.abs().max().item() == 0, "other taps must stay untouched"
+    # frame view rows
+    T = 3
+    full = q(rnd((B, T, h, w, C), 44), dtype)
+    p = q(rnd((B * h * w, 48), 45), dtype)
+    ref = p.t() @ full[:, 1].reshape(-1, C)
+    fd = full.to(DEV, dtype).contiguous()
+    dw = torch.zeros((48, C), dtype=torch.float32, device=DEV)
+    ops.pw_wgrad(p.to(DEV, dtype).contiguous(), None, dw, M=B * h * w, K=C, N=48, dw_sn=C, dw_sk=1,
+                 dtype=ops.dt_code(dtype), row_mode=ops.ROWS_FRAME, rpg=h * w, gstride=T * h * w * C,
+                 q_ptr=fd.data_ptr() + 1 * h * w * C * fd.element_size())
+    close(dw, ref, dtype, "frame", scale=ref.abs().max().item())
+
+
+# --------------------------------------------------------------------------------- depthwise
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("C,T", [(54, 3), (108, 5)])
+def test_dw333_fwd_bwd(dtype, stride, C, T):
+    _need_gpu()
+    from change3d_amd import ops
+    B, H, W = 2, 12, 20
+    Cp = ops.cpad(C)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    a = q(rnd((B, T, H, W, C), 50), dtype)
+    scale, shift = rnd((C,), 51).abs() + 0.5, rnd((C,), 52, 0.3)
+    w = rnd((C, 1, 3, 3, 3), 53, 0.3)
+    a_r = a.clone().requires_grad_(True)
+    w_r = w.clone().requires_grad_(True)
+    ra = torch.relu(a_r * scale + shift).permute(0, 4, 1, 2, 3)
+    bref = F.conv3d(ra, w_r, stride=(1, stride, stride), padding=1, groups=C)   # [B,C,T,Ho,Wo]
+    ss = torch.cat([padc(scale, Cp), padc(shift, Cp)]).to(DEV)
+    ad = padc(a, Cp).to(DEV, dtype).contiguous()
+    b = torch.full((B, T, Ho, Wo, Cp), float("nan"), dtype=dtype, device=DEV)
+    nc = torch.zeros(B * Cp * 2, dtype=torch.float64, device=DEV)
+    ops.dw_fwd(ad, ss, w.to(DEV).contiguous(), b, nc, B, T, H, W, C, stride, ops.dt_code(dtype))
+    bre = bref.detach().permute(0, 2, 3, 4, 1)
+    close(b[..., :C], bre, dtype, "dw fwd", scale=bre.abs().max().item())
+    if Cp > C:
+        assert (b[..., C:].float() == 0).all()
+    bq = b[..., :C].float().cpu().double()
+    s = nc.cpu().view(B, Cp, 2)[:, :C]
+    assert torch.allclose(s[..., 0], bq.sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[..., 1], (bq * bq).sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+    # backward: db = cA*t1 + cB[n] + cC*b ; check data grad (with relu mask) + sums + weight grad
+    t1 = q(rnd((B, T, Ho, Wo, C), 54), dtype)
+    cA, cC, cB = rnd((C,), 55), rnd((C,), 56, 0.1), rnd((B, C), 57, 0.1)
+    bst = b[..., :C].float().cpu()
+    db = cA * t1 + cB[:, None, None, None, :] + cC * bst
+    bref.backward(db.permute(0, 4, 1, 2, 3))
+    t2_ref = a_r.grad                                   # includes relu mask and scale...
+    # device returns d(relu out) masked, i.e. grad wrt pa = a*scale+shift  => divide scale out
+    t2_ref = t2_ref / scale
+    t2 = torch.empty_like(ad)
+    dsums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    t1d = padc(t1, Cp).to(DEV, dtype).contiguous()
+    ops.dw_bwd_data(t1d, b, padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV),
+                    w.to(DEV).contiguous(), ad, ss, t2, dsums, B, T, H, W, C, stride, ops.dt_code(dtype))
+    close(t2[..., :C], t2_ref, dtype, "dw bwd data", scale=t2_ref.abs().max().item())
+    t2q = t2[..., :C].float().cpu().double()
+    sd = dsums.cpu()
+    assert torch.allclose(sd[:C], t2q.sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(sd[C:], (t2q * a.double()).sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3)
+    dw = torch.zeros((C, 27), dtype=torch.float32, device=DEV)
+    ops.dw_wgrad(t1d, b, padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV), ad, ss, dw,
+                 B, T, H, W, C, stride, ops.dt_code(dtype))
+    close(dw, w_r.grad.view(C, 27), dtype, "dw wgrad", scale=w_r.grad.abs().max().item())
+
+
+# --------------------------------------------------------------------------- loss / optimizer
+def test_bce_dice_and_adam():
+    _need_gpu()
+    from change3d_amd.model.utils import BCEDiceLoss
+    from change3d_amd import ops
+    p = torch.sigmoid(rnd((2, 1, 32, 32), 60, 3.0))
+    p[0, 0, 0, 0], p[0, 0, 0, 1] = 1.0, 0.0  # saturated probabilities exercise the clamps
+    t = (rnd((2, 1, 32, 32), 61) > 0.8).float()
+    pr = p.clone().requires_grad_(True)
+    bce = F.binary_cross_entropy(pr, t)
+    inter = (pr * t).sum()
+    lref = bce + 1 - (2 * inter + 1e-5) / (pr.sum() + t.sum() + 1e-5)
+    lref.backward()
+    pd = p.to(DEV).requires_grad_(True)
+    loss = BCEDiceLoss(pd, t.to(DEV))
+    (loss * 1.0).backward()
+    assert abs(loss.item() - lref.item()) < 1e-5 * max(1.0, abs(lref.item()))
+    gd, gr = pd.grad.cpu(), pr.grad
+    assert torch.allclose(gd, gr, rtol=1e-4, atol=1e-6 * gr.abs().max().item() + 1e-9), (gd - gr).abs().max()
+    # Adam
+    n = 1000
+    w0, g0 = rnd((n,), 62), rnd((n,), 63)
+    wr = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.Adam([wr], 2e-4, (0.9, 0.99), eps=1e-8, weight_decay=1e-4)
+    wd = w0.to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        wr.grad = g0 * step
+        opt.step()
+        bc1, bc2 = 1 - 0.9 ** step, 1 - 0.99 ** step
+        ops.adam_step(wd, (g0 * step).to(DEV), m, v, n, None, 2e-4, bc1, bc2 ** 0.5, 0.9, 0.99, 1e-8, 1e-4)
+    assert torch.allclose(wd.cpu(), wr.detach(), rtol=1e-6, atol=1e-7), (wd.cpu() - wr.detach()).abs().max()
+
+
+def test_confusion_matrix():
+    _need_gpu()
+    from change3d_amd.utils.metric_tool import ConfuseMatrixMeter, get_confuse_matrix
+    p = torch.rand(2, 1, 64, 64)
+    p[0, 0, 0, :8] = 0.5  # strict '>' 0.5
+    t = (torch.rand(2, 1, 64, 64) > 0.9).float()
+    meter = ConfuseMatrixMeter(2)
+    meter.update_cm_device(p.to(DEV), t.to(DEV))
+    meter.sync()
+    pred = torch.where(p > 0.5, torch.ones_like(p), torch.zeros_like(p)).long()
+    ref = get_confuse_matrix(2, t.numpy(), pred.numpy())
+    assert (meter.sum == ref).all(), (meter.sum, ref)
