@@ -45,11 +45,26 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size, batch=2, timed=2):
+def usable_cores():
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota
+    (os.cpu_count() reports the host's 256 logical CPUs inside a small-quota container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except OSError:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(size, batch=2, timed=2, budget_s=25.0):
     """Reference arithmetic (oracle = torch-CPU fp32 eager NCDHW port of the reference path),
-    same loss / Adam, on all host cores.  Bounded sample: 1 warm-up + `timed` steps of B=`batch`."""
+    same loss / Adam, on the usable host cores.  Bounded sample: 1 warm-up + up to `timed` steps
+    of B=`batch`, stopping early once `budget_s` seconds of timed work are spent."""
     from oracle import model as om, synth
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     net = om.Trainer(om.make_args(size=size))
     net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25))
@@ -65,14 +80,20 @@ def cpu_baseline(size, batch=2, timed=2):
         opt.step()
         return loss.item()
 
-    one()
     t0 = time.time()
-    for _ in range(timed):
-        one()
-    dt = time.time() - t0
-    return {"value": round(batch * timed / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{timed} timed steps (+1 warm-up) of B={batch} {size}x{size} pairs, fp32, torch-CPU eager, "
-                      f"{cores} threads"}
+    one()
+    warm = time.time() - t0
+    done, t0 = 0, time.time()
+    if warm > budget_s:  # very slow host: the warm-up step is the sample
+        done, dt = 1, warm
+    else:
+        while done < timed and time.time() - t0 < budget_s:
+            one()
+            done += 1
+        dt = time.time() - t0
+    return {"value": round(batch * done / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{done} timed steps of B={batch} {size}x{size} pairs (1 warm-up, {warm:.1f}s), fp32, torch-CPU "
+                      f"eager NCDHW, {cores} threads"}
 
 
 def main():

@@ -20,7 +20,7 @@ vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
 class PwArgs(C.Structure):
     _fields_ = [("x", vp), ("x2", vp), ("y", vp), ("e1", vp), ("w", vp), ("pro_p", vp), ("pro_gate", vp),
-                ("epi_p", vp), ("epi_gate", vp), ("stats", vp),
+                ("epi_p", vp), ("epi_gate", vp), ("epi_q", vp), ("stats", vp),
                 ("M", i64), ("gstride", i64), ("rows_per_sample", i64),
                 ("K", i32), ("Kp", i32), ("N", i32), ("Np", i32), ("w_sn", i32), ("w_sk", i32),
                 ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32),
@@ -51,11 +51,11 @@ SIGNATURES = {
     "c3d_se_bn_bwd_coef": (i32, [vp, vp, i32, f64, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp,
                                  vp, vp, vp, vp, vp, vp]),
     "c3d_dw333_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "c3d_dw333_bwd_data": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
+    "c3d_dw333_bwd_data": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
                                  i32, vp]),
     "c3d_dw333_wgrad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_block_out_fwd": (i32, [vp, vp, vp, vp, i32, vp, i64, i32, i32, vp]),
-    "c3d_block_out_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "c3d_block_out_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "c3d_frame_absdiff": (i32, [vp, vp, i32, i32, i64, i32, i32, i32, i32, vp]),
     "c3d_enhance_apply": (i32, [vp, vp, vp, i32, i32, i64, i32, i32, i32, vp]),
     "c3d_enhance_bwd_mask": (i32, [vp, vp, vp, i32, i32, i64, i32, i32, i32, vp]),

@@ -22,7 +22,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && training && nbt) *nbt += 1;
   if (c >= Cp) return;
-  if (c >= C) { ss[c] = 0.f; ss[Cp + c] = 0.f; return; }
+  if (c >= C) { ss[c] = 0.f; ss[Cp + c] = 0.f; if (mr) { mr[c] = 0.f; mr[Cp + c] = 0.f; } return; }
   double mean, var;
   if (training) {
     mean = sums[c] / count;
@@ -42,7 +42,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   const float sc = gamma[c] * rstd;
   ss[c] = sc;
   ss[Cp + c] = beta[c] - meanf * sc;
-  if (mr) { mr[c] = meanf; mr[C + c] = rstd; }
+  if (mr) { mr[c] = meanf; mr[Cp + c] = rstd; }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void bn_se_finalize_kernel(
   const double count = cnt_per_sample * B;
   if (tid == 0 && training && nbt) *nbt += 1;
   for (int c = tid; c < Cp; c += blockDim.x) {
-    if (c >= C) { ss[c] = 0.f; ss[Cp + c] = 0.f; continue; }
+    if (c >= C) { ss[c] = 0.f; ss[Cp + c] = 0.f; if (mr) { mr[c] = 0.f; mr[Cp + c] = 0.f; } continue; }
     double mean, var;
     if (training) {
       double s1 = 0, s2 = 0;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void bn_se_finalize_kernel(
     const float sh = beta[c] - meanf * sc;
     ss[c] = sc;
     ss[Cp + c] = sh;
-    if (mr) { mr[c] = meanf; mr[C + c] = rstd; }
+    if (mr) { mr[c] = meanf; mr[Cp + c] = rstd; }
     if (w1) {
       for (int n = 0; n < B; ++n)
         z[(size_t)n * C + c] = fmaf(sc, (float)(nc[((size_t)n * Cp + c) * 2] / cnt_per_sample), sh);
@@ -114,16 +114,17 @@ __global__ __launch_bounds__(256) void bn_se_finalize_kernel(
 }
 
 // -------------------------------------------------------------------------------------------
-// BN backward coefficients: dsums [2][C] = (sum g, sum g*x).  dx = A*g + B + C*x.
+// BN backward coefficients: dsums [2][C] = (sum g, sum g*xhat), xhat = (x-mean)*rstd accumulated
+// CENTRED by the producer (as ATen does; avoids the sum(g*x) - mean*sum(g) cancellation).
+// dx = A*g + B + C*x.
 __global__ void bn_bwd_coef_kernel(const double* __restrict__ dsums, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ mr, int C, int Cp, float* __restrict__ coef,
                                    float* dgamma, float* dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cp) return;
   if (c >= C) { coef[c] = 0.f; coef[Cp + c] = 0.f; coef[2 * Cp + c] = 0.f; return; }
-  const double mean = mr[c], rstd = mr[C + c];
-  const double s1 = dsums[c], sgx = dsums[C + c];
-  const double s2 = rstd * (sgx - mean * s1);  // sum g * xhat
+  const double mean = mr[c], rstd = mr[Cp + c];
+  const double s1 = dsums[c], s2 = dsums[C + c];  // sum g, sum g * xhat
   const double A = (double)gamma[c] * rstd;
   const double Cc = -A * rstd * s2 / count;
   const double Bc = -A * s1 / count - Cc * mean;
@@ -136,7 +137,7 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ dsums, double coun
 
 // -------------------------------------------------------------------------------------------
 // SE backward + BN_b backward coefficients.
-//   nc3 [B][Cp][3] = per (n,c): sum dq*pb (d gate), sum t1, sum t1*b
+//   nc3 [B][Cp][3] = per (n,c): sum dq*pb (d gate), sum t1, sum t1*bhat   (bhat = (b-mean)*rstd)
 //   ncf [B][Cp][2] = forward per (n,c): sum b, sum b^2
 //   db = A[c]*t1 + Bnc[n][c] + Cc[c]*b
 __global__ __launch_bounds__(256) void se_bn_bwd_coef_kernel(
@@ -203,14 +204,15 @@ __global__ __launch_bounds__(256) void se_bn_bwd_coef_kernel(
       for (int n = 0; n < B; ++n) coefB[(size_t)n * Cp + c] = 0.f;
       continue;
     }
-    const double mean = mr[c], rstd = mr[C + c];
-    double s1 = 0, sgb = 0;
+    const double mean = mr[c], rstd = mr[Cp + c];
+    double s1 = 0, s2 = 0;
     for (int n = 0; n < B; ++n) {
       const double dzn = se ? (double)dz[(size_t)n * C + c] : 0.0;
       s1 += nc3[((size_t)n * Cp + c) * 3 + 1] + dzn;
-      sgb += nc3[((size_t)n * Cp + c) * 3 + 2] + dzn / cnt_per_sample * ncf[((size_t)n * Cp + c) * 2];
+      // the uniform SE term dz/cnt multiplies sum_thw bhat = rstd * (sum b - cnt*mean)
+      s2 += nc3[((size_t)n * Cp + c) * 3 + 2] +
+            dzn / cnt_per_sample * rstd * (ncf[((size_t)n * Cp + c) * 2] - cnt_per_sample * mean);
     }
-    const double s2 = rstd * (sgb - mean * s1);
     const double A = (double)gamma[c] * rstd;
     const double Cc = -A * rstd * s2 / count;
     coefA[c] = (float)A;

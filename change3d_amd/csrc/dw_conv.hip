@@ -7,7 +7,7 @@
 //              out = raw conv output b; epilogue = per-(sample,channel) sum / sum-of-squares
 //              (feeds BN_b statistics and the SE squeeze).
 //   bwd_data : in  = db = A[c]*t1 + B[n][c] + C[c]*b applied while staging (BN_b/SE backward);
-//              out = t2 = dconv * (a*scale_a+shift_a > 0); epilogue = per-channel sum t2, sum t2*a
+//              out = t2 = dconv * (a*scale_a+shift_a > 0); epilogue = per-channel sum t2, sum t2*ahat
 //   wgrad    : dW[c][kt][ky][kx] += sum db[out] * relu(bn(a))[in]
 //
 // All T frames of a spatial tile are resident in LDS (T = 3 for BCD, 5 for SCD).  A thread
@@ -174,8 +174,8 @@ template <typename T, int S, int TH, int TW>
 __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
     const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
     const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
-    const T* __restrict__ a, const float* __restrict__ ss_a, T* __restrict__ t2, double* __restrict__ dsums,
-    const DwGeom g) {
+    const T* __restrict__ a, const float* __restrict__ ss_a, const float* __restrict__ mr_a, T* __restrict__ t2,
+    double* __restrict__ dsums, const DwGeom g) {
   typedef typename LdsStore<T>::type L;
   // dra[iy] gathers db[(iy + 1 - ky)/S]; for a TH-row tile starting at y0 (multiple of S*... ) the
   // db rows needed span floor((y0-1)/S) .. floor((y0+TH)/S)
@@ -281,10 +281,11 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
     }
   }
 
-  float sa[8], sb[8], s1[8], s2[8];
+  float sa[8], sb[8], s1[8], s2[8], ma[8], ra[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     sa[j] = c_ok ? ss_a[cbase + j] : 0.f; sb[j] = c_ok ? ss_a[g.Cp + cbase + j] : 0.f;
+    ma[j] = c_ok ? mr_a[cbase + j] : 0.f; ra[j] = c_ok ? mr_a[g.Cp + cbase + j] : 0.f;
     s1[j] = 0.f; s2[j] = 0.f;
   }
   if (p_ok) {
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
           const float pa = fmaf(av[j], sa[j], sb[j]);
           const float d = round_as<T>(pa > 0.f ? acc[t][j] : 0.f);
           o[j] = d;
-          s1[j] += d; s2[j] += d * av[j];
+          s1[j] += d; s2[j] += d * ((av[j] - ma[j]) * ra[j]);
         }
         Vec8<T>::store(t2 + off, o);
       }
@@ -484,8 +485,8 @@ int launch_fwd(const void* x, const float* ss, const float* w, void* y, double* 
 
 template <typename T, int S>
 int launch_bwd_data(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC,
-                    const float* w, const void* a, const float* ss_a, void* t2, double* dsums, const DwGeom& g,
-                    hipStream_t stream) {
+                    const float* w, const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums,
+                    const DwGeom& g, hipStream_t stream) {
   constexpr int TH = 8, TW = 8;
   constexpr int DH = (S == 1) ? TH + 2 : TH / 2 + 2, DW_ = (S == 1) ? TW + 2 : TW / 2 + 2;
   constexpr int NTHR = TH * TW * DW_CV;
@@ -502,7 +503,7 @@ int launch_bwd_data(const void* t1, const void* bb, const float* cA, const float
   dim3 grid(((g.W + TW - 1) / TW) * ((g.H + TH - 1) / TH), (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), g.B);
   dw_bwd_data_kernel<T, S, TH, TW><<<grid, dim3(NTHR), lds, stream>>>(
       reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, w, reinterpret_cast<const T*>(a),
-      ss_a, reinterpret_cast<T*>(t2), dsums, g);
+      ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, g);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -557,20 +558,20 @@ extern "C" int c3d_dw333_fwd(const void* x, const float* ss, const float* w, voi
 }
 
 extern "C" int c3d_dw333_bwd_data(const void* t1, const void* b, const float* coefA, const float* coefB,
-                                  const float* coefC, const float* w, const void* a, const float* ss_a, void* t2,
-                                  double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
+                                  const float* coefC, const float* w, const void* a, const float* ss_a,
+                                  const float* mr_a, void* t2, double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
                                   int32_t stride, int32_t dtype, void* stream) {
   DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
-  if (!t1 || !b || !coefA || !coefB || !coefC || !w || !a || !ss_a || !t2 || !dsums || !geom_ok(g))
+  if (!t1 || !b || !coefA || !coefB || !coefC || !w || !a || !ss_a || !mr_a || !t2 || !dsums || !geom_ok(g))
     return C3D_E_BADARG;
   if (stride == 2 && ((H | W) & 1)) return C3D_E_UNSUPPORTED;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == C3D_DT_F32)
-    return stride == 1 ? launch_bwd_data<float, 1>(t1, b, coefA, coefB, coefC, w, a, ss_a, t2, dsums, g, s)
-                       : launch_bwd_data<float, 2>(t1, b, coefA, coefB, coefC, w, a, ss_a, t2, dsums, g, s);
+    return stride == 1 ? launch_bwd_data<float, 1>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, g, s)
+                       : launch_bwd_data<float, 2>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, g, s);
   if (dtype == C3D_DT_BF16)
-    return stride == 1 ? launch_bwd_data<bf16_t, 1>(t1, b, coefA, coefB, coefC, w, a, ss_a, t2, dsums, g, s)
-                       : launch_bwd_data<bf16_t, 2>(t1, b, coefA, coefB, coefC, w, a, ss_a, t2, dsums, g, s);
+    return stride == 1 ? launch_bwd_data<bf16_t, 1>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, g, s)
+                       : launch_bwd_data<bf16_t, 2>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, g, s);
   return C3D_E_BADARG;
 }
 

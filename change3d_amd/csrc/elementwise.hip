@@ -42,16 +42,23 @@ __global__ void block_out_fwd_kernel(const T* __restrict__ c, const float* __res
   }
 }
 
-// g = dy * (y > 0); dsums_c += (sum g, sum g*c); dsums_1 += (sum g, sum g*s) when the shortcut has BN
+// g = dy * (y > 0); dsums_c += (sum g, sum g*chat); dsums_1 += (sum g, sum g*shat) when the shortcut
+// has BN, with chat = (c - mean)*rstd accumulated centred (mr = mean[Cp], rstd[Cp]).
 template <typename T>
 __global__ void block_out_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ c,
-                                     const T* __restrict__ s, T* __restrict__ g, double* __restrict__ dsums_c,
+                                     const T* __restrict__ s, T* __restrict__ g, const float* __restrict__ mr_c,
+                                     const float* __restrict__ mr_1, double* __restrict__ dsums_c,
                                      double* __restrict__ dsums_1, int64_t nvec, int G, int C) {
   extern __shared__ float red[];  // [blockDim][24]
   const int v = threadIdx.x % G;
-  float s1[8], s2[8], s3[8];
+  const int Cp = G * 8;
+  float s1[8], s2[8], s3[8], mc[8], rc[8], m1[8], r1[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; s3[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = 0.f; s2[j] = 0.f; s3[j] = 0.f;
+    mc[j] = mr_c[v * 8 + j]; rc[j] = mr_c[Cp + v * 8 + j];
+    m1[j] = s ? mr_1[v * 8 + j] : 0.f; r1[j] = s ? mr_1[Cp + v * 8 + j] : 0.f;
+  }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     float d[8], yv[8], cv[8], sv[8];
@@ -63,8 +70,8 @@ __global__ void block_out_bwd_kernel(const T* __restrict__ dy, const T* __restri
     for (int j = 0; j < 8; ++j) {
       const float gg = yv[j] > 0.f ? d[j] : 0.f;
       d[j] = gg;
-      s1[j] += gg; s2[j] += gg * cv[j];
-      if (s) s3[j] += gg * sv[j];
+      s1[j] += gg; s2[j] += gg * ((cv[j] - mc[j]) * rc[j]);
+      if (s) s3[j] += gg * ((sv[j] - m1[j]) * r1[j]);
     }
     Vec8<T>::store(g + i * 8, d);
   }
@@ -224,10 +231,10 @@ extern "C" int c3d_block_out_fwd(const void* c, const float* ss_c, const void* s
 }
 
 extern "C" int c3d_block_out_bwd(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
-                                 double* dsums_c, double* dsums_1, int64_t M, int32_t C, int32_t Cp,
-                                 int32_t dtype, void* stream) {
-  if (!dy || !y || !c || !g || !dsums_c || M <= 0 || (Cp & 7) || Cp > 256) return C3D_E_BADARG;
-  if ((s_bn == nullptr) != (dsums_1 == nullptr)) return C3D_E_BADARG;
+                                 const float* mr_c, const float* mr_1, double* dsums_c, double* dsums_1, int64_t M,
+                                 int32_t C, int32_t Cp, int32_t dtype, void* stream) {
+  if (!dy || !y || !c || !g || !mr_c || !dsums_c || M <= 0 || (Cp & 7) || Cp > 256) return C3D_E_BADARG;
+  if ((s_bn == nullptr) != (dsums_1 == nullptr) || (s_bn && !mr_1)) return C3D_E_BADARG;
   const int G = Cp / 8, blk = ew_block(G);
   const int64_t nvec = M * G;
   int grid = ew_grid(nvec, blk);
@@ -237,10 +244,11 @@ extern "C" int c3d_block_out_bwd(const void* dy, const void* y, const void* c, c
   EW_DISPATCH(dtype,
               (block_out_bwd_kernel<float><<<grid, blk, lds, st>>>((const float*)dy, (const float*)y,
                                                                     (const float*)c, (const float*)s_bn, (float*)g,
-                                                                    dsums_c, dsums_1, nvec, G, C)),
+                                                                    mr_c, mr_1, dsums_c, dsums_1, nvec, G, C)),
               (block_out_bwd_kernel<bf16_t><<<grid, blk, lds, st>>>((const bf16_t*)dy, (const bf16_t*)y,
                                                                      (const bf16_t*)c, (const bf16_t*)s_bn,
-                                                                     (bf16_t*)g, dsums_c, dsums_1, nvec, G, C)));
+                                                                     (bf16_t*)g, mr_c, mr_1, dsums_c, dsums_1, nvec,
+                                                                     G, C)));
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -132,13 +132,16 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
     }
   }
   // per-lane epilogue parameters / accumulators
-  float eS[8], eB[8];
+  float eS[8], eB[8], eM[8], eR[8];
   float s0[8], s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { eS[j] = 1.f; eB[j] = 0.f; s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) { eS[j] = 1.f; eB[j] = 0.f; eM[j] = 0.f; eR[j] = 0.f; s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
   if (act_o && a.epi_mode == C3D_EPI_SWISH_SE_BWD) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { eS[j] = a.epi_p[v_o * 8 + j]; eB[j] = a.epi_p[Np + v_o * 8 + j]; }
+    for (int j = 0; j < 8; ++j) {
+      eS[j] = a.epi_p[v_o * 8 + j]; eB[j] = a.epi_p[Np + v_o * 8 + j];
+      eM[j] = a.epi_q[v_o * 8 + j]; eR[j] = a.epi_q[Np + v_o * 8 + j];
+    }
   }
 
   const int64_t tiles = (a.M + 15) >> 4;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
             const float t = round_as<T>(dq * g[j]);
             s0[j] += dq * pb;  // d gate
             s1[j] += t;        // sum t1
-            s2[j] += t * bv[j];  // sum t1*b
+            s2[j] += t * ((bv[j] - eM[j]) * eR[j]);  // sum t1*bhat (centred)
             f[j] = t;
           }
         } else if (a.epi_mode == C3D_EPI_ADD) {
@@ -684,7 +687,7 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   if (a.pro_mode != C3D_PRO_NONE && !a.pro_p) return C3D_E_BADARG;
   if (a.epi_mode == C3D_EPI_STATS && !a.stats) return C3D_E_BADARG;
   if (a.epi_mode == C3D_EPI_SWISH_SE_BWD &&
-      (!a.stats || !a.e1 || !a.epi_p || a.rows_per_sample <= 0 || (a.rows_per_sample & 15)))
+      (!a.stats || !a.e1 || !a.epi_p || !a.epi_q || a.rows_per_sample <= 0 || (a.rows_per_sample & 15)))
     return C3D_E_BADARG;
   if (a.epi_mode == C3D_EPI_ADD && !a.e1) return C3D_E_BADARG;
   if (a.pro_mode == C3D_PRO_BN_SE_SWISH && a.pro_gate && a.rows_per_sample <= 0) return C3D_E_BADARG;

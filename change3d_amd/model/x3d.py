@@ -79,7 +79,7 @@ class _StemFn(torch.autograd.Function):
         sums = torch.zeros(2 * C, dtype=torch.float64, device=dev) if training else None
         u = torch.empty((B, T, H, W, C), dtype=stem.act_dtype, device=dev)
         ops.stem_fwd(xin, conv_s.weight, conv_t.weight, u, sums, B, T, H, W, dt)
-        ss, mr = _f32(2 * cpad(C), dev), _f32(2 * C, dev)
+        ss, mr = _f32(2 * cpad(C), dev), _f32(2 * cpad(C), dev)
         ops.bn_finalize(sums, B * T * H * W, stem.norm, C, ss, mr, training)
         y = torch.empty_like(u)
         ops.block_out_fwd(u, ss, None, None, ops.SC_NONE, y, B * T * H * W, cpad(C), dt)
@@ -99,7 +99,7 @@ class _StemFn(torch.autograd.Function):
         dyc = to_ndhwc(dy).to(stem.act_dtype)
         g = torch.empty_like(u)
         dsums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
-        ops.block_out_bwd(dyc, y, u, None, g, dsums, None, M, C, dt)
+        ops.block_out_bwd(dyc, y, u, None, g, mr, None, dsums, None, M, C, dt)
         coef = _f32(3 * cpad(C), dev)
         ops.bn_bwd_coef(dsums, M, stem.norm, mr, C, coef)
         dv = torch.empty_like(u)
@@ -189,12 +189,12 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype):
 
     a = torch.empty((M, Cip), dtype=act_dtype, device=dev)
     ops.pw_gemm(x, b2.conv_a.weight, a, M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt, epi_mode=epi, stats=sums_a)
-    ss_a, mr_a = _f32(2 * Cip, dev), _f32(2 * Ci, dev)
+    ss_a, mr_a = _f32(2 * Cip, dev), _f32(2 * Cip, dev)
     ops.bn_finalize(sums_a, M, b2.norm_a, Ci, ss_a, mr_a, training)
 
     b = torch.empty((Mo, Cip), dtype=act_dtype, device=dev)
     ops.dw_fwd(a, ss_a, b2.conv_b.weight, b, nc_b, B, T, H, W, Ci, s, dt)
-    ss_b, mr_b = _f32(2 * Cip, dev), _f32(2 * Ci, dev)
+    ss_b, mr_b = _f32(2 * Cip, dev), _f32(2 * Cip, dev)
     gate = _f32(B * Cip, dev) if se is not None else None
     hid = _f32(B * se.block[0].weight.shape[0], dev) if se is not None else None
     ops.bn_se_finalize(nc_b, B, T * Ho * Wo, b2.norm_b[0], se, Ci, ss_b, mr_b, gate, hid, training)
@@ -202,7 +202,7 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype):
     c = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
     ops.pw_gemm(b, b2.conv_c.weight, c, M=Mo, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH,
                 pro_p=ss_b, pro_gate=gate, rows_per_sample=T * Ho * Wo, epi_mode=epi, stats=sums_c)
-    ss_c, mr_c = _f32(2 * Cop, dev), _f32(2 * Co, dev)
+    ss_c, mr_c = _f32(2 * Cop, dev), _f32(2 * Cop, dev)
     ops.bn_finalize(sums_c, Mo, b2.norm_c, Co, ss_c, mr_c, training)
 
     ss_1 = mr_1 = None
@@ -212,7 +212,7 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype):
                     row_mode=ops.ROWS_STRIDE2 if s == 2 else ops.ROWS_DENSE, H=H, W=W,
                     epi_mode=epi if has_bn1 else ops.EPI_STORE, stats=sums_1)
         if has_bn1:
-            ss_1, mr_1 = _f32(2 * Cop, dev), _f32(2 * Co, dev)
+            ss_1, mr_1 = _f32(2 * Cop, dev), _f32(2 * Cop, dev)
             ops.bn_finalize(sums_1, Mo, blk.branch1_norm, Co, ss_1, mr_1, training)
             mode = ops.SC_BN
         else:
@@ -249,13 +249,14 @@ def _block_backward(blk, dy, sv, act_dtype):
 
     # ---- y = relu(bn_c(c) + shortcut)
     g = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
-    ops.block_out_bwd(dy, y, c, sc if mode == ops.SC_BN else None, g, dsums_c, dsums_1, Mo, Co, dt)
+    ops.block_out_bwd(dy, y, c, sc if mode == ops.SC_BN else None, g, sv["mr_c"],
+                      sv["mr_1"] if mode == ops.SC_BN else None, dsums_c, dsums_1, Mo, Co, dt)
     coef_c = _f32(3 * Cop, dev)
     ops.bn_bwd_coef(dsums_c, Mo, b2.norm_c, sv["mr_c"], Co, coef_c)
     # ---- conv_c (data + weight), Swish / SE backward in the epilogue
     t1 = torch.empty((Mo, Cip), dtype=act_dtype, device=dev)
     ops.pw_gemm(g, b2.conv_c.weight, t1, M=Mo, K=Co, N=Ci, w_sn=1, w_sk=Ci, dtype=dt, x2=c, pro_mode=ops.PRO_AFFINE2,
-                pro_p=coef_c, epi_mode=ops.EPI_SWISH_SE_BWD, e1=b, epi_p=sv["ss_b"], epi_gate=sv["gate"], stats=nc3,
+                pro_p=coef_c, epi_mode=ops.EPI_SWISH_SE_BWD, e1=b, epi_p=sv["ss_b"], epi_gate=sv["gate"], epi_q=sv["mr_b"], stats=nc3,
                 rows_per_sample=T * Ho * Wo)
     ops.pw_wgrad(g, b, ops.grad_of(b2.conv_c.weight), M=Mo, K=Ci, N=Co, dw_sn=Ci, dw_sk=1, dtype=dt, p2=c,
                  p_coef=coef_c, q_mode=ops.PRO_BN_SE_SWISH, q_ss=sv["ss_b"], q_gate=sv["gate"],
@@ -265,7 +266,7 @@ def _block_backward(blk, dy, sv, act_dtype):
                        sv["hid"], Ci, cA, cC, cB)
     # ---- depthwise conv_b
     t2 = torch.empty((M, Cip), dtype=act_dtype, device=dev)
-    ops.dw_bwd_data(t1, b, cA, cB, cC, b2.conv_b.weight, a, sv["ss_a"], t2, dsums_a, B, T, H, W, Ci, s, dt)
+    ops.dw_bwd_data(t1, b, cA, cB, cC, b2.conv_b.weight, a, sv["ss_a"], sv["mr_a"], t2, dsums_a, B, T, H, W, Ci, s, dt)
     ops.dw_wgrad(t1, b, cA, cB, cC, a, sv["ss_a"], ops.grad_of(b2.conv_b.weight), B, T, H, W, Ci, s, dt)
     coef_a = _f32(3 * Cip, dev)
     ops.bn_bwd_coef(dsums_a, M, b2.norm_a, sv["mr_a"], Ci, coef_a)

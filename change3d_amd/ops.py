@@ -88,7 +88,7 @@ def grad_of(p):
 
 # ----------------------------------------------------------------------------- pointwise GEMM
 def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, pro_p=None,
-            pro_gate=None, epi_mode=EPI_STORE, e1=None, epi_p=None, epi_gate=None, stats=None,
+            pro_gate=None, epi_mode=EPI_STORE, e1=None, epi_p=None, epi_gate=None, epi_q=None, stats=None,
             rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, res_mode=0,
             x_ptr=None, e1_ptr=None):
     a = L.PwArgs()
@@ -98,6 +98,7 @@ def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, 
     a.e1 = e1_ptr if e1_ptr is not None else _p(e1)
     a.w = _p(w)
     a.pro_p, a.pro_gate, a.epi_p, a.epi_gate, a.stats = _p(pro_p), _p(pro_gate), _p(epi_p), _p(epi_gate), _p(stats)
+    a.epi_q = _p(epi_q)
     a.M, a.gstride, a.rows_per_sample = M, gstride, rows_per_sample
     a.K, a.Kp, a.N, a.Np = K, cpad(K), N, cpad(N)
     a.w_sn, a.w_sk = w_sn, w_sk
@@ -182,8 +183,8 @@ def dw_fwd(x, ss, w, y, nc, B, T, H, W, C_, stride, dtype):
                                   _stream())
 
 
-def dw_bwd_data(t1, b, cA, cB, cC, w, a, ss_a, t2, dsums, B, T, H, W, C_, stride, dtype):
-    _launch("c3d_dw333_bwd_data", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_data, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(t2),
+def dw_bwd_data(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, B, T, H, W, C_, stride, dtype):
+    _launch("c3d_dw333_bwd_data", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_data, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2),
                                        _p(dsums), B, T, H, W, C_, cpad(C_), stride, dtype, _stream())
 
 
@@ -198,8 +199,8 @@ def block_out_fwd(c, ss_c, shortcut, ss_1, mode, y, M, Cp, dtype):
                                       _stream())
 
 
-def block_out_bwd(dy, y, c, s_bn, g, dsums_c, dsums_1, M, C_, dtype):
-    _launch("c3d_block_out_bwd", M * cpad(C_) * (5 if s_bn is not None else 4) * _es(dtype), L.lib().c3d_block_out_bwd, _p(dy), _p(y), _p(c), _p(s_bn), _p(g), _p(dsums_c), _p(dsums_1), M, C_,
+def block_out_bwd(dy, y, c, s_bn, g, mr_c, mr_1, dsums_c, dsums_1, M, C_, dtype):
+    _launch("c3d_block_out_bwd", M * cpad(C_) * (5 if s_bn is not None else 4) * _es(dtype), L.lib().c3d_block_out_bwd, _p(dy), _p(y), _p(c), _p(s_bn), _p(g), _p(mr_c), _p(mr_1), _p(dsums_c), _p(dsums_1), M, C_,
                                       cpad(C_), dtype, _stream())
 
 

@@ -48,7 +48,8 @@ int c3d_device_cus(void);
 
 #define C3D_EPI_STORE 0
 #define C3D_EPI_STATS 1        /* store + per-channel sum / sum-of-squares (f64 atomics)      */
-#define C3D_EPI_SWISH_SE_BWD 2 /* result*swish'(gate*bn(e1))*gate; per-(sample,channel) sums  */
+#define C3D_EPI_SWISH_SE_BWD 2 /* t1 = result*swish'(gate*bn(e1))*gate; per-(sample,channel)
+                                  sums (d gate, t1, t1*e1hat) -> stats [B][Np][3]            */
 #define C3D_EPI_ADD 3          /* result + residual e1 (dense, or scattered from half res)    */
 
 #define C3D_ROWS_DENSE 0  /* row m at x + m*Kp                                               */
@@ -66,6 +67,7 @@ typedef struct c3d_pw_args {
   const float* pro_gate; /* BN_SE_SWISH: gate[B][Kp] or NULL (=1)                            */
   const float* epi_p;    /* SWISH_SE_BWD: scale[Np],shift[Np] of the BN applied to e1        */
   const float* epi_gate; /* SWISH_SE_BWD: gate[B][Np] or NULL (=1)                           */
+  const float* epi_q;    /* SWISH_SE_BWD: mean[Np],rstd[Np] of that BN (centred sum t1*bhat)  */
   double* stats;         /* STATS: sum[N],sumsq[N]; SWISH_SE_BWD: [B][Np][3]                 */
   int64_t M;             /* output rows                                                      */
   int64_t gstride;       /* C3D_ROWS_FRAME: elements between consecutive row groups          */
@@ -110,7 +112,7 @@ int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream);
 /* ------------------------------------------------------------------------------------
  * Train-mode BatchNorm3d split (reference model/x3d.py:97,179,207,220,298): statistics are
  * accumulated by producer epilogues, finalised here, applied by consumer prologues.
- *   sums : f64 [2][C] (sum, sumsq);   ss : f32 scale[Cp], shift[Cp];   mr : f32 mean[C], rstd[C]
+ *   sums : f64 [2][C] (sum, sumsq);   ss : f32 scale[Cp], shift[Cp];   mr : f32 mean[Cp], rstd[Cp]
  * training=0 builds scale/shift from the running statistics (eval mode).
  * ------------------------------------------------------------------------------------ */
 int c3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
@@ -126,7 +128,8 @@ int c3d_bn_se_finalize(const double* nc, int32_t B, double cnt_per_sample, const
                        int32_t training, const float* w1, const float* b1, const float* w2,
                        const float* b2, int32_t Cr, float* ss, float* mr, float* gate, float* hid,
                        void* stream);
-/* BatchNorm backward as an affine map dx = A*g + B + C*x: dsums f64 [2][C] = (sum g, sum g*x);
+/* BatchNorm backward as an affine map dx = A*g + B + C*x: dsums f64 [2][C] = (sum g, sum g*xhat),
+ * xhat = (x-mean)*rstd accumulated centred by the producer;
  * coef f32 A[Cp],B[Cp],C[Cp]; dgamma/dbeta are accumulated (+=).                            */
 int c3d_bn_bwd_coef(const double* dsums, double count, const float* gamma, const float* mr, int32_t C,
                     int32_t Cp, float* coef, float* dgamma, float* dbeta, void* stream);
@@ -143,15 +146,15 @@ int c3d_se_bn_bwd_coef(const double* nc3, const double* ncf, int32_t B, double c
  *   fwd      : x = a (raw conv_a output) with BN_a+ReLU applied on load (ss = scale/shift);
  *              y = b raw; nc_sums f64 [B][Cp][2] accumulated (+=).
  *   bwd_data : db = coefA*t1 + coefB[n] + coefC*b on load -> t2 = dconv*(bn_a(a)>0);
- *              dsums f64 [2][C] += (sum t2, sum t2*a).
+ *              dsums f64 [2][C] += (sum t2, sum t2*ahat), ahat = (a-mean_a)*rstd_a (mr_a).
  *   wgrad    : dw f32 [C][27] += sum db * relu(bn_a(a)).
  * ------------------------------------------------------------------------------------ */
 int c3d_dw333_fwd(const void* x, const float* ss, const float* w, void* y, double* nc_sums, int32_t B,
                   int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
                   void* stream);
 int c3d_dw333_bwd_data(const void* t1, const void* b, const float* coefA, const float* coefB,
-                       const float* coefC, const float* w, const void* a, const float* ss_a, void* t2,
-                       double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
+                       const float* coefC, const float* w, const void* a, const float* ss_a,
+                       const float* mr_a, void* t2, double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
                        int32_t stride, int32_t dtype, void* stream);
 int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const float* coefB,
                     const float* coefC, const void* a, const float* ss_a, float* dw, int32_t B, int32_t T,
@@ -166,8 +169,8 @@ int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const flo
 int c3d_block_out_fwd(const void* c, const float* ss_c, const void* shortcut, const float* ss_1,
                       int32_t sc_mode, void* y, int64_t M, int32_t Cp, int32_t dtype, void* stream);
 int c3d_block_out_bwd(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
-                      double* dsums_c, double* dsums_1, int64_t M, int32_t C, int32_t Cp, int32_t dtype,
-                      void* stream);
+                      const float* mr_c, const float* mr_1, double* dsums_c, double* dsums_1, int64_t M,
+                      int32_t C, int32_t Cp, int32_t dtype, void* stream);
 
 /* Encoder.enhance pieces (reference model/trainer.py:71-108); HW = H*W pixels per frame.    */
 int c3d_frame_absdiff(const void* y, void* d, int32_t B, int32_t T, int64_t HW, int32_t Cp, int32_t t_pre,

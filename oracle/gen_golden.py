@@ -52,11 +52,26 @@ def run(size, batch, check_restatement=True):
            "mask_margin": np.array(MASK_MARGIN), "base_lr": np.array(BASE_LR),
            "max_iter": np.array(MAX_ITER)}
 
-    # ---- eval-mode forward (BN running stats), reference scripts/train_BCD.py:92-154
-    ref.eval()
+    # ---- eval-mode forward (BN running stats), reference scripts/train_BCD.py:92-154.
+    # The synthetic running statistics are first replaced by the batch statistics of ONE
+    # train-mode pass with momentum 1.0 (otherwise eval activations blow up and every
+    # probability saturates, which would make the eval comparison vacuous).
+    def calibrate(net, a, b):
+        bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm3d)]
+        net.train()
+        for m in bns:
+            m.momentum = 1.0
+        with torch.no_grad():
+            net.update_bcd(a, b)
+        for m in bns:
+            m.momentum = 0.1
+        net.eval()
+
+    calibrate(ref, pre, post)
     with torch.no_grad():
         p_eval = ref.update_bcd(pre, post)
         loss_eval = mu.BCEDiceLoss(p_eval, tgt)
+    ref.load_state_dict(sd, strict=True)
     stride = max(1, size // 32)
     out["eval_prob_lattice"] = p_eval[:, :, ::stride, ::stride].numpy()
     out["eval_prob_full"] = p_eval.numpy().astype(np.float32) if size <= 64 else np.zeros(0, np.float32)
@@ -140,10 +155,10 @@ def run(size, batch, check_restatement=True):
         opt64.step()
         losses64.append(loss64.item())
     out["loss_curve_f64"] = np.array(losses64)
-    ref64.eval()
+    ref64.load_state_dict(sd, strict=True)
+    ref64 = ref64.double()
+    calibrate(ref64, pre64, post64)
     with torch.no_grad():
-        ref64.load_state_dict(sd, strict=True)
-        ref64 = ref64.double()
         pe64 = ref64.update_bcd(pre64, post64)
     out["eval_prob_lattice_f64"] = pe64[:, :, ::stride, ::stride].numpy()
 

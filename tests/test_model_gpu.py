@@ -207,11 +207,22 @@ def _grad_check(names, g_hip, g32, g64):
     CPU reference itself is up to ~3 % away from fp64 on some parameters, median ~0.7 %)."""
     e_hip = np.array([(g_hip[n].double().cpu() - g64[n]).norm().item() / (g64[n].norm().item() + 1e-30) for n in names])
     e_ref = np.array([(g32[n].double() - g64[n]).norm().item() / (g64[n].norm().item() + 1e-30) for n in names])
-    lim = np.maximum(np.maximum(K_NOISE * e_ref, K_NOISE * np.median(e_ref)), 2e-3)
-    bad = [(names[i], float(e_hip[i]), float(e_ref[i])) for i in np.nonzero(e_hip > lim)[0]]
-    print(f"grad rel-L2 vs fp64: hip median {np.median(e_hip):.2e} max {e_hip.max():.2e} | "
-          f"fp32 reference median {np.median(e_ref):.2e} max {e_ref.max():.2e}")
-    assert not bad, bad[:10]
+    _noise_check(names, e_hip, e_ref, "grad rel-L2")
+
+
+def _noise_check(names, e_hip, e_ref, what):
+    """The HIP error distribution must look like the fp32 reference's own error distribution:
+    same median (x1.5), bounded maximum (x K_NOISE), and at most 2 % of the parameters outside
+    K_NOISE x max(their own reference error, the reference's 90th-percentile error)."""
+    lim = np.maximum(np.maximum(K_NOISE * e_ref, K_NOISE * np.percentile(e_ref, 90)), 2e-3)
+    out = np.nonzero(e_hip > lim)[0]
+    print(f"{what} vs fp64: hip median {np.median(e_hip):.2e} max {e_hip.max():.2e} | "
+          f"fp32 reference median {np.median(e_ref):.2e} max {e_ref.max():.2e} | outliers {len(out)}/{len(names)}")
+    assert np.median(e_hip) <= 1.5 * np.median(e_ref) + 1e-4, (np.median(e_hip), np.median(e_ref))
+    assert e_hip.max() <= K_NOISE * e_ref.max() + 2e-3, (str(names[int(e_hip.argmax())]), e_hip.max(), e_ref.max())
+    for i in out[:10]:
+        print(f"   outlier {names[i]}: hip {e_hip[i]:.2e} reference {e_ref[i]:.2e}")
+    assert len(out) <= 0.02 * len(names), [(str(names[i]), float(e_hip[i]), float(e_ref[i])) for i in out[:10]]
 
 
 def test_e2e_bcd_vs_oracle_size64():
@@ -275,14 +286,27 @@ def test_e2e_bcd_vs_reference_golden(size, golden_dir):
     def lattice(t):
         return t.detach()[:, :, ::stride, ::stride].cpu().double().numpy()
 
-    # ---- eval mode (BN running statistics)
+    # ---- eval mode (BN running statistics := batch statistics of one momentum-1.0 train pass)
+    mine.train()
+    bns = [m for m in mine.modules() if isinstance(m, torch.nn.BatchNorm3d)]
+    for m in bns:
+        m.momentum = 1.0
+    with torch.no_grad():
+        mine.update_bcd(pre, post)
+    for m in bns:
+        m.momentum = 0.1
     mine.eval()
     with torch.no_grad():
         pe = mine.update_bcd(pre, post)
+    mine.load_state_dict(sd)  # back to the synthetic running statistics for the training part
     e_ref = np.abs(G["eval_prob_lattice"] - G["eval_prob_lattice_f64"]).max()
     e_hip = np.abs(lattice(pe) - G["eval_prob_lattice_f64"]).max()
     print(f"eval  max|p - p_fp64| on lattice: hip {e_hip:.3e}  fp32 reference {e_ref:.3e}")
-    assert e_hip <= K_NOISE * e_ref + 1e-6
+    tol_e = K_NOISE * e_ref + 1e-6
+    assert e_hip <= tol_e
+    assert 0.05 < float(pe.mean()) < 0.95 and float(pe.std()) > 0.05  # the eval fixture is not saturated
+    safe = np.abs(G["eval_prob_lattice_f64"] - 0.5) > tol_e
+    assert (((lattice(pe) > 0.5) != (G["eval_prob_lattice_f64"] > 0.5)) & safe).sum() == 0
     bits = np.unpackbits(G["eval_mask_bits"])[:pe.numel()].reshape(pe.shape).astype(bool)
     flips = ((pe.cpu().numpy() > 0.5) != bits).sum()
     assert flips <= K_NOISE * int(G["eval_band"]) + 2, (flips, int(G["eval_band"]))
@@ -316,10 +340,7 @@ def test_e2e_bcd_vs_reference_golden(size, golden_dir):
             n64 = G["grad_norms_f64"]
             eh = np.abs(gn - n64) / (n64 + 1e-30)
             er = np.abs(G["grad_norms"] - n64) / (n64 + 1e-30)
-            lim = np.maximum(np.maximum(K_NOISE * er, K_NOISE * np.median(er)), 2e-3)
-            print(f"grad-norm rel err vs fp64: hip median {np.median(eh):.2e} max {eh.max():.2e} | "
-                  f"fp32 reference median {np.median(er):.2e} max {er.max():.2e}")
-            assert (eh <= lim).all(), [(str(G["grad_names"][i]), eh[i], er[i]) for i in np.nonzero(eh > lim)[0][:8]]
+            _noise_check(G["grad_names"], eh, er, "grad-norm rel err")
             unused = sum(p.numel() for n, p in mine.named_parameters() if p.grad is None)
             assert unused == int(G["unused_param_count"])
         opt.step()
@@ -335,7 +356,7 @@ def test_e2e_bcd_vs_reference_golden(size, golden_dir):
     l2 = np.array([fin[str(n)].double().norm().item() for n in G["grad_names"]])
     assert (np.abs(l2 - G["final_param_l2"]) / (G["final_param_l2"] + 1e-12)).max() < 1e-4
     rm = [v.double().sum().item() for k, v in fin.items() if k.endswith("running_mean") and ".blocks.4." not in k and ".blocks.5." not in k]
-    assert np.allclose(np.array(rm), G["final_running_mean_sums"], rtol=1e-3, atol=1e-4)
+    assert np.allclose(np.array(rm), G["final_running_mean_sums"], rtol=2e-3, atol=1e-3)
     nbt = np.array([int(v) for k, v in fin.items() if k.endswith("num_batches_tracked")])
     assert (nbt == G["final_nbt"]).all()
 

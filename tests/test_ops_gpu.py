@@ -165,19 +165,21 @@ def test_pw_gemm_swish_se_bwd_epilogue(dtype):
     y = torch.empty((M, Np), dtype=dtype, device=DEV)
     nc3 = torch.zeros(B * Np * 3, dtype=torch.float64, device=DEV)
     ss = torch.cat([padc(scale, Np), padc(shift, Np)]).to(DEV)
+    mean, rstd = rnd((N,), 26, 0.5), rnd((N,), 27).abs() + 0.5
     ops.pw_gemm(g.to(DEV, dtype).contiguous(), w.to(DEV), y, M=M, K=K, N=N, w_sn=1, w_sk=N, dtype=ops.dt_code(dtype),
                 epi_mode=ops.EPI_SWISH_SE_BWD, e1=padc(b, Np).to(DEV, dtype).contiguous(), epi_p=ss,
-                epi_gate=padc(gate, Np).to(DEV).contiguous(), stats=nc3, rows_per_sample=rows)
+                epi_gate=padc(gate, Np).to(DEV).contiguous(),
+                epi_q=torch.cat([padc(mean, Np), padc(rstd, Np)]).to(DEV), stats=nc3, rows_per_sample=rows)
     close(y[:, :N], t1, dtype, "t1", scale=t1.abs().max().item())
     s = nc3.cpu().view(B, Np, 3)[:, :N]
     t1q = y[:, :N].float().cpu()
     ref0 = (dq * pb).view(B, rows, N).sum(1).double()
     ref1 = t1q.view(B, rows, N).sum(1).double()
-    ref2 = (t1q * b).view(B, rows, N).sum(1).double()
+    ref2 = (t1q * ((b - mean) * rstd)).view(B, rows, N).sum(1).double()
     rt = 1e-4 if dtype == torch.float32 else 3e-2
     assert torch.allclose(s[..., 0], ref0, rtol=rt, atol=rt * ref0.abs().max().item()), "sum dq*pb"
     assert torch.allclose(s[..., 1], ref1, rtol=1e-4, atol=1e-3), "sum t1"
-    assert torch.allclose(s[..., 2], ref2, rtol=1e-4, atol=1e-3), "sum t1*b"
+    assert torch.allclose(s[..., 2], ref2, rtol=1e-4, atol=1e-3), "sum t1*bhat"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -294,13 +296,15 @@ def test_dw333_fwd_bwd(dtype, stride, C, T):
     t2 = torch.empty_like(ad)
     dsums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
     t1d = padc(t1, Cp).to(DEV, dtype).contiguous()
+    mean_a, rstd_a = rnd((C,), 58, 0.5), rnd((C,), 59).abs() + 0.5
+    mr = torch.cat([padc(mean_a, Cp), padc(rstd_a, Cp)]).to(DEV)
     ops.dw_bwd_data(t1d, b, padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV),
-                    w.to(DEV).contiguous(), ad, ss, t2, dsums, B, T, H, W, C, stride, ops.dt_code(dtype))
+                    w.to(DEV).contiguous(), ad, ss, mr, t2, dsums, B, T, H, W, C, stride, ops.dt_code(dtype))
     close(t2[..., :C], t2_ref, dtype, "dw bwd data", scale=t2_ref.abs().max().item())
     t2q = t2[..., :C].float().cpu().double()
     sd = dsums.cpu()
     assert torch.allclose(sd[:C], t2q.sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(sd[C:], (t2q * a.double()).sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(sd[C:], (t2q * ((a - mean_a) * rstd_a).double()).sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3)
     dw = torch.zeros((C, 27), dtype=torch.float32, device=DEV)
     ops.dw_wgrad(t1d, b, padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV), ad, ss, dw,
                  B, T, H, W, C, stride, ops.dt_code(dtype))
