@@ -14,6 +14,7 @@ PRO_NONE, PRO_BN_SE_SWISH, PRO_AFFINE2 = 0, 1, 2
 EPI_STORE, EPI_STATS, EPI_SWISH_SE_BWD, EPI_ADD = 0, 1, 2, 3
 ROWS_DENSE, ROWS_FRAME, ROWS_STRIDE2, ROWS_S2SHIFT = 0, 1, 2, 3
 SC_NONE, SC_IDENTITY, SC_BN, SC_RAW = 0, 1, 2, 3
+STAT_STRIPES = 16
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -44,7 +45,7 @@ SIGNATURES = {
     "c3d_pw_gemm": (i32, [C.POINTER(PwArgs), vp]),
     "c3d_pw_wgrad_ws_floats": (i64, [i32, i32]),
     "c3d_pw_wgrad": (i32, [C.POINTER(PwWgradArgs), vp]),
-    "c3d_bn_finalize": (i32, [vp, f64, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp]),
+    "c3d_bn_finalize": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp]),
     "c3d_bn_se_finalize": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp, vp,
                                  i32, vp, vp, vp, vp, vp]),
     "c3d_bn_bwd_coef": (i32, [vp, f64, vp, vp, i32, i32, vp, vp, vp, vp]),

@@ -15,7 +15,7 @@ namespace {
 
 // -------------------------------------------------------------------------------------------
 // sums: [2][C] (sum, sumsq) per channel.
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int stripes, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    int64_t* nbt, float momentum, float eps, int C, int Cp, int training,
                                    float* __restrict__ ss, float* __restrict__ mr) {
@@ -25,8 +25,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   if (c >= C) { ss[c] = 0.f; ss[Cp + c] = 0.f; if (mr) { mr[c] = 0.f; mr[Cp + c] = 0.f; } return; }
   double mean, var;
   if (training) {
-    mean = sums[c] / count;
-    var = sums[C + c] / count - mean * mean;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < stripes; ++k) { s1 += sums[(size_t)k * 2 * C + c]; s2 += sums[(size_t)k * 2 * C + C + c]; }
+    mean = s1 / count;
+    var = s2 / count - mean * mean;
     if (var < 0) var = 0;
     if (running_mean) {
       const double unb = count > 1 ? var * count / (count - 1) : var;
@@ -228,16 +230,16 @@ __global__ __launch_bounds__(256) void se_bn_bwd_coef_kernel(
 
 }  // namespace
 
-extern "C" int c3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+extern "C" int c3d_bn_finalize(const double* sums, int32_t stripes, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                float momentum, float eps, int32_t C, int32_t Cp, int32_t training, float* ss,
                                float* mr, void* stream) {
   if (!gamma || !beta || !ss || C <= 0 || Cp < C) return C3D_E_BADARG;
-  if (training && !sums) return C3D_E_BADARG;
+  if (training && (!sums || stripes < 1)) return C3D_E_BADARG;
   if (!training && (!running_mean || !running_var)) return C3D_E_BADARG;
   bn_finalize_kernel<<<dim3((Cp + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-      sums, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, C, Cp, training, ss,
-      mr);
+      sums, stripes, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, C, Cp,
+      training, ss, mr);
   C3D_CHECK_LAUNCH();
   return 0;
 }

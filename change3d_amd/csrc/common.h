@@ -70,7 +70,9 @@ template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float f) { *p
 // sigmoid: accurate expf on the f32 (parity) path, hardware v_exp on the bf16 (throughput) path
 template <typename T> __device__ __forceinline__ float sigmoid_t(float x);
 template <> __device__ __forceinline__ float sigmoid_t<float>(float x) { return 1.0f / (1.0f + expf(-x)); }
-template <> __device__ __forceinline__ float sigmoid_t<bf16_t>(float x) { return 1.0f / (1.0f + __expf(-x)); }
+template <> __device__ __forceinline__ float sigmoid_t<bf16_t>(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));  // v_exp + v_rcp (1 ulp): ample for bf16 storage
+}
 
 // ---- wave / block reductions -----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1,0 +1,379 @@
+// Weight gradient of the pointwise-convolution family (see pw_gemm.hip for the forward/data path).
+#include "common.h"
+#include "../../include/change3d_hip.h"
+#include "pw_common.h"
+
+namespace {
+
+// =============================================================================================
+// Weight gradient:  dW[n, k] += sum_m P(m, n) * Q(m, k)
+//
+// The reduction runs over data rows, so both MFMA operands are needed "transposed"
+// (8 consecutive rows of one channel per lane).  Each thread loads an 8-row x 8-channel
+// register block (8 coalescing-friendly 16-byte loads), applies the operand prologue in f32
+// and packs along the ROW axis - the transpose is pure register naming - then writes one
+// 16-byte LDS vector per channel.  A workgroup shares 64-row tiles; its 4 waves split the
+// (n-tile, k-tile) grid and keep <= 4x4 16x16 accumulators each across the whole row range;
+// per-workgroup partials go to a workspace and a second tiny kernel reduces them into dW.
+// =============================================================================================
+template <typename T> struct MmaT;  // transposed-operand LDS tiles [channel][row]
+template <> struct MmaT<bf16_t> {
+  typedef bf16_t lds_t;
+  static constexpr int KSTEP = 32;
+  static constexpr int MPAD = 8;
+  typedef uint4 frag_t;
+  static __device__ __forceinline__ frag_t load(const lds_t* base, int ch, int ks, int ml, int lane) {
+    return *reinterpret_cast<const uint4*>(base + ch * ml + ks * 32 + (lane >> 4) * 8);
+  }
+  static __device__ __forceinline__ f32x4_t mma(frag_t a, frag_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void store8(lds_t* p, const float (&f)[8]) { Vec8<bf16_t>::store(p, f); }
+};
+template <> struct MmaT<float> {
+  typedef float lds_t;
+  static constexpr int KSTEP = 4;
+  static constexpr int MPAD = 4;
+  typedef float frag_t;
+  static __device__ __forceinline__ frag_t load(const lds_t* base, int ch, int ks, int ml, int lane) {
+    return base[ch * ml + ks * 4 + (lane >> 4)];
+  }
+  static __device__ __forceinline__ f32x4_t mma(frag_t a, frag_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void store8(lds_t* p, const float (&f)[8]) { Vec8<float>::store(p, f); }
+};
+
+constexpr int WG_THREADS = 512;  // 8 waves: threads 0-255 stage P, 256-511 stage Q
+constexpr int WG_MAXMT = 128;    // rows per tile (multiple of 32; taller for narrow channel counts)
+
+__device__ __forceinline__ int64_t q_row_offset(const c3d_pw_wgrad_args& a, int64_t m) {
+  if (a.row_mode == C3D_ROWS_DENSE) return m * a.Kp;
+  if (a.row_mode == C3D_ROWS_FRAME) {
+    const uint32_t g = (uint32_t)m / (uint32_t)a.rpg;
+    const uint32_t r = (uint32_t)m - g * (uint32_t)a.rpg;
+    return (int64_t)g * a.gstride + (int64_t)r * a.Kp;
+  }
+  const uint32_t Wo = (uint32_t)a.W >> 1, Ho = (uint32_t)a.H >> 1;
+  const uint32_t um = (uint32_t)m;
+  const uint32_t wo = um % Wo;
+  const uint32_t t = um / Wo;
+  const uint32_t ho = t % Ho;
+  const uint32_t bt = t / Ho;
+  if (a.row_mode == C3D_ROWS_STRIDE2) return (((int64_t)bt * a.H + 2 * ho) * a.W + 2 * wo) * a.Kp;
+  // S2SHIFT: pixel (2ho + dy, 2wo + dx), rows outside the image read as zero (offset -1)
+  const int yy = 2 * (int)ho + a.dy, xx = 2 * (int)wo + a.dx;
+  if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) return -1;
+  return (((int64_t)bt * a.H + yy) * a.W + xx) * a.Kp;
+}
+
+template <typename T> struct RawW;
+template <> struct RawW<bf16_t> {
+  typedef uint4 type;
+  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ type zero() { return make_uint4(0, 0, 0, 0); }
+  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+};
+template <> struct RawW<float> {
+  struct type { float4 a, b; };
+  static __device__ __forceinline__ type load(const float* p) {
+    type t; t.a = *reinterpret_cast<const float4*>(p); t.b = *reinterpret_cast<const float4*>(p + 4); return t;
+  }
+  static __device__ __forceinline__ type zero() { type t; t.a = make_float4(0, 0, 0, 0); t.b = t.a; return t; }
+  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
+    f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w; f[4] = v.b.x; f[5] = v.b.y; f[6] = v.b.z; f[7] = v.b.w;
+  }
+};
+
+// Transpose buffer: WG_RPT rows x 8 channels per thread, written out as one row-vector per channel
+// (the transpose is pure register naming).
+constexpr int WG_RPT = 4;
+template <typename T> struct ColBuf;
+template <> struct ColBuf<bf16_t> {
+  uint32_t w[8][2];
+  __device__ __forceinline__ void put2(int rp, const float (&f0)[8], const float (&f1)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j][rp] = pack_bf16x2(f0[j], f1[j]);
+  }
+  __device__ __forceinline__ void store(bf16_t* dst, int j) const {
+    *reinterpret_cast<uint2*>(dst) = make_uint2(w[j][0], w[j][1]);
+  }
+};
+template <> struct ColBuf<float> {
+  float w[8][4];
+  __device__ __forceinline__ void put2(int rp, const float (&f0)[8], const float (&f1)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w[j][2 * rp] = f0[j]; w[j][2 * rp + 1] = f1[j]; }
+  }
+  __device__ __forceinline__ void store(float* dst, int j) const {
+    *reinterpret_cast<float4*>(dst) = make_float4(w[j][0], w[j][1], w[j][2], w[j][3]);
+  }
+};
+
+// HASP2: the P operand carries the AFFINE2 prologue (second tensor + coefficients)
+template <typename T, bool HASP2>
+__global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad_args a, const int tiles_per_wg,
+                                                              const int WN, const int WK, const int MT) {
+  typedef MmaT<T> MM;
+  typedef typename MM::lds_t lds_t;
+  typedef RawW<T> RW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Kp = a.Kp, Np = a.Np;
+  const int NT = (Np + 15) >> 4, KT = (Kp + 15) >> 4;
+  const int ML = MT + MM::MPAD;
+  const size_t buf_elems = (size_t)(NT + KT) * 16 * ML;
+  lds_t* base = reinterpret_cast<lds_t*>(smem);
+
+  // zero both buffers once (covers the channel-padding rows, which are never written again)
+  for (size_t i = (size_t)tid * 8; i < 2 * buf_elems; i += (size_t)WG_THREADS * 8) {
+    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    MM::store8(base + i, z);
+  }
+
+  const int Gp = Np >> 3, Gq = Kp >> 3;
+  const int half = tid >> 8;                 // 0: stages the P tile, 1: stages the Q tile
+  const int t256 = tid & 255;
+  const int nrg = MT / WG_RPT;               // row groups (WG_RPT rows each) per tile
+  const int vv = t256 / nrg, rg = t256 - vv * nrg;
+  const bool p_act = half == 0 && vv < Gp, q_act = half == 1 && vv < Gq;
+  float cA[8], cB[8], cC[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { cA[j] = 1.f; cB[j] = 0.f; cC[j] = 0.f; }
+  if (HASP2 && p_act) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cA[j] = a.p_coef[vv * 8 + j]; cB[j] = a.p_coef[Np + vv * 8 + j]; cC[j] = a.p_coef[2 * Np + vv * 8 + j];
+    }
+  }
+  if (q_act && a.q_mode == C3D_PRO_BN_SE_SWISH) {  // Q side reuses cA/cB as scale/shift
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cA[j] = a.q_ss[vv * 8 + j]; cB[j] = a.q_ss[Kp + vv * 8 + j]; }
+  }
+
+  const int wn_i = wave % WN, wk_i = wave / WN;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const T* P = reinterpret_cast<const T*>(a.p);
+  const T* P2 = reinterpret_cast<const T*>(a.p2);
+  const T* Q = reinterpret_cast<const T*>(a.q);
+  const int64_t tiles = (a.M + MT - 1) / MT;
+  const int64_t t0 = (int64_t)blockIdx.x * tiles_per_wg;
+  int64_t t1 = t0 + tiles_per_wg;
+  if (t1 > tiles) t1 = tiles;
+
+  typename RW::type r1[WG_RPT];
+  typename RW::type r2[HASP2 ? WG_RPT : 1];
+  unsigned vmask = 0;  // which of the WG_RPT rows were real
+
+#define WG_ISSUE(TILE)                                                                          \
+  {                                                                                             \
+    const int64_t rbase_ = (TILE) * MT + rg * WG_RPT;                                           \
+    vmask = 0;                                                                                  \
+    _Pragma("unroll") for (int r = 0; r < WG_RPT; ++r) {                                        \
+      const int64_t m_ = rbase_ + r;                                                            \
+      r1[r] = RW::zero();                                                                       \
+      if (HASP2) r2[HASP2 ? r : 0] = RW::zero();                                                \
+      if (m_ < a.M) {                                                                           \
+        if (p_act) {                                                                            \
+          r1[r] = RW::load(P + m_ * Np + vv * 8);                                               \
+          if (HASP2) r2[HASP2 ? r : 0] = RW::load(P2 + m_ * Np + vv * 8);                       \
+          vmask |= 1u << r;                                                                     \
+        } else if (q_act) {                                                                     \
+          const int64_t qo_ = q_row_offset(a, m_);                                              \
+          if (qo_ >= 0) { r1[r] = RW::load(Q + qo_ + vv * 8); vmask |= 1u << r; }               \
+        }                                                                                       \
+      }                                                                                         \
+    }                                                                                           \
+  }
+
+  __syncthreads();  // zero fill complete
+  if (t0 < t1) WG_ISSUE(t0)
+  int cur = 0;
+  for (int64_t tile = t0; tile < t1; ++tile, cur ^= 1) {
+    lds_t* PT = base + (size_t)cur * buf_elems;
+    lds_t* QT = PT + (size_t)NT * 16 * ML;
+    // ---- convert + prologue + transpose (register naming) -> LDS -------------------------------
+    if (p_act || q_act) {
+      ColBuf<T> cb;
+      float g[8];
+      const bool swish = q_act && a.q_mode == C3D_PRO_BN_SE_SWISH;
+      int64_t gn = -1;
+#pragma unroll
+      for (int rp = 0; rp < WG_RPT / 2; ++rp) {
+        float fr[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = 2 * rp + h;
+          float (&f)[8] = fr[h];
+          RW::cvt(r1[r], f);
+          const bool real = (vmask >> r) & 1u;
+          if (HASP2 && p_act) {
+            float f2[8];
+            RW::cvt(r2[HASP2 ? r : 0], f2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = real ? fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j])) : 0.f;
+          } else if (swish) {
+            const int64_t m = tile * MT + rg * WG_RPT + r;
+            const int64_t n = real ? (int64_t)((uint32_t)m / (uint32_t)a.rows_per_sample) : gn;
+            if (a.q_gate && real && n != gn) {
+              const float* gp = a.q_gate + n * Kp + vv * 8;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) g[j] = gp[j];
+              gn = n;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float qv = (a.q_gate ? g[j] : 1.f) * fmaf(f[j], cA[j], cB[j]);
+              f[j] = real ? qv * sigmoid_t<T>(qv) : 0.f;
+            }
+          }
+        }
+        cb.put2(rp, fr[0], fr[1]);
+      }
+      lds_t* dst = (p_act ? PT : QT) + (size_t)(vv * 8) * ML + rg * WG_RPT;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cb.store(dst + (size_t)j * ML, j);
+    }
+    // ---- prefetch the next tile while this one is multiplied -----------------------------------
+    if (tile + 1 < t1) WG_ISSUE(tile + 1)
+    __syncthreads();  // the only barrier per tile (LDS tiles are double buffered)
+    for (int ks = 0; ks < MT / MM::KSTEP; ++ks) {
+      typename MM::frag_t pa[4], qb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int nt = wn_i + i * WN;
+        if (nt < NT) pa[i] = MM::load(PT, nt * 16 + (lane & 15), ks, ML, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kt = wk_i + j * WK;
+        if (kt < KT) qb[j] = MM::load(QT, kt * 16 + (lane & 15), ks, ML, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (wn_i + i * WN < NT) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (wk_i + j * WK < KT) acc[i][j] = MM::mma(pa[i], qb[j], acc[i][j]);
+          }
+        }
+      }
+    }
+  }
+#undef WG_ISSUE
+
+  // partials -> workspace [grid][N][K]
+  float* wsb = a.ws + (size_t)blockIdx.x * a.N * a.K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nt = wn_i + i * WN;
+    if (nt >= NT) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kt = wk_i + j * WK;
+      if (kt >= KT) continue;
+      const int k = kt * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nt * 16 + (lane >> 4) * 4 + r;
+        if (n < a.N && k < a.K) wsb[(size_t)n * a.K + k] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+__global__ void pw_wgrad_reduce_kernel(const float* __restrict__ ws, float* dw, int N, int K, int parts,
+                                       int sn, int sk) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * K) return;
+  float s = 0.f;
+  for (int p = 0; p < parts; ++p) s += ws[(size_t)p * N * K + idx];
+  const int n = idx / K, k = idx - n * K;
+  dw[(size_t)n * sn + (size_t)k * sk] += s;
+}
+
+constexpr int WGRAD_MAX_PARTS = 256;
+
+template <typename T>
+int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
+  typedef MmaT<T> MM;
+  const int NT = (a.Np + 15) >> 4, KT = (a.Kp + 15) >> 4;
+  // rows per tile: as tall as 256 staging threads per operand allow (WG_RPT rows x 8 channels each)
+  const int maxG = (a.Np > a.Kp ? a.Np : a.Kp) >> 3;
+  int MT = (256 / maxG) * WG_RPT / 32 * 32;
+  if (MT > WG_MAXMT) MT = WG_MAXMT;
+  if (MT < 32) return C3D_E_UNSUPPORTED;
+  size_t lds = 0;
+  for (; MT >= 32; MT -= 32) {
+    lds = (size_t)2 * (NT + KT) * 16 * (MT + MM::MPAD) * sizeof(typename MM::lds_t);
+    if (lds <= 160 * 1024) break;
+  }
+  if (MT < 32) return C3D_E_UNSUPPORTED;
+  // wave grid: WN*WK = 8 with ceil(NT/WN) <= 4 and ceil(KT/WK) <= 4
+  int WN = 0, WK = 0;
+  const int cand[4][2] = {{8, 1}, {4, 2}, {2, 4}, {1, 8}};
+  int best = 1 << 30;
+  for (int c = 0; c < 4; ++c) {
+    const int tn = (NT + cand[c][0] - 1) / cand[c][0], tk = (KT + cand[c][1] - 1) / cand[c][1];
+    if (tn > 4 || tk > 4) continue;
+    const int cost = tn * tk * 4 + tn + tk;  // MFMAs dominate, then fragment loads
+    if (cost < best) { best = cost; WN = cand[c][0]; WK = cand[c][1]; }
+  }
+  if (WN == 0) return C3D_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_kernel<T, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_kernel<T, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e1 != hipSuccess) return (int)e1;
+    if (e2 != hipSuccess) return (int)e2;
+    attr_set = true;
+  }
+  const int64_t tiles = (a.M + MT - 1) / MT;
+  int64_t blocks = (tiles + 3) / 4;  // >= 4 tiles per workgroup when there is enough work
+  const int64_t cap = device_cus() < WGRAD_MAX_PARTS ? device_cus() : WGRAD_MAX_PARTS;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  const int tpw = (int)((tiles + blocks - 1) / blocks);
+  blocks = (tiles + tpw - 1) / tpw;
+  if (a.p_coef)
+    pw_wgrad_kernel<T, true><<<dim3((unsigned)blocks), dim3(WG_THREADS), lds, stream>>>(a, tpw, WN, WK, MT);
+  else
+    pw_wgrad_kernel<T, false><<<dim3((unsigned)blocks), dim3(WG_THREADS), lds, stream>>>(a, tpw, WN, WK, MT);
+  C3D_CHECK_LAUNCH();
+  const int nk = a.N * a.K;
+  pw_wgrad_reduce_kernel<<<dim3((nk + 255) / 256), dim3(256), 0, stream>>>(a.ws, a.dw, a.N, a.K, (int)blocks,
+                                                                            a.dw_sn, a.dw_sk);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t c3d_pw_wgrad_ws_floats(int32_t N, int32_t K) { return (int64_t)WGRAD_MAX_PARTS * N * K; }
+
+extern "C" int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream) {
+  if (!args || !args->p || !args->q || !args->dw || !args->ws) return C3D_E_BADARG;
+  const c3d_pw_wgrad_args& a = *args;
+  if (a.M <= 0 || (a.Kp & 7) || (a.Np & 7) || a.K > a.Kp || a.N > a.Np || a.Kp > 224 || a.Np > 224)
+    return C3D_E_BADARG;
+  if (a.p_coef && !a.p2) return C3D_E_BADARG;
+  if (a.q_mode == C3D_PRO_BN_SE_SWISH && (!a.q_ss || (a.q_gate && a.rows_per_sample <= 0))) return C3D_E_BADARG;
+  if (a.M >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (a.dtype == C3D_DT_F32) return launch_wgrad<float>(a, s);
+  if (a.dtype == C3D_DT_BF16) return launch_wgrad<bf16_t>(a, s);
+  return C3D_E_BADARG;
+}

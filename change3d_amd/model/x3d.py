@@ -179,18 +179,19 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype):
     se = b2.norm_b[1] if blk.use_se else None
     has_bn1 = blk.branch1_norm is not None
     # f64 accumulators in one zeroed buffer
-    n_acc = 2 * Ci + B * Cip * 2 + 2 * Co + (2 * Co if has_bn1 else 0)
+    S = ops.STAT_STRIPES  # pointwise-GEMM statistics are accumulated in S striped sets
+    n_acc = S * 2 * Ci + B * Cip * 2 + S * 2 * Co + (S * 2 * Co if has_bn1 else 0)
     acc = torch.zeros(n_acc, dtype=torch.float64, device=dev)
-    sums_a, o = acc[:2 * Ci], 2 * Ci
+    sums_a, o = acc[:S * 2 * Ci], S * 2 * Ci
     nc_b, o = acc[o:o + B * Cip * 2], o + B * Cip * 2
-    sums_c, o = acc[o:o + 2 * Co], o + 2 * Co
-    sums_1 = acc[o:o + 2 * Co] if has_bn1 else None
+    sums_c, o = acc[o:o + S * 2 * Co], o + S * 2 * Co
+    sums_1 = acc[o:o + S * 2 * Co] if has_bn1 else None
     epi = ops.EPI_STATS if training else ops.EPI_STORE
 
     a = torch.empty((M, Cip), dtype=act_dtype, device=dev)
     ops.pw_gemm(x, b2.conv_a.weight, a, M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt, epi_mode=epi, stats=sums_a)
     ss_a, mr_a = _f32(2 * Cip, dev), _f32(2 * Cip, dev)
-    ops.bn_finalize(sums_a, M, b2.norm_a, Ci, ss_a, mr_a, training)
+    ops.bn_finalize(sums_a, M, b2.norm_a, Ci, ss_a, mr_a, training, stripes=S)
 
     b = torch.empty((Mo, Cip), dtype=act_dtype, device=dev)
     ops.dw_fwd(a, ss_a, b2.conv_b.weight, b, nc_b, B, T, H, W, Ci, s, dt)
@@ -203,7 +204,7 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype):
     ops.pw_gemm(b, b2.conv_c.weight, c, M=Mo, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH,
                 pro_p=ss_b, pro_gate=gate, rows_per_sample=T * Ho * Wo, epi_mode=epi, stats=sums_c)
     ss_c, mr_c = _f32(2 * Cop, dev), _f32(2 * Cop, dev)
-    ops.bn_finalize(sums_c, Mo, b2.norm_c, Co, ss_c, mr_c, training)
+    ops.bn_finalize(sums_c, Mo, b2.norm_c, Co, ss_c, mr_c, training, stripes=S)
 
     ss_1 = mr_1 = None
     if blk.branch1_conv is not None:
@@ -213,7 +214,7 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype):
                     epi_mode=epi if has_bn1 else ops.EPI_STORE, stats=sums_1)
         if has_bn1:
             ss_1, mr_1 = _f32(2 * Cop, dev), _f32(2 * Cop, dev)
-            ops.bn_finalize(sums_1, Mo, blk.branch1_norm, Co, ss_1, mr_1, training)
+            ops.bn_finalize(sums_1, Mo, blk.branch1_norm, Co, ss_1, mr_1, training, stripes=S)
             mode = ops.SC_BN
         else:
             mode = ops.SC_RAW

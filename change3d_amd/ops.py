@@ -11,7 +11,7 @@ import torch
 from . import _lib as L
 from ._lib import (DT_BF16, DT_F32, EPI_ADD, EPI_STATS, EPI_STORE, EPI_SWISH_SE_BWD, PRO_AFFINE2,  # noqa: F401
                    PRO_BN_SE_SWISH, PRO_NONE, ROWS_DENSE, ROWS_FRAME, ROWS_S2SHIFT, ROWS_STRIDE2, SC_BN,
-                   SC_IDENTITY, SC_NONE, SC_RAW)
+                   SC_IDENTITY, SC_NONE, SC_RAW, STAT_STRIPES)
 
 
 def cpad(c):
@@ -138,8 +138,8 @@ def pw_wgrad(p, q, dw, *, M, K, N, dw_sn, dw_sk, dtype, p2=None, p_coef=None, q_
 
 
 # ------------------------------------------------------------------------------- BN / SE
-def bn_finalize(sums, count, bn, C_, ss, mr, training):
-    _launch("c3d_bn_finalize", 0, L.lib().c3d_bn_finalize, _p(sums), float(count), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+def bn_finalize(sums, count, bn, C_, ss, mr, training, stripes=1):
+    _launch("c3d_bn_finalize", 0, L.lib().c3d_bn_finalize, _p(sums), stripes, float(count), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
                                     _p(bn.running_var), _p(bn.num_batches_tracked) if training else None,
                                     float(bn.momentum), float(bn.eps), C_, cpad(C_), 1 if training else 0,
                                     _p(ss), _p(mr), _stream())

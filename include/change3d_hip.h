@@ -47,7 +47,9 @@ int c3d_device_cus(void);
 #define C3D_PRO_AFFINE2 2     /* out = A*x + B + C*x2   (BatchNorm backward applied on load)  */
 
 #define C3D_EPI_STORE 0
-#define C3D_EPI_STATS 1        /* store + per-channel sum / sum-of-squares (f64 atomics)      */
+#define C3D_EPI_STATS 1        /* store + per-channel sum / sum-of-squares into one of
+                                  C3D_STAT_STRIPES striped f64 accumulator sets               */
+#define C3D_STAT_STRIPES 16
 #define C3D_EPI_SWISH_SE_BWD 2 /* t1 = result*swish'(gate*bn(e1))*gate; per-(sample,channel)
                                   sums (d gate, t1, t1*e1hat) -> stats [B][Np][3]            */
 #define C3D_EPI_ADD 3          /* result + residual e1 (dense, or scattered from half res)    */
@@ -68,7 +70,7 @@ typedef struct c3d_pw_args {
   const float* epi_p;    /* SWISH_SE_BWD: scale[Np],shift[Np] of the BN applied to e1        */
   const float* epi_gate; /* SWISH_SE_BWD: gate[B][Np] or NULL (=1)                           */
   const float* epi_q;    /* SWISH_SE_BWD: mean[Np],rstd[Np] of that BN (centred sum t1*bhat)  */
-  double* stats;         /* STATS: sum[N],sumsq[N]; SWISH_SE_BWD: [B][Np][3]                 */
+  double* stats;         /* STATS: [C3D_STAT_STRIPES][2][N]; SWISH_SE_BWD: [B][Np][3]         */
   int64_t M;             /* output rows                                                      */
   int64_t gstride;       /* C3D_ROWS_FRAME: elements between consecutive row groups          */
   int64_t rows_per_sample; /* output rows per batch sample (gate / per-sample sums)          */
@@ -112,10 +114,10 @@ int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream);
 /* ------------------------------------------------------------------------------------
  * Train-mode BatchNorm3d split (reference model/x3d.py:97,179,207,220,298): statistics are
  * accumulated by producer epilogues, finalised here, applied by consumer prologues.
- *   sums : f64 [2][C] (sum, sumsq);   ss : f32 scale[Cp], shift[Cp];   mr : f32 mean[Cp], rstd[Cp]
+ *   sums : f64 [stripes][2][C] (sum, sumsq), summed over the stripes;   ss : f32 scale[Cp], shift[Cp];   mr : f32 mean[Cp], rstd[Cp]
  * training=0 builds scale/shift from the running statistics (eval mode).
  * ------------------------------------------------------------------------------------ */
-int c3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+int c3d_bn_finalize(const double* sums, int32_t stripes, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float momentum, float eps, int32_t C, int32_t Cp, int32_t training, float* ss,
                     float* mr, void* stream);

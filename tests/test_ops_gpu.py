@@ -62,7 +62,7 @@ def test_pw_gemm_plain_stats(dtype, K, N):
     ref = x @ w.t()
     xd = padc(x, Kp).to(DEV, dtype).contiguous()
     y = torch.full((M, Np), float("nan"), dtype=dtype, device=DEV)
-    stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    stats = torch.zeros(ops.STAT_STRIPES * 2 * N, dtype=torch.float64, device=DEV)
     ops.pw_gemm(xd, w.to(DEV), y, M=M, K=K, N=N, w_sn=K, w_sk=1, dtype=ops.dt_code(dtype),
                 epi_mode=ops.EPI_STATS, stats=stats)
     torch.cuda.synchronize()
@@ -70,7 +70,7 @@ def test_pw_gemm_plain_stats(dtype, K, N):
     if Np > N:
         assert (y[:, N:].float() == 0).all(), "pad channels must be zero"
     yq = y[:, :N].float().cpu().double()
-    s = stats.cpu()
+    s = stats.cpu().view(ops.STAT_STRIPES, 2 * N).sum(0)
     assert torch.allclose(s[:N], yq.sum(0), rtol=1e-5, atol=1e-3), "column sums"
     assert torch.allclose(s[N:], (yq * yq).sum(0), rtol=1e-5, atol=1e-3), "column sums of squares"
 
@@ -166,8 +166,10 @@ def test_pw_gemm_swish_se_bwd_epilogue(dtype):
     nc3 = torch.zeros(B * Np * 3, dtype=torch.float64, device=DEV)
     ss = torch.cat([padc(scale, Np), padc(shift, Np)]).to(DEV)
     mean, rstd = rnd((N,), 26, 0.5), rnd((N,), 27).abs() + 0.5
-    ops.pw_gemm(g.to(DEV, dtype).contiguous(), w.to(DEV), y, M=M, K=K, N=N, w_sn=1, w_sk=N, dtype=ops.dt_code(dtype),
-                epi_mode=ops.EPI_SWISH_SE_BWD, e1=padc(b, Np).to(DEV, dtype).contiguous(), epi_p=ss,
+    ident = torch.cat([torch.ones(K), torch.zeros(K), torch.zeros(K)]).to(DEV)  # AFFINE2 with A=1,B=0,C=0
+    gd = g.to(DEV, dtype).contiguous()
+    ops.pw_gemm(gd, w.to(DEV), y, M=M, K=K, N=N, w_sn=1, w_sk=N, dtype=ops.dt_code(dtype), x2=gd,
+                pro_mode=ops.PRO_AFFINE2, pro_p=ident, epi_mode=ops.EPI_SWISH_SE_BWD, e1=padc(b, Np).to(DEV, dtype).contiguous(), epi_p=ss,
                 epi_gate=padc(gate, Np).to(DEV).contiguous(),
                 epi_q=torch.cat([padc(mean, Np), padc(rstd, Np)]).to(DEV), stats=nc3, rows_per_sample=rows)
     close(y[:, :N], t1, dtype, "t1", scale=t1.abs().max().item())
