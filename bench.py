@@ -144,23 +144,23 @@ def main():
 
     graph = None
     use_graph = not a.no_graph and world == 1  # N>1: the overlapped all-reduce is issued from inside backward
-    # eager warm-up (also instantiates workspaces / function attributes before any capture)
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
     adjust_learning_rate(margs, opt, 0, 0, MAX_ITER)
     opt.prepare_step()
-    state["loss"], state["prob"] = fwd_bwd()
-    sync.finish()
-    opt.launch()
-    torch.cuda.synchronize()
     if use_graph:
+        # every pre-capture step runs on the capture stream (autograd's AccumulateGrad nodes remember
+        # the stream they were created on; a default-stream step before capture breaks it)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                fwd_bwd()
+                for _ in range(2):
+                    state["loss"], state["prob"] = fwd_bwd()
+                    opt.launch()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):
                 state["loss"], state["prob"] = fwd_bwd()
                 opt.launch()
             torch.cuda.synchronize()
@@ -169,6 +169,11 @@ def main():
                 print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+    else:
+        state["loss"], state["prob"] = fwd_bwd()
+        sync.finish()
+        opt.launch()
+        torch.cuda.synchronize()
 
     def step():
         adjust_learning_rate(margs, opt, 0, state["it"], MAX_ITER)

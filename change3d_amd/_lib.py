@@ -48,13 +48,15 @@ SIGNATURES = {
     "c3d_bn_finalize": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp]),
     "c3d_bn_se_finalize": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp, vp,
                                  i32, vp, vp, vp, vp, vp]),
-    "c3d_bn_bwd_coef": (i32, [vp, f64, vp, vp, i32, i32, vp, vp, vp, vp]),
+    "c3d_bn_bwd_coef": (i32, [vp, i32, f64, vp, vp, i32, i32, vp, vp, vp, vp]),
     "c3d_se_bn_bwd_coef": (i32, [vp, vp, i32, f64, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp,
                                  vp, vp, vp, vp, vp, vp]),
     "c3d_dw333_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_dw333_bwd_data": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
                                  i32, vp]),
     "c3d_dw333_wgrad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "c3d_dw333_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
+                            i32, vp]),
     "c3d_block_out_fwd": (i32, [vp, vp, vp, vp, i32, vp, i64, i32, i32, vp]),
     "c3d_block_out_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "c3d_frame_absdiff": (i32, [vp, vp, i32, i32, i64, i32, i32, i32, i32, vp]),

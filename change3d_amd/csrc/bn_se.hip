@@ -119,14 +119,15 @@ __global__ __launch_bounds__(256) void bn_se_finalize_kernel(
 // BN backward coefficients: dsums [2][C] = (sum g, sum g*xhat), xhat = (x-mean)*rstd accumulated
 // CENTRED by the producer (as ATen does; avoids the sum(g*x) - mean*sum(g) cancellation).
 // dx = A*g + B + C*x.
-__global__ void bn_bwd_coef_kernel(const double* __restrict__ dsums, double count, const float* __restrict__ gamma,
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ dsums, int stripes, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ mr, int C, int Cp, float* __restrict__ coef,
                                    float* dgamma, float* dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cp) return;
   if (c >= C) { coef[c] = 0.f; coef[Cp + c] = 0.f; coef[2 * Cp + c] = 0.f; return; }
   const double mean = mr[c], rstd = mr[Cp + c];
-  const double s1 = dsums[c], s2 = dsums[C + c];  // sum g, sum g * xhat
+  double s1 = 0, s2 = 0;  // sum g, sum g * xhat (over the striped accumulator sets)
+  for (int k = 0; k < stripes; ++k) { s1 += dsums[(size_t)k * 2 * C + c]; s2 += dsums[(size_t)k * 2 * C + C + c]; }
   const double A = (double)gamma[c] * rstd;
   const double Cc = -A * rstd * s2 / count;
   const double Bc = -A * s1 / count - Cc * mean;
@@ -261,11 +262,11 @@ extern "C" int c3d_bn_se_finalize(const double* nc, int32_t B, double cnt_per_sa
   return 0;
 }
 
-extern "C" int c3d_bn_bwd_coef(const double* dsums, double count, const float* gamma, const float* mr, int32_t C,
+extern "C" int c3d_bn_bwd_coef(const double* dsums, int32_t stripes, double count, const float* gamma, const float* mr, int32_t C,
                                int32_t Cp, float* coef, float* dgamma, float* dbeta, void* stream) {
-  if (!dsums || !gamma || !mr || !coef || C <= 0 || Cp < C) return C3D_E_BADARG;
+  if (!dsums || stripes < 1 || !gamma || !mr || !coef || C <= 0 || Cp < C) return C3D_E_BADARG;
   bn_bwd_coef_kernel<<<dim3((Cp + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-      dsums, count, gamma, mr, C, Cp, coef, dgamma, dbeta);
+      dsums, stripes, count, gamma, mr, C, Cp, coef, dgamma, dbeta);
   C3D_CHECK_LAUNCH();
   return 0;
 }

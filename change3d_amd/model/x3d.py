@@ -239,14 +239,15 @@ def _block_backward(blk, dy, sv, act_dtype):
     se = b2.norm_b[1] if blk.use_se else None
     mode = sv["mode"]
     x, a, b, c, sc, y = sv["x"], sv["a"], sv["b"], sv["c"], sv["sc"], sv["y"]
-    n_acc = 2 * Co + (2 * Co if mode == ops.SC_BN else 0) + B * Cip * 3 + 2 * Ci
+    S = ops.STAT_STRIPES
+    n_acc = 2 * Co + (2 * Co if mode == ops.SC_BN else 0) + B * Cip * 3 + S * 2 * Ci
     acc = torch.zeros(n_acc, dtype=torch.float64, device=dev)
     dsums_c, o = acc[:2 * Co], 2 * Co
     dsums_1 = None
     if mode == ops.SC_BN:
         dsums_1, o = acc[o:o + 2 * Co], o + 2 * Co
     nc3, o = acc[o:o + B * Cip * 3], o + B * Cip * 3
-    dsums_a = acc[o:o + 2 * Ci]
+    dsums_a = acc[o:o + S * 2 * Ci]
 
     # ---- y = relu(bn_c(c) + shortcut)
     g = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
@@ -267,10 +268,13 @@ def _block_backward(blk, dy, sv, act_dtype):
                        sv["hid"], Ci, cA, cC, cB)
     # ---- depthwise conv_b
     t2 = torch.empty((M, Cip), dtype=act_dtype, device=dev)
+    # (c3d_dw333_bwd, the single-pass fused variant, is exported and tested but currently slower than
+    # the split pair on MI355X — LDS-read bound; see DESIGN.md "what comes next")
     ops.dw_bwd_data(t1, b, cA, cB, cC, b2.conv_b.weight, a, sv["ss_a"], sv["mr_a"], t2, dsums_a, B, T, H, W, Ci, s, dt)
     ops.dw_wgrad(t1, b, cA, cB, cC, a, sv["ss_a"], ops.grad_of(b2.conv_b.weight), B, T, H, W, Ci, s, dt)
+    stripes_a = 1
     coef_a = _f32(3 * Cip, dev)
-    ops.bn_bwd_coef(dsums_a, M, b2.norm_a, sv["mr_a"], Ci, coef_a)
+    ops.bn_bwd_coef(dsums_a, M, b2.norm_a, sv["mr_a"], Ci, coef_a, stripes=stripes_a)
     # ---- shortcut branch
     dx = torch.empty((B, T, H, W, Cinp), dtype=act_dtype, device=dev)
     if blk.branch1_conv is not None:

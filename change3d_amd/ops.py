@@ -159,8 +159,8 @@ def bn_se_finalize(nc, B, cnt, bn, se, C_, ss, mr, gate, hid, training):
                                        _stream())
 
 
-def bn_bwd_coef(dsums, count, bn, mr, C_, coef):
-    _launch("c3d_bn_bwd_coef", 0, L.lib().c3d_bn_bwd_coef, _p(dsums), float(count), _p(bn.weight), _p(mr), C_, cpad(C_), _p(coef),
+def bn_bwd_coef(dsums, count, bn, mr, C_, coef, stripes=1):
+    _launch("c3d_bn_bwd_coef", 0, L.lib().c3d_bn_bwd_coef, _p(dsums), stripes, float(count), _p(bn.weight), _p(mr), C_, cpad(C_), _p(coef),
                                     _p(grad_of(bn.weight)), _p(grad_of(bn.bias)), _stream())
 
 
@@ -191,6 +191,13 @@ def dw_bwd_data(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, B, T, H, W, C_, 
 def dw_wgrad(t1, b, cA, cB, cC, a, ss_a, dw, B, T, H, W, C_, stride, dtype):
     _launch("c3d_dw333_wgrad", (t1.numel() + b.numel() + a.numel()) * _es(dtype), L.lib().c3d_dw333_wgrad, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(a), _p(ss_a), _p(dw), B, T, H, W,
                                     C_, cpad(C_), stride, dtype, _stream())
+
+
+def dw_bwd(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, dw, B, T, H, W, C_, stride, dtype):
+    """fused data + weight gradient; dsums is [STAT_STRIPES][2][C]."""
+    _launch("c3d_dw333_bwd", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd,
+            _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2), _p(dsums), _p(dw),
+            B, T, H, W, C_, cpad(C_), stride, dtype, _stream())
 
 
 # ----------------------------------------------------------------------------- elementwise

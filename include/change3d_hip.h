@@ -130,10 +130,10 @@ int c3d_bn_se_finalize(const double* nc, int32_t B, double cnt_per_sample, const
                        int32_t training, const float* w1, const float* b1, const float* w2,
                        const float* b2, int32_t Cr, float* ss, float* mr, float* gate, float* hid,
                        void* stream);
-/* BatchNorm backward as an affine map dx = A*g + B + C*x: dsums f64 [2][C] = (sum g, sum g*xhat),
+/* BatchNorm backward as an affine map dx = A*g + B + C*x: dsums f64 [stripes][2][C] = (sum g, sum g*xhat),
  * xhat = (x-mean)*rstd accumulated centred by the producer;
  * coef f32 A[Cp],B[Cp],C[Cp]; dgamma/dbeta are accumulated (+=).                            */
-int c3d_bn_bwd_coef(const double* dsums, double count, const float* gamma, const float* mr, int32_t C,
+int c3d_bn_bwd_coef(const double* dsums, int32_t stripes, double count, const float* gamma, const float* mr, int32_t C,
                     int32_t Cp, float* coef, float* dgamma, float* dbeta, void* stream);
 /* SE backward + BN_b backward: nc3 f64 [B][Cp][3] from C3D_EPI_SWISH_SE_BWD, ncf = forward nc.
  * db = coefA[c]*t1 + coefB[n][c] + coefC[c]*b.  FC / BN parameter gradients accumulated (+=). */
@@ -162,6 +162,12 @@ int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const flo
                     const float* coefC, const void* a, const float* ss_a, float* dw, int32_t B, int32_t T,
                     int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
                     void* stream);
+/* bwd_data + wgrad fused (one staging of the tiles, prefetched, persistent workgroups);
+ * dsums is f64 [C3D_STAT_STRIPES][2][C]. */
+int c3d_dw333_bwd(const void* t1, const void* b, const float* coefA, const float* coefB, const float* coefC,
+                  const float* w, const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums,
+                  float* dw, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride,
+                  int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Res-block output y = relu(bn_c(c) + shortcut) (reference model/x3d.py:326-327; also the
