@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void bn_se_finalize_kernel(
     double mean, var;
     if (training) {
       double s1 = 0, s2 = 0;
+#pragma unroll 8
       for (int n = 0; n < B; ++n) { s1 += nc[((size_t)n * Cp + c) * 2]; s2 += nc[((size_t)n * Cp + c) * 2 + 1]; }
       mean = s1 / count;
       var = s2 / count - mean * mean;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void bn_se_finalize_kernel(
     ss[Cp + c] = sh;
     if (mr) { mr[c] = meanf; mr[Cp + c] = rstd; }
     if (w1) {
+#pragma unroll 8
       for (int n = 0; n < B; ++n)
         z[(size_t)n * C + c] = fmaf(sc, (float)(nc[((size_t)n * Cp + c) * 2] / cnt_per_sample), sh);
     }
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(256) void se_bn_bwd_coef_kernel(
   const double count = cnt_per_sample * B;
   const bool se = w1 != nullptr;
   if (se) {
+#pragma unroll 4
     for (int i = tid; i < B * C; i += blockDim.x) {
       const int n = i / C, c = i - n * C;
       const float g = gate[(size_t)n * Cp + c];
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(256) void se_bn_bwd_coef_kernel(
     }
     const double mean = mr[c], rstd = mr[Cp + c];
     double s1 = 0, s2 = 0;
+#pragma unroll 8
     for (int n = 0; n < B; ++n) {
       const double dzn = se ? (double)dz[(size_t)n * C + c] : 0.0;
       s1 += nc3[((size_t)n * Cp + c) * 3 + 1] + dzn;

@@ -14,6 +14,7 @@
 // owns one output pixel and one 8-channel vector for all T frames.
 #include "common.h"
 #include "../../include/change3d_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -790,6 +791,212 @@ int launch_bwd_fused_t(const void* t1, const void* bb, const float* cA, const fl
   return launch_bwd_fused<T, S, 5>(t1, bb, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, dw, g, stream);
 }
 
+// ----------------------------------------------------------------------------------------------
+// Forward v2 (stride 1).  Mapping chosen from the round-1 profile (v1 was LDS-read bound at
+// 3.7 FMA per LDS read):
+//   * wave  = one 8-channel vector; the LDS tile is stored as per-vector planes [cv][t][y][x][8] so a
+//     wave's lanes read consecutive 16-byte pixels (conflict-free) and weights are wave-uniform
+//     (LDS broadcast reads);
+//   * lane  = a 2-pixel strip along x; the 4 input pixels of a kernel row stay in registers for all
+//     kx / kt taps and all T frames (about 11 FMA per LDS read);
+//   * workgroup = 8x16 output pixels x 32 channels, walks `tiles_per_wg` tiles of one sample keeping
+//     the per-(sample,channel) statistics in registers, with the next tile's raw rows prefetched.
+constexpr int V2_TH = 8, V2_TW = 16, V2_IH = V2_TH + 2, V2_IW = V2_TW + 2;
+
+__device__ __forceinline__ void lds_ld8v2(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// LDS plane geometry of the v2 kernels: one plane per (channel vector, half vector) holding a float4
+// per pixel, [t][iy][ix]; the plane stride is padded by one float4 so the 8 planes of a pixel fall on
+// distinct bank groups (conflict-free staging writes), and lanes walk x so stencil reads are dense.
+template <int TT> struct V2Geo {
+  static constexpr int PLANE = TT * V2_IH * V2_IW + 1;          // float4 units
+  static constexpr int NI = TT * V2_IH * V2_IW * DW_CV;         // staged 8-channel vectors per tile
+  static constexpr int SL = (NI + 255) / 256;
+};
+
+template <typename T, int TT>
+__global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x, const float* __restrict__ ss,
+                                                        const float* __restrict__ w, T* __restrict__ y,
+                                                        double* __restrict__ nc, const DwGeom g,
+                                                        const int tiles_per_wg) {
+  typedef RawD<T> RW;
+  typedef V2Geo<TT> G;
+  constexpr int NI = G::NI, SL = G::SL, PLANE = G::PLANE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);                  // [27][32]
+  float4* tile = reinterpret_cast<float4*>(wl + 27 * 32);      // [4 cv][2 halves][PLANE]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wcv = __builtin_amdgcn_readfirstlane(tid >> 6);    // this wave's channel vector
+  const int lx = lane & 15, yp = lane >> 4;                    // lane = column x, row pair (2yp, 2yp+1)
+  const int tiles_x = (g.W + V2_TW - 1) / V2_TW, tiles_y = (g.H + V2_TH - 1) / V2_TH;
+  const int ntiles = tiles_x * tiles_y;
+  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int c0 = chunk * DW_CV * 8;
+  // staging role: item i = tid + 256*slot -> (cv = i & 3, pixel = i >> 2)
+  const int scv = tid & 3;
+  const int sbase = c0 + scv * 8;
+  const bool s_ok = sbase < g.Cp;
+  const int cbase = c0 + wcv * 8;       // compute role
+  const bool c_ok = cbase < g.Cp;
+
+  for (int i = tid; i < 27 * 32; i += 256) {
+    const int tap = i / 32, c = c0 + (i & 31);
+    wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
+  }
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = s_ok ? ss[sbase + j] : 0.f; sh[j] = s_ok ? ss[g.Cp + sbase + j] : 0.f; }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+
+  typename RW::type raw[SL];
+  unsigned vmask = 0;
+#define V2_ISSUE(TL)                                                                            \
+  {                                                                                             \
+    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                       \
+    vmask = 0;                                                                                  \
+    _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                         \
+      const int i_ = tid + sl * 256;                                                            \
+      const int p_ = i_ >> 2;                                                                   \
+      const int ix_ = p_ % V2_IW, q_ = p_ / V2_IW;                                              \
+      const int iy_ = q_ % V2_IH, t_ = q_ / V2_IH;                                              \
+      const int gy_ = ty_ * V2_TH - 1 + iy_, gx_ = tx_ * V2_TW - 1 + ix_;                       \
+      if (i_ < NI && s_ok && t_ < g.T && gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W) {     \
+        raw[sl] = RW::load(x + ((((size_t)b * g.T + t_) * g.H + gy_) * g.W + gx_) * g.Cp + sbase); \
+        vmask |= 1u << sl;                                                                      \
+      }                                                                                         \
+    }                                                                                           \
+  }
+
+  const int tl0 = blockIdx.x * tiles_per_wg;
+  int tl1 = tl0 + tiles_per_wg;
+  if (tl1 > ntiles) tl1 = ntiles;
+  if (tl0 < tl1) V2_ISSUE(tl0)
+  for (int tl = tl0; tl < tl1; ++tl) {
+    const int tx = tl % tiles_x, ty = tl / tiles_x;
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int i = tid + sl * 256;
+      if (i < NI) {
+        float f[8];
+        if ((vmask >> sl) & 1u) {
+          RW::cvt(raw[sl], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = 0.f;
+        }
+        const int p = i >> 2;  // = (t*IH + iy)*IW + ix
+        tile[(scv * 2 + 0) * PLANE + p] = make_float4(f[0], f[1], f[2], f[3]);
+        tile[(scv * 2 + 1) * PLANE + p] = make_float4(f[4], f[5], f[6], f[7]);
+      }
+    }
+    if (tl + 1 < tl1) V2_ISSUE(tl + 1)
+    __syncthreads();
+
+    float acc[TT][2][8];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][py][j] = 0.f;
+    const float4* pl0 = tile + (wcv * 2 + 0) * PLANE;
+    const float4* pl1 = tile + (wcv * 2 + 1) * PLANE;
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll 1
+      for (int kx = 0; kx < 3; ++kx) {
+        float wk[3][8];  // wave-uniform: broadcast LDS reads
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) lds_ld8v2(wl + (kt * 9 + ky * 3 + kx) * 32 + wcv * 8, wk[kt]);
+#pragma unroll
+        for (int ti = 0; ti < TT; ++ti) {
+          float in[2][8];
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            const int p = (ti * V2_IH + 2 * yp + py + ky) * V2_IW + lx + kx;
+            const float4 h0 = pl0[p], h1 = pl1[p];
+            in[py][0] = h0.x; in[py][1] = h0.y; in[py][2] = h0.z; in[py][3] = h0.w;
+            in[py][4] = h1.x; in[py][5] = h1.y; in[py][6] = h1.z; in[py][7] = h1.w;
+          }
+#pragma unroll
+          for (int kt = 0; kt < 3; ++kt) {
+            const int to = ti - kt + 1;  // out[to] += in[to + kt - 1] * w[kt]
+            if (to >= 0 && to < TT) {
+#pragma unroll
+              for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[to][py][j] = fmaf(in[py][j], wk[kt][j], acc[to][py][j]);
+            }
+          }
+        }
+      }
+    }
+    const int ox = tx * V2_TW + lx;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      const int oy = ty * V2_TH + 2 * yp + py;
+      if (c_ok && oy < g.H && ox < g.W) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          if (t < g.T) {
+            T* dst = y + ((((size_t)b * g.T + t) * g.H + oy) * g.W + ox) * g.Cp + cbase;
+            Vec8<T>::store(dst, acc[t][py]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float r = round_as<T>(acc[t][py][j]);
+              s1[j] += r; s2[j] = fmaf(r, r, s2[j]);
+            }
+          }
+        }
+      }
+    }
+  }
+#undef V2_ISSUE
+  if (nc == nullptr) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float r1 = wave_sum(s1[j]), r2 = wave_sum(s2[j]);
+    const int c = cbase + j;
+    if (lane == 0 && c < g.C) {
+      atomicAdd(nc + ((size_t)b * g.Cp + c) * 2, (double)r1);
+      atomicAdd(nc + ((size_t)b * g.Cp + c) * 2 + 1, (double)r2);
+    }
+  }
+}
+
+template <typename T, int TT>
+int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, double* nc, const DwGeom& g,
+                  hipStream_t stream) {
+  const size_t lds = 27 * 32 * sizeof(float) + (size_t)DW_CV * 2 * V2Geo<TT>::PLANE * sizeof(float4);
+  if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2_kernel<T, TT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int ntiles = ((g.W + V2_TW - 1) / V2_TW) * ((g.H + V2_TH - 1) / V2_TH);
+  int tpw = 16;  // swept on MI355X: 1:427us 4:255 8:240 16:233 32:250 (stage-1 shape)
+  if (const char* e = getenv("C3D_DW_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;  // tuning knob
+  if (tpw > ntiles) tpw = ntiles;
+  dim3 grid((ntiles + tpw - 1) / tpw, (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), g.B);
+  dw_fwd_v2_kernel<T, TT><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
+                                                            reinterpret_cast<T*>(y), nc, g, tpw);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T, int S> struct DwTile;  // forward / wgrad output tile per workgroup
 template <typename T> struct DwTile<T, 1> { static constexpr int TH = 8, TW = 8; };
 template <typename T> struct DwTile<T, 2> { static constexpr int TH = 4, TW = 8; };
@@ -883,6 +1090,15 @@ extern "C" int c3d_dw333_fwd(const void* x, const float* ss, const float* w, voi
   DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
   if (!x || !ss || !w || !y || !geom_ok(g)) return C3D_E_BADARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stride == 1) {  // v2 mapping (wave = channel vector, lane = x-strip)
+    int rc = C3D_E_UNSUPPORTED;
+    if (dtype == C3D_DT_F32) rc = T <= 3 ? launch_fwd_v2<float, 3>(x, ss, w, y, nc_sums, g, s)
+                                         : launch_fwd_v2<float, 5>(x, ss, w, y, nc_sums, g, s);
+    else if (dtype == C3D_DT_BF16) rc = T <= 3 ? launch_fwd_v2<bf16_t, 3>(x, ss, w, y, nc_sums, g, s)
+                                               : launch_fwd_v2<bf16_t, 5>(x, ss, w, y, nc_sums, g, s);
+    else return C3D_E_BADARG;
+    if (rc != C3D_E_UNSUPPORTED) return rc;
+  }
   if (dtype == C3D_DT_F32) return stride == 1 ? launch_fwd<float, 1>(x, ss, w, y, nc_sums, g, s)
                                               : launch_fwd<float, 2>(x, ss, w, y, nc_sums, g, s);
   if (dtype == C3D_DT_BF16) return stride == 1 ? launch_fwd<bf16_t, 1>(x, ss, w, y, nc_sums, g, s)

@@ -347,7 +347,7 @@ def test_e2e_bcd_vs_reference_golden(size, golden_dir):
         meter.update_cm_device(prob, tgt)
         losses.append(loss.item())
     losses = np.array(losses)
-    l_tol = K_NOISE * np.abs(G["loss_curve"] - G["loss_curve_f64"]) + 2e-5
+    l_tol = K_NOISE * np.abs(G["loss_curve"] - G["loss_curve_f64"]).max() + 1e-4
     print(f"loss curve hip {losses} ref32 {G['loss_curve']} ref64 {G['loss_curve_f64']}")
     assert (np.abs(losses - G["loss_curve_f64"]) <= l_tol).all(), (losses, G["loss_curve"], G["loss_curve_f64"])
     meter.sync()
