@@ -17,14 +17,15 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 enum { C3D_F32 = 0, C3D_BF16 = 1 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// f32 -> bf16, round-to-nearest-even in hardware (gfx950 v_cvt_pk_bf16_f32: one instruction per
+// PAIR; the integer-arithmetic rounding it replaces cost ~12 VALU per pair in every epilogue)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 // ---- 8-element vector load / store (global or LDS), converting to/from f32 ---------------
 template <typename T> struct Vec8;

@@ -12,7 +12,7 @@
 //
 // All T frames of a spatial tile are resident in LDS (T = 3 for BCD, 5 for SCD).  A thread
 // owns one output pixel and one 8-channel vector for all T frames.
-#include "common.h"
+#include "pw_common.h"  // common.h + device_cus()
 #include "../../include/change3d_hip.h"
 #include <cstdlib>
 
@@ -334,131 +334,6 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
 }
 
 // ----------------------------------------------------------------------------------------------
-// Weight gradient.  block = 64 pixels x DW_CV vectors x 3 temporal taps = 768 threads; a
-// workgroup walks `tiles_per_wg` spatial tiles of one (sample, channel chunk) keeping its
-// 9x8 partial sums in registers, then reduces across pixels once.
-template <typename T, int S, int TH, int TW>
-__global__ __launch_bounds__(TH * TW * DW_CV * 3) void dw_wgrad_kernel(
-    const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
-    const float* __restrict__ coefB, const float* __restrict__ coefC, const T* __restrict__ a,
-    const float* __restrict__ ss_a, float* __restrict__ dw, const DwGeom g, const int tiles_per_wg) {
-  typedef typename LdsStore<T>::type L;
-  constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
-  constexpr int NPIX = TH * TW;
-  constexpr int NTHR = NPIX * DW_CV * 3;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* red = reinterpret_cast<float*>(smem);                 // [27][32] workgroup accumulator
-  L* atile = reinterpret_cast<L*>(red + 27 * 32);              // [T][IH][IW][32]  relu(bn(a))
-  L* dtile = atile + (size_t)g.T * IH * IW * 32;               // [T][TH][TW][32]  db
-
-  const int tid = threadIdx.x;
-  const int tiles_x = (g.Wo + TW - 1) / TW, tiles_y = (g.Ho + TH - 1) / TH;
-  const int ntiles = tiles_x * tiles_y;
-  const int chunk = blockIdx.y, b = blockIdx.z;
-  const int c0 = chunk * DW_CV * 8;
-  const int cv = tid % DW_CV;
-  const int cbase = c0 + cv * 8;
-  const bool c_ok = cbase < g.Cp;
-  const int pix = (tid / DW_CV) % NPIX;
-  const int kt = tid / (DW_CV * NPIX);
-  const int px = pix % TW, py = pix / TW;
-
-  for (int i = tid; i < 27 * 32; i += NTHR) red[i] = 0.f;
-  float sa[8], sb[8], cA[8], cB[8], cC[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    sa[j] = c_ok ? ss_a[cbase + j] : 0.f; sb[j] = c_ok ? ss_a[g.Cp + cbase + j] : 0.f;
-    cA[j] = c_ok ? coefA[cbase + j] : 0.f;
-    cB[j] = c_ok ? coefB[(size_t)b * g.Cp + cbase + j] : 0.f;
-    cC[j] = c_ok ? coefC[cbase + j] : 0.f;
-  }
-  float acc[9][8];
-#pragma unroll
-  for (int k = 0; k < 9; ++k)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
-
-  int tile0 = blockIdx.x * tiles_per_wg, tile1 = tile0 + tiles_per_wg;
-  if (tile1 > ntiles) tile1 = ntiles;
-  for (int tl = tile0; tl < tile1; ++tl) {
-    const int tx = tl % tiles_x, ty = tl / tiles_x;
-    const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
-    __syncthreads();
-    for (int i = tid; i < g.T * IH * IW * DW_CV; i += NTHR) {  // NTHR % DW_CV == 0
-      const int p = i / DW_CV;
-      const int ix = p % IW;
-      const int q = p / IW;
-      const int iy = q % IH, t = q / IH;
-      const int gy = iy0 + iy, gx = ix0 + ix;
-      float f[8];
-      if (c_ok && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
-        Vec8<T>::load(a + ((((size_t)b * g.T + t) * g.H + gy) * g.W + gx) * g.Cp + cbase, f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sa[j], sb[j]), 0.f);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = 0.f;
-      }
-      Vec8<L>::store(atile + (size_t)p * 32 + cv * 8, f);
-    }
-    for (int i = tid; i < g.T * NPIX * DW_CV; i += NTHR) {
-      const int p = i / DW_CV;
-      const int ox = p % TW;
-      const int q = p / TW;
-      const int oy = q % TH, t = q / TH;
-      const int gy = ty * TH + oy, gx = tx * TW + ox;
-      float f[8];
-      if (c_ok && gy < g.Ho && gx < g.Wo) {
-        const size_t off = ((((size_t)b * g.T + t) * g.Ho + gy) * g.Wo + gx) * g.Cp + cbase;
-        float f2[8];
-        Vec8<T>::load(t1 + off, f);
-        Vec8<T>::load(bb + off, f2);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j]));
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = 0.f;
-      }
-      Vec8<L>::store(dtile + (size_t)p * 32 + cv * 8, f);
-    }
-    __syncthreads();
-    for (int to = 0; to < g.T; ++to) {
-      const int ti = to + kt - 1;
-      if (ti < 0 || ti >= g.T) continue;
-      float d[8];
-      Vec8<L>::load(dtile + ((size_t)(to * TH + py) * TW + px) * 32 + cv * 8, d);
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          float r[8];
-          Vec8<L>::load(atile + ((size_t)(ti * IH + py * S + ky) * IW + px * S + kx) * 32 + cv * 8, r);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] = fmaf(d[j], r[j], acc[ky * 3 + kx][j]);
-        }
-      }
-    }
-  }
-  // reduce across the pixels of each wave (lanes with equal cv; kt is wave-uniform: 256 | pix*cv)
-  const int lane = tid & 63;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = acc[k][j];
-#pragma unroll
-      for (int o = DW_CV; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-      if (lane < DW_CV) atomicAdd(&red[(kt * 9 + k) * 32 + lane * 8 + j], v);
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < 27 * 32; i += NTHR) {
-    const int tap = i / 32, c = c0 + (i & 31);
-    if (c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, red[i]);
-  }
-}
-
-// ----------------------------------------------------------------------------------------------
 // Fused backward: data gradient AND weight gradient from ONE staging of the (t1, b) and a tiles.
 //   * a workgroup walks `tiles_per_wg` 8x8 input-resolution tiles of one (sample, 32-channel chunk);
 //     the next tile's raw rows are prefetched into registers while the current one is processed;
@@ -487,6 +362,521 @@ template <> struct RawD<float> {
     f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w; f[4] = v.b.x; f[5] = v.b.y; f[6] = v.b.z; f[7] = v.b.w;
   }
 };
+
+// Asynchronous LDS vector read of 8 tile elements with an explicit wait, for hand-pipelined
+// inner loops (inline asm: the wait names the destination so its consumers cannot move above it).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <typename P> __device__ __forceinline__ uint32_t lds_addr(const P* p) {
+  return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));
+}
+template <typename L> struct LdsVec;
+template <> struct LdsVec<bf16_t> {
+  static constexpr int N = 1;  // LDS instructions per issue
+  struct raw_t { u32x4_t v; };
+  static __device__ __forceinline__ void issue(raw_t& r, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r.v) : "v"(addr));
+  }
+  template <int CNT> static __device__ __forceinline__ void wait(raw_t& r) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r.v) : "n"(CNT));
+  }
+  static __device__ __forceinline__ void cvt(const raw_t& r, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(r.v[i] << 16);
+      f[2 * i + 1] = __uint_as_float(r.v[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void cvt2(const raw_t& r, f32x2_t (&f)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = f32x2_t{__uint_as_float(r.v[i] << 16), __uint_as_float(r.v[i] & 0xffff0000u)};
+  }
+};
+template <> struct LdsVec<float> {
+  static constexpr int N = 2;
+  struct raw_t { u32x4_t a, b; };
+  static __device__ __forceinline__ void issue(raw_t& r, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(r.a), "=&v"(r.b) : "v"(addr));
+  }
+  template <int CNT> static __device__ __forceinline__ void wait(raw_t& r) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r.a), "+v"(r.b) : "n"(CNT));
+  }
+  static __device__ __forceinline__ void cvt(const raw_t& r, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = __uint_as_float(r.a[i]); f[4 + i] = __uint_as_float(r.b[i]); }
+  }
+  static __device__ __forceinline__ void cvt2(const raw_t& r, f32x2_t (&f)[4]) {
+    f[0] = f32x2_t{__uint_as_float(r.a[0]), __uint_as_float(r.a[1])};
+    f[1] = f32x2_t{__uint_as_float(r.a[2]), __uint_as_float(r.a[3])};
+    f[2] = f32x2_t{__uint_as_float(r.b[0]), __uint_as_float(r.b[1])};
+    f[3] = f32x2_t{__uint_as_float(r.b[2]), __uint_as_float(r.b[3])};
+  }
+};
+
+// Consumer side of the weight gradient: one thread = (output pixel, 8-channel vector, temporal tap kt);
+// acc[ky*3+kx][pair] += db[to] * a[to+kt-1][ky][kx] over the frames of one LDS-resident tile.
+// Explicit one-deep LDS pipeline: left to itself the compiler issues all nine tap reads, converts
+// them, and only then starts the FMAs (~160 live VGPRs; the budget of a 1024-thread workgroup is
+// 128) -- the empty asm after each tap pins that tap's FMAs in place.
+template <typename L, int S, int TH, int TW>
+__device__ __forceinline__ void wgrad_tile_taps(f32x2_t (&acc)[9][4], const L* atile, const L* dtile, const int T,
+                                                const int kt, const int px, const int py, const int cv) {
+  constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+  for (int to = 0; to < T; ++to) {
+    const int ti = to + kt - 1;
+    if (ti < 0 || ti >= T) continue;
+    const uint32_t d_addr = lds_addr(dtile + ((size_t)(to * TH + py) * TW + px) * 32 + cv * 8);
+    const uint32_t a_addr = lds_addr(atile + ((size_t)(ti * IH + py * S) * IW + px * S) * 32 + cv * 8);
+    typename LdsVec<L>::raw_t dr, rr[2];
+    LdsVec<L>::issue(dr, d_addr);
+    LdsVec<L>::issue(rr[0], a_addr);
+    LdsVec<L>::template wait<LdsVec<L>::N>(dr);
+    f32x2_t d[4];
+    LdsVec<L>::cvt2(dr, d);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (k < 8) {
+        const int kn = k + 1;
+        LdsVec<L>::issue(rr[kn & 1], a_addr + (uint32_t)(((kn / 3) * IW + (kn % 3)) * 32 * sizeof(L)));
+        LdsVec<L>::template wait<LdsVec<L>::N>(rr[k & 1]);
+      } else {
+        LdsVec<L>::template wait<0>(rr[k & 1]);
+      }
+      f32x2_t r[4];
+      LdsVec<L>::cvt2(rr[k & 1], r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[k][j] = __builtin_elementwise_fma(d[j], r[j], acc[k][j]);
+      asm volatile("" : "+v"(acc[k][0]), "+v"(acc[k][1]), "+v"(acc[k][2]), "+v"(acc[k][3]));
+    }
+  }
+}
+
+// Reduce the per-thread partial sums across the pixels of each wave (lanes with equal channel
+// vector; kt is wave-uniform) into the workgroup's [27][32] LDS accumulator.
+__device__ __forceinline__ void wgrad_reduce_to_lds(const f32x2_t (&acc)[9][4], float* red, const int kt,
+                                                    const int lane) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = acc[k][j >> 1][j & 1];
+#pragma unroll
+      for (int o = DW_CV; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (lane < DW_CV) atomicAdd(&red[(kt * 9 + k) * 32 + lane * 8 + j], v);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Weight gradient, producer/consumer waves.
+//   * consumer threads = TH*TW pixels x DW_CV channel vectors x 3 temporal taps; each keeps its
+//     9x8 partial sums in registers for the whole walk of the workgroup;
+//   * DW_LOADERS extra threads stage the NEXT tile (relu(bn(a)) with halo, db = A*t1 + B + C*b)
+//     into the other LDS buffer while the consumers run the current one: one barrier per tile and
+//     the global-load latency never sits in front of the FMAs (the single-buffer kernel this
+//     replaces waited 71 % of its cycles);
+//   * a workgroup walks `items_per_wg` consecutive (sample, tile) items of one 32-channel chunk,
+//     so even the 32x32 stage-3 maps give every CU a long walk and one flush.
+constexpr int DW_LOADERS = 256;
+constexpr int DW_LB = 4;  // raw vectors in flight per loader thread and batch
+
+template <typename T, int S, int TH, int TW>
+__global__ __launch_bounds__(TH * TW * DW_CV * 3 + DW_LOADERS) void dw_wgrad_kernel(
+    const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
+    const float* __restrict__ coefB, const float* __restrict__ coefC, const T* __restrict__ a,
+    const float* __restrict__ ss_a, float* __restrict__ dw, const DwGeom g, const int items_per_wg,
+    const int nbuf) {
+  typedef typename LdsStore<T>::type L;
+  typedef typename RawD<T>::type Raw;
+  constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+  constexpr int NPIX = TH * TW;
+  constexpr int NCOMP = NPIX * DW_CV * 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                 // [27][32] workgroup accumulator
+  L* bufs = reinterpret_cast<L*>(red + 27 * 32);
+  const int a_elems = g.T * IH * IW * 32, d_elems = g.T * NPIX * 32;
+  const int buf_elems = a_elems + d_elems;                      // [T][IH][IW][32] relu(bn(a)) | [T][TH][TW][32] db
+
+  const int tid = threadIdx.x;
+  const int tiles_x = (g.Wo + TW - 1) / TW, tiles_y = (g.Ho + TH - 1) / TH;
+  const int ntiles = tiles_x * tiles_y;
+  const int c0 = blockIdx.y * DW_CV * 8;
+  const int item0 = blockIdx.x * items_per_wg;
+  int item1 = item0 + items_per_wg;
+  if (item1 > g.B * ntiles) item1 = g.B * ntiles;
+  const int nit = item1 - item0;
+  for (int i = tid; i < 27 * 32; i += NCOMP + DW_LOADERS) red[i] = 0.f;
+
+  if (tid >= NCOMP) {
+    // ------------------------------- producer waves -------------------------------------------
+    const int lt = tid - NCOMP;
+    const int cv = lt % DW_CV;
+    const int cbase = c0 + cv * 8;
+    const bool c_ok = cbase < g.Cp;
+    float sa[8], sb[8], cA[8], cC[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sa[j] = c_ok ? ss_a[cbase + j] : 0.f; sb[j] = c_ok ? ss_a[g.Cp + cbase + j] : 0.f;
+      cA[j] = c_ok ? coefA[cbase + j] : 0.f; cC[j] = c_ok ? coefC[cbase + j] : 0.f;
+    }
+    const int NA = g.T * IH * IW * DW_CV, ND = g.T * NPIX * DW_CV;
+    auto stage = [&](const int item, L* __restrict__ atile) {
+      L* __restrict__ dtile = atile + a_elems;
+      const int b = item / ntiles, tl = item - b * ntiles;
+      const int tx = tl % tiles_x, ty = tl / tiles_x;
+      const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
+      float cB[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cB[j] = c_ok ? coefB[(size_t)b * g.Cp + cbase + j] : 0.f;
+      for (int base = lt; base < NA; base += DW_LOADERS * DW_LB) {
+        Raw raw[DW_LB];
+        int pp[DW_LB];
+        bool ok[DW_LB];
+#pragma unroll
+        for (int u = 0; u < DW_LB; ++u) {
+          const int i = base + u * DW_LOADERS;
+          const int p = i / DW_CV;
+          const int ix = p % IW;
+          const int q = p / IW;
+          const int iy = q % IH, t = q / IH;
+          const int gy = iy0 + iy, gx = ix0 + ix;
+          pp[u] = i < NA ? p : -1;
+          ok[u] = i < NA && c_ok && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+          if (ok[u]) raw[u] = RawD<T>::load(a + ((((size_t)b * g.T + t) * g.H + gy) * g.W + gx) * g.Cp + cbase);
+        }
+#pragma unroll
+        for (int u = 0; u < DW_LB; ++u) {
+          if (pp[u] < 0) continue;
+          float f[8];
+          if (ok[u]) {
+            RawD<T>::cvt(raw[u], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sa[j], sb[j]), 0.f);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.f;
+          }
+          Vec8<L>::store(atile + (size_t)pp[u] * 32 + cv * 8, f);
+          __builtin_amdgcn_sched_barrier(0);  // convert one vector at a time (register budget)
+        }
+      }
+      constexpr int DB = DW_LB / 2;
+      for (int base = lt; base < ND; base += DW_LOADERS * DB) {
+        Raw r1[DB], r2[DB];
+        int pp[DB];
+        bool ok[DB];
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+          const int i = base + u * DW_LOADERS;
+          const int p = i / DW_CV;
+          const int ox = p % TW;
+          const int q = p / TW;
+          const int oy = q % TH, t = q / TH;
+          const int gy = ty * TH + oy, gx = tx * TW + ox;
+          pp[u] = i < ND ? p : -1;
+          ok[u] = i < ND && c_ok && gy < g.Ho && gx < g.Wo;
+          if (ok[u]) {
+            const size_t off = ((((size_t)b * g.T + t) * g.Ho + gy) * g.Wo + gx) * g.Cp + cbase;
+            r1[u] = RawD<T>::load(t1 + off);
+            r2[u] = RawD<T>::load(bb + off);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+          if (pp[u] < 0) continue;
+          float f[8];
+          if (ok[u]) {
+            float f2[8];
+            RawD<T>::cvt(r1[u], f);
+            RawD<T>::cvt(r2[u], f2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j]));
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.f;
+          }
+          Vec8<L>::store(dtile + (size_t)pp[u] * 32 + cv * 8, f);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    if (nit > 0) stage(item0, bufs);
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      if (nbuf == 2) {
+        if (it + 1 < nit) stage(item0 + it + 1, bufs + (size_t)((it + 1) & 1) * buf_elems);
+        __syncthreads();
+      } else {
+        __syncthreads();                                   // consumers done with the only buffer
+        if (it + 1 < nit) stage(item0 + it + 1, bufs);
+        __syncthreads();
+      }
+    }
+    __syncthreads();                                       // matches the consumers' flush barrier
+  } else {
+    // ------------------------------- consumer waves -------------------------------------------
+    const int cv = tid % DW_CV;
+    const int pix = (tid / DW_CV) % NPIX;
+    const int kt = tid / (DW_CV * NPIX);
+    const int px = pix % TW, py = pix / TW;
+    f32x2_t acc[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[k][j] = f32x2_t{0.f, 0.f};
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      const L* __restrict__ atile = bufs + (size_t)(nbuf == 2 ? (it & 1) : 0) * buf_elems;
+      const L* __restrict__ dtile = atile + a_elems;
+      wgrad_tile_taps<L, S, TH, TW>(acc, atile, dtile, g.T, kt, px, py, cv);
+      __syncthreads();
+      if (nbuf != 2) __syncthreads();
+    }
+    wgrad_reduce_to_lds(acc, red, kt, tid & 63);
+    __syncthreads();
+    for (int i = tid; i < 27 * 32; i += NCOMP) {
+      const int tap = i / 32, c = c0 + (i & 31);
+      if (c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, red[i]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Weight gradient, bf16, LDS-DMA producer (gfx950 global_load_lds_dwordx4).
+// The register-staged producer above is latency bound: 256 loader threads can keep only ~16 KB
+// in flight, one tile costs ~7 us to land and the consumers need ~2.7 us to eat it.  Here the
+// loader waves DMA the RAW rows of tile i+2 straight into one of three LDS slots (no staging
+// registers, a whole 43 KB tile in flight per CU), then convert tile i+1 IN PLACE
+// (raw a -> relu(bn(a)), raw (t1, b) -> db written over t1) while the consumers run tile i.
+//   * a wave-instruction lands 64 vectors = 1 KB contiguously, so the raw image IS the
+//     [pixel][32 channels] tile layout the consumers read; halo pixels outside the image are
+//     loaded from a clamped address and overwritten with zeros by the in-place pass;
+//   * every loader wave issues exactly NI DMA instructions per tile (surplus ones land in a sink
+//     KB), so "tile i+1 has landed" is the counted  s_waitcnt vmcnt(NI)  with tile i+2 in flight;
+//   * barriers are raw s_barrier + lgkmcnt(0): a __syncthreads() fence would drain the DMA queue;
+//     the loader's LDS traffic is inline asm for the same reason (the compiler would put
+//     vmcnt(0) in front of any LDS access it can see while a DMA is pending).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ void wg_barrier_raw() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int S, int TH, int TW, int TT> struct WgDma {
+  static constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, NPIX = TH * TW;
+  static constexpr int NCOMP = NPIX * DW_CV * 3;
+  static constexpr int NLW = DW_LOADERS / 64;                                  // loader waves
+  static constexpr int NA_V = TT * IH * IW * DW_CV, ND_V = TT * NPIX * DW_CV;  // vectors per tile
+  static constexpr int NA_I = (NA_V + 63) / 64, ND_I = (ND_V + 63) / 64;       // wave-instructions
+  static constexpr int NA_W = (NA_I + NLW - 1) / NLW, ND_W = (ND_I + NLW - 1) / NLW;
+  static constexpr int NI = NA_W + 2 * ND_W;                                   // DMA instr / wave / tile
+  static constexpr int A_BYTES = NA_I * 1024, D_BYTES = ND_I * 1024;
+  static constexpr int SINK_OFF = A_BYTES + 2 * D_BYTES;
+  static constexpr int SLOT_BYTES = SINK_OFF + 1024;
+  static constexpr int NSLOT = 3;
+  static constexpr int MAXB = 8;  // samples one workgroup walk may touch (their coefB rows sit in LDS)
+  static constexpr int FIXED_BYTES = (27 * 32 + MAXB * 32) * 4;
+  static constexpr int LDS_BYTES = FIXED_BYTES + NSLOT * SLOT_BYTES;
+  static_assert(NI <= 63, "vmcnt is a 6-bit counter");
+};
+
+template <int S, int TH, int TW, int TT>
+__global__ __launch_bounds__(TH * TW * DW_CV * 3 + DW_LOADERS) void dw_wgrad_dma_kernel(
+    const bf16_t* __restrict__ t1, const bf16_t* __restrict__ bb, const float* __restrict__ coefA,
+    const float* __restrict__ coefB, const float* __restrict__ coefC, const bf16_t* __restrict__ a,
+    const float* __restrict__ ss_a, float* __restrict__ dw, const DwGeom g, const int items_per_wg) {
+  typedef WgDma<S, TH, TW, TT> G;
+  constexpr int IH = G::IH, IW = G::IW, NPIX = G::NPIX, NCOMP = G::NCOMP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);   // [27][32] workgroup accumulator
+  float* cbs = red + 27 * 32;                    // [MAXB][32] per-sample coefB rows of this chunk
+  unsigned char* slots = smem + G::FIXED_BYTES;
+
+  const int tid = threadIdx.x;
+  const int tiles_x = (g.Wo + TW - 1) / TW, tiles_y = (g.Ho + TH - 1) / TH;
+  const int ntiles = tiles_x * tiles_y;
+  const int c0 = blockIdx.y * DW_CV * 8;
+  const int item0 = blockIdx.x * items_per_wg;
+  int item1 = item0 + items_per_wg;
+  if (item1 > g.B * ntiles) item1 = g.B * ntiles;
+  const int nit = item1 - item0;
+  const int b0 = item0 / ntiles;
+  const int nb = nit > 0 ? (item1 - 1) / ntiles - b0 + 1 : 0;
+  for (int i = tid; i < 27 * 32; i += NCOMP + DW_LOADERS) red[i] = 0.f;
+  for (int i = tid; i < nb * 32; i += NCOMP + DW_LOADERS) {
+    const int c = c0 + (i & 31);
+    cbs[i] = c < g.Cp ? coefB[(size_t)(b0 + (i >> 5)) * g.Cp + c] : 0.f;
+  }
+  wg_barrier_raw();
+
+  if (tid >= NCOMP) {
+    // ------------------------------- producer waves -------------------------------------------
+    const int lane = tid & 63;
+    const int lw = (tid - NCOMP) >> 6;
+    const int cv = lane & (DW_CV - 1);            // vector index = instr*64 + lane, so cv = lane % 4
+    const int cbase = c0 + cv * 8;
+    const bool c_ok = cbase < g.Cp;
+    const int cb_ld = c_ok ? cbase : c0;          // clamped channel offset for the DMA source
+    float sa[8], sb[8], cA[8], cC[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sa[j] = c_ok ? ss_a[cbase + j] : 0.f; sb[j] = c_ok ? ss_a[g.Cp + cbase + j] : 0.f;
+      cA[j] = c_ok ? coefA[cbase + j] : 0.f; cC[j] = c_ok ? coefC[cbase + j] : 0.f;
+    }
+    float cB[8];
+    int cur_b = -1;
+
+    auto issue = [&](const int item, const int slot) {
+      unsigned char* sl = slots + slot * G::SLOT_BYTES;
+      const int b = item / ntiles, tl = item - b * ntiles;
+      const int tx = tl % tiles_x, ty = tl / tiles_x;
+      const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
+#pragma unroll
+      for (int r = 0; r < G::NA_W; ++r) {
+        const int q = lw + G::NLW * r;
+        unsigned char* dst = sl + (q < G::NA_I ? q * 1024 : G::SINK_OFF);
+        int i = q * 64 + lane;
+        if (i > G::NA_V - 1) i = G::NA_V - 1;
+        const int p = i / DW_CV;
+        const int ix = p % IW;
+        const int qq = p / IW;
+        const int iy = qq % IH, t = qq / IH;
+        int gy = iy0 + iy, gx = ix0 + ix;
+        gy = gy < 0 ? 0 : (gy > g.H - 1 ? g.H - 1 : gy);
+        gx = gx < 0 ? 0 : (gx > g.W - 1 ? g.W - 1 : gx);
+        const bf16_t* src = a + ((((size_t)b * g.T + t) * g.H + gy) * g.W + gx) * g.Cp + cb_ld;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < G::ND_W; ++r) {
+        const int q = lw + G::NLW * r;
+        unsigned char* dst = sl + (q < G::ND_I ? G::A_BYTES + q * 1024 : G::SINK_OFF);
+        unsigned char* dst2 = sl + (q < G::ND_I ? G::A_BYTES + G::D_BYTES + q * 1024 : G::SINK_OFF);
+        int i = q * 64 + lane;
+        if (i > G::ND_V - 1) i = G::ND_V - 1;
+        const int p = i / DW_CV;
+        const int ox = p % TW;
+        const int qq = p / TW;
+        const int oy = qq % TH, t = qq / TH;
+        int gy = ty * TH + oy, gx = tx * TW + ox;
+        gy = gy > g.Ho - 1 ? g.Ho - 1 : gy;
+        gx = gx > g.Wo - 1 ? g.Wo - 1 : gx;
+        const size_t off = ((((size_t)b * g.T + t) * g.Ho + gy) * g.Wo + gx) * g.Cp + cb_ld;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(t1 + off), (lds_ptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(bb + off), (lds_ptr_t)dst2, 16, 0, 0);
+      }
+    };
+
+    auto convert = [&](const int item, const int slot) {
+      const uint32_t sl = lds_addr(slots + slot * G::SLOT_BYTES);
+      const int b = item / ntiles, tl = item - b * ntiles;
+      const int tx = tl % tiles_x, ty = tl / tiles_x;
+      const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
+      if (b != cur_b) {  // wave-uniform
+        LdsVec<float>::raw_t r;
+        LdsVec<float>::issue(r, lds_addr(cbs + (b - b0) * 32 + cv * 8));
+        LdsVec<float>::template wait<0>(r);
+        LdsVec<float>::cvt(r, cB);
+        cur_b = b;
+      }
+#pragma unroll
+      for (int r = 0; r < G::NA_W; ++r) {
+        const int q = lw + G::NLW * r;
+        const int i = q * 64 + lane;
+        if (q < G::NA_I && i < G::NA_V) {
+          const int p = i / DW_CV;
+          const int ix = p % IW;
+          const int qq = p / IW;
+          const int iy = qq % IH;
+          const int gy = iy0 + iy, gx = ix0 + ix;
+          const uint32_t addr = sl + (uint32_t)i * 16u;
+          u32x4_t out = {0u, 0u, 0u, 0u};
+          if (c_ok && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+            LdsVec<bf16_t>::raw_t raw;
+            LdsVec<bf16_t>::issue(raw, addr);
+            LdsVec<bf16_t>::template wait<0>(raw);
+            float f[8];
+            LdsVec<bf16_t>::cvt(raw, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sa[j], sb[j]), 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
+          }
+          asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(out) : "memory");
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < G::ND_W; ++r) {
+        const int q = lw + G::NLW * r;
+        const int i = q * 64 + lane;
+        if (q < G::ND_I && i < G::ND_V) {
+          const int p = i / DW_CV;
+          const int ox = p % TW;
+          const int oy = (p / TW) % TH;
+          const int gy = ty * TH + oy, gx = tx * TW + ox;
+          const uint32_t addr = sl + (uint32_t)(G::A_BYTES + i * 16);
+          u32x4_t out = {0u, 0u, 0u, 0u};
+          if (c_ok && gy < g.Ho && gx < g.Wo) {
+            LdsVec<bf16_t>::raw_t r1, r2;
+            LdsVec<bf16_t>::issue(r1, addr);
+            LdsVec<bf16_t>::issue(r2, addr + (uint32_t)G::D_BYTES);
+            LdsVec<bf16_t>::template wait<0>(r2);
+            asm volatile("" : "+v"(r1.v));  // r1 is complete as well: LDS returns in order
+            float f[8], f2[8];
+            LdsVec<bf16_t>::cvt(r1, f);
+            LdsVec<bf16_t>::cvt(r2, f2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
+          }
+          asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(out) : "memory");
+        }
+      }
+    };
+
+    if (nit > 0) issue(item0, 0);
+    if (nit > 1) issue(item0 + 1, 1);
+    if (nit > 0) {
+      if (nit > 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::NI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      convert(item0, 0);
+    }
+    wg_barrier_raw();
+    for (int it = 0; it < nit; ++it) {
+      if (it + 2 < nit) issue(item0 + it + 2, (it + 2) % G::NSLOT);
+      if (it + 1 < nit) {
+        if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        convert(item0 + it + 1, (it + 1) % G::NSLOT);
+      }
+      wg_barrier_raw();
+    }
+    wg_barrier_raw();  // matches the consumers' flush barrier
+  } else {
+    // ------------------------------- consumer waves -------------------------------------------
+    const int cv = tid % DW_CV;
+    const int pix = (tid / DW_CV) % NPIX;
+    const int kt = tid / (DW_CV * NPIX);
+    const int px = pix % TW, py = pix / TW;
+    f32x2_t acc[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[k][j] = f32x2_t{0.f, 0.f};
+    wg_barrier_raw();
+    for (int it = 0; it < nit; ++it) {
+      const bf16_t* atile = reinterpret_cast<const bf16_t*>(slots + (it % G::NSLOT) * G::SLOT_BYTES);
+      const bf16_t* dtile = reinterpret_cast<const bf16_t*>(slots + (it % G::NSLOT) * G::SLOT_BYTES + G::A_BYTES);
+      wgrad_tile_taps<bf16_t, S, TH, TW>(acc, atile, dtile, TT, kt, px, py, cv);
+      wg_barrier_raw();
+    }
+    wgrad_reduce_to_lds(acc, red, kt, tid & 63);
+    wg_barrier_raw();
+    for (int i = tid; i < 27 * 32; i += NCOMP) {
+      const int tap = i / 32, c = c0 + (i & 31);
+      if (c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, red[i]);
+    }
+  }
+}
 
 template <typename T, int S, int TT>
 __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
@@ -1052,9 +1442,12 @@ template <typename T, int S>
 int launch_wgrad(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const void* a,
                  const float* ss_a, float* dw, const DwGeom& g, hipStream_t stream) {
   constexpr int TH = DwTile<T, S>::TH, TW = DwTile<T, S>::TW;
-  constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, NTHR = TH * TW * DW_CV * 3;
+  constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, NTHR = TH * TW * DW_CV * 3 + DW_LOADERS;
   typedef typename LdsStore<T>::type L;
-  const size_t lds = 27 * 32 * sizeof(float) + (size_t)g.T * (IH * IW + TH * TW) * 32 * sizeof(L);
+  const size_t buf = (size_t)g.T * (IH * IW + TH * TW) * 32 * sizeof(L);
+  const size_t fixed = 27 * 32 * sizeof(float);
+  const int nbuf = fixed + 2 * buf <= 160 * 1024 ? 2 : 1;
+  const size_t lds = fixed + nbuf * buf;
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1064,12 +1457,50 @@ int launch_wgrad(const void* t1, const void* bb, const float* cA, const float* c
     attr_set = true;
   }
   const int ntiles = ((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH);
-  int tpw = 8;
-  if (tpw > ntiles) tpw = ntiles;
-  dim3 grid((ntiles + tpw - 1) / tpw, (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), g.B);
+  const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
+  const long items = (long)g.B * ntiles;
+  // one workgroup is resident per CU: size the walk so that the whole grid is ONE round of workgroups
+  static const int env_wgs = getenv("C3D_DWWG_WGS") ? atoi(getenv("C3D_DWWG_WGS")) : 0;
+  const long target = env_wgs > 0 ? env_wgs : device_cus();
+  long gx = target / chunks;
+  if (gx < 1) gx = 1;
+  const long ipw = (items + gx - 1) / gx;
+  dim3 grid((unsigned)((items + ipw - 1) / ipw), chunks, 1);
   dw_wgrad_kernel<T, S, TH, TW><<<grid, dim3(NTHR), lds, stream>>>(
       reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, reinterpret_cast<const T*>(a),
-      ss_a, dw, g, tpw);
+      ss_a, dw, g, (int)ipw, nbuf);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+// bf16, T = 3: LDS-DMA producer.  Returns C3D_E_UNSUPPORTED when the geometry does not fit (the
+// caller then uses the register-staged kernel).
+template <int S>
+int launch_wgrad_dma(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const void* a,
+                     const float* ss_a, float* dw, const DwGeom& g, hipStream_t stream) {
+  constexpr int TH = DwTile<bf16_t, S>::TH, TW = DwTile<bf16_t, S>::TW;
+  typedef WgDma<S, TH, TW, 3> G;
+  if (g.T != 3 || G::LDS_BYTES > 160 * 1024) return C3D_E_UNSUPPORTED;
+  const int ntiles = ((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH);
+  const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
+  const long items = (long)g.B * ntiles;
+  static const int env_wgs = getenv("C3D_DWWG_WGS") ? atoi(getenv("C3D_DWWG_WGS")) : 0;
+  const long target = env_wgs > 0 ? env_wgs : device_cus();
+  long gx = target / chunks;
+  if (gx < 1) gx = 1;
+  const long ipw = (items + gx - 1) / gx;
+  if ((ipw + ntiles - 2) / ntiles + 1 > G::MAXB) return C3D_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_dma_kernel<S, TH, TW, 3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((items + ipw - 1) / ipw), chunks, 1);
+  dw_wgrad_dma_kernel<S, TH, TW, 3><<<grid, dim3(G::NCOMP + DW_LOADERS), G::LDS_BYTES, stream>>>(
+      reinterpret_cast<const bf16_t*>(t1), reinterpret_cast<const bf16_t*>(bb), cA, cB, cC,
+      reinterpret_cast<const bf16_t*>(a), ss_a, dw, g, (int)ipw);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -1134,9 +1565,16 @@ extern "C" int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA
   if (dtype == C3D_DT_F32)
     return stride == 1 ? launch_wgrad<float, 1>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s)
                        : launch_wgrad<float, 2>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
-  if (dtype == C3D_DT_BF16)
+  if (dtype == C3D_DT_BF16) {
+    static const bool no_dma = getenv("C3D_DWWG_NODMA") != nullptr;
+    if (!no_dma) {
+      const int rc = stride == 1 ? launch_wgrad_dma<1>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s)
+                                 : launch_wgrad_dma<2>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
+      if (rc != C3D_E_UNSUPPORTED) return rc;
+    }
     return stride == 1 ? launch_wgrad<bf16_t, 1>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s)
                        : launch_wgrad<bf16_t, 2>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
+  }
   return C3D_E_BADARG;
 }
 

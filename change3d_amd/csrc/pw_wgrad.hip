@@ -2,6 +2,7 @@
 #include "common.h"
 #include "../../include/change3d_hip.h"
 #include "pw_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __res
   }
 }
 
-constexpr int WGRAD_MAX_PARTS = 256;
+constexpr int WGRAD_MAX_PARTS = 512;
 
 template <typename T>
 int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
@@ -333,6 +334,8 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   const int maxG = (a.Np > a.Kp ? a.Np : a.Kp) >> 3;
   int MT = (256 / maxG) * WG_RPT / 32 * 32;
   if (MT > WG_MAXMT) MT = WG_MAXMT;
+  static const int mt_env = getenv("C3D_WG_MT") ? atoi(getenv("C3D_WG_MT")) : 0;  // tuning knob
+  if (mt_env >= 32 && mt_env < MT) MT = mt_env / 32 * 32;
   if (MT < 32) return C3D_E_UNSUPPORTED;
   size_t lds = 0;
   for (; MT >= 32; MT -= 32) {
@@ -363,7 +366,9 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   }
   const int64_t tiles = (a.M + MT - 1) / MT;
   int64_t blocks = (tiles + 3) / 4;  // >= 4 tiles per workgroup when there is enough work
-  const int64_t cap = device_cus() < WGRAD_MAX_PARTS ? device_cus() : WGRAD_MAX_PARTS;
+  static const int cap_env = getenv("C3D_WG_BLOCKS") ? atoi(getenv("C3D_WG_BLOCKS")) : 0;  // tuning knob
+  int64_t cap = device_cus() < WGRAD_MAX_PARTS ? device_cus() : WGRAD_MAX_PARTS;
+  if (cap_env > 0 && cap_env <= WGRAD_MAX_PARTS) cap = cap_env;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   const int tpw = (int)((tiles + blocks - 1) / blocks);

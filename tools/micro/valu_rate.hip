@@ -1,0 +1,59 @@
+// VALU issue-rate probe (gfx950): v_fma_f32 vs v_pk_fma_f32 vs v_dot2c_f32_bf16, 16 independent chains.
+// build: hipcc --offload-arch=gfx950 -O3 tools/micro/valu_rate.hip -o /tmp/valu_rate
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int NCH = 16, ITERS = 4096;
+
+template <int MODE> __global__ __launch_bounds__(256) void probe(float* out, uint32_t seed) {
+  float acc[NCH];
+  f32x2_t acc2[NCH];
+  const uint32_t a = seed + threadIdx.x, b = seed * 3 + threadIdx.x;
+  const float fa = __uint_as_float((a & 0x7fffff) | 0x3f800000), fb = __uint_as_float((b & 0x7fffff) | 0x3c800000);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) { acc[i] = (float)i; acc2[i] = f32x2_t{(float)i, 1.f}; }
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (MODE == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa), "v"(fb));
+      if (MODE == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc2[i]) : "v"(f32x2_t{fa, fb}), "v"(f32x2_t{fb, fa}));
+      if (MODE == 2) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+      if (MODE == 3) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(acc[i]) : "v"(a));
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) s += acc[i] + acc2[i][0] + acc2[i][1];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int MODE> void run(const char* name, float* out, int waves_per_simd) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int blocks = 256 * waves_per_simd;  // 256 threads = 4 waves = one per SIMD
+  probe<MODE><<<blocks, 256>>>(out, 1);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  probe<MODE><<<blocks, 256>>>(out, 2);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double instr_per_simd = (double)ITERS * NCH * waves_per_simd;
+  printf("%-22s waves/SIMD=%d  %.3f ms  -> %.2f cycles per wave-instruction at 2.4 GHz\n", name, waves_per_simd, ms,
+         ms * 1e-3 * 2.4e9 / instr_per_simd);
+}
+
+int main() {
+  float* out;
+  hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+  for (int w : {1, 2, 4}) {
+    run<0>("v_fma_f32", out, w);
+    run<1>("v_pk_fma_f32", out, w);
+    run<2>("v_dot2c_f32_bf16", out, w);
+    run<3>("v_lshlrev_b32", out, w);
+  }
+  return 0;
+}

@@ -22,3 +22,10 @@ for _ in range(3):
     elif which == "pwa": ops.pw_gemm(x, wa, a_.view(M, Cip), M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt, epi_mode=ops.EPI_STATS, stats=stats)
     elif which == "pwc": ops.pw_gemm(b_.view(M, Cip), wc, x, M=M, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH, pro_p=ss, pro_gate=gate, rows_per_sample=T * H * H, epi_mode=ops.EPI_STATS, stats=stats)
 torch.cuda.synchronize()
+if which in ("pwwg", "pwwgc"):
+    coef3 = torch.rand(3 * Cip, device=DEV); coefo = torch.rand(3 * Co, device=DEV)
+    dwa, dwc = torch.zeros(Ci, Cin, device=DEV), torch.zeros(Co, Ci, device=DEV)
+    for _ in range(3):
+        if which == "pwwg": ops.pw_wgrad(a_.view(M, Cip), x, dwa, M=M, K=Cin, N=Ci, dw_sn=Cin, dw_sk=1, dtype=dt, p2=b_.view(M, Cip), p_coef=coef3)
+        else: ops.pw_wgrad(x if Cin == Co else rt(M, Co), b_.view(M, Cip), dwc, M=M, K=Ci, N=Co, dw_sn=Ci, dw_sk=1, dtype=dt, p2=x if Cin == Co else rt(M, Co), p_coef=coefo, q_mode=ops.PRO_BN_SE_SWISH, q_ss=ss, q_gate=gate, rows_per_sample=T * H * H)
+    torch.cuda.synchronize()
