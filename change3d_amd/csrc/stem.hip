@@ -129,15 +129,23 @@ __global__ __launch_bounds__(ST_THREADS) void stem_fwd_kernel(const float* __res
     }
   }
   if (!sums) return;
-  // cv = tid % 3 is not lane-periodic in a wave (64 % 3 != 0): reduce through LDS atomics
-  for (int i = tid; i < 3 * 16; i += ST_THREADS) red[i] = 0.f;
+  // cv = tid % 3 is not lane-periodic in a wave (64 % 3 != 0): reduce through LDS atomics.  The
+  // partial sums go in as 2^-40 fixed point: integer adds are associative, so the result does not
+  // depend on the order in which the waves arrive (f32 LDS atomics made the BN_stem statistics --
+  // and, amplified by 55 train-mode BN layers, every gradient -- differ from run to run).
+  unsigned long long* red64 = reinterpret_cast<unsigned long long*>(red);  // [3][16]
+  for (int i = tid; i < 3 * 16; i += ST_THREADS) red64[i] = 0ull;
   __syncthreads();
+  constexpr float FX = 1099511627776.f;  // 2^40: |partial| < 2^23 is exact down to 2^-40
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { atomicAdd(&red[cv * 16 + j], s1[j]); atomicAdd(&red[cv * 16 + 8 + j], s2[j]); }
+  for (int j = 0; j < 8; ++j) {
+    atomicAdd(&red64[cv * 16 + j], (unsigned long long)(long long)(s1[j] * FX));
+    atomicAdd(&red64[cv * 16 + 8 + j], (unsigned long long)(long long)(s2[j] * FX));
+  }
   __syncthreads();
   if (tid < 48) {
     const int vv = tid / 16, k = tid & 15;
-    atomicAdd(sums + (size_t)(k >> 3) * ST_C + vv * 8 + (k & 7), (double)red[tid]);
+    atomicAdd(sums + (size_t)(k >> 3) * ST_C + vv * 8 + (k & 7), (double)(long long)red64[tid] * (1.0 / 1099511627776.0));
   }
 }
 

@@ -26,8 +26,32 @@ def dt_code(dtype):
     raise TypeError(f"unsupported activation dtype {dtype} (float32 | bfloat16)")
 
 
+TRACE = None      # debug: list of (kernel name, [(shape, dtype, checksum), ...]) when tracing is on
+_TRACE_ARGS = []
+
+
+def trace_begin():
+    """Debug aid (tools/determinism.py): after every launch, checksum every tensor the wrapper
+    passed to it.  Two runs from identical state must give identical traces; the first differing
+    entry names the kernel whose output is not reproducible."""
+    global TRACE
+    TRACE = []
+    _TRACE_ARGS.clear()
+
+
+def trace_end():
+    global TRACE
+    t, TRACE = TRACE, None
+    _TRACE_ARGS.clear()
+    return t
+
+
 def _p(t):
-    return None if t is None else t.data_ptr()
+    if t is None:
+        return None
+    if TRACE is not None:
+        _TRACE_ARGS.append(t)
+    return t.data_ptr()
 
 
 def _stream():
@@ -73,6 +97,10 @@ def _launch(name, nbytes, fn, *args):
         rc = fn(*args)
     if rc != 0:
         raise L.Change3DHipError(f"{name} failed with code {rc}")
+    if TRACE is not None:
+        TRACE.append((name, [(tuple(t.shape), str(t.dtype), float(t.detach().double().abs().sum().item()))
+                             for t in _TRACE_ARGS]))
+        _TRACE_ARGS.clear()
 
 
 def _es(dtype):
