@@ -47,10 +47,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int stripes,
   if (mr) { mr[c] = meanf; mr[Cp + c] = rstd; }
 }
 
+constexpr int SE_THREADS = 1024;  // single-workgroup layer kernels: width buys latency
+
 // -------------------------------------------------------------------------------------------
 // Depthwise-conv output statistics arrive per (sample, channel): nc[B][Cp][2].
 // Produces BN_b scale/shift (+running stats), and the SE gate[B][Cp].
-__global__ __launch_bounds__(256) void bn_se_finalize_kernel(
+__global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
     const double* __restrict__ nc, int B, double cnt_per_sample, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
     float eps, int C, int Cp, int training, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -62,17 +64,22 @@ __global__ __launch_bounds__(256) void bn_se_finalize_kernel(
   const int tid = threadIdx.x;
   const double count = cnt_per_sample * B;
   if (tid == 0 && training && nbt) *nbt += 1;
-  for (int c = tid; c < Cp; c += blockDim.x) {
-    if (c >= C) { ss[c] = 0.f; ss[Cp + c] = 0.f; if (mr) { mr[c] = 0.f; mr[Cp + c] = 0.f; } continue; }
+  // 4 lanes per channel split the batch loop (one workgroup does the whole layer: latency, not
+  // bandwidth, is what this kernel costs, so every serial loop is spread over adjacent lanes)
+  for (int idx = tid; idx < Cp * 4; idx += blockDim.x) {
+    const int c = idx >> 2, q = idx & 3;
+    if (c >= C) { if (q == 0) { ss[c] = 0.f; ss[Cp + c] = 0.f; if (mr) { mr[c] = 0.f; mr[Cp + c] = 0.f; } } continue; }
     double mean, var;
     if (training) {
       double s1 = 0, s2 = 0;
-#pragma unroll 8
-      for (int n = 0; n < B; ++n) { s1 += nc[((size_t)n * Cp + c) * 2]; s2 += nc[((size_t)n * Cp + c) * 2 + 1]; }
+#pragma unroll 4
+      for (int n = q; n < B; n += 4) { s1 += nc[((size_t)n * Cp + c) * 2]; s2 += nc[((size_t)n * Cp + c) * 2 + 1]; }
+      s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+      s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
       mean = s1 / count;
       var = s2 / count - mean * mean;
       if (var < 0) var = 0;
-      if (running_mean) {
+      if (running_mean && q == 0) {
         const double unb = count > 1 ? var * count / (count - 1) : var;
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
@@ -85,24 +92,28 @@ __global__ __launch_bounds__(256) void bn_se_finalize_kernel(
     const float meanf = (float)mean;
     const float sc = gamma[c] * rstd;
     const float sh = beta[c] - meanf * sc;
-    ss[c] = sc;
-    ss[Cp + c] = sh;
-    if (mr) { mr[c] = meanf; mr[Cp + c] = rstd; }
+    if (q == 0) {
+      ss[c] = sc;
+      ss[Cp + c] = sh;
+      if (mr) { mr[c] = meanf; mr[Cp + c] = rstd; }
+    }
     if (w1) {
-#pragma unroll 8
-      for (int n = 0; n < B; ++n)
+#pragma unroll 4
+      for (int n = q; n < B; n += 4)
         z[(size_t)n * C + c] = fmaf(sc, (float)(nc[((size_t)n * Cp + c) * 2] / cnt_per_sample), sh);
     }
   }
   if (!w1) return;  // no SE in this block: consumers take gate = 1 (NULL)
   __syncthreads();
-  for (int i = tid; i < B * Cr; i += blockDim.x) {
+  for (int idx = tid; idx < B * Cr * 8; idx += blockDim.x) {  // 8 lanes per (sample, hidden unit)
+    const int i = idx >> 3, q = idx & 7;
     const int n = i / Cr, r = i - n * Cr;
-    float a = b1[r];
-    for (int c = 0; c < C; ++c) a = fmaf(w1[(size_t)r * C + c], z[(size_t)n * C + c], a);
+    float a = 0.f;
+    for (int c = q; c < C; c += 8) a = fmaf(w1[(size_t)r * C + c], z[(size_t)n * C + c], a);
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+    a += b1[r];
     a = a > 0.f ? a : 0.f;
-    h[i] = a;
-    if (hid) hid[i] = a;
+    if (q == 0) { h[i] = a; if (hid) hid[i] = a; }
   }
   __syncthreads();
   for (int i = tid; i < B * Cp; i += blockDim.x) {
@@ -145,7 +156,7 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ dsums, int stripes
 //   nc3 [B][Cp][3] = per (n,c): sum dq*pb (d gate), sum t1, sum t1*bhat   (bhat = (b-mean)*rstd)
 //   ncf [B][Cp][2] = forward per (n,c): sum b, sum b^2
 //   db = A[c]*t1 + Bnc[n][c] + Cc[c]*b
-__global__ __launch_bounds__(256) void se_bn_bwd_coef_kernel(
+__global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
     const double* __restrict__ nc3, const double* __restrict__ ncf, int B, double cnt_per_sample,
     const float* __restrict__ gamma, const float* __restrict__ mr, const float* __restrict__ ss, int C, int Cp,
     const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ gate,
@@ -168,11 +179,13 @@ __global__ __launch_bounds__(256) void se_bn_bwd_coef_kernel(
       zz[i] = fmaf(ss[c], (float)(ncf[((size_t)n * Cp + c) * 2] / cnt_per_sample), ss[Cp + c]);
     }
     __syncthreads();
-    for (int i = tid; i < B * Cr; i += blockDim.x) {
+    for (int idx = tid; idx < B * Cr * 8; idx += blockDim.x) {  // 8 lanes per (sample, hidden unit)
+      const int i = idx >> 3, q = idx & 7;
       const int n = i / Cr, r = i - n * Cr;
       float a = 0.f;
-      for (int c = 0; c < C; ++c) a = fmaf(w2[(size_t)c * Cr + r], du[(size_t)n * C + c], a);
-      dh[i] = hid[i] > 0.f ? a : 0.f;
+      for (int c = q; c < C; c += 8) a = fmaf(w2[(size_t)c * Cr + r], du[(size_t)n * C + c], a);
+      a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+      if (q == 0) dh[i] = hid[i] > 0.f ? a : 0.f;
     }
     __syncthreads();
     for (int i = tid; i < B * C; i += blockDim.x) {
@@ -204,32 +217,36 @@ __global__ __launch_bounds__(256) void se_bn_bwd_coef_kernel(
     }
     __syncthreads();
   }
-  for (int c = tid; c < Cp; c += blockDim.x) {
+  for (int idx = tid; idx < Cp * 4; idx += blockDim.x) {  // 4 lanes per channel split the batch loops
+    const int c = idx >> 2, q = idx & 3;
     if (c >= C) {
-      coefA[c] = 0.f; coefC[c] = 0.f;
-      for (int n = 0; n < B; ++n) coefB[(size_t)n * Cp + c] = 0.f;
+      if (q == 0) { coefA[c] = 0.f; coefC[c] = 0.f; }
+      for (int n = q; n < B; n += 4) coefB[(size_t)n * Cp + c] = 0.f;
       continue;
     }
     const double mean = mr[c], rstd = mr[Cp + c];
     double s1 = 0, s2 = 0;
-#pragma unroll 8
-    for (int n = 0; n < B; ++n) {
+#pragma unroll 4
+    for (int n = q; n < B; n += 4) {
       const double dzn = se ? (double)dz[(size_t)n * C + c] : 0.0;
       s1 += nc3[((size_t)n * Cp + c) * 3 + 1] + dzn;
       // the uniform SE term dz/cnt multiplies sum_thw bhat = rstd * (sum b - cnt*mean)
       s2 += nc3[((size_t)n * Cp + c) * 3 + 2] +
             dzn / cnt_per_sample * rstd * (ncf[((size_t)n * Cp + c) * 2] - cnt_per_sample * mean);
     }
+    s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+    s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
     const double A = (double)gamma[c] * rstd;
     const double Cc = -A * rstd * s2 / count;
-    coefA[c] = (float)A;
-    coefC[c] = (float)Cc;
-    for (int n = 0; n < B; ++n) {
+    if (q == 0) { coefA[c] = (float)A; coefC[c] = (float)Cc; }
+    for (int n = q; n < B; n += 4) {
       const double dzn = se ? (double)dz[(size_t)n * C + c] : 0.0;
       coefB[(size_t)n * Cp + c] = (float)(A * dzn / cnt_per_sample - A * s1 / count - Cc * mean);
     }
-    if (dgamma) dgamma[c] += (float)s2;
-    if (dbeta) dbeta[c] += (float)s1;
+    if (q == 0) {
+      if (dgamma) dgamma[c] += (float)s2;
+      if (dbeta) dbeta[c] += (float)s1;
+    }
   }
 }
 
@@ -259,7 +276,7 @@ extern "C" int c3d_bn_se_finalize(const double* nc, int32_t B, double cnt_per_sa
   if (w1 && (!b1 || !w2 || !b2 || !gate || Cr <= 0)) return C3D_E_BADARG;
   const size_t lds = w1 ? ((size_t)B * C + (size_t)B * Cr) * sizeof(float) : 0;
   if (lds > 64 * 1024) return C3D_E_UNSUPPORTED;
-  bn_se_finalize_kernel<<<dim3(1), dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(
+  bn_se_finalize_kernel<<<dim3(1), dim3(SE_THREADS), lds, reinterpret_cast<hipStream_t>(stream)>>>(
       nc, B, cnt_per_sample, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, C, Cp,
       training, w1, b1, w2, b2, Cr, ss, mr, gate, hid);
   C3D_CHECK_LAUNCH();
@@ -294,7 +311,7 @@ extern "C" int c3d_se_bn_bwd_coef(const double* nc3, const double* ncf, int32_t 
       attr_set = true;
     }
   }
-  se_bn_bwd_coef_kernel<<<dim3(1), dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(
+  se_bn_bwd_coef_kernel<<<dim3(1), dim3(SE_THREADS), lds, reinterpret_cast<hipStream_t>(stream)>>>(
       nc3, ncf, B, cnt_per_sample, gamma, mr, ss, C, Cp, w1, w2, gate, hid, Cr, coefA, coefC, coefB, dgamma, dbeta,
       dw1, db1, dw2, db2);
   C3D_CHECK_LAUNCH();

@@ -242,7 +242,12 @@ __global__ __launch_bounds__(ST_THREADS) void stem_bwd_dv_kernel(
 }
 
 // dv -> d w_t[c][ci][ky][kx] and d(perception frames)[ci][k][y][x] (sum over batch)
-constexpr int SW_THREADS = ST_TH * ST_TW;  // 128: one pixel per thread
+// 512 threads: waves 0-1 = one pixel per thread (input gradient), waves 2-7 = four row-slices of
+// 96 threads (81 active: tap x channel vector) accumulating d w_t concurrently.  (The first version
+// ran the d w_t loop on 81 threads of a 128-thread workgroup: 1.9 ms of a 50 ms step.)
+constexpr int SW_PIX = ST_TH * ST_TW;      // 128
+constexpr int SW_SLICES = 4, SW_SLICE_T = 96;
+constexpr int SW_THREADS = SW_PIX + SW_SLICES * SW_SLICE_T;
 template <typename T>
 __global__ __launch_bounds__(SW_THREADS) void stem_bwd_wx_kernel(
     const float* __restrict__ x, const float* __restrict__ w_t, const T* __restrict__ dv, float* __restrict__ dw_t,
@@ -255,24 +260,32 @@ __global__ __launch_bounds__(SW_THREADS) void stem_bwd_wx_kernel(
   const int tid = threadIdx.x;
   const int tiles_x = (g.W + ST_TW - 1) / ST_TW, tiles_y = (g.H + ST_TH - 1) / ST_TH;
   const int ntiles = tiles_x * tiles_y;
-  const int b = blockIdx.y;
   for (int i = tid; i < 27 * ST_C; i += SW_THREADS) {
     const int tap = i / ST_C, c = i - tap * ST_C;
     wt[i] = w_t[c * 27 + tap];
   }
-  const int px = tid % ST_TW, py = tid / ST_TW;
-  // weight-gradient ownership: thread < 81 owns (tap = tid / 3, channel vector = tid % 3)
-  const int wtap = tid / 3, wcv = tid % 3;
+  const int px = tid % ST_TW, py = (tid / ST_TW) % ST_TH;
+  // weight-gradient ownership: slice thread l < 81 owns (tap = l / 3, channel vector = l % 3) for the
+  // output rows [slice * ST_TH / SW_SLICES, ...) of every tile
+  const int wl = tid >= SW_PIX ? (tid - SW_PIX) % SW_SLICE_T : SW_SLICE_T, wslice = tid >= SW_PIX ? (tid - SW_PIX) / SW_SLICE_T : 0;
+  const bool w_role = wl < 81;
+  const int wtap = w_role ? wl / 3 : 0, wcv = wl % 3;
   const int wci = wtap / 9, wky = (wtap % 9) / 3, wkx = wtap % 3;
   float dwacc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) dwacc[j] = 0.f;
-
-  int tl0 = blockIdx.x * tiles_per_wg, tl1 = tl0 + tiles_per_wg;
-  if (tl1 > ntiles) tl1 = ntiles;
-  for (int tl = tl0; tl < tl1; ++tl) {
-    const int tx = tl % tiles_x, ty = tl / tiles_x;
-    const int y0 = ty * ST_TH, x0 = tx * ST_TW;
+  // A workgroup owns ONE spatial tile and walks the samples b = blockIdx.y, +gridDim.y, ...: the
+  // batch-summed input gradient and d w_t stay in registers and are flushed once (the per-sample
+  // version issued 6 M + 5 M same-address f32 atomics per step and was bound by them).
+  float dxacc[ST_MAXT][ST_CI];
+#pragma unroll
+  for (int k = 0; k < ST_MAXT; ++k)
+#pragma unroll
+    for (int ci = 0; ci < ST_CI; ++ci) dxacc[k][ci] = 0.f;
+  const int tl = blockIdx.x;
+  const int tx = tl % tiles_x, ty = tl / tiles_x;
+  const int y0 = ty * ST_TH, x0 = tx * ST_TW;
+  for (int b = blockIdx.y; b < g.B; b += gridDim.y) {
     __syncthreads();
     load_x_tile(xt, x, g, b, y0, x0, tid, SW_THREADS);
     for (int i = tid; i < g.T * ST_IH * ST_IW * 3; i += SW_THREADS) {
@@ -294,13 +307,14 @@ __global__ __launch_bounds__(SW_THREADS) void stem_bwd_wx_kernel(
     __syncthreads();
     // ---- d input for the perception frames --------------------------------------------------
     const int gy = y0 + py, gx = x0 + px;
-    if (dP && gy < g.H && gx < g.W) {
+    if (dP && tid < SW_PIX && gy < g.H && gx < g.W) {
+#pragma unroll 1
       for (int k = 0; k < n_frames; ++k) {
         const int t = t_first + k;
         float dx[ST_CI] = {0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
         for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
+#pragma unroll 1
           for (int kx = 0; kx < 3; ++kx) {
             // out pixel q = p - (k - 1)  =>  local tile coords (py + 1 - (ky - 1)) ...
             const float* dp = dt_ + ((size_t)(t * ST_IH + py + 2 - ky) * ST_IW + px + 2 - kx) * ST_C;
@@ -316,15 +330,20 @@ __global__ __launch_bounds__(SW_THREADS) void stem_bwd_wx_kernel(
         for (int ci = 0; ci < ST_CI; ++ci) {
           if (per_sample)  // dP is a full NCDHW gradient [B][3][T][H][W]
             dP[((((size_t)b * ST_CI + ci) * g.T + t) * g.H + gy) * g.W + gx] = dx[ci];
-          else             // dP is [3][n_frames][H][W], summed over the batch
-            atomicAdd(dP + (((size_t)ci * n_frames + k) * g.H + gy) * g.W + gx, dx[ci]);
+        }
+        if (!per_sample) {  // dP is [3][n_frames][H][W], summed over the batch: flushed after the walk
+#pragma unroll
+          for (int kk = 0; kk < ST_MAXT; ++kk)  // static register indexing (k is a runtime value)
+#pragma unroll
+            for (int ci = 0; ci < ST_CI; ++ci) dxacc[kk][ci] += kk == k ? dx[ci] : 0.f;
         }
       }
     }
     // ---- d w_t ---------------------------------------------------------------------------------
-    if (tid < 81) {
+    if (w_role) {
+      constexpr int ROWS = ST_TH / SW_SLICES;
       for (int t = 0; t < g.T; ++t) {
-        for (int qy = 0; qy < ST_TH; ++qy) {
+        for (int qy = wslice * ROWS; qy < (wslice + 1) * ROWS; ++qy) {
           for (int qx = 0; qx < ST_TW; ++qx) {
             const float xin = xt[((wci * g.T + t) * ST_IH + qy + wky) * ST_IW + qx + wkx];
             const float* dp = dt_ + ((size_t)(t * ST_IH + qy + 1) * ST_IW + qx + 1) * ST_C + wcv * 8;
@@ -339,9 +358,37 @@ __global__ __launch_bounds__(SW_THREADS) void stem_bwd_wx_kernel(
       }
     }
   }
-  if (tid < 81) {
+  if (dP && !per_sample && tid < SW_PIX) {
+    const int gy = y0 + py, gx = x0 + px;
+    if (gy < g.H && gx < g.W) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(dw_t + (size_t)(wcv * 8 + j) * 27 + wtap, dwacc[j]);
+      for (int k = 0; k < ST_MAXT; ++k) {
+        if (k < n_frames) {
+#pragma unroll
+          for (int ci = 0; ci < ST_CI; ++ci) {
+            float* dst = dP + (((size_t)ci * n_frames + k) * g.H + gy) * g.W + gx;
+            if (gridDim.y == 1) *dst += dxacc[k][ci];     // sole owner of this pixel
+            else atomicAdd(dst, dxacc[k][ci]);
+          }
+        }
+      }
+    }
+  }
+  // d w_t: add the four row-slices through LDS, then one atomic per weight and workgroup
+  __syncthreads();
+  float* wred = dt_;  // [SW_SLICES - 1][81][8]
+  if (w_role && wslice > 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wred[((wslice - 1) * 81 + wl) * 8 + j] = dwacc[j];
+  }
+  __syncthreads();
+  if (w_role && wslice == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = dwacc[j];
+      for (int sl = 0; sl < SW_SLICES - 1; ++sl) v += wred[(sl * 81 + wl) * 8 + j];
+      atomicAdd(dw_t + (size_t)(wcv * 8 + j) * 27 + wtap, v);
+    }
   }
 }
 
@@ -393,8 +440,12 @@ extern "C" int c3d_stem_bwd_wx(const float* x, const float* w_t, const void* dv,
   StemGeom g{B, T, H, W};
   const size_t lds = (27 * ST_C + (size_t)ST_CI * T * ST_IH * ST_IW + (size_t)T * ST_IH * ST_IW * ST_C) * sizeof(float);
   const int ntiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
-  const int tpw = ntiles >= 8 ? 8 : ntiles;
-  dim3 grid((ntiles + tpw - 1) / tpw, B);
+  // one workgroup per tile walking the batch; split the batch only when there are too few tiles
+  int bsplit = (2 * 256 + ntiles - 1) / ntiles;
+  if (bsplit > B) bsplit = B;
+  if (bsplit < 1) bsplit = 1;
+  const int tpw = 1;
+  dim3 grid(ntiles, bsplit);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr_set = false;
   if (!attr_set) {
