@@ -248,8 +248,17 @@ def main():
                  "GBps": round(v["bytes_total"] / max(v["ms_total"], 1e-9) / 1e6, 1)} for k, v in table]
         out["kernel_time_ms_eager_step"] = round(tot, 3)
         if a.kernel_table:
+            ops.PROFILE_DETAIL = True   # second eager step: pointwise kernels keyed by GEMM shape/mode
+            ops.profile_begin()
+            fwd_bwd()
+            opt.launch()
+            shapes = ops.profile_end()
+            ops.PROFILE_DETAIL = False
+            srows = [{"kernel": k, "launches": v["launches"], "ms_total": round(v["ms_total"], 3),
+                      "GBps": round(v["bytes_total"] / max(v["ms_total"], 1e-9) / 1e6, 1)}
+                     for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms_total"]) if "[" in k]
             with open(a.kernel_table, "w") as f:
-                json.dump({"ms_per_step": ms_per_step, "kernels": rows}, f, indent=1)
+                json.dump({"ms_per_step": ms_per_step, "kernels": rows, "pointwise_by_shape": srows}, f, indent=1)
         for r in rows:
             print(f"[kernels] {r['kernel']:24s} x{r['launches']:4d} {r['ms_total']:9.3f} ms {r['GBps']:8.1f} GB/s",
                   file=sys.stderr)

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "../../include/change3d_hip.h"
 #include "pw_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -83,8 +84,7 @@ constexpr int PW_SLOTS = 8;  // raw 8-channel vectors per lane per iteration (~8
 // Output staging type: plain-store / statistics epilogues round once to the storage type anyway,
 // the arithmetic epilogues (Swish/SE backward, residual add) keep the f32 accumulator.
 template <typename T, int EPI> struct OutStage { typedef float type; };
-template <> struct OutStage<bf16_t, C3D_EPI_STORE> { typedef bf16_t type; };
-template <> struct OutStage<bf16_t, C3D_EPI_STATS> { typedef bf16_t type; };
+template <int EPI> struct OutStage<bf16_t, EPI> { typedef bf16_t type; };  // halves the result tile: 8 waves/CU fit
 
 struct PwLaunch {
   int tiles_per_wave;  // 16-row sub-tiles per wave (contiguous range)
@@ -422,15 +422,48 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
       for (int wv = 0; wv < WAVES; ++wv) acc += red[(wv * 2 + which) * Np + c];
       atomicAdd(dst + which * a.N + c, (double)acc);
     }
-  } else if (EPI == C3D_EPI_SWISH_SE_BWD && cur_n >= 0) {
+  } else if (EPI == C3D_EPI_SWISH_SE_BWD) {
+    // Per-(sample, channel) sums.  The waves of a workgroup almost always end inside the same
+    // sample: combine them through LDS and issue ONE f64 atomic per value and workgroup (the
+    // per-wave flush was 660 k same-address atomics = 40 % of the stage-3 kernel's time).
+    float* red = reinterpret_cast<float*>(smem + L.wave_off);        // [WAVES][3][Np], X regions are dead now
+    int* ncur = reinterpret_cast<int*>(red + (size_t)WAVES * 3 * Np);  // [WAVES]
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float r0 = strided_lane_sum(s0[j], lane, Go, RPo);
       const float r1 = strided_lane_sum(s1[j], lane, Go, RPo);
       const float r2 = strided_lane_sum(s2[j], lane, Go, RPo);
       if (lane < Go) {
-        double* d = a.stats + ((int64_t)cur_n * Np + v_o * 8 + j) * 3;
-        atomicAdd(d, (double)r0); atomicAdd(d + 1, (double)r1); atomicAdd(d + 2, (double)r2);
+        red[(wave * 3 + 0) * Np + v_o * 8 + j] = r0;
+        red[(wave * 3 + 1) * Np + v_o * 8 + j] = r1;
+        red[(wave * 3 + 2) * Np + v_o * 8 + j] = r2;
+      }
+    }
+    if (lane == 0) ncur[wave] = (int)cur_n;
+    __syncthreads();
+    int n_all = -1;
+    bool uniform = true;
+    for (int wv = 0; wv < WAVES; ++wv) {
+      const int nw = ncur[wv];
+      if (nw < 0) continue;          // a wave without tiles contributes nothing
+      if (n_all < 0) n_all = nw;
+      else if (nw != n_all) uniform = false;
+    }
+    if (uniform) {
+      if (n_all >= 0) {
+        for (int i = tid; i < 3 * Np; i += WAVES * 64) {
+          const int which = i / Np, c = i - which * Np;
+          float acc = 0.f;
+          for (int wv = 0; wv < WAVES; ++wv)
+            if (ncur[wv] >= 0) acc += red[(wv * 3 + which) * Np + c];
+          atomicAdd(a.stats + ((int64_t)n_all * Np + c) * 3 + which, (double)acc);
+        }
+      }
+    } else if (cur_n >= 0) {
+      for (int i = lane; i < 3 * Np; i += 64) {
+        const int which = i / Np, c = i - which * Np;
+        atomicAdd(a.stats + ((int64_t)cur_n * Np + c) * 3 + which, (double)red[(wave * 3 + which) * Np + c]);
       }
     }
   }
@@ -499,7 +532,10 @@ int launch_pw(const c3d_pw_args& a, hipStream_t stream) {
   // prefer 8 waves per workgroup (one weight copy per 8 waves) when LDS allows it
   PwLaunch L;
   size_t lds = 0;
-  if (plan_pw<T, NT, PRO, EPI, 8>(a, L, lds) && (L.tpi * ((((a.Kp >> 3) + 3) >> 2)) >= 4 || lds <= 80 * 1024))
+  static const int force8 = getenv("C3D_PW_FORCE8") ? atoi(getenv("C3D_PW_FORCE8")) : 0;  // tuning knob
+  const bool e1_epi = EPI == C3D_EPI_SWISH_SE_BWD || EPI == C3D_EPI_ADD;  // epilogues with exposed companion loads
+  if (plan_pw<T, NT, PRO, EPI, 8>(a, L, lds) &&
+      (L.tpi * ((((a.Kp >> 3) + 3) >> 2)) >= 4 || lds <= 80 * 1024 || force8 == 2 || (force8 == 1 && e1_epi)))
     return launch_pw_w<T, NT, PRO, EPI, 8>(a, stream);
   if (plan_pw<T, NT, PRO, EPI, 4>(a, L, lds)) return launch_pw_w<T, NT, PRO, EPI, 4>(a, stream);
   if (sizeof(T) == 4) return launch_pw_w<float, NT, PRO, EPI, 2>(a, stream);  // f32 parity path only

@@ -85,6 +85,17 @@ def profile_end():
     return out
 
 
+PROFILE_DETAIL = False  # profile keys carry the GEMM shape/mode (tools/profile_shapes.py)
+
+
+def _detail(name, a):
+    if PROFILE is None or not PROFILE_DETAIL:
+        return name
+    if name == "c3d_pw_gemm":
+        return f"{name}[M={a.M} K={a.K} N={a.N} pro={a.pro_mode} epi={a.epi_mode} rows={a.row_mode}]"
+    return f"{name}[M={a.M} K={a.K} N={a.N} q={a.q_mode} rows={a.row_mode}]"
+
+
 def _launch(name, nbytes, fn, *args):
     prof = PROFILE
     if prof is not None:
@@ -132,7 +143,7 @@ def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, 
     a.w_sn, a.w_sk = w_sn, w_sk
     a.row_mode, a.rpg, a.H, a.W = row_mode, rpg, H, W
     a.pro_mode, a.epi_mode, a.res_mode, a.dtype = pro_mode, epi_mode, res_mode, dtype
-    _launch("c3d_pw_gemm", a.M * (a.Kp * (2 if x2 is not None else 1) + a.Np * (2 if (e1 is not None or e1_ptr is not None) else 1)) * _es(dtype), L.lib().c3d_pw_gemm, C.byref(a), _stream())
+    _launch(_detail("c3d_pw_gemm", a), a.M * (a.Kp * (2 if x2 is not None else 1) + a.Np * (2 if (e1 is not None or e1_ptr is not None) else 1)) * _es(dtype), L.lib().c3d_pw_gemm, C.byref(a), _stream())
 
 
 _wgrad_ws = {}
@@ -162,7 +173,7 @@ def pw_wgrad(p, q, dw, *, M, K, N, dw_sn, dw_sk, dtype, p2=None, p_coef=None, q_
     a.dw_sn, a.dw_sk = dw_sn, dw_sk
     a.row_mode, a.rpg, a.H, a.W, a.dy, a.dx = row_mode, rpg, H, W, dy, dx
     a.q_mode, a.dtype = q_mode, dtype
-    _launch("c3d_pw_wgrad", a.M * (a.Np * (2 if p2 is not None else 1) + a.Kp) * _es(dtype), L.lib().c3d_pw_wgrad, C.byref(a), _stream())
+    _launch(_detail("c3d_pw_wgrad", a), a.M * (a.Np * (2 if p2 is not None else 1) + a.Kp) * _es(dtype), L.lib().c3d_pw_wgrad, C.byref(a), _stream())
 
 
 # ------------------------------------------------------------------------------- BN / SE
