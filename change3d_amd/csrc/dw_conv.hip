@@ -29,6 +29,35 @@ struct DwGeom {
   int B, T, H, W, Ho, Wo, C, Cp, stride;
 };
 
+// raw (unconverted) 8-element vectors: what a register prefetch holds between issue and use
+template <typename T> struct RawD;
+template <> struct RawD<bf16_t> {
+  typedef uint4 type;
+  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+};
+template <> struct RawD<float> {
+  struct type { float4 a, b; };
+  static __device__ __forceinline__ type load(const float* p) {
+    type t; t.a = *reinterpret_cast<const float4*>(p); t.b = *reinterpret_cast<const float4*>(p + 4); return t;
+  }
+  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
+    f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w; f[4] = v.b.x; f[5] = v.b.y; f[6] = v.b.z; f[7] = v.b.w;
+  }
+};
+
+
+__device__ __forceinline__ void lds_ld8(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
 // ----------------------------------------------------------------------------------------------
 // Forward.  grid = (tiles_x*tiles_y, channel chunks, B); block = TH*TW*DW_CV threads.
 template <typename T, int S, int TH, int TW>
@@ -171,26 +200,36 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_fwd_kernel(
 // ----------------------------------------------------------------------------------------------
 // Data gradient.  Output positions are INPUT-resolution pixels; the staged tile is db at
 // output resolution (+halo), built on load from (t1, b, coefA, coefB[n], coefC).
-template <typename T, int S, int TH, int TW>
+//   * a workgroup walks `tiles_per_wg` tiles of one (sample, 32-channel chunk): the next tile's raw
+//     (t1, b) rows and this tile's `a` rows (mask + BN_a-backward sums) are in flight while the
+//     taps of the current tile run, and the BN_a sums are flushed once per workgroup (the
+//     one-tile-per-workgroup version was bound by load latency and by 64 f64 atomics per tile);
+//   * the staged db tile is f32 in two half-vector planes [half][t][y][x][cv] of float4: no
+//     bf16->f32 conversion per tap (integer VALU ops run at half the f32 FMA rate on gfx950) and a
+//     wave's lanes read consecutive 16 B (conflict-free);
+//   * per-channel coefficient vectors live in LDS (register budget: 3 workgroups per CU).
+template <typename T, int S, int TH, int TW, int TT>
 __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
     const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
     const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
     const T* __restrict__ a, const float* __restrict__ ss_a, const float* __restrict__ mr_a, T* __restrict__ t2,
-    double* __restrict__ dsums, const DwGeom g) {
-  typedef typename LdsStore<T>::type L;
-  // dra[iy] gathers db[(iy + 1 - ky)/S]; for a TH-row tile starting at y0 (multiple of S*... ) the
-  // db rows needed span floor((y0-1)/S) .. floor((y0+TH)/S)
+    double* __restrict__ dsums, const DwGeom g, const int tiles_per_wg) {
+  typedef RawD<T> RW;
   constexpr int DH = (S == 1) ? TH + 2 : TH / 2 + 2;
   constexpr int DW_ = (S == 1) ? TW + 2 : TW / 2 + 2;
   constexpr int NTHR = TH * TW * DW_CV;
+  constexpr int NI = TT * DH * DW_ * DW_CV;       // staged vectors per tile
+  constexpr int SL = (NI + NTHR - 1) / NTHR;      // prefetch slots per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* wl = reinterpret_cast<float*>(smem);
-  float* red = wl + 27 * 32;
-  L* tile = reinterpret_cast<L*>(red + (NTHR / 64) * DW_CV * 16);  // [T][DH][DW_][32]
+  float* wl = reinterpret_cast<float*>(smem);     // [27][32]
+  float* cf = wl + 27 * 32;                       // [7][32]: cA, cB(sample), cC, sa, sb, ma, ra
+  float* red = cf + 7 * 32;                       // [waves][DW_CV][16]
+  float4* tile = reinterpret_cast<float4*>(red + (NTHR / 64) * DW_CV * 16);  // [2][TT][DH][DW_][DW_CV]
+  constexpr int plane = NI;                       // float4 units per half-vector plane
 
   const int tid = threadIdx.x;
-  const int tiles_x = (g.W + TW - 1) / TW;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+  const int ntiles = tiles_x * tiles_y;
   const int chunk = blockIdx.y, b = blockIdx.z;
   const int c0 = chunk * DW_CV * 8;
   const int cv = tid % DW_CV;
@@ -201,112 +240,153 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
     const int tap = i / 32, c = c0 + (i & 31);
     wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
   }
-  float cA[8], cB[8], cC[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    cA[j] = c_ok ? coefA[cbase + j] : 0.f;
-    cB[j] = c_ok ? coefB[(size_t)b * g.Cp + cbase + j] : 0.f;
-    cC[j] = c_ok ? coefC[cbase + j] : 0.f;
-  }
-  const int y0 = ty * TH, x0 = tx * TW;
-  // first db row/col held in the tile
-  const int dy0 = (S == 1) ? y0 - 1 : (y0 >> 1) - 1;
-  const int dx0 = (S == 1) ? x0 - 1 : (x0 >> 1) - 1;
-  const int items = g.T * DH * DW_ * DW_CV;
-  for (int i = tid; i < items; i += NTHR) {
-    const int p = i / DW_CV;
-    const int ix = p % DW_;
-    const int q = p / DW_;
-    const int iy = q % DH, t = q / DH;
-    const int gy = dy0 + iy, gx = dx0 + ix;
-    float f[8];
-    if (c_ok && gy >= 0 && gy < g.Ho && gx >= 0 && gx < g.Wo) {
-      const size_t off = ((((size_t)b * g.T + t) * g.Ho + gy) * g.Wo + gx) * g.Cp + cbase;
-      float f2[8];
-      Vec8<T>::load(t1 + off, f);
-      Vec8<T>::load(bb + off, f2);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j]));
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = 0.f;
+  for (int i = tid; i < 7 * 32; i += NTHR) {
+    const int k = i >> 5, c = c0 + (i & 31);
+    float v = 0.f;
+    if (c < g.Cp) {
+      v = k == 0 ? coefA[c] : k == 1 ? coefB[(size_t)b * g.Cp + c] : k == 2 ? coefC[c] : k == 3 ? ss_a[c]
+        : k == 4 ? ss_a[g.Cp + c] : k == 5 ? mr_a[c] : mr_a[g.Cp + c];
     }
-    Vec8<L>::store(tile + (size_t)p * 32 + cv * 8, f);
+    cf[i] = v;
   }
-  __syncthreads();
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+
+  typename RW::type r1[SL], r2[SL];
+  unsigned vmask = 0;
+#define BD_ISSUE(TL)                                                                             \
+  {                                                                                              \
+    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                        \
+    const int dy0_ = (S == 1) ? ty_ * TH - 1 : ((ty_ * TH) >> 1) - 1;                            \
+    const int dx0_ = (S == 1) ? tx_ * TW - 1 : ((tx_ * TW) >> 1) - 1;                            \
+    vmask = 0;                                                                                   \
+    _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                          \
+      const int i_ = tid + sl * NTHR;                                                            \
+      const int p_ = i_ / DW_CV;                                                                 \
+      const int ix_ = p_ % DW_, q_ = p_ / DW_;                                                   \
+      const int iy_ = q_ % DH, t_ = q_ / DH;                                                     \
+      const int gy_ = dy0_ + iy_, gx_ = dx0_ + ix_;                                              \
+      if (i_ < NI && c_ok && t_ < g.T && gy_ >= 0 && gy_ < g.Ho && gx_ >= 0 && gx_ < g.Wo) {    \
+        const size_t off_ = ((((size_t)b * g.T + t_) * g.Ho + gy_) * g.Wo + gx_) * g.Cp + cbase; \
+        r1[sl] = RW::load(t1 + off_);                                                            \
+        r2[sl] = RW::load(bb + off_);                                                            \
+        vmask |= 1u << sl;                                                                       \
+      }                                                                                          \
+    }                                                                                            \
+  }
 
   const int pix = tid / DW_CV;
   const int px = pix % TW, py = pix / TW;
-  const int iy = y0 + py, ix = x0 + px;
-  const bool p_ok = c_ok && iy < g.H && ix < g.W;
-
-  float acc[DW_MAXT][8];
+  const int tl0 = blockIdx.x * tiles_per_wg;
+  int tl1 = tl0 + tiles_per_wg;
+  if (tl1 > ntiles) tl1 = ntiles;
+  if (tl0 < tl1) BD_ISSUE(tl0)
+  for (int tl = tl0; tl < tl1; ++tl) {
+    const int tx = tl % tiles_x, ty = tl / tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int dy0 = (S == 1) ? y0 - 1 : (y0 >> 1) - 1;   // first db row/col held in the tile
+    const int dx0 = (S == 1) ? x0 - 1 : (x0 >> 1) - 1;
+    __syncthreads();   // the previous tile's taps are done (and wl/cf are visible on the first pass)
+    {
+      float cA[8], cB[8], cC[8];
+      lds_ld8(cf + 0 * 32 + cv * 8, cA);
+      lds_ld8(cf + 1 * 32 + cv * 8, cB);
+      lds_ld8(cf + 2 * 32 + cv * 8, cC);
 #pragma unroll
-  for (int t = 0; t < DW_MAXT; ++t)
+      for (int sl = 0; sl < SL; ++sl) {
+        const int i = tid + sl * NTHR;
+        if (i < NI) {
+          float f[8];
+          if ((vmask >> sl) & 1u) {
+            float f2[8];
+            RW::cvt(r1[sl], f);
+            RW::cvt(r2[sl], f2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-
+            for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j]));
+          } else {
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int ny = iy + 1 - ky;  // = S * oy
-    if (S == 2 && (ny & 1)) continue;
-    const int ly = ((S == 1) ? ny : (ny >> 1)) - dy0;  // arithmetic shift: ny >= -1... ny even here
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int nx = ix + 1 - kx;
-      if (S == 2 && (nx & 1)) continue;
-      const int lx = ((S == 1) ? nx : (nx >> 1)) - dx0;
-      float wk[3][8];
-#pragma unroll
-      for (int kt = 0; kt < 3; ++kt) {
-        const float4 w0 = *reinterpret_cast<const float4*>(wl + (kt * 9 + ky * 3 + kx) * 32 + cv * 8);
-        const float4 w1 = *reinterpret_cast<const float4*>(wl + (kt * 9 + ky * 3 + kx) * 32 + cv * 8 + 4);
-        wk[kt][0] = w0.x; wk[kt][1] = w0.y; wk[kt][2] = w0.z; wk[kt][3] = w0.w;
-        wk[kt][4] = w1.x; wk[kt][5] = w1.y; wk[kt][6] = w1.z; wk[kt][7] = w1.w;
+            for (int j = 0; j < 8; ++j) f[j] = 0.f;
+          }
+          tile[i] = make_float4(f[0], f[1], f[2], f[3]);            // i = p * DW_CV + cv
+          tile[plane + i] = make_float4(f[4], f[5], f[6], f[7]);
+        }
       }
+    }
+    // this tile's `a` rows (epilogue operands) first, then the next tile's raw rows: vmcnt is in
+    // order, so the epilogue waits only for what it needs
+    const int iy = y0 + py, ix = x0 + px;
+    const bool p_ok = c_ok && iy < g.H && ix < g.W;
+    typename RW::type ar[TT];
+    if (p_ok) {
 #pragma unroll
-      for (int to = 0; to < DW_MAXT; ++to) {
-        if (to < g.T) {
-          float v[8];
-          Vec8<L>::load(tile + ((size_t)(to * DH + ly) * DW_ + lx) * 32 + cv * 8, v);
+      for (int t = 0; t < TT; ++t)
+        if (t < g.T) ar[t] = RW::load(a + ((((size_t)b * g.T + t) * g.H + iy) * g.W + ix) * g.Cp + cbase);
+    }
+    if (tl + 1 < tl1) BD_ISSUE(tl + 1)
+    __syncthreads();
+
+    float acc[TT][8];
 #pragma unroll
-          for (int kt = 0; kt < 3; ++kt) {
-            const int ti = to + kt - 1;  // d in[ti] += d out[to] * w[kt]
-            if (ti >= 0 && ti < DW_MAXT && ti < g.T) {
+    for (int t = 0; t < TT; ++t)
 #pragma unroll
-              for (int j = 0; j < 8; ++j) acc[ti][j] = fmaf(v[j], wk[kt][j], acc[ti][j]);
+      for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ny = iy + 1 - ky;  // = S * oy
+      if (S == 2 && (ny & 1)) continue;
+      const int ly = ((S == 1) ? ny : (ny >> 1)) - dy0;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int nx = ix + 1 - kx;
+        if (S == 2 && (nx & 1)) continue;
+        const int lx = ((S == 1) ? nx : (nx >> 1)) - dx0;
+        float wk[3][8];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) lds_ld8(wl + (kt * 9 + ky * 3 + kx) * 32 + cv * 8, wk[kt]);
+#pragma unroll
+        for (int to = 0; to < TT; ++to) {
+          if (to < g.T) {
+            const int pi = ((to * DH + ly) * DW_ + lx) * DW_CV + cv;
+            const float4 h0 = tile[pi], h1 = tile[plane + pi];
+            const float v[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+              const int ti = to + kt - 1;  // d in[ti] += d out[to] * w[kt]
+              if (ti >= 0 && ti < TT && ti < g.T) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[ti][j] = fmaf(v[j], wk[kt][j], acc[ti][j]);
+              }
             }
           }
         }
       }
     }
-  }
-
-  float sa[8], sb[8], s1[8], s2[8], ma[8], ra[8];
+    if (p_ok) {
+      float sa[8], sb[8], ma[8], ra[8];
+      lds_ld8(cf + 3 * 32 + cv * 8, sa);
+      lds_ld8(cf + 4 * 32 + cv * 8, sb);
+      lds_ld8(cf + 5 * 32 + cv * 8, ma);
+      lds_ld8(cf + 6 * 32 + cv * 8, ra);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    sa[j] = c_ok ? ss_a[cbase + j] : 0.f; sb[j] = c_ok ? ss_a[g.Cp + cbase + j] : 0.f;
-    ma[j] = c_ok ? mr_a[cbase + j] : 0.f; ra[j] = c_ok ? mr_a[g.Cp + cbase + j] : 0.f;
-    s1[j] = 0.f; s2[j] = 0.f;
-  }
-  if (p_ok) {
+      for (int t = 0; t < TT; ++t) {
+        if (t < g.T) {
+          const size_t off = ((((size_t)b * g.T + t) * g.H + iy) * g.W + ix) * g.Cp + cbase;
+          float av[8], o[8];
+          RW::cvt(ar[t], av);
 #pragma unroll
-    for (int t = 0; t < DW_MAXT; ++t) {
-      if (t < g.T) {
-        const size_t off = ((((size_t)b * g.T + t) * g.H + iy) * g.W + ix) * g.Cp + cbase;
-        float av[8], o[8];
-        Vec8<T>::load(a + off, av);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pa = fmaf(av[j], sa[j], sb[j]);
-          const float d = round_as<T>(pa > 0.f ? acc[t][j] : 0.f);
-          o[j] = d;
-          s1[j] += d; s2[j] += d * ((av[j] - ma[j]) * ra[j]);
+          for (int j = 0; j < 8; ++j) {
+            const float pa = fmaf(av[j], sa[j], sb[j]);
+            const float d = round_as<T>(pa > 0.f ? acc[t][j] : 0.f);
+            o[j] = d;
+            s1[j] += d; s2[j] += d * ((av[j] - ma[j]) * ra[j]);
+          }
+          Vec8<T>::store(t2 + off, o);
         }
-        Vec8<T>::store(t2 + off, o);
       }
     }
   }
+#undef BD_ISSUE
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -332,36 +412,6 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
     if (c < g.C) atomicAdd(dsums + (size_t)(k >> 3) * g.C + c, (double)s);
   }
 }
-
-// ----------------------------------------------------------------------------------------------
-// Fused backward: data gradient AND weight gradient from ONE staging of the (t1, b) and a tiles.
-//   * a workgroup walks `tiles_per_wg` 8x8 input-resolution tiles of one (sample, 32-channel chunk);
-//     the next tile's raw rows are prefetched into registers while the current one is processed;
-//   * phase 2 (256 threads = pixel x channel-vector): t2 = dconv(db) * (bn_a(a) > 0), BN_a-backward
-//     sums kept in registers for the whole walk;
-//   * phase 3 (216 threads = 27 taps x 4 channel-vectors x 2 pixel halves): weight-gradient partial
-//     sums kept in registers for the whole walk;
-//   * one flush per workgroup (statistics into C3D_STAT_STRIPES striped f64 sets, dW via f32 atomics).
-template <typename T> struct RawD;
-template <> struct RawD<bf16_t> {
-  typedef uint4 type;
-  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
-  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-  }
-};
-template <> struct RawD<float> {
-  struct type { float4 a, b; };
-  static __device__ __forceinline__ type load(const float* p) {
-    type t; t.a = *reinterpret_cast<const float4*>(p); t.b = *reinterpret_cast<const float4*>(p + 4); return t;
-  }
-  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
-    f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w; f[4] = v.b.x; f[5] = v.b.y; f[6] = v.b.z; f[7] = v.b.w;
-  }
-};
 
 // Asynchronous LDS vector read of 8 tile elements with an explicit wait, for hand-pipelined
 // inner loops (inline asm: the wait names the destination so its consumers cannot move above it).
@@ -878,6 +928,15 @@ __global__ __launch_bounds__(TH * TW * DW_CV * 3 + DW_LOADERS) void dw_wgrad_dma
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Fused backward: data gradient AND weight gradient from ONE staging of the (t1, b) and a tiles.
+//   * a workgroup walks `tiles_per_wg` 8x8 input-resolution tiles of one (sample, 32-channel chunk);
+//     the next tile's raw rows are prefetched into registers while the current one is processed;
+//   * phase 2 (256 threads = pixel x channel-vector): t2 = dconv(db) * (bn_a(a) > 0), BN_a-backward
+//     sums kept in registers for the whole walk;
+//   * phase 3 (216 threads = 27 taps x 4 channel-vectors x 2 pixel halves): weight-gradient partial
+//     sums kept in registers for the whole walk;
+//   * one flush per workgroup (statistics into C3D_STAT_STRIPES striped f64 sets, dW via f32 atomics).
 template <typename T, int S, int TT>
 __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
     const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
@@ -1413,29 +1472,44 @@ int launch_fwd(const void* x, const float* ss, const float* w, void* y, double* 
   return 0;
 }
 
-template <typename T, int S>
-int launch_bwd_data(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC,
-                    const float* w, const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums,
-                    const DwGeom& g, hipStream_t stream) {
+template <typename T, int S, int TT>
+int launch_bwd_data_t(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC,
+                      const float* w, const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums,
+                      const DwGeom& g, hipStream_t stream) {
   constexpr int TH = 8, TW = 8;
   constexpr int DH = (S == 1) ? TH + 2 : TH / 2 + 2, DW_ = (S == 1) ? TW + 2 : TW / 2 + 2;
   constexpr int NTHR = TH * TW * DW_CV;
-  const size_t lds = (27 * 32 + (NTHR / 64) * DW_CV * 16) * sizeof(float) +
-                     (size_t)g.T * DH * DW_ * 32 * sizeof(typename LdsStore<T>::type);
+  const size_t lds = (27 * 32 + 7 * 32 + (NTHR / 64) * DW_CV * 16) * sizeof(float) +
+                     (size_t)TT * DH * DW_ * 32 * sizeof(float);
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_data_kernel<T, S, TH, TW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_data_kernel<T, S, TH, TW, TT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  dim3 grid(((g.W + TW - 1) / TW) * ((g.H + TH - 1) / TH), (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), g.B);
-  dw_bwd_data_kernel<T, S, TH, TW><<<grid, dim3(NTHR), lds, stream>>>(
+  const int ntiles = ((g.W + TW - 1) / TW) * ((g.H + TH - 1) / TH);
+  const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
+  // walk length: enough workgroups to fill the chip a few times over, tiles to amortise the prologue
+  static const int env_tpw = getenv("C3D_DWBD_TPW") ? atoi(getenv("C3D_DWBD_TPW")) : 0;
+  int tpw = env_tpw > 0 ? env_tpw : 16;
+  while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 4L * device_cus()) tpw >>= 1;
+  if (tpw > ntiles) tpw = ntiles;
+  dim3 grid((ntiles + tpw - 1) / tpw, chunks, g.B);
+  dw_bwd_data_kernel<T, S, TH, TW, TT><<<grid, dim3(NTHR), lds, stream>>>(
       reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, w, reinterpret_cast<const T*>(a),
-      ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, g);
+      ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, g, tpw);
   C3D_CHECK_LAUNCH();
   return 0;
+}
+
+template <typename T, int S>
+int launch_bwd_data(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC,
+                    const float* w, const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums,
+                    const DwGeom& g, hipStream_t stream) {
+  if (g.T <= 3) return launch_bwd_data_t<T, S, 3>(t1, bb, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, g, stream);
+  return launch_bwd_data_t<T, S, 5>(t1, bb, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, g, stream);
 }
 
 template <typename T, int S>
