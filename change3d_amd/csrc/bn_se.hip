@@ -47,7 +47,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int stripes,
   if (mr) { mr[c] = meanf; mr[Cp + c] = rstd; }
 }
 
-constexpr int SE_THREADS = 1024;  // single-workgroup layer kernels: width buys latency
+constexpr int SE_THREADS = 1024;  // layer kernels: width buys latency
+constexpr int SE_SLICES = 8;      // channel slices (workgroups) of the SE layer kernels
 
 // -------------------------------------------------------------------------------------------
 // Depthwise-conv output statistics arrive per (sample, channel): nc[B][Cp][2].
@@ -63,12 +64,17 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
   float* h = sm + (size_t)B * C;
   const int tid = threadIdx.x;
   const double count = cnt_per_sample * B;
-  if (tid == 0 && training && nbt) *nbt += 1;
-  // 4 lanes per channel split the batch loop (one workgroup does the whole layer: latency, not
-  // bandwidth, is what this kernel costs, so every serial loop is spread over adjacent lanes)
+  // gridDim.x workgroups each recompute the cheap whole-layer parts (statistics, FC1) and OWN a
+  // channel slice [c_lo, c_hi) of everything that is written (running statistics, scale/shift, gate)
+  const int cs = (Cp + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int c_lo = (int)blockIdx.x * cs, c_hi = c_lo + cs < Cp ? c_lo + cs : Cp;
+  if (tid == 0 && blockIdx.x == 0 && training && nbt) *nbt += 1;
+  // 4 lanes per channel split the batch loop (latency, not bandwidth, is what this kernel costs, so
+  // every serial loop is spread over adjacent lanes)
   for (int idx = tid; idx < Cp * 4; idx += blockDim.x) {
     const int c = idx >> 2, q = idx & 3;
-    if (c >= C) { if (q == 0) { ss[c] = 0.f; ss[Cp + c] = 0.f; if (mr) { mr[c] = 0.f; mr[Cp + c] = 0.f; } } continue; }
+    const bool own = c >= c_lo && c < c_hi;
+    if (c >= C) { if (q == 0 && own) { ss[c] = 0.f; ss[Cp + c] = 0.f; if (mr) { mr[c] = 0.f; mr[Cp + c] = 0.f; } } continue; }
     double mean, var;
     if (training) {
       double s1 = 0, s2 = 0;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
       mean = s1 / count;
       var = s2 / count - mean * mean;
       if (var < 0) var = 0;
-      if (running_mean && q == 0) {
+      if (running_mean && q == 0 && own) {
         const double unb = count > 1 ? var * count / (count - 1) : var;
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
     const float meanf = (float)mean;
     const float sc = gamma[c] * rstd;
     const float sh = beta[c] - meanf * sc;
-    if (q == 0) {
+    if (q == 0 && own) {
       ss[c] = sc;
       ss[Cp + c] = sh;
       if (mr) { mr[c] = meanf; mr[Cp + c] = rstd; }
@@ -113,18 +119,19 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
     a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
     a += b1[r];
     a = a > 0.f ? a : 0.f;
-    if (q == 0) { h[i] = a; if (hid) hid[i] = a; }
+    if (q == 0) { h[i] = a; if (hid && blockIdx.x == 0) hid[i] = a; }
   }
   __syncthreads();
-  for (int i = tid; i < B * Cp; i += blockDim.x) {
-    const int n = i / Cp, c = i - n * Cp;
+  const int cw = c_hi - c_lo;
+  for (int i = tid; i < B * cw; i += blockDim.x) {
+    const int n = i / cw, c = c_lo + (i - n * cw);
     float g = 0.f;
     if (c < C) {
       float a = b2[c];
       for (int r = 0; r < Cr; ++r) a = fmaf(w2[(size_t)c * Cr + r], h[(size_t)n * Cr + r], a);
       g = 1.0f / (1.0f + expf(-a));
     }
-    gate[i] = g;
+    gate[(size_t)n * Cp + c] = g;
   }
 }
 
@@ -170,6 +177,11 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
   const int tid = threadIdx.x;
   const double count = cnt_per_sample * B;
   const bool se = w1 != nullptr;
+  // channel-sliced over gridDim.x workgroups: d gate and the FC2-backward hidden gradient need every
+  // channel and are recomputed by each workgroup; everything written is owned by slice [c_lo, c_hi)
+  const int cs = (Cp + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int c_lo = (int)blockIdx.x * cs, c_hi = c_lo + cs < Cp ? c_lo + cs : Cp;
+  const int cw = c_hi - c_lo;
   if (se) {
 #pragma unroll 4
     for (int i = tid; i < B * C; i += blockDim.x) {
@@ -188,15 +200,17 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
       if (q == 0) dh[i] = hid[i] > 0.f ? a : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < B * C; i += blockDim.x) {
-      const int n = i / C, c = i - n * C;
+    for (int i = tid; i < B * cw; i += blockDim.x) {
+      const int n = i / cw, c = c_lo + (i - n * cw);
+      if (c >= C) continue;
       float a = 0.f;
       for (int r = 0; r < Cr; ++r) a = fmaf(w1[(size_t)r * C + c], dh[(size_t)n * Cr + r], a);
-      dz[i] = a;
+      dz[(size_t)n * C + c] = a;
     }
     // parameter gradients of the two FCs
-    for (int i = tid; i < C * Cr; i += blockDim.x) {
-      const int c = i / Cr, r = i - c * Cr;  // w2[c][r]
+    for (int i = tid; i < cw * Cr; i += blockDim.x) {
+      const int c = c_lo + i / Cr, r = i % Cr;  // w2[c][r]
+      if (c >= C) continue;
       float a = 0.f, b = 0.f;
       for (int n = 0; n < B; ++n) {
         a = fmaf(du[(size_t)n * C + c], hid[(size_t)n * Cr + r], a);
@@ -205,20 +219,22 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
       dw2[(size_t)c * Cr + r] += a;
       dw1[(size_t)r * C + c] += b;
     }
-    for (int c = tid; c < C; c += blockDim.x) {
+    for (int c = c_lo + tid; c < c_hi && c < C; c += blockDim.x) {
       float a = 0.f;
       for (int n = 0; n < B; ++n) a += du[(size_t)n * C + c];
       db2[c] += a;
     }
-    for (int r = tid; r < Cr; r += blockDim.x) {
-      float a = 0.f;
-      for (int n = 0; n < B; ++n) a += dh[(size_t)n * Cr + r];
-      db1[r] += a;
+    if (blockIdx.x == 0) {
+      for (int r = tid; r < Cr; r += blockDim.x) {
+        float a = 0.f;
+        for (int n = 0; n < B; ++n) a += dh[(size_t)n * Cr + r];
+        db1[r] += a;
+      }
     }
     __syncthreads();
   }
-  for (int idx = tid; idx < Cp * 4; idx += blockDim.x) {  // 4 lanes per channel split the batch loops
-    const int c = idx >> 2, q = idx & 3;
+  for (int idx = tid; idx < cw * 4; idx += blockDim.x) {  // 4 lanes per channel split the batch loops
+    const int c = c_lo + (idx >> 2), q = idx & 3;
     if (c >= C) {
       if (q == 0) { coefA[c] = 0.f; coefC[c] = 0.f; }
       for (int n = q; n < B; n += 4) coefB[(size_t)n * Cp + c] = 0.f;
@@ -276,7 +292,7 @@ extern "C" int c3d_bn_se_finalize(const double* nc, int32_t B, double cnt_per_sa
   if (w1 && (!b1 || !w2 || !b2 || !gate || Cr <= 0)) return C3D_E_BADARG;
   const size_t lds = w1 ? ((size_t)B * C + (size_t)B * Cr) * sizeof(float) : 0;
   if (lds > 64 * 1024) return C3D_E_UNSUPPORTED;
-  bn_se_finalize_kernel<<<dim3(1), dim3(SE_THREADS), lds, reinterpret_cast<hipStream_t>(stream)>>>(
+  bn_se_finalize_kernel<<<dim3(w1 ? SE_SLICES : 1), dim3(SE_THREADS), lds, reinterpret_cast<hipStream_t>(stream)>>>(
       nc, B, cnt_per_sample, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, C, Cp,
       training, w1, b1, w2, b2, Cr, ss, mr, gate, hid);
   C3D_CHECK_LAUNCH();
@@ -311,7 +327,7 @@ extern "C" int c3d_se_bn_bwd_coef(const double* nc3, const double* ncf, int32_t 
       attr_set = true;
     }
   }
-  se_bn_bwd_coef_kernel<<<dim3(1), dim3(SE_THREADS), lds, reinterpret_cast<hipStream_t>(stream)>>>(
+  se_bn_bwd_coef_kernel<<<dim3(w1 ? SE_SLICES : 1), dim3(SE_THREADS), lds, reinterpret_cast<hipStream_t>(stream)>>>(
       nc3, ncf, B, cnt_per_sample, gamma, mr, ss, C, Cp, w1, w2, gate, hid, Cr, coefA, coefC, coefB, dgamma, dbeta,
       dw1, db1, dw2, db2);
   C3D_CHECK_LAUNCH();

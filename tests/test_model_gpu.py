@@ -361,6 +361,37 @@ def test_e2e_bcd_vs_reference_golden(size, golden_dir):
     assert (nbt == G["final_nbt"]).all()
 
 
+def test_step_is_reproducible():
+    """Two forward+backward passes from identical state: activations (hence the loss) must be
+    bit-identical and every gradient reproducible up to f32 leaf-gradient atomics.  (Statistics are
+    reduced in fixed order or in fixed point; an order-dependent f32 reduction in ONE BatchNorm is
+    amplified by the 55 train-mode BN layers behind it into percent-level gradient noise.)"""
+    _need_gpu()
+    from change3d_amd.model.utils import BCEDiceLoss
+    from oracle import synth
+    _, mine, _ = _build_pair(64)
+    pre, post, tgt = synth.synth_batch(2, 64, seed=3)
+    pre, post, tgt = pre.to(DEV), post.to(DEV), tgt.to(DEV)
+    mine.train()
+    state = {k: v.clone() for k, v in mine.state_dict().items()}
+    runs = []
+    for _ in range(3):
+        mine.load_state_dict(state)
+        for p_ in mine.parameters():
+            p_.grad = None
+        prob = mine.update_bcd(pre, post)
+        loss = BCEDiceLoss(prob, tgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((prob.detach().clone(), loss.item(),
+                     {n: p_.grad.detach().clone() for n, p_ in mine.named_parameters() if p_.grad is not None}))
+    p0, l0, g0 = runs[0]
+    for p1, l1, g1 in runs[1:]:
+        assert torch.equal(p0, p1) and l0 == l1
+        worst = max(((g1[n] - g0[n]).double().norm() / (g0[n].double().norm() + 1e-30)).item() for n in g0)
+        assert worst < 2e-5, worst
+
+
 def test_e2e_bf16_tracks_f32():
     """Throughput path (bf16 activations): not bit-parity — report and bound the drift."""
     _need_gpu()

@@ -327,6 +327,57 @@ def test_dw333_fwd_bwd(dtype, stride, C, T):
         assert torch.allclose(sdf[C:], (t2fq * ((a - mean_a) * rstd_a).double()).sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,stride", [
+    (5, 20, 28, 216, 1),    # ragged tiles, 7 channel chunks with an empty last vector
+    (3, 18, 18, 54, 2),     # ragged stride-2 map
+    (40, 24, 24, 54, 1),    # workgroup walks cross sample boundaries (per-sample coefB rows)
+    (1100, 8, 8, 54, 1),    # one tile per sample: a walk touches > 8 samples (LDS-DMA kernel declines)
+])
+def test_dw333_backward_walks(dtype, B, H, W, C, stride):
+    """Backward depthwise kernels on shapes that exercise the tile walks: the LDS-DMA weight-gradient
+    producer (bf16, T=3), its register-staged fallback, and the walking data-gradient kernel."""
+    _need_gpu()
+    from change3d_amd import ops
+    T = 3
+    Cp = ops.cpad(C)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    a = q(rnd((B, T, H, W, C), 150), dtype)
+    scale, shift = rnd((C,), 151).abs() + 0.5, rnd((C,), 152, 0.3)
+    w = rnd((C, 1, 3, 3, 3), 153, 0.3)
+    a_r = a.clone().requires_grad_(True)
+    w_r = w.clone().requires_grad_(True)
+    bref = F.conv3d(torch.relu(a_r * scale + shift).permute(0, 4, 1, 2, 3), w_r, stride=(1, stride, stride),
+                    padding=1, groups=C)
+    bst = q(bref.detach().permute(0, 2, 3, 4, 1), dtype)
+    t1 = q(rnd((B, T, Ho, Wo, C), 154), dtype)
+    cA, cC, cB = rnd((C,), 155), rnd((C,), 156, 0.1), rnd((B, C), 157, 0.1)
+    db = cA * t1 + cB[:, None, None, None, :] + cC * bst
+    bref.backward(db.permute(0, 4, 1, 2, 3))
+    t2_ref = a_r.grad / scale
+    ss = torch.cat([padc(scale, Cp), padc(shift, Cp)]).to(DEV)
+    mean_a, rstd_a = rnd((C,), 158, 0.5), rnd((C,), 159).abs() + 0.5
+    mr = torch.cat([padc(mean_a, Cp), padc(rstd_a, Cp)]).to(DEV)
+    ad = padc(a, Cp).to(DEV, dtype).contiguous()
+    bd = padc(bst, Cp).to(DEV, dtype).contiguous()
+    t1d = padc(t1, Cp).to(DEV, dtype).contiguous()
+    cAd, cBd, cCd = padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV)
+    wd = w.to(DEV).contiguous()
+    t2 = torch.full_like(ad, float("nan"))
+    dsums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    ops.dw_bwd_data(t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, dsums, B, T, H, W, C, stride, ops.dt_code(dtype))
+    close(t2[..., :C], t2_ref, dtype, "dw bwd data", scale=t2_ref.abs().max().item())
+    t2q = t2[..., :C].float().cpu().double()
+    sd = dsums.cpu()
+    assert torch.allclose(sd[:C], t2q.sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3 * max(1.0, B / 8))
+    assert torch.allclose(sd[C:], (t2q * ((a - mean_a) * rstd_a).double()).sum((0, 1, 2, 3)), rtol=1e-5,
+                          atol=1e-3 * max(1.0, B / 8))
+    dw = torch.zeros((C, 27), dtype=torch.float32, device=DEV)
+    ops.dw_wgrad(t1d, bd, cAd, cBd, cCd, ad, ss, dw, B, T, H, W, C, stride, ops.dt_code(dtype))
+    # the reduction runs over B*T*Ho*Wo products: scale the absolute tolerance with its length
+    close(dw, w_r.grad.view(C, 27), dtype, "dw wgrad", scale=w_r.grad.abs().max().item())
+
+
 # --------------------------------------------------------------------------- loss / optimizer
 def test_bce_dice_and_adam():
     _need_gpu()
