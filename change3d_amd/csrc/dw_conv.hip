@@ -52,6 +52,28 @@ template <> struct RawD<float> {
 };
 
 
+// XCD-aware workgroup order.  A 32-channel chunk reads 64 B of every 112/224/432-byte pixel row, so
+// the chunks of one tile share their 128-byte lines: counters showed the depthwise kernels fetching
+// ~1.8x their input when sibling chunks ran far apart (3-D grid: chunk = blockIdx.y).  Workgroups are
+// dealt round-robin to the 8 XCDs (one L2 each) in flattened-id order, so a 1-D grid decoded as
+//   id -> (xcd = id % 8, k = id / 8), chunk = k % chunks, group = (k / chunks) * 8 + xcd
+// makes the chunks of a group consecutive arrivals on ONE XCD: the second chunk hits that L2.
+constexpr int N_XCD = 8;
+struct ChunkOrder {
+  int chunk, group;   // group = index over (tile groups x samples); < 0: padding workgroup
+};
+__device__ __forceinline__ ChunkOrder chunk_order(const int chunks, const int ngroups) {
+  const int id = blockIdx.x, xcd = id % N_XCD, k = id / N_XCD;
+  ChunkOrder o;
+  o.chunk = k % chunks;
+  o.group = (k / chunks) * N_XCD + xcd;
+  if (o.group >= ngroups) o.group = -1;
+  return o;
+}
+inline unsigned chunk_order_grid(const int chunks, const long ngroups) {
+  return (unsigned)(((ngroups + N_XCD - 1) / N_XCD) * N_XCD * chunks);
+}
+
 __device__ __forceinline__ void lds_ld8(const float* p, float (&f)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p);
   const float4 b = *reinterpret_cast<const float4*>(p + 4);
@@ -230,7 +252,10 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
   const int tid = threadIdx.x;
   const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y;
-  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int gx = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
+  const ChunkOrder co = chunk_order((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), gx * g.B);
+  if (co.group < 0) return;
+  const int chunk = co.chunk, b = co.group / gx, tg = co.group % gx;
   const int c0 = chunk * DW_CV * 8;
   const int cv = tid % DW_CV;
   const int cbase = c0 + cv * 8;
@@ -278,7 +303,7 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
 
   const int pix = tid / DW_CV;
   const int px = pix % TW, py = pix / TW;
-  const int tl0 = blockIdx.x * tiles_per_wg;
+  const int tl0 = tg * tiles_per_wg;
   int tl1 = tl0 + tiles_per_wg;
   if (tl1 > ntiles) tl1 = ntiles;
   if (tl0 < tl1) BD_ISSUE(tl0)
@@ -549,8 +574,11 @@ __global__ __launch_bounds__(TH * TW * DW_CV * 3 + DW_LOADERS) void dw_wgrad_ker
   const int tid = threadIdx.x;
   const int tiles_x = (g.Wo + TW - 1) / TW, tiles_y = (g.Ho + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y;
-  const int c0 = blockIdx.y * DW_CV * 8;
-  const int item0 = blockIdx.x * items_per_wg;
+  const int n_wg_items = (g.B * ntiles + items_per_wg - 1) / items_per_wg;
+  const ChunkOrder co = chunk_order((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), n_wg_items);
+  if (co.group < 0) return;
+  const int c0 = co.chunk * DW_CV * 8;
+  const int item0 = co.group * items_per_wg;
   int item1 = item0 + items_per_wg;
   if (item1 > g.B * ntiles) item1 = g.B * ntiles;
   const int nit = item1 - item0;
@@ -743,8 +771,11 @@ __global__ __launch_bounds__(TH * TW * DW_CV * 3 + DW_LOADERS) void dw_wgrad_dma
   const int tid = threadIdx.x;
   const int tiles_x = (g.Wo + TW - 1) / TW, tiles_y = (g.Ho + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y;
-  const int c0 = blockIdx.y * DW_CV * 8;
-  const int item0 = blockIdx.x * items_per_wg;
+  const int n_wg_items = (g.B * ntiles + items_per_wg - 1) / items_per_wg;
+  const ChunkOrder co = chunk_order((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), n_wg_items);
+  if (co.group < 0) return;
+  const int c0 = co.chunk * DW_CV * 8;
+  const int item0 = co.group * items_per_wg;
   int item1 = item0 + items_per_wg;
   if (item1 > g.B * ntiles) item1 = g.B * ntiles;
   const int nit = item1 - item0;
@@ -1284,7 +1315,10 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
   const int lx = lane & 15, yp = lane >> 4;                    // lane = column x, row pair (2yp, 2yp+1)
   const int tiles_x = (g.W + V2_TW - 1) / V2_TW, tiles_y = (g.H + V2_TH - 1) / V2_TH;
   const int ntiles = tiles_x * tiles_y;
-  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int gx = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
+  const ChunkOrder co = chunk_order((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), gx * g.B);
+  if (co.group < 0) return;
+  const int chunk = co.chunk, b = co.group / gx, tg = co.group % gx;
   const int c0 = chunk * DW_CV * 8;
   // staging role: item i = tid + 256*slot -> (cv = i & 3, pixel = i >> 2)
   const int scv = tid & 3;
@@ -1323,7 +1357,7 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
     }                                                                                           \
   }
 
-  const int tl0 = blockIdx.x * tiles_per_wg;
+  const int tl0 = tg * tiles_per_wg;
   int tl1 = tl0 + tiles_per_wg;
   if (tl1 > ntiles) tl1 = ntiles;
   if (tl0 < tl1) V2_ISSUE(tl0)
@@ -1439,7 +1473,7 @@ int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, doubl
   int tpw = 16;  // swept on MI355X: 1:427us 4:255 8:240 16:233 32:250 (stage-1 shape)
   if (const char* e = getenv("C3D_DW_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;  // tuning knob
   if (tpw > ntiles) tpw = ntiles;
-  dim3 grid((ntiles + tpw - 1) / tpw, (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), g.B);
+  dim3 grid(chunk_order_grid((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), (long)((ntiles + tpw - 1) / tpw) * g.B));
   dw_fwd_v2_kernel<T, TT><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
                                                             reinterpret_cast<T*>(y), nc, g, tpw);
   C3D_CHECK_LAUNCH();
@@ -1496,7 +1530,7 @@ int launch_bwd_data_t(const void* t1, const void* bb, const float* cA, const flo
   int tpw = env_tpw > 0 ? env_tpw : 16;
   while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 4L * device_cus()) tpw >>= 1;
   if (tpw > ntiles) tpw = ntiles;
-  dim3 grid((ntiles + tpw - 1) / tpw, chunks, g.B);
+  dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
   dw_bwd_data_kernel<T, S, TH, TW, TT><<<grid, dim3(NTHR), lds, stream>>>(
       reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, w, reinterpret_cast<const T*>(a),
       ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, g, tpw);
@@ -1537,9 +1571,10 @@ int launch_wgrad(const void* t1, const void* bb, const float* cA, const float* c
   static const int env_wgs = getenv("C3D_DWWG_WGS") ? atoi(getenv("C3D_DWWG_WGS")) : 0;
   const long target = env_wgs > 0 ? env_wgs : device_cus();
   long gx = target / chunks;
+  if (gx >= N_XCD) gx = gx / N_XCD * N_XCD;  // whole XCD rows: the chunk-sibling order deals groups 8 at a time
   if (gx < 1) gx = 1;
   const long ipw = (items + gx - 1) / gx;
-  dim3 grid((unsigned)((items + ipw - 1) / ipw), chunks, 1);
+  dim3 grid(chunk_order_grid(chunks, (items + ipw - 1) / ipw));
   dw_wgrad_kernel<T, S, TH, TW><<<grid, dim3(NTHR), lds, stream>>>(
       reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, reinterpret_cast<const T*>(a),
       ss_a, dw, g, (int)ipw, nbuf);
@@ -1561,6 +1596,7 @@ int launch_wgrad_dma(const void* t1, const void* bb, const float* cA, const floa
   static const int env_wgs = getenv("C3D_DWWG_WGS") ? atoi(getenv("C3D_DWWG_WGS")) : 0;
   const long target = env_wgs > 0 ? env_wgs : device_cus();
   long gx = target / chunks;
+  if (gx >= N_XCD) gx = gx / N_XCD * N_XCD;  // whole XCD rows: the chunk-sibling order deals groups 8 at a time
   if (gx < 1) gx = 1;
   const long ipw = (items + gx - 1) / gx;
   if ((ipw + ntiles - 2) / ntiles + 1 > G::MAXB) return C3D_E_UNSUPPORTED;
@@ -1571,7 +1607,7 @@ int launch_wgrad_dma(const void* t1, const void* bb, const float* cA, const floa
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  dim3 grid((unsigned)((items + ipw - 1) / ipw), chunks, 1);
+  dim3 grid(chunk_order_grid(chunks, (items + ipw - 1) / ipw));
   dw_wgrad_dma_kernel<S, TH, TW, 3><<<grid, dim3(G::NCOMP + DW_LOADERS), G::LDS_BYTES, stream>>>(
       reinterpret_cast<const bf16_t*>(t1), reinterpret_cast<const bf16_t*>(bb), cA, cB, cC,
       reinterpret_cast<const bf16_t*>(a), ss_a, dw, g, (int)ipw);

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-end measurement on the GPU box (run through gpurun):
+#   1. bench.py (default flags)                         -> gpurun_out/bench.json
+#   2. rocprofv3 --kernel-trace --stats of the same cmd -> gpurun_out/prof_stats/
+#   3. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE need 3 + 2 of the 4 TCC slots) of one eager
+#      step                                             -> gpurun_out/pmc_fetch/, gpurun_out/pmc_write/
+# tools/summarize_rocprof.py turns 2 and 3 into the small JSON files committed under profiles/.
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
+tail -c 2000 gpurun_out/bench.json
+rm -rf gpurun_out/prof_stats gpurun_out/pmc_fetch gpurun_out/pmc_write
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- \
+    python bench.py --no-cpu-baseline > gpurun_out/prof_stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  d=gpurun_out/pmc_$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- \
+      python bench.py --no-cpu-baseline --no-graph --no-kernel-profile --steps 1 --warmup 1 > $d.log 2>&1
+done
+python tools/summarize_rocprof.py gpurun_out r01
+ls -la gpurun_out/*.json
