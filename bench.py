@@ -59,7 +59,7 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(size, batch=2, timed=2, budget_s=25.0):
+def cpu_baseline(size, batch=2, timed=6, budget_s=20.0):
     """Reference arithmetic (oracle = torch-CPU fp32 eager NCDHW port of the reference path),
     same loss / Adam, on the usable host cores.  Bounded sample: 1 warm-up + up to `timed` steps
     of B=`batch`, stopping early once `budget_s` seconds of timed work are spent."""
@@ -94,6 +94,24 @@ def cpu_baseline(size, batch=2, timed=2, budget_s=25.0):
     return {"value": round(batch * done / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{done} timed steps of B={batch} {size}x{size} pairs (1 warm-up, {warm:.1f}s), fp32, torch-CPU "
                       f"eager NCDHW, {cores} threads"}
+
+
+def pmc_traffic(entry):
+    """HBM bytes per launch of `entry` from the committed counter summary (rocprofv3 --pmc cannot run
+    inside this process): profiles/r*_pmc_traffic.json, produced by tools/profile_round.sh from separate
+    FETCH_SIZE / WRITE_SIZE passes of this same workload and corrected as the MI355X guide prescribes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return {}
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        e = d["by_entry"][entry]
+        return {"traffic": int(e["hbm_bytes_per_launch"]),
+                "traffic_source": f"profiles/{os.path.basename(files[-1])}: {d['corrections']}"}
+    except (KeyError, ValueError, OSError):
+        return {}
 
 
 def main():
@@ -244,6 +262,7 @@ def main():
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                            "share_of_kernel_time": round(d["ms_total"] / max(tot, 1e-9), 3)}
+        out["roofline"].update(pmc_traffic(name))
         rows = [{"kernel": k, "launches": v["launches"], "ms_total": round(v["ms_total"], 3),
                  "GBps": round(v["bytes_total"] / max(v["ms_total"], 1e-9) / 1e6, 1)} for k, v in table]
         out["kernel_time_ms_eager_step"] = round(tot, 3)
