@@ -168,7 +168,32 @@ class X3DResBlock(nn.Module):
         self.branch2 = b2
 
 
-def _block_forward(blk, x, B, T, H, W, training, act_dtype):
+class _AccPool:
+    """One zero-filled f64 buffer per stage pass; blocks take their accumulator sets from it (one fill
+    kernel per stage instead of one per block)."""
+
+    def __init__(self, n, dev):
+        self.buf, self.off = torch.zeros(n, dtype=torch.float64, device=dev), 0
+
+    def take(self, n):
+        v = self.buf[self.off:self.off + n]
+        self.off += n
+        assert self.off <= self.buf.numel()
+        return v
+
+
+def _n_acc_fwd(blk, B):
+    S = ops.STAT_STRIPES
+    return (S * 2 * blk.cinner + B * cpad(blk.cinner) * 2 + S * 2 * blk.cout
+            + (S * 2 * blk.cout if blk.branch1_norm is not None else 0))
+
+
+def _n_acc_bwd(blk, B):
+    S = ops.STAT_STRIPES
+    return 4 * blk.cout + B * cpad(blk.cinner) * 3 + S * 2 * blk.cinner   # upper bound (shortcut BN or not)
+
+
+def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None):
     """x: [B,T,H,W,Cin] contiguous.  Returns (y, saved-for-backward dict)."""
     dev, dt = x.device, ops.dt_code(act_dtype)
     b2 = blk.branch2
@@ -181,7 +206,7 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype):
     # f64 accumulators in one zeroed buffer
     S = ops.STAT_STRIPES  # pointwise-GEMM statistics are accumulated in S striped sets
     n_acc = S * 2 * Ci + B * Cip * 2 + S * 2 * Co + (S * 2 * Co if has_bn1 else 0)
-    acc = torch.zeros(n_acc, dtype=torch.float64, device=dev)
+    acc = pool.take(n_acc) if pool is not None else torch.zeros(n_acc, dtype=torch.float64, device=dev)
     sums_a, o = acc[:S * 2 * Ci], S * 2 * Ci
     nc_b, o = acc[o:o + B * Cip * 2], o + B * Cip * 2
     sums_c, o = acc[o:o + S * 2 * Co], o + S * 2 * Co
@@ -228,7 +253,7 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype):
     return y, saved
 
 
-def _block_backward(blk, dy, sv, act_dtype):
+def _block_backward(blk, dy, sv, act_dtype, pool=None):
     """dy: [B,T,Ho,Wo,Co] contiguous.  Returns dx [B,T,H,W,Cin]; parameter grads accumulate in .grad."""
     dev, dt = dy.device, ops.dt_code(act_dtype)
     b2 = blk.branch2
@@ -241,7 +266,7 @@ def _block_backward(blk, dy, sv, act_dtype):
     x, a, b, c, sc, y = sv["x"], sv["a"], sv["b"], sv["c"], sv["sc"], sv["y"]
     S = ops.STAT_STRIPES
     n_acc = 2 * Co + (2 * Co if mode == ops.SC_BN else 0) + B * Cip * 3 + S * 2 * Ci
-    acc = torch.zeros(n_acc, dtype=torch.float64, device=dev)
+    acc = pool.take(n_acc) if pool is not None else torch.zeros(n_acc, dtype=torch.float64, device=dev)
     dsums_c, o = acc[:2 * Co], 2 * Co
     dsums_1 = None
     if mode == ops.SC_BN:
@@ -310,8 +335,9 @@ class _StageFn(torch.autograd.Function):
         cur = to_ndhwc(x.detach()).to(stage.act_dtype)
         keep = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
         saved = []
+        pool = _AccPool(sum(_n_acc_fwd(blk, B) for blk in stage.res_blocks), cur.device)
         for blk in stage.res_blocks:
-            cur, sv = _block_forward(blk, cur, B, T, H, W, stage.training, stage.act_dtype)
+            cur, sv = _block_forward(blk, cur, B, T, H, W, stage.training, stage.act_dtype, pool)
             H, W = sv["dims"][4], sv["dims"][5]
             if keep:
                 saved.append(sv)
@@ -322,8 +348,9 @@ class _StageFn(torch.autograd.Function):
     def backward(ctx, dy):
         stage, saved = ctx.stage, ctx.saved
         cur = to_ndhwc(dy).to(stage.act_dtype)
+        pool = _AccPool(sum(_n_acc_bwd(blk, dy.shape[0]) for blk in stage.res_blocks), cur.device)
         for blk, sv in zip(reversed(list(stage.res_blocks)), reversed(saved)):
-            cur = _block_backward(blk, cur, sv, stage.act_dtype)
+            cur = _block_backward(blk, cur, sv, stage.act_dtype, pool)
             sv.clear()
         if stage.post_backward is not None:  # data-parallel hook: this stage's grads are final
             stage.post_backward()
