@@ -87,22 +87,29 @@ class _DecoderFn(torch.autograd.Function):
             conv, convt = ups[lvl - 1][0], ups[lvl - 1][1]
             M = B * h * w
             # dcur is d(out) at [B,2h,2w,Cout]
-            ops.col_sum(dcur, ops.grad_of(convt.bias), B * 4 * h * w, Cout, dt)
+            gb, gw = ops.grad_of(convt.bias), ops.grad_of(convt.weight)  # gw: [Cin=Cout][Cout][4][4]
             dt_ = torch.empty((M, cpad(Cout)), dtype=act, device=dev)
             ops.convT_bwd_data(dcur, convt.weight, dt_, B, h, w, Cout, dt)
-            gw = ops.grad_of(convt.weight)  # [Cin=Cout][Cout][4][4]
-            for ky in range(4):
-                for kx in range(4):
-                    ops.pw_wgrad(t, dcur, None, M=M, K=Cout, N=Cout, dw_sn=Cout * 16, dw_sk=16, dtype=dt,
-                                 row_mode=ops.ROWS_S2SHIFT, H=2 * h, W=2 * w, dy=ky - 1, dx=kx - 1,
-                                 dw_ptr=gw.data_ptr() + (ky * 4 + kx) * 4)
+
+            def convt_param_grads(dcur=dcur, t=t, gb=gb, gw=gw, M=M, h=h, w=w, Cout=Cout):
+                ops.col_sum(dcur, gb, B * 4 * h * w, Cout, dt)
+                for ky in range(4):
+                    for kx in range(4):
+                        ops.pw_wgrad(t, dcur, None, M=M, K=Cout, N=Cout, dw_sn=Cout * 16, dw_sk=16, dtype=dt,
+                                     row_mode=ops.ROWS_S2SHIFT, H=2 * h, W=2 * w, dy=ky - 1, dx=kx - 1,
+                                     dw_ptr=gw.data_ptr() + (ky * 4 + kx) * 4)
+
+            ops.side_run(convt_param_grads, dcur, t)   # leaves of the backward graph: side stream
             dx = torch.empty((B, h, w, cpad(Cin)), dtype=act, device=dev)
             ops.pw_gemm(dt_, conv.weight, dx, M=M, K=Cout, N=Cin, w_sn=1, w_sk=Cin, dtype=dt)
+            gc = ops.grad_of(conv.weight)
             if x_dense is None:
-                ops.pw_wgrad(dt_, None, ops.grad_of(conv.weight), M=M, K=Cin, N=Cout, dw_sn=Cin, dw_sk=1, dtype=dt,
-                             row_mode=ops.ROWS_FRAME, rpg=h * w, gstride=bstride, q_ptr=ptr)
+                ops.side_run(lambda dt_=dt_, gc=gc, M=M, Cin=Cin, Cout=Cout, h=h, w=w, bstride=bstride, ptr=ptr:
+                             ops.pw_wgrad(dt_, None, gc, M=M, K=Cin, N=Cout, dw_sn=Cin, dw_sk=1, dtype=dt,
+                                          row_mode=ops.ROWS_FRAME, rpg=h * w, gstride=bstride, q_ptr=ptr), dt_)
             else:
-                ops.pw_wgrad(dt_, x_dense, ops.grad_of(conv.weight), M=M, K=Cin, N=Cout, dw_sn=Cin, dw_sk=1, dtype=dt)
+                ops.side_run(lambda dt_=dt_, x_dense=x_dense, gc=gc, M=M, Cin=Cin, Cout=Cout:
+                             ops.pw_wgrad(dt_, x_dense, gc, M=M, K=Cin, N=Cout, dw_sn=Cin, dw_sk=1, dtype=dt), dt_, x_dense)
             grads[lvl] = dx.permute(0, 3, 1, 2)  # d c_{lvl+1}: skip grad at that level == d(c_f) == dx
             dcur = dx
         return grads[0], grads[1], grads[2], grads[3], None, None

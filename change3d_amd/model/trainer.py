@@ -53,7 +53,8 @@ class _EnhanceFn(torch.autograd.Function):
         ops.enhance_bwd_mask(doc, e, de, B, T, H * W, cpad(C), t_mid, dt)
         dd = torch.empty_like(d)
         ops.pw_gemm(de, weight, dd, M=M2, K=C, N=C, w_sn=1, w_sk=C, dtype=dt)
-        ops.pw_wgrad(de, d, ops.grad_of(weight), M=M2, K=C, N=C, dw_sn=C, dw_sk=1, dtype=dt)
+        gw = ops.grad_of(weight)
+        ops.side_run(lambda: ops.pw_wgrad(de, d, gw, M=M2, K=C, N=C, dw_sn=C, dw_sk=1, dtype=dt), de, d)
         dx = torch.empty_like(xc)
         ops.enhance_bwd_apply(doc, xc, dd, dx, B, T, H * W, cpad(C), 0, t_post, dt)
         return to_logical(dx), None, None

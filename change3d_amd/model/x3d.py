@@ -16,6 +16,8 @@ raise NotImplementedError.  Activations between kernels are channels-last
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -285,9 +287,11 @@ def _block_backward(blk, dy, sv, act_dtype, pool=None):
     ops.pw_gemm(g, b2.conv_c.weight, t1, M=Mo, K=Co, N=Ci, w_sn=1, w_sk=Ci, dtype=dt, x2=c, pro_mode=ops.PRO_AFFINE2,
                 pro_p=coef_c, epi_mode=ops.EPI_SWISH_SE_BWD, e1=b, epi_p=sv["ss_b"], epi_gate=sv["gate"], epi_q=sv["mr_b"], stats=nc3,
                 rows_per_sample=T * Ho * Wo)
-    ops.pw_wgrad(g, b, ops.grad_of(b2.conv_c.weight), M=Mo, K=Ci, N=Co, dw_sn=Ci, dw_sk=1, dtype=dt, p2=c,
-                 p_coef=coef_c, q_mode=ops.PRO_BN_SE_SWISH, q_ss=sv["ss_b"], q_gate=sv["gate"],
-                 rows_per_sample=T * Ho * Wo)
+    gw_c = ops.grad_of(b2.conv_c.weight)
+    ops.side_run(lambda: ops.pw_wgrad(g, b, gw_c, M=Mo, K=Ci, N=Co, dw_sn=Ci, dw_sk=1, dtype=dt, p2=c,
+                                  p_coef=coef_c, q_mode=ops.PRO_BN_SE_SWISH, q_ss=sv["ss_b"], q_gate=sv["gate"],
+                                  rows_per_sample=T * Ho * Wo),
+             g, b, c, coef_c, sv["ss_b"], sv["gate"])
     cA, cC, cB = _f32(Cip, dev), _f32(Cip, dev), _f32(B * Cip, dev)
     ops.se_bn_bwd_coef(nc3, sv["nc_b"], B, T * Ho * Wo, b2.norm_b[0], sv["mr_b"], sv["ss_b"], se, sv["gate"],
                        sv["hid"], Ci, cA, cC, cB)
@@ -296,7 +300,9 @@ def _block_backward(blk, dy, sv, act_dtype, pool=None):
     # (c3d_dw333_bwd, the single-pass fused variant, is exported and tested but currently slower than
     # the split pair on MI355X — LDS-read bound; see DESIGN.md "what comes next")
     ops.dw_bwd_data(t1, b, cA, cB, cC, b2.conv_b.weight, a, sv["ss_a"], sv["mr_a"], t2, dsums_a, B, T, H, W, Ci, s, dt)
-    ops.dw_wgrad(t1, b, cA, cB, cC, a, sv["ss_a"], ops.grad_of(b2.conv_b.weight), B, T, H, W, Ci, s, dt)
+    gw_b = ops.grad_of(b2.conv_b.weight)
+    ops.side_run(lambda: ops.dw_wgrad(t1, b, cA, cB, cC, a, sv["ss_a"], gw_b, B, T, H, W, Ci, s, dt),
+             t1, b, cA, cB, cC, a, sv["ss_a"])
     stripes_a = 1
     coef_a = _f32(3 * Cip, dev)
     ops.bn_bwd_coef(dsums_a, M, b2.norm_a, sv["mr_a"], Ci, coef_a, stripes=stripes_a)
@@ -310,20 +316,23 @@ def _block_backward(blk, dy, sv, act_dtype, pool=None):
             ops.bn_bwd_coef(dsums_1, Mo, blk.branch1_norm, sv["mr_1"], Co, coef_1)
             ops.pw_gemm(g, blk.branch1_conv.weight, dxs, M=Mo, K=Co, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=sc,
                         pro_mode=ops.PRO_AFFINE2, pro_p=coef_1)
-            ops.pw_wgrad(g, x, ops.grad_of(blk.branch1_conv.weight), M=Mo, K=Cin, N=Co, dw_sn=Cin, dw_sk=1,
-                         dtype=dt, p2=sc, p_coef=coef_1, row_mode=rm, H=H, W=W)
+            gw_1 = ops.grad_of(blk.branch1_conv.weight)
+            ops.side_run(lambda: ops.pw_wgrad(g, x, gw_1, M=Mo, K=Cin, N=Co, dw_sn=Cin, dw_sk=1,
+                                          dtype=dt, p2=sc, p_coef=coef_1, row_mode=rm, H=H, W=W), g, x, sc, coef_1)
         else:
             ops.pw_gemm(g, blk.branch1_conv.weight, dxs, M=Mo, K=Co, N=Cin, w_sn=1, w_sk=Cin, dtype=dt)
-            ops.pw_wgrad(g, x, ops.grad_of(blk.branch1_conv.weight), M=Mo, K=Cin, N=Co, dw_sn=Cin, dw_sk=1,
-                         dtype=dt, row_mode=rm, H=H, W=W)
+            gw_1 = ops.grad_of(blk.branch1_conv.weight)
+            ops.side_run(lambda: ops.pw_wgrad(g, x, gw_1, M=Mo, K=Cin, N=Co, dw_sn=Cin, dw_sk=1,
+                                          dtype=dt, row_mode=rm, H=H, W=W), g, x)
         res, res_mode = dxs, (1 if s == 2 else 0)
     else:
         res, res_mode = g, 0
     # ---- conv_a (data + weight); the shortcut gradient is added in the epilogue
     ops.pw_gemm(t2, b2.conv_a.weight, dx, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=a,
                 pro_mode=ops.PRO_AFFINE2, pro_p=coef_a, epi_mode=ops.EPI_ADD, e1=res, res_mode=res_mode, H=H, W=W)
-    ops.pw_wgrad(t2, x, ops.grad_of(b2.conv_a.weight), M=M, K=Cin, N=Ci, dw_sn=Cin, dw_sk=1, dtype=dt, p2=a,
-                 p_coef=coef_a)
+    gw_a = ops.grad_of(b2.conv_a.weight)
+    ops.side_run(lambda: ops.pw_wgrad(t2, x, gw_a, M=M, K=Cin, N=Ci, dw_sn=Cin, dw_sk=1, dtype=dt, p2=a,
+                                  p_coef=coef_a), t2, x, a, coef_a)
     return dx
 
 
@@ -349,9 +358,16 @@ class _StageFn(torch.autograd.Function):
         stage, saved = ctx.stage, ctx.saved
         cur = to_ndhwc(dy).to(stage.act_dtype)
         pool = _AccPool(sum(_n_acc_bwd(blk, dy.shape[0]) for blk in stage.res_blocks), cur.device)
+        prev_mark = None   # side-stream weight gradients may lag the data-gradient chain by one block
         for blk, sv in zip(reversed(list(stage.res_blocks)), reversed(saved)):
             cur = _block_backward(blk, cur, sv, stage.act_dtype, pool)
+            ops.side_run(lambda: None, dict(sv))   # keep the saved activations alive until the side work is done
             sv.clear()
+            if prev_mark is not None:
+                ops.side_join(prev_mark)
+            prev_mark = ops.side_mark()
+        if stage.post_backward is not None:  # data-parallel hook: this stage's grads must be final
+            ops.side_join()
         if stage.post_backward is not None:  # data-parallel hook: this stage's grads are final
             stage.post_backward()
         return to_logical(cur).to(ctx.x_dtype), None, None

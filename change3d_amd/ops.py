@@ -6,6 +6,8 @@ launch on `torch.cuda.current_stream()` and never synchronise.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -88,6 +90,65 @@ def profile_end():
 PROFILE_DETAIL = False  # profile keys carry the GEMM shape/mode (tools/profile_shapes.py)
 
 
+# ---------------------------------------------------------------------------- side stream
+# Weight gradients (and the stem's input gradient) are leaves of the backward graph.  Launched on a
+# side stream they fill the chip while the data-gradient chain sits in single-workgroup coefficient
+# kernels and in kernel tails (eager launch only: a HIP-graph replay runs its branches one after
+# another).  Everything is joined back at the end of the autograd pass (engine callback), so callers
+# see ordinary stream semantics: after backward() returns, p.grad is safe to read on the current stream.
+SIDE_STREAM = os.environ.get("C3D_WGRAD_SIDE", "1") != "0"
+_side_streams = {}
+_side_pending = []      # (seq, done_event, tensors kept alive until the event has been waited for)
+_side_state = {"seq": 0, "cb": False}
+
+
+def _side_end_of_backward():
+    _side_state["cb"] = False
+    side_join()
+
+
+def side_run(fn, *tensors):
+    """Run `fn` (kernel launches) on the side stream after everything issued so far on the current
+    stream.  Only inside an autograd backward pass (that is where the join callback can be queued);
+    anywhere else `fn` runs inline."""
+    if SIDE_STREAM and not _side_state["cb"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_side_end_of_backward)
+            _side_state["cb"] = True
+        except RuntimeError:
+            pass
+    if not (SIDE_STREAM and _side_state["cb"]):
+        fn()
+        return
+    dev = torch.cuda.current_device()
+    st = _side_streams.get(dev)
+    if st is None:
+        st = _side_streams[dev] = torch.cuda.Stream(dev)
+    ev = torch.cuda.Event()
+    ev.record()
+    with torch.cuda.stream(st):
+        st.wait_event(ev)
+        fn()
+        done = torch.cuda.Event()
+        done.record()
+    _side_state["seq"] += 1
+    _side_pending.append((_side_state["seq"], done, [t for t in tensors if t is not None]))
+
+
+def side_mark():
+    return _side_state["seq"]
+
+
+def side_join(upto=None):
+    """Make the current stream wait for the side work issued up to mark `upto` (default: all of it)
+    and release the tensors it was reading."""
+    last = None
+    while _side_pending and (upto is None or _side_pending[0][0] <= upto):
+        last = _side_pending.pop(0)
+    if last is not None:
+        torch.cuda.current_stream().wait_event(last[1])
+
+
 def _detail(name, a):
     if PROFILE is None or not PROFILE_DETAIL:
         return name
@@ -150,7 +211,7 @@ _wgrad_ws = {}
 
 
 def _ws(device, n_floats):
-    key = (device.index,)
+    key = (device.index, _stream())   # one workspace per stream: weight gradients may run on a side stream
     buf = _wgrad_ws.get(key)
     if buf is None or buf.numel() < n_floats:
         buf = torch.empty(int(n_floats), dtype=torch.float32, device=device)
