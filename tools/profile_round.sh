@@ -14,9 +14,14 @@ tail -c 2000 gpurun_out/bench.json
 rm -rf gpurun_out/prof_stats gpurun_out/pmc_fetch gpurun_out/pmc_write
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- \
     python bench.py --no-cpu-baseline > gpurun_out/prof_stats.log 2>&1
+# same command with the side stream off: kernels run one at a time (the mode bench.py's per-kernel
+# HIP-event table is taken in)
+rm -rf gpurun_out/prof_stats_serial
+C3D_WGRAD_SIDE=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats_serial -- \
+    python bench.py --no-cpu-baseline > gpurun_out/prof_stats_serial.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   d=gpurun_out/pmc_$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
-  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- \
+  C3D_WGRAD_SIDE=0 timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- \
       python bench.py --no-cpu-baseline --no-graph --no-kernel-profile --steps 1 --warmup 1 > $d.log 2>&1
 done
 python tools/summarize_rocprof.py gpurun_out r01

@@ -36,32 +36,34 @@ def entry_of(kname):
 
 
 def find(d, pat):
-    r = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
-    return r[0] if r else None
+    r = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True), key=os.path.getmtime)
+    return r[-1] if r else None
 
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
-    # ---- kernel stats
-    f = find(os.path.join(root, "prof_stats"), "*kernel_stats.csv")
-    if f:
-        rows = list(csv.DictReader(open(f)))
-        agg = defaultdict(lambda: [0, 0.0])
-        for r in rows:
-            e = entry_of(r["Name"])
-            agg[e][0] += int(r["Calls"])
-            agg[e][1] += float(r["TotalDurationNs"])
-        out = [{"entry": e, "calls": c, "total_ms": round(t / 1e6, 3), "avg_us": round(t / c / 1e3, 2)}
-               for e, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])]
-        json.dump({"source": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline",
-                   "note": "all launches of the run (warm-up, graph capture, 20 graph replays, 1 eager profile step)",
-                   "by_entry": out,
-                   "top_kernels": [{"name": r["Name"][:160], "calls": int(r["Calls"]),
-                                    "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
-                                    "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3),
-                                    "pct": float(r["Percentage"])} for r in rows[:40]]},
-                  open(os.path.join(root, f"{tag}_rocprof_kernel_stats.json"), "w"), indent=1)
-        print("kernel stats:", f)
+    # ---- kernel stats (default run: side stream on; "_serial": side stream off)
+    for sub, suffix, cmd in (("prof_stats", "", "python bench.py --no-cpu-baseline"),
+                             ("prof_stats_serial", "_serial", "C3D_WGRAD_SIDE=0 python bench.py --no-cpu-baseline")):
+      f = find(os.path.join(root, sub), "*kernel_stats.csv")
+      if f:
+          rows = list(csv.DictReader(open(f)))
+          agg = defaultdict(lambda: [0, 0.0])
+          for r in rows:
+              e = entry_of(r["Name"])
+              agg[e][0] += int(r["Calls"])
+              agg[e][1] += float(r["TotalDurationNs"])
+          out = [{"entry": e, "calls": c, "total_ms": round(t / 1e6, 3), "avg_us": round(t / c / 1e3, 2)}
+                 for e, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+          json.dump({"source": "rocprofv3 --kernel-trace --stats -- " + cmd,
+                     "note": "all launches of the run (warm-up, graph capture, 20 graph replays, 1 eager profile step)",
+                     "by_entry": out,
+                     "top_kernels": [{"name": r["Name"][:160], "calls": int(r["Calls"]),
+                                      "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
+                                      "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3),
+                                      "pct": float(r["Percentage"])} for r in rows[:40]]},
+                    open(os.path.join(root, f"{tag}_rocprof_kernel_stats{suffix}.json"), "w"), indent=1)
+          print("kernel stats:", f)
     # ---- PMC traffic
     traffic = {}
     for key, sub, col, corr in (("fetch", "pmc_fetch", "FETCH_SIZE", 2.0), ("write", "pmc_write", "WRITE_SIZE", 1.0)):
