@@ -126,11 +126,17 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    # (test hooks: C3D_DIST_DEVICE / C3D_DIST_BACKEND let a 1-GPU box run the N>1 code path with gloo)
+    local = int(os.environ.get("C3D_DIST_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("C3D_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from oracle import synth  # deterministic synthetic weights / batches only (not the checker here)
     from oracle.model import make_args
