@@ -28,6 +28,7 @@ sys.dont_write_bytecode = True
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 A_BCD_ELEMS = 159_784_960        # materialised activation elements per sample
+A_SCD_ELEMS = 269_280_000        # same for the SCD path (K=3, T=5; SURVEY.md §8d: 269.28 M)
 
 
 def parse():
@@ -35,7 +36,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 for BCD = BASELINE config, 16 for SCD)")
+    ap.add_argument("--task", choices=["bcd", "scd"], default="bcd",
+                    help="bcd = the north-star workload; scd = SURVEY.md 8(f).1 (K=3, T=5, three decoders, 7 classes)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--graph", action="store_true",
@@ -147,7 +150,10 @@ def main():
     from change3d_amd.utils.metric_tool import ConfuseMatrixMeter
 
     act = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    margs = make_args(size=a.size)
+    scd = a.task == "scd"
+    if a.batch <= 0:
+        a.batch = 16 if scd else 32
+    margs = make_args(num_perception_frame=3, size=a.size, dataset="SECOND", num_class=7) if scd else make_args(size=a.size)
     margs.act_dtype = act
     margs.lr_mode, margs.lr, margs.max_epochs, margs.step_loss = "poly", 2e-4, 1, 100
     net = Trainer(margs)
@@ -158,11 +164,21 @@ def main():
     opt = FusedAdam(arena, lr=margs.lr, capturable=True)
     meter = ConfuseMatrixMeter(2)
     pre, post, tgt = (t.to(dev) for t in synth.synth_batch(a.batch, a.size, seed=rank))
+    if scd:
+        from change3d_amd.model.utils import ChangeSimilarity, CrossEntropyLoss2d
+        from change3d_amd.scripts.train_SCD import scd_loss
+        labels = synth.synth_scd_labels(a.batch, a.size, seed=rank).to(dev)
+        seg_loss, sim_loss = CrossEntropyLoss2d(ignore_index=0), ChangeSimilarity()
     MAX_ITER = 80000
     state = {"it": 0, "loss": None, "prob": None}
 
     def fwd_bwd():
         opt.zero_grad()
+        if scd:   # reference scripts/train_SCD.py:216-233
+            masks = net.update_scd(pre, post)
+            loss = scd_loss(seg_loss, sim_loss, masks, labels)[0]
+            loss.backward()
+            return loss.detach(), masks[2].detach()
         prob = net.update_bcd(pre, post)
         loss = BCEDiceLoss(prob, tgt)
         loss.backward()
@@ -240,13 +256,15 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = a.batch * world * a.steps / elapsed
     es = 2 if a.dtype == "bf16" else 4
-    bytes_per_sample = 5 * A_BCD_ELEMS * es * (a.size / 256.0) ** 2
+    bytes_per_sample = 5 * (A_SCD_ELEMS if scd else A_BCD_ELEMS) * es * (a.size / 256.0) ** 2
     out = {
-        "metric": "train images/sec (256x256 pairs, X3D-L BCD)", "value": round(value, 2), "unit": "images/s",
+        "metric": f"train images/sec (256x256 pairs, X3D-L {a.task.upper()})", "value": round(value, 2), "unit": "images/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"BCD X3D-L {a.dtype}, B={a.batch}/GPU, {a.size}x{a.size} synthetic LEVIR-CD-shaped "
-                               f"pairs, T=3, train step (fwd+BCE/Dice+bwd+Adam)",
+        "config": {"workload": f"{a.task.upper()} X3D-L {a.dtype}, B={a.batch}/GPU, {a.size}x{a.size} synthetic "
+                               f"{'SECOND' if scd else 'LEVIR-CD'}-shaped "
+                               f"pairs, T={5 if scd else 3}, train step (fwd+{'0.5*CE+BCE/Dice+ChangeSimilarity' if scd else 'BCE/Dice'}"
+                               f"+bwd+Adam)",
                    "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "hip_graph": graph is not None, "final_loss": round(final_loss, 5)},
         "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_sample": bytes_per_sample,
@@ -298,7 +316,7 @@ def main():
             print(f"[kernels] {r['kernel']:24s} x{r['launches']:4d} {r['ms_total']:9.3f} ms {r['GBps']:8.1f} GB/s",
                   file=sys.stderr)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.size)
+        out["cpu_baseline"] = cpu_baseline(a.size) if not scd else None   # the CPU leg times the BCD oracle only
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -74,6 +74,10 @@ SIGNATURES = {
     "c3d_head3x3_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_bce_dice_fwd": (i32, [vp, vp, i64, vp, vp, vp]),
     "c3d_bce_dice_bwd": (i32, [vp, vp, vp, vp, i64, vp, vp]),
+    "c3d_ce2d_fwd": (i32, [vp, vp, i64, i32, i64, i64, i64, i64, vp, vp, vp]),
+    "c3d_ce2d_bwd": (i32, [vp, vp, vp, vp, i64, i32, i64, i64, i64, i64, vp, vp]),
+    "c3d_cossim_fwd": (i32, [vp, vp, vp, i64, i32, i64, i64, i64, i64, i64, vp, vp, vp]),
+    "c3d_cossim_bwd": (i32, [vp, vp, vp, vp, i64, i32, i64, i64, i64, i64, i64, vp, vp, vp]),
     "c3d_adam_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
     "c3d_confusion2": (i32, [vp, vp, i64, vp, vp]),
 }

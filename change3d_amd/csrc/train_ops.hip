@@ -113,6 +113,173 @@ inline int grid_for(int64_t n, int block, int cap) {
   return (int)g;
 }
 
+
+// ---- SCD losses (reference model/utils.py:171-203, scripts/train_SCD.py:226-229) ----
+// Logits are NCHW f32 views: element (b, c, p) at x[b*bstride + c*cstride + p], p < HW.
+constexpr int SCD_MAXC = 8;
+
+// CrossEntropyLoss2d: nll_loss(log_softmax(x, 1), target, ignore_index, 'mean').  sums = (sum nll, count).
+__global__ __launch_bounds__(256) void ce2d_reduce_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
+                                                          int64_t npix, int64_t HW, int64_t bstride, int64_t cstride,
+                                                          int NC, int64_t ignore_index, double* __restrict__ sums) {
+  __shared__ double red[4][2];
+  double s_l = 0, s_n = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+    const int64_t t = tgt[i];
+    if (t == ignore_index) continue;
+    const int64_t b = i / HW, p = i - b * HW;
+    const float* xp = x + b * bstride + p;
+    float v[SCD_MAXC], m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < SCD_MAXC; ++c) {
+      v[c] = c < NC ? xp[c * cstride] : -INFINITY;
+      m = fmaxf(m, v[c]);
+    }
+    float se = 0.f, vt = 0.f;
+#pragma unroll
+    for (int c = 0; c < SCD_MAXC; ++c) {
+      if (c < NC) se += expf(v[c] - m);
+      if (c == (int)t) vt = v[c];
+    }
+    s_l += (double)(m + logf(se) - vt);
+    s_n += 1.0;
+  }
+  s_l = wave_sum_d(s_l); s_n = wave_sum_d(s_n);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = s_l; red[wave][1] = s_n; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double a = 0;
+    for (int w = 0; w < 4; ++w) a += red[w][threadIdx.x];
+    atomicAdd(sums + threadIdx.x, a);
+  }
+}
+
+__global__ void ce2d_finalize_kernel(const double* __restrict__ sums, float* __restrict__ loss) {
+  loss[0] = (float)(sums[0] / sums[1]);   // 0/0 = NaN, as nll_loss gives when every pixel is ignored
+}
+
+__global__ __launch_bounds__(256) void ce2d_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
+                                                       const double* __restrict__ sums, const float* __restrict__ dloss,
+                                                       int64_t npix, int64_t HW, int64_t bstride, int64_t cstride, int NC,
+                                                       int64_t ignore_index, float* __restrict__ dx) {
+  const float scale = (dloss ? dloss[0] : 1.f) / (float)sums[1];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+    const int64_t t = tgt[i];
+    const int64_t b = i / HW, p = i - b * HW;
+    float* dp = dx + b * NC * HW + p;   // dx is a dense [B][NC][HW] tensor
+    if (t == ignore_index) {
+      for (int c = 0; c < NC; ++c) dp[c * HW] = 0.f;
+      continue;
+    }
+    const float* xp = x + b * bstride + p;
+    float v[SCD_MAXC], m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < SCD_MAXC; ++c) {
+      v[c] = c < NC ? xp[c * cstride] : -INFINITY;
+      m = fmaxf(m, v[c]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < SCD_MAXC; ++c) {
+      v[c] = c < NC ? expf(v[c] - m) : 0.f;
+      se += v[c];
+    }
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int c = 0; c < SCD_MAXC; ++c)
+      if (c < NC) dp[c * HW] = scale * (v[c] * inv - (c == (int)t ? 1.f : 0.f));
+  }
+}
+
+// ChangeSimilarity: cosine_embedding_loss(softmax(x1), softmax(x2), +1 unchanged / -1 changed, margin 0, 'mean')
+// with ATen's formula cos = <p1,p2> / sqrt((|p1|^2 + 1e-12)(|p2|^2 + 1e-12)).
+__device__ __forceinline__ void softmax_c(const float* xp, int64_t cstride, int NC, float (&p)[SCD_MAXC]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < SCD_MAXC; ++c) {
+    p[c] = c < NC ? xp[c * cstride] : -INFINITY;
+    m = fmaxf(m, p[c]);
+  }
+  float se = 0.f;
+#pragma unroll
+  for (int c = 0; c < SCD_MAXC; ++c) {
+    p[c] = c < NC ? expf(p[c] - m) : 0.f;
+    se += p[c];
+  }
+  const float inv = 1.f / se;
+#pragma unroll
+  for (int c = 0; c < SCD_MAXC; ++c) p[c] *= inv;
+}
+
+__global__ __launch_bounds__(256) void cossim_reduce_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                            const int64_t* __restrict__ change, int64_t npix, int64_t HW,
+                                                            int64_t bs1, int64_t cs1, int64_t bs2, int64_t cs2, int NC,
+                                                            double* __restrict__ sums) {
+  __shared__ double red[4];
+  double s = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+    const int64_t b = i / HW, p = i - b * HW;
+    float p1[SCD_MAXC], p2[SCD_MAXC];
+    softmax_c(x1 + b * bs1 + p, cs1, NC, p1);
+    softmax_c(x2 + b * bs2 + p, cs2, NC, p2);
+    float dot = 0.f, n1 = 1e-12f, n2 = 1e-12f;
+#pragma unroll
+    for (int c = 0; c < SCD_MAXC; ++c) { dot = fmaf(p1[c], p2[c], dot); n1 = fmaf(p1[c], p1[c], n1); n2 = fmaf(p2[c], p2[c], n2); }
+    const float cs = dot / sqrtf(n1 * n2);
+    s += (double)(change[i] != 0 ? fmaxf(cs, 0.f) : 1.f - cs);
+  }
+  s = wave_sum_d(s);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sums, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void cossim_finalize_kernel(const double* __restrict__ sums, int64_t npix, float* __restrict__ loss) {
+  loss[0] = (float)(sums[0] / (double)npix);
+}
+
+__global__ __launch_bounds__(256) void cossim_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                         const int64_t* __restrict__ change, const float* __restrict__ dloss,
+                                                         int64_t npix, int64_t HW, int64_t bs1, int64_t cs1, int64_t bs2,
+                                                         int64_t cs2, int NC, float* __restrict__ dx1, float* __restrict__ dx2) {
+  const float scale = (dloss ? dloss[0] : 1.f) / (float)npix;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+    const int64_t b = i / HW, p = i - b * HW;
+    float p1[SCD_MAXC], p2[SCD_MAXC];
+    softmax_c(x1 + b * bs1 + p, cs1, NC, p1);
+    softmax_c(x2 + b * bs2 + p, cs2, NC, p2);
+    float dot = 0.f, n1 = 1e-12f, n2 = 1e-12f;
+#pragma unroll
+    for (int c = 0; c < SCD_MAXC; ++c) { dot = fmaf(p1[c], p2[c], dot); n1 = fmaf(p1[c], p1[c], n1); n2 = fmaf(p2[c], p2[c], n2); }
+    const float den = sqrtf(n1 * n2), cs = dot / den;
+    // d loss / d cos: -1 where unchanged; where changed the hinge max(cos, 0) passes 1 for cos > 0
+    const float gcos = scale * (change[i] != 0 ? (cs > 0.f ? 1.f : 0.f) : -1.f);
+    float g1[SCD_MAXC], g2[SCD_MAXC], a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < SCD_MAXC; ++c) {
+      g1[c] = gcos * (p2[c] / den - cs * p1[c] / n1);   // d loss / d p1
+      g2[c] = gcos * (p1[c] / den - cs * p2[c] / n2);
+      a1 = fmaf(g1[c], p1[c], a1);
+      a2 = fmaf(g2[c], p2[c], a2);
+    }
+    float* d1 = dx1 + b * NC * HW + p;
+    float* d2 = dx2 + b * NC * HW + p;
+#pragma unroll
+    for (int c = 0; c < SCD_MAXC; ++c) {
+      if (c < NC) {
+        d1[c * HW] = p1[c] * (g1[c] - a1);            // softmax backward
+        d2[c * HW] = p2[c] * (g2[c] - a2);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int c3d_bce_dice_fwd(const float* prob, const float* target, int64_t n, double* sums4, float* loss,
@@ -158,3 +325,57 @@ extern "C" int c3d_confusion2(const float* prob, const float* target, int64_t n,
 
 extern "C" int c3d_abi_version(void) { return 1; }
 extern "C" const char* c3d_build_info(void) { return "change3d_hip gfx950 (MI355X) hipcc " __VERSION__; }
+
+extern "C" int c3d_ce2d_fwd(const float* logits, const int64_t* target, int64_t B, int32_t NC, int64_t HW,
+                            int64_t bstride, int64_t cstride, int64_t ignore_index, double* sums2, float* loss,
+                            void* stream) {
+  if (!logits || !target || !sums2 || !loss || B <= 0 || HW <= 0 || NC < 1 || NC > SCD_MAXC) return C3D_E_BADARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(sums2, 0, 2 * sizeof(double), s);
+  if (e != hipSuccess) return (int)e;
+  const int64_t n = B * HW;
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  ce2d_reduce_kernel<<<grid, 256, 0, s>>>(logits, target, n, HW, bstride, cstride, NC, ignore_index, sums2);
+  ce2d_finalize_kernel<<<1, 1, 0, s>>>(sums2, loss);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_ce2d_bwd(const float* logits, const int64_t* target, const double* sums2, const float* dloss,
+                            int64_t B, int32_t NC, int64_t HW, int64_t bstride, int64_t cstride,
+                            int64_t ignore_index, float* dlogits, void* stream) {
+  if (!logits || !target || !sums2 || !dlogits || B <= 0 || HW <= 0 || NC < 1 || NC > SCD_MAXC) return C3D_E_BADARG;
+  const int64_t n = B * HW;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  ce2d_bwd_kernel<<<grid, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(logits, target, sums2, dloss, n, HW, bstride,
+                                                                          cstride, NC, ignore_index, dlogits);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_cossim_fwd(const float* x1, const float* x2, const int64_t* label_change, int64_t B, int32_t NC,
+                              int64_t HW, int64_t bstride1, int64_t cstride1, int64_t bstride2, int64_t cstride2,
+                              double* sums1, float* loss, void* stream) {
+  if (!x1 || !x2 || !label_change || !sums1 || !loss || B <= 0 || HW <= 0 || NC < 1 || NC > SCD_MAXC) return C3D_E_BADARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(sums1, 0, sizeof(double), s);
+  if (e != hipSuccess) return (int)e;
+  const int64_t n = B * HW;
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  cossim_reduce_kernel<<<grid, 256, 0, s>>>(x1, x2, label_change, n, HW, bstride1, cstride1, bstride2, cstride2, NC, sums1);
+  cossim_finalize_kernel<<<1, 1, 0, s>>>(sums1, n, loss);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_cossim_bwd(const float* x1, const float* x2, const int64_t* label_change, const float* dloss,
+                              int64_t B, int32_t NC, int64_t HW, int64_t bstride1, int64_t cstride1, int64_t bstride2,
+                              int64_t cstride2, float* dx1, float* dx2, void* stream) {
+  if (!x1 || !x2 || !label_change || !dx1 || !dx2 || B <= 0 || HW <= 0 || NC < 1 || NC > SCD_MAXC) return C3D_E_BADARG;
+  const int64_t n = B * HW;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  cossim_bwd_kernel<<<grid, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x1, x2, label_change, dloss, n, HW, bstride1,
+                                                                            cstride1, bstride2, cstride2, NC, dx1, dx2);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

@@ -97,6 +97,85 @@ def BCEDiceLoss(inputs, targets):
     return _BCEDiceFn.apply(inputs, targets)
 
 
+def _pixel_contiguous(x):
+    """f32 NCHW view with contiguous pixels (a channel slice such as `mask[:, 1:]` qualifies)."""
+    x = x.detach()
+    if x.dtype != torch.float32:
+        x = x.float()
+    B, C, H, W = x.shape
+    if (W > 1 and x.stride(3) != 1) or (H > 1 and x.stride(2) != W):
+        x = x.contiguous()
+    return x
+
+
+class _CE2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, targets, ignore_index):
+        ops.require_gpu(inputs, "loss input")
+        x = _pixel_contiguous(inputs)
+        t = targets.detach().contiguous().long()
+        sums = torch.empty(2, dtype=torch.float64, device=x.device)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        ops.ce2d_fwd(x, t, ignore_index, sums, loss)
+        ctx.saved, ctx.ignore_index = (x, t, sums), ignore_index
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        x, t, sums = ctx.saved
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        ops.ce2d_bwd(x, t, ctx.ignore_index, sums, dloss.detach().reshape(1).contiguous().float(), dx)
+        return dx, None, None
+
+
+class CrossEntropyLoss2d(nn.Module):
+    """reference model/utils.py:171-178: `nll_loss(log_softmax(inputs, 1), targets, ignore_index, 'mean')` as
+    one fused HIP pass (scripts/train_SCD.py:226 uses ignore_index=0)."""
+
+    def __init__(self, weight=None, ignore_index=-1):
+        super().__init__()
+        if weight is not None:
+            raise NotImplementedError("class weights are not used by any Change3D path")
+        self.ignore_index = ignore_index
+
+    def forward(self, inputs, targets):
+        return _CE2dFn.apply(inputs, targets, self.ignore_index)
+
+
+class _ChangeSimFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, label_change):
+        ops.require_gpu(x1, "loss input")
+        a, b = _pixel_contiguous(x1), _pixel_contiguous(x2)
+        lc = label_change.detach().reshape(a.shape[0], -1).contiguous().long()
+        sums = torch.empty(1, dtype=torch.float64, device=a.device)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        ops.cossim_fwd(a, b, lc, sums, loss)
+        ctx.saved = (a, b, lc)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        a, b, lc = ctx.saved
+        da = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+        db = torch.empty(b.shape, dtype=torch.float32, device=a.device)
+        ops.cossim_bwd(a, b, lc, dloss.detach().reshape(1).contiguous().float(), da, db)
+        return da, db, None
+
+
+class ChangeSimilarity(nn.Module):
+    """reference model/utils.py:180-203: cosine-embedding loss between the per-pixel class distributions of
+    the two semantic heads (+1 where unchanged, -1 where changed), softmax fused in."""
+
+    def __init__(self, reduction="mean"):
+        super().__init__()
+        if reduction != "mean":
+            raise NotImplementedError("the reference only uses reduction='mean'")
+
+    def forward(self, x1, x2, label_change):
+        return _ChangeSimFn.apply(x1, x2, label_change)
+
+
 # ----------------------------------------------------------------------------- arenas + Adam
 class ParamArena:
     """One flat f32 buffer for parameters and one for their gradients.

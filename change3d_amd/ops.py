@@ -377,6 +377,39 @@ def bce_dice_bwd(prob, target, sums4, dloss, dprob):
                                      _stream())
 
 
+def _nchw_view(x):
+    """(B, NC, HW, batch stride, channel stride) of an f32 NCHW view whose pixels are contiguous."""
+    B, NC, H, W = x.shape
+    assert x.dtype == torch.float32 and (W == 1 or x.stride(3) == 1) and (H == 1 or x.stride(2) == W)
+    return B, NC, H * W, x.stride(0), x.stride(1)
+
+
+def ce2d_fwd(logits, target, ignore_index, sums2, loss):
+    B, NC, HW, bs, cs = _nchw_view(logits)
+    _launch("c3d_ce2d_fwd", B * HW * (NC * 4 + 8), L.lib().c3d_ce2d_fwd, _p(logits), _p(target), B, NC, HW, bs, cs,
+            ignore_index, _p(sums2), _p(loss), _stream())
+
+
+def ce2d_bwd(logits, target, ignore_index, sums2, dloss, dlogits):
+    B, NC, HW, bs, cs = _nchw_view(logits)
+    _launch("c3d_ce2d_bwd", B * HW * (NC * 8 + 8), L.lib().c3d_ce2d_bwd, _p(logits), _p(target), _p(sums2), _p(dloss),
+            B, NC, HW, bs, cs, ignore_index, _p(dlogits), _stream())
+
+
+def cossim_fwd(x1, x2, label_change, sums1, loss):
+    B, NC, HW, bs1, cs1 = _nchw_view(x1)
+    _, _, _, bs2, cs2 = _nchw_view(x2)
+    _launch("c3d_cossim_fwd", B * HW * (NC * 8 + 8), L.lib().c3d_cossim_fwd, _p(x1), _p(x2), _p(label_change), B, NC, HW,
+            bs1, cs1, bs2, cs2, _p(sums1), _p(loss), _stream())
+
+
+def cossim_bwd(x1, x2, label_change, dloss, dx1, dx2):
+    B, NC, HW, bs1, cs1 = _nchw_view(x1)
+    _, _, _, bs2, cs2 = _nchw_view(x2)
+    _launch("c3d_cossim_bwd", B * HW * (NC * 16 + 8), L.lib().c3d_cossim_bwd, _p(x1), _p(x2), _p(label_change), _p(dloss),
+            B, NC, HW, bs1, cs1, bs2, cs2, _p(dx1), _p(dx2), _stream())
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, n, hp_dev, lr, bc1, bc2_sqrt, beta1, beta2, eps, wd):
     _launch("c3d_adam_step", n * 28, L.lib().c3d_adam_step, _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, _p(hp_dev), lr, bc1, bc2_sqrt,
                                   beta1, beta2, eps, wd, _stream())

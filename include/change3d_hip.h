@@ -246,6 +246,28 @@ int c3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta1, float beta2, float eps, float weight_decay, void* stream);
 int c3d_confusion2(const float* prob, const float* target, int64_t n, unsigned long long* cm4, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * SCD losses.  Logits are f32 NCHW views: element (b, c, p) at
+ * x[b*bstride + c*cstride + p], p < HW, NC <= 8 classes; labels are int64 [B][HW].
+ *   c3d_ce2d_*   : CrossEntropyLoss2d(ignore_index) = nll_loss(log_softmax(x, 1), target, 'mean' over the
+ *                  non-ignored pixels) (reference model/utils.py:171-178; used with ignore_index=0 at
+ *                  scripts/train_SCD.py:226).  sums2 = (sum nll, count), zeroed by the call.
+ *   c3d_cossim_* : ChangeSimilarity = cosine_embedding_loss(softmax(x1), softmax(x2), +1 where
+ *                  label_change == 0 / -1 elsewhere, margin 0, 'mean') (reference model/utils.py:180-203).
+ * Backward writes dense [B][NC][HW] gradients scaled by dloss[0] (NULL = 1).
+ * ------------------------------------------------------------------------------------ */
+int c3d_ce2d_fwd(const float* logits, const int64_t* target, int64_t B, int32_t NC, int64_t HW, int64_t bstride,
+                 int64_t cstride, int64_t ignore_index, double* sums2, float* loss, void* stream);
+int c3d_ce2d_bwd(const float* logits, const int64_t* target, const double* sums2, const float* dloss, int64_t B,
+                 int32_t NC, int64_t HW, int64_t bstride, int64_t cstride, int64_t ignore_index, float* dlogits,
+                 void* stream);
+int c3d_cossim_fwd(const float* x1, const float* x2, const int64_t* label_change, int64_t B, int32_t NC, int64_t HW,
+                   int64_t bstride1, int64_t cstride1, int64_t bstride2, int64_t cstride2, double* sums1, float* loss,
+                   void* stream);
+int c3d_cossim_bwd(const float* x1, const float* x2, const int64_t* label_change, const float* dloss, int64_t B,
+                   int32_t NC, int64_t HW, int64_t bstride1, int64_t cstride1, int64_t bstride2, int64_t cstride2,
+                   float* dx1, float* dx2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,8 @@ Adam as in `scripts/train_BCD.py:284-290`) on PyTorch-CPU fp32 with seeded synth
 weights/inputs from `oracle/synth.py`, first asserting that the repo's restatement
 (`oracle/model.py`) reproduces it bit-for-bit, then writes small fixtures:
 
-    tests/golden/bcd_s{S}_b{B}.npz
+    tests/golden/bcd_s{S}_b{B}.npz      (BCD: update_bcd, BCE+Dice, 3 Adam steps, eval mode)
+    tests/golden/scd_s64_b{B}.npz       (SCD, SURVEY.md 8(f).1: update_scd + the train_SCD.py loss)
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden [--sizes 64 256]
 The fixtures are DATA (inputs are regenerated from seeds; expected outputs are stored).
@@ -180,15 +181,79 @@ def run(size, batch, check_restatement=True):
     print(f"[gen_golden] wrote {path} ({os.path.getsize(path) / 1024:.1f} kB); losses {losses}")
 
 
+def run_scd(size, batch):
+    """SURVEY.md 8(f).1 fixture: the REAL reference `Trainer.update_scd` (K=3, T=5, three decoders, 7 classes)
+    and the loss of `scripts/train_SCD.py:226-229` built from the reference's own `CrossEntropyLoss2d`,
+    `ChangeSimilarity` and `BCEDiceLoss`; the restatement must reproduce both bit-for-bit."""
+    tr, mu, _ = ref_import.import_reference()
+    args = om.make_args(num_perception_frame=3, size=size, dataset="SECOND", num_class=7)
+    ref = tr.Trainer(args)
+    sd = synth.synth_state_dict(ref, seed=WEIGHT_SEED, mask_margin=MASK_MARGIN)
+    ref.load_state_dict(sd, strict=True)
+    pre, post, _ = synth.synth_batch(batch, size, seed=DATA_SEED)
+    labels = synth.synth_scd_labels(batch, size, seed=DATA_SEED)
+    seg_loss, sim_loss = mu.CrossEntropyLoss2d(ignore_index=0), mu.ChangeSimilarity()
+
+    def ref_loss(net, a, b, dt):
+        pm, qm, cm = net.update_scd(a, b)
+        lc = labels[:, 2].long()
+        pl, ql = labels[:, 0].long() * lc, labels[:, 1].long() * lc
+        segm = seg_loss(pm, pl) + seg_loss(qm, ql)
+        binary = mu.BCEDiceLoss(cm, lc.unsqueeze(1).to(dt))
+        sim = sim_loss(pm[:, 1:], qm[:, 1:], lc.unsqueeze(1))
+        return (pm, qm, cm), segm * 0.5 + binary + sim
+
+    ref.train()
+    outs, loss = ref_loss(ref, pre, post, torch.float32)
+    loss.backward()
+    names = [n for n, p in ref.named_parameters() if p.grad is not None]
+    named = dict(ref.named_parameters())
+    stride = max(size // 32, 1)
+    out = {"meta": np.array([size, batch, WEIGHT_SEED, DATA_SEED, 3, 7], dtype=np.int64),
+           "loss": np.array(loss.item()), "grad_names": np.array(names),
+           "grad_norms": np.array([named[n].grad.norm().item() for n in names])}
+    for k, o in zip(("pre", "post", "change"), outs):
+        out[f"{k}_lattice"] = o.detach()[:, :, ::stride, ::stride].numpy()
+    out["pre_argmax_bits"] = np.packbits((outs[0].detach().argmax(1) == labels[:, 0]).numpy().reshape(-1))
+    ref64 = tr.Trainer(args)
+    ref64.load_state_dict(sd, strict=True)
+    ref64 = ref64.double().train()
+    outs64, loss64 = ref_loss(ref64, pre.double(), post.double(), torch.float64)
+    loss64.backward()
+    named64 = dict(ref64.named_parameters())
+    out["loss_f64"] = np.array(loss64.item())
+    out["grad_norms_f64"] = np.array([named64[n].grad.norm().item() for n in names])
+    for k, o in zip(("pre", "post", "change"), outs64):
+        out[f"{k}_lattice_f64"] = o.detach()[:, :, ::stride, ::stride].numpy()
+    # restatement == reference, bit for bit (outputs, loss, every gradient)
+    ora = om.Trainer(om.make_args(num_perception_frame=3, size=size, dataset="SECOND", num_class=7))
+    ora.load_state_dict(sd, strict=True)
+    ora.train()
+    oo = ora.update_scd(pre, post)
+    lo = om.scd_loss(*oo, labels)
+    lo.backward()
+    assert all(torch.equal(a, b) for a, b in zip(oo, outs)) and lo.item() == loss.item(), (lo.item(), loss.item())
+    on = dict(ora.named_parameters())
+    assert all(torch.equal(on[n].grad, named[n].grad) for n in names)
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(GOLDEN_DIR, f"scd_s{size}_b{batch}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[gen_golden] SCD restatement == reference; wrote {path} ({os.path.getsize(path) / 1024:.1f} kB); "
+          f"loss {loss.item():.6f} (fp64 {loss64.item():.6f})")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", type=int, nargs="+", default=[64, 256])
     ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--scd-only", action="store_true", help="only regenerate the SCD fixture")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    for s in a.sizes:
-        run(s, a.batch)
+    if not a.scd_only:
+        for s in a.sizes:
+            run(s, a.batch)
+    run_scd(64, a.batch)
 
 
 if __name__ == "__main__":

@@ -282,6 +282,35 @@ def bce_dice_loss(inputs, targets):
     return bce + 1 - dice
 
 
+def cross_entropy_2d(inputs, targets, ignore_index=-1):
+    """reference model/utils.py:171-178 (`CrossEntropyLoss2d`): NLL of log_softmax over dim 1, mean over
+    the pixels whose label is not `ignore_index`."""
+    return F.nll_loss(F.log_softmax(inputs, dim=1), targets, ignore_index=ignore_index, reduction="mean")
+
+
+def change_similarity(x1, x2, label_change):
+    """reference model/utils.py:180-203 (`ChangeSimilarity`): CosineEmbeddingLoss(margin 0, mean) between
+    the per-pixel class distributions softmax(x1), softmax(x2); target +1 where unchanged, -1 where changed."""
+    b, c, h, w = x1.size()
+    p1 = F.softmax(x1, dim=1).permute(0, 2, 3, 1).reshape(b * h * w, c)
+    p2 = F.softmax(x2, dim=1).permute(0, 2, 3, 1).reshape(b * h * w, c)
+    target = ((~label_change.bool()).float() - label_change.float()).reshape(b * h * w)
+    return F.cosine_embedding_loss(p1, p2, target, margin=0.0, reduction="mean")
+
+
+def scd_loss(pre_mask, post_mask, change_mask, labels):
+    """reference scripts/train_SCD.py:209-229: labels (B,3,H,W) = [pre classes, post classes, change];
+    the class maps are zeroed where nothing changed, class 0 is ignored by the segmentation loss, and the
+    similarity term sees the logits of classes 1.. only."""
+    label_change = labels[:, 2].long()
+    pre_label = labels[:, 0].long() * label_change
+    post_label = labels[:, 1].long() * label_change
+    segm = cross_entropy_2d(pre_mask, pre_label, ignore_index=0) + cross_entropy_2d(post_mask, post_label, ignore_index=0)
+    binary = bce_dice_loss(change_mask, label_change.unsqueeze(1).to(change_mask.dtype))
+    sim = change_similarity(pre_mask[:, 1:], post_mask[:, 1:], label_change.unsqueeze(1))
+    return segm * 0.5 + binary + sim
+
+
 def poly_lr(base_lr, it, max_iter, epoch):
     """reference model/utils.py:130-143 (lr_mode='poly' + epoch-0 warm-up)."""
     lr = base_lr * (1 - it * 1.0 / max_iter) ** 0.9

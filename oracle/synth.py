@@ -61,6 +61,18 @@ def synth_batch(batch, size=256, seed=0):
     return torch.from_numpy(imgs[0]), torch.from_numpy(imgs[1]), torch.from_numpy(tgt)
 
 
+def synth_scd_labels(batch, size=256, seed=0, num_class=7):
+    """SCD labels as `scripts/train_SCD.py:209-217` sees them after the loader: (B,3,S,S) int64 =
+    [pre class map in 0..num_class-1, post class map, change mask in {0,1}] (blocky class maps, the
+    change mask of `synth_batch` with the same seed)."""
+    rng = np.random.default_rng(2000 + seed)
+    cell = max(size // 8, 1)
+    grid = rng.integers(0, num_class, size=(2, batch, (size + cell - 1) // cell, (size + cell - 1) // cell))
+    maps = np.repeat(np.repeat(grid, cell, axis=2), cell, axis=3)[:, :, :size, :size]
+    change = synth_batch(batch, size, seed)[2].numpy()[:, 0].astype(np.int64)
+    return torch.from_numpy(np.stack([maps[0], maps[1], change], axis=1).astype(np.int64))
+
+
 def synth_tensor(shape, seed, scale=1.0):
     rng = np.random.default_rng(seed)
     return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))

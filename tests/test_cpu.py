@@ -63,6 +63,32 @@ def test_oracle_matches_reference_golden_s64(golden_dir):
     assert abs(sc["IoU"] - G["scores"][1]) < 1e-12 and abs(sc["F1"] - G["scores"][2]) < 1e-12
 
 
+def test_oracle_scd_matches_reference_golden_s64(golden_dir):
+    """the oracle's SCD restatement (update_scd + the train_SCD.py loss) against the fixture
+    the real reference produced."""
+    from oracle import model as om, synth
+    G = np.load(os.path.join(golden_dir, "scd_s64_b2.npz"))
+    size, batch = int(G["meta"][0]), int(G["meta"][1])
+    net = om.Trainer(om.make_args(num_perception_frame=int(G["meta"][4]), size=size, dataset="SECOND",
+                                  num_class=int(G["meta"][5])))
+    net.load_state_dict(synth.synth_state_dict(net, seed=int(G["meta"][2]), mask_margin=0.25))
+    pre, post, _ = synth.synth_batch(batch, size, seed=int(G["meta"][3]))
+    labels = synth.synth_scd_labels(batch, size, seed=int(G["meta"][3]))
+    net.train()
+    outs = net.update_scd(pre, post)
+    loss = om.scd_loss(*outs, labels)
+    loss.backward()
+    stride = max(size // 32, 1)
+    for k, o in zip(("pre", "post", "change"), outs):
+        assert np.abs(o.detach()[:, :, ::stride, ::stride].numpy() - G[f"{k}_lattice"]).max() < 2e-5
+    assert abs(loss.item() - float(G["loss"])) < 1e-5
+    named = dict(net.named_parameters())
+    gn = np.array([named[str(n)].grad.double().norm().item() for n in G["grad_names"]])
+    assert np.allclose(gn, G["grad_norms"], rtol=2e-3, atol=1e-9)
+    assert np.array_equal(np.packbits((outs[0].detach().argmax(1) == labels[:, 0]).numpy().reshape(-1)),
+                          G["pre_argmax_bits"])
+
+
 def test_oracle_structure_matches_published_counts():
     from oracle import model as om
     net = om.Trainer(om.make_args(size=256))

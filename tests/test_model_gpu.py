@@ -361,6 +361,100 @@ def test_e2e_bcd_vs_reference_golden(size, golden_dir):
     assert (nbt == G["final_nbt"]).all()
 
 
+def _build_pair_k(size, k, num_class, act_dtype=torch.float32):
+    from oracle import model as om, synth
+    from change3d_amd.model.trainer import Trainer
+    ref = om.Trainer(om.make_args(num_perception_frame=k, size=size, dataset="SECOND", num_class=num_class))
+    sd = synth.synth_state_dict(ref, seed=16, mask_margin=0.25)
+    ref.load_state_dict(sd)
+    args2 = om.make_args(num_perception_frame=k, size=size, dataset="SECOND", num_class=num_class)
+    args2.act_dtype = act_dtype
+    mine = Trainer(args2)
+    mine.load_state_dict(sd)
+    return ref, mine.to(DEV), sd
+
+
+def test_e2e_scd_forward_backward_vs_oracle_size64():
+    """the SCD path (K=3 perception frames, T=5, three decoders, 7-class logits) through
+    the same kernels, against the oracle.  A fixed linear functional of the three outputs drives backward."""
+    _need_gpu()
+    from oracle import model as om, synth
+    from change3d_amd.model.utils import hot_path_named_params
+    ref, mine, sd = _build_pair_k(64, 3, 7)
+    ref64 = om.Trainer(om.make_args(num_perception_frame=3, size=64, dataset="SECOND", num_class=7))
+    ref64.load_state_dict(sd)
+    ref64 = ref64.double()
+    pre, post, _ = synth.synth_batch(2, 64, seed=5)
+    ref.train(); mine.train(); ref64.train()
+    outs_r = ref.update_scd(pre, post)
+    outs_64 = ref64.update_scd(pre.double(), post.double())
+    outs_d = mine.update_scd(pre.to(DEV), post.to(DEV))
+    probes = [synth.synth_tensor(tuple(o.shape), 40 + i, 1.0 / o[0].numel()) for i, o in enumerate(outs_r)]
+    sum((o * p).sum() for o, p in zip(outs_r, probes)).backward()
+    sum((o * p.double()).sum() for o, p in zip(outs_64, probes)).backward()
+    sum((o * p.to(DEV)).sum() for o, p in zip(outs_d, probes)).backward()
+    torch.cuda.synchronize()
+    for name, o_d, o_r, o_64 in zip(("pre", "post", "change"), outs_d, outs_r, outs_64):
+        assert o_d.shape == o_r.shape
+        scale = max(1.0, o_64.detach().abs().max().item())
+        e_hip = (o_d.detach().cpu().double() - o_64.detach()).abs().max().item() / scale
+        e_ref = (o_r.detach().double() - o_64.detach()).abs().max().item() / scale
+        print(f"SCD {name}: max rel err vs fp64: hip {e_hip:.3e}  fp32 reference {e_ref:.3e}")
+        assert e_hip <= K_NOISE * e_ref + 1e-6, (name, e_hip, e_ref)
+    # argmax masks (reference scripts/train_SCD.py:241-246): identical wherever the fp64 top-2 margin is safe
+    for o_d, o_r, o_64 in zip(outs_d[:2], outs_r[:2], outs_64[:2]):
+        top2 = o_64.detach().topk(2, dim=1).values
+        margin = top2[:, 0] - top2[:, 1]
+        tol = K_NOISE * (o_r.detach().double() - o_64.detach()).abs().max().item() * 2 + 1e-6
+        safe = margin > tol
+        assert ((o_d.detach().cpu().argmax(1) != o_64.detach().argmax(1)) & safe).sum().item() == 0
+    names = [n for n, _ in hot_path_named_params(mine)]
+    g_hip = {n: p.grad for n, p in hot_path_named_params(mine)}
+    g32 = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+    g64 = {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
+    assert set(names) == set(g32.keys())
+    _grad_check(names, g_hip, g32, g64)
+
+
+def test_e2e_scd_vs_reference_golden(golden_dir):
+    """SCD training step (update_scd + the loss of scripts/train_SCD.py:226-229) against the fixture produced
+    by the REAL reference (tests/golden/scd_s64_b2.npz, oracle/gen_golden.py::run_scd)."""
+    _need_gpu()
+    from oracle import synth
+    from change3d_amd.model.utils import BCEDiceLoss, ChangeSimilarity, CrossEntropyLoss2d, hot_path_named_params
+    G = np.load(os.path.join(golden_dir, "scd_s64_b2.npz"), allow_pickle=False)
+    size, batch = int(G["meta"][0]), int(G["meta"][1])
+    _, mine, _ = _build_pair_k(size, 3, 7)
+    pre, post, _ = synth.synth_batch(batch, size, seed=int(G["meta"][3]))
+    labels = synth.synth_scd_labels(batch, size, seed=int(G["meta"][3])).to(DEV)
+    mine.train()
+    pm, qm, cm = mine.update_scd(pre.to(DEV), post.to(DEV))
+    lc = labels[:, 2].long()
+    pl, ql = labels[:, 0].long() * lc, labels[:, 1].long() * lc
+    seg, sim = CrossEntropyLoss2d(ignore_index=0), ChangeSimilarity()
+    loss = (seg(pm, pl) + seg(qm, ql)) * 0.5 + BCEDiceLoss(cm, lc.unsqueeze(1).float()) + sim(pm[:, 1:], qm[:, 1:], lc.unsqueeze(1))
+    loss.backward()
+    torch.cuda.synchronize()
+    stride = max(size // 32, 1)
+    for k, o in zip(("pre", "post", "change"), (pm, qm, cm)):
+        lat = o.detach()[:, :, ::stride, ::stride].cpu().double().numpy()
+        scale = max(1.0, np.abs(G[f"{k}_lattice_f64"]).max())
+        e_hip = np.abs(lat - G[f"{k}_lattice_f64"]).max() / scale
+        e_ref = np.abs(G[f"{k}_lattice"].astype(np.float64) - G[f"{k}_lattice_f64"]).max() / scale
+        print(f"SCD {k}: max rel err vs fp64 on lattice: hip {e_hip:.3e}  fp32 reference {e_ref:.3e}")
+        assert e_hip <= K_NOISE * e_ref + 1e-6, (k, e_hip, e_ref)
+    l_ref, l_64 = float(G["loss"]), float(G["loss_f64"])
+    print(f"SCD loss hip {loss.item():.6f} ref32 {l_ref:.6f} ref64 {l_64:.6f}")
+    assert abs(loss.item() - l_64) <= K_NOISE * abs(l_ref - l_64) + 1e-4
+    named = dict(hot_path_named_params(mine))
+    names = [str(n) for n in G["grad_names"]]
+    assert set(names) == set(named.keys())
+    gn = np.array([named[n].grad.double().norm().item() for n in names])
+    eh = np.abs(gn - G["grad_norms_f64"]) / (G["grad_norms_f64"] + 1e-30)
+    er = np.abs(G["grad_norms"] - G["grad_norms_f64"]) / (G["grad_norms_f64"] + 1e-30)
+    _noise_check(G["grad_names"], eh, er, "SCD grad-norm rel err")
+
+
 def test_step_is_reproducible():
     """Two forward+backward passes from identical state: activations (hence the loss) must be
     bit-identical and every gradient reproducible up to f32 leaf-gradient atomics.  (Statistics are

@@ -425,3 +425,34 @@ def test_confusion_matrix():
     pred = torch.where(p > 0.5, torch.ones_like(p), torch.zeros_like(p)).long()
     ref = get_confuse_matrix(2, t.numpy(), pred.numpy())
     assert (meter.sum == ref).all(), (meter.sum, ref)
+
+
+def test_scd_losses_vs_torch():
+    """CrossEntropyLoss2d(ignore_index=0) and ChangeSimilarity (reference model/utils.py:171-203) through the
+    C ABI, on channel-sliced logits exactly as scripts/train_SCD.py:226-228 passes them."""
+    _need_gpu()
+    from change3d_amd.model.utils import ChangeSimilarity, CrossEntropyLoss2d
+    B, NC, H, W = 3, 7, 20, 24
+    pre, post = rnd((B, NC, H, W), 300, 2.0), rnd((B, NC, H, W), 301, 2.0)
+    g = np.random.default_rng(302)
+    lab = torch.from_numpy(g.integers(0, NC, size=(B, H, W))).long()
+    chg = torch.from_numpy((g.random((B, H, W)) < 0.3).astype(np.int64))
+    lab = lab * chg
+    pr, qr = pre.clone().requires_grad_(True), post.clone().requires_grad_(True)
+    ce_ref = F.nll_loss(F.log_softmax(pr, 1), lab, ignore_index=0)
+    p1 = F.softmax(pr[:, 1:], 1).permute(0, 2, 3, 1).reshape(-1, NC - 1)
+    p2 = F.softmax(qr[:, 1:], 1).permute(0, 2, 3, 1).reshape(-1, NC - 1)
+    tgt = ((~chg.bool()).float() - chg.float()).reshape(-1)
+    sim_ref = F.cosine_embedding_loss(p1, p2, tgt, margin=0.0)
+    (0.5 * ce_ref + 2.0 * sim_ref).backward()
+    pd, qd = pre.to(DEV).requires_grad_(True), post.to(DEV).requires_grad_(True)
+    ce = CrossEntropyLoss2d(ignore_index=0)(pd, lab.to(DEV))
+    sim = ChangeSimilarity()(pd[:, 1:], qd[:, 1:], chg.to(DEV).unsqueeze(1))
+    (0.5 * ce + 2.0 * sim).backward()
+    assert abs(ce.item() - ce_ref.item()) < 2e-6 * max(1.0, abs(ce_ref.item()))
+    assert abs(sim.item() - sim_ref.item()) < 2e-6
+    close(pd.grad, pr.grad, torch.float32, "d pre", scale=pr.grad.abs().max().item())
+    close(qd.grad, qr.grad, torch.float32, "d post", scale=qr.grad.abs().max().item())
+    # every pixel ignored -> NaN, as torch
+    z = torch.zeros_like(lab)
+    assert torch.isnan(CrossEntropyLoss2d(ignore_index=0)(pd.detach(), z.to(DEV))).item()
