@@ -294,7 +294,8 @@ def main():
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                            "share_of_kernel_time": round(d["ms_total"] / max(tot, 1e-9), 3),
                            "timing": "HIP events on the launch stream, one eager step with the side stream off"}
-        out["roofline"].update(pmc_traffic(name))
+        if not scd:   # the committed counter summary is a BCD run
+            out["roofline"].update(pmc_traffic(name))
         ops.SIDE_STREAM = side_was
         rows = [{"kernel": k, "launches": v["launches"], "ms_total": round(v["ms_total"], 3),
                  "GBps": round(v["bytes_total"] / max(v["ms_total"], 1e-9) / 1e6, 1)} for k, v in table]
