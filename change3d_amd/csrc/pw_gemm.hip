@@ -117,63 +117,9 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
   os_t* Os = reinterpret_cast<os_t*>(wreg + L.os_off);
   float* Gs = reinterpret_cast<float*>(wreg + L.gs_off);  // gate of the current sample [Kp]
 
-  // ---- stage weights: zero fill, then vectorised fill along W's contiguous dimension -------
-  {
-    const int wtot = NT * 16 * KL;  // elements, multiple of 8
-    for (int i = tid * 8; i < wtot; i += WAVES * 64 * 8) {
-      float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      MM::store8(Ws + i, z);
-    }
-    if (PRO != C3D_PRO_NONE) {
-      const int np = (PRO == C3D_PRO_AFFINE2 ? 3 : 2) * Kp;
-      for (int i = tid; i < np; i += WAVES * 64) Pp[i] = a.pro_p[i];
-    }
-    __syncthreads();
-    const bool kc = (a.w_sk == 1);
-    const int CL = kc ? a.K : a.N, OLn = kc ? a.N : a.K;
-    const int ostride = kc ? a.w_sn : a.w_sk;
-    int VW = 1;
-    if ((CL & 3) == 0 && (ostride & 3) == 0 && ((uintptr_t)a.w & 15) == 0) VW = 4;
-    else if ((CL & 1) == 0 && (ostride & 1) == 0 && ((uintptr_t)a.w & 7) == 0) VW = 2;
-    const int vpr = CL / VW, total = OLn * vpr;
-    const float inv = 1.0f / (float)vpr;
-    for (int base = tid; base < total; base += WAVES * 64 * 4) {
-      float v[4][4];
-      int oo[4], ii[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = base + u * WAVES * 64;
-        oo[u] = -1;
-        if (idx < total) {
-          const int o = __float2int_rz(((float)idx + 0.5f) * inv);
-          const int i = idx - o * vpr;
-          oo[u] = o; ii[u] = i * VW;
-          const float* src = a.w + (size_t)o * ostride + i * VW;
-          if (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
-          else if (VW == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
-          else v[u][0] = src[0];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (oo[u] >= 0) {
-          for (int e = 0; e < VW; ++e) {
-            const int n = kc ? oo[u] : ii[u] + e;
-            const int k = kc ? ii[u] + e : oo[u];
-            Ws[n * KL + k] = MM::cvt(v[u][e]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // each wave zeroes its X region once: the K-padding columns [Kp, Kpad) are never written later
-  for (int i = lane * 8; i < L.xs_rows * KL; i += 64 * 8) {
-    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    MM::store8(Xs + i, z);
-  }
-
+  // The first tile's rows (and the per-lane epilogue parameters) are requested BEFORE the weights are
+  // staged: a launch is a chain of dependent global round trips (parameters, weights, first tile,
+  // epilogue operands: ~16 us even for a 4-workgroup grid), so the independent ones must overlap.
   // ---- lane maps -----------------------------------------------------------------------------
   const int Gi = Kp >> 3;                       // input: flat map, slot i = lane + 64*q over 16*Gi vectors
   const int Q = (Gi + 3) >> 2;                  // vector slots per lane per 16-row sub-tile
@@ -240,6 +186,64 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
   }
 
   if (t0 < t1) { PW_ISSUE(t0) }
+
+  // ---- stage weights: zero fill, then vectorised fill along W's contiguous dimension -------
+  {
+    const int wtot = NT * 16 * KL;  // elements, multiple of 8
+    for (int i = tid * 8; i < wtot; i += WAVES * 64 * 8) {
+      float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      MM::store8(Ws + i, z);
+    }
+    if (PRO != C3D_PRO_NONE) {
+      const int np = (PRO == C3D_PRO_AFFINE2 ? 3 : 2) * Kp;
+      for (int i = tid; i < np; i += WAVES * 64) Pp[i] = a.pro_p[i];
+    }
+    __syncthreads();
+    const bool kc = (a.w_sk == 1);
+    const int CL = kc ? a.K : a.N, OLn = kc ? a.N : a.K;
+    const int ostride = kc ? a.w_sn : a.w_sk;
+    int VW = 1;
+    if ((CL & 3) == 0 && (ostride & 3) == 0 && ((uintptr_t)a.w & 15) == 0) VW = 4;
+    else if ((CL & 1) == 0 && (ostride & 1) == 0 && ((uintptr_t)a.w & 7) == 0) VW = 2;
+    const int vpr = CL / VW, total = OLn * vpr;
+    const float inv = 1.0f / (float)vpr;
+    for (int base = tid; base < total; base += WAVES * 64 * 4) {
+      float v[4][4];
+      int oo[4], ii[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * WAVES * 64;
+        oo[u] = -1;
+        if (idx < total) {
+          const int o = __float2int_rz(((float)idx + 0.5f) * inv);
+          const int i = idx - o * vpr;
+          oo[u] = o; ii[u] = i * VW;
+          const float* src = a.w + (size_t)o * ostride + i * VW;
+          if (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
+          else if (VW == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
+          else v[u][0] = src[0];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (oo[u] >= 0) {
+          for (int e = 0; e < VW; ++e) {
+            const int n = kc ? oo[u] : ii[u] + e;
+            const int k = kc ? ii[u] + e : oo[u];
+            Ws[n * KL + k] = MM::cvt(v[u][e]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // each wave zeroes its X region once: the K-padding columns [Kp, Kpad) are never written later
+  for (int i = lane * 8; i < L.xs_rows * KL; i += 64 * 8) {
+    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    MM::store8(Xs + i, z);
+  }
+
   for (int64_t it0 = t0; it0 < t1; it0 += L.tpi) {
     // ---------------- convert + prologue -> LDS (all sub-tiles of this iteration) ------------
 #pragma unroll
@@ -400,70 +404,81 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
 #undef PW_ISSUE
 
   // ---- final flush of per-lane partial sums -------------------------------------------------
-  if (EPI == C3D_EPI_STATS) {
-    // lanes -> wave (shuffles) -> workgroup (LDS) -> ONE f64 atomic per channel per workgroup, into
-    // one of C3D_STAT_STRIPES accumulator sets (keeps same-address atomic contention low)
-    float* red = reinterpret_cast<float*>(smem + L.wave_off);  // [WAVES][2][Np], X regions are dead now
+  // lanes -> LDS ([value][lane] per wave, the X regions are dead now) -> one thread per output sums the
+  // RPo row-lanes of every wave -> ONE f64 atomic per value and workgroup.  (The lane step used to be
+  // RPo dependent ds_bpermute shuffles per value: 7-14 us per launch on the narrow layers, Go = 3..7.)
+  constexpr int NV = EPI == C3D_EPI_SWISH_SE_BWD ? 24 : 16;   // partial sums per lane
+  if (EPI == C3D_EPI_STATS || EPI == C3D_EPI_SWISH_SE_BWD) {
+    const bool dump = (size_t)L.wave_bytes >= (size_t)64 * NV * sizeof(float) + WAVES * sizeof(int);
+    float* mine = reinterpret_cast<float*>(smem + L.wave_off + (size_t)wave * L.wave_bytes);   // [NV][64]
+    int* ncur = reinterpret_cast<int*>(smem + L.wave_off + (size_t)WAVES * L.wave_bytes - WAVES * sizeof(int));
     __syncthreads();
+    if (dump) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float r0 = strided_lane_sum(s0[j], lane, Go, RPo);
-      const float r1 = strided_lane_sum(s1[j], lane, Go, RPo);
-      if (lane < Go) {
-        red[(wave * 2 + 0) * Np + v_o * 8 + j] = r0;
-        red[(wave * 2 + 1) * Np + v_o * 8 + j] = r1;
+      for (int j = 0; j < 8; ++j) {
+        mine[j * 64 + lane] = s0[j];
+        mine[(8 + j) * 64 + lane] = s1[j];
+        if (EPI == C3D_EPI_SWISH_SE_BWD) mine[(16 + j) * 64 + lane] = s2[j];
       }
-    }
-    __syncthreads();
-    double* dst = a.stats + (size_t)(blockIdx.x % C3D_STAT_STRIPES) * 2 * a.N;
-    for (int i = tid; i < 2 * a.N; i += WAVES * 64) {
-      const int which = i / a.N, c = i - which * a.N;
-      float acc = 0.f;
-      for (int wv = 0; wv < WAVES; ++wv) acc += red[(wv * 2 + which) * Np + c];
-      atomicAdd(dst + which * a.N + c, (double)acc);
-    }
-  } else if (EPI == C3D_EPI_SWISH_SE_BWD) {
-    // Per-(sample, channel) sums.  The waves of a workgroup almost always end inside the same
-    // sample: combine them through LDS and issue ONE f64 atomic per value and workgroup (the
-    // per-wave flush was 660 k same-address atomics = 40 % of the stage-3 kernel's time).
-    float* red = reinterpret_cast<float*>(smem + L.wave_off);        // [WAVES][3][Np], X regions are dead now
-    int* ncur = reinterpret_cast<int*>(red + (size_t)WAVES * 3 * Np);  // [WAVES]
-    __syncthreads();
+    } else {   // tiny LDS regions: shuffle the row-lanes together, result in lanes < Go, stored at [value][v_o]
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float r0 = strided_lane_sum(s0[j], lane, Go, RPo);
-      const float r1 = strided_lane_sum(s1[j], lane, Go, RPo);
-      const float r2 = strided_lane_sum(s2[j], lane, Go, RPo);
-      if (lane < Go) {
-        red[(wave * 3 + 0) * Np + v_o * 8 + j] = r0;
-        red[(wave * 3 + 1) * Np + v_o * 8 + j] = r1;
-        red[(wave * 3 + 2) * Np + v_o * 8 + j] = r2;
-      }
-    }
-    if (lane == 0) ncur[wave] = (int)cur_n;
-    __syncthreads();
-    int n_all = -1;
-    bool uniform = true;
-    for (int wv = 0; wv < WAVES; ++wv) {
-      const int nw = ncur[wv];
-      if (nw < 0) continue;          // a wave without tiles contributes nothing
-      if (n_all < 0) n_all = nw;
-      else if (nw != n_all) uniform = false;
-    }
-    if (uniform) {
-      if (n_all >= 0) {
-        for (int i = tid; i < 3 * Np; i += WAVES * 64) {
-          const int which = i / Np, c = i - which * Np;
-          float acc = 0.f;
-          for (int wv = 0; wv < WAVES; ++wv)
-            if (ncur[wv] >= 0) acc += red[(wv * 3 + which) * Np + c];
-          atomicAdd(a.stats + ((int64_t)n_all * Np + c) * 3 + which, (double)acc);
+      for (int j = 0; j < 8; ++j) {
+        const float r0 = strided_lane_sum(s0[j], lane, Go, RPo);
+        const float r1 = strided_lane_sum(s1[j], lane, Go, RPo);
+        const float r2 = EPI == C3D_EPI_SWISH_SE_BWD ? strided_lane_sum(s2[j], lane, Go, RPo) : 0.f;
+        if (lane < Go) {
+          mine[j * Go + lane] = r0;
+          mine[(8 + j) * Go + lane] = r1;
+          if (EPI == C3D_EPI_SWISH_SE_BWD) mine[(16 + j) * Go + lane] = r2;
         }
       }
-    } else if (cur_n >= 0) {
-      for (int i = lane; i < 3 * Np; i += 64) {
-        const int which = i / Np, c = i - which * Np;
-        atomicAdd(a.stats + ((int64_t)cur_n * Np + c) * 3 + which, (double)red[(wave * 3 + which) * Np + c]);
+    }
+    if (EPI == C3D_EPI_SWISH_SE_BWD && lane == 0) ncur[wave] = (int)cur_n;
+    __syncthreads();
+    // value (which, channel c = v*8 + j) of wave wv
+    auto wave_value = [&](const int wv, const int which, const int c) -> float {
+      const float* base = reinterpret_cast<const float*>(smem + L.wave_off + (size_t)wv * L.wave_bytes);
+      const int v = c >> 3, j = c & 7;
+      if (!dump) return base[(which * 8 + j) * Go + v];
+      float acc = 0.f;
+      for (int rr = 0; rr < RPo; ++rr) acc += base[(which * 8 + j) * 64 + rr * Go + v];
+      return acc;
+    };
+    if (EPI == C3D_EPI_STATS) {
+      // into one of C3D_STAT_STRIPES accumulator sets (keeps same-address atomic contention low)
+      double* dst = a.stats + (size_t)(blockIdx.x % C3D_STAT_STRIPES) * 2 * a.N;
+      for (int i = tid; i < 2 * a.N; i += WAVES * 64) {
+        const int which = i / a.N, c = i - which * a.N;
+        float acc = 0.f;
+        for (int wv = 0; wv < WAVES; ++wv) acc += wave_value(wv, which, c);
+        atomicAdd(dst + which * a.N + c, (double)acc);
+      }
+    } else {
+      // Per-(sample, channel) sums.  The waves of a workgroup almost always end inside the same sample:
+      // combine them (the per-wave flush was 660 k same-address atomics = 40 % of the stage-3 kernel).
+      int n_all = -1;
+      bool uniform = true;
+      for (int wv = 0; wv < WAVES; ++wv) {
+        const int nw = ncur[wv];
+        if (nw < 0) continue;          // a wave without tiles contributes nothing
+        if (n_all < 0) n_all = nw;
+        else if (nw != n_all) uniform = false;
+      }
+      if (uniform) {
+        if (n_all >= 0) {
+          for (int i = tid; i < 3 * Np; i += WAVES * 64) {
+            const int which = i / Np, c = i - which * Np;
+            float acc = 0.f;
+            for (int wv = 0; wv < WAVES; ++wv)
+              if (ncur[wv] >= 0) acc += wave_value(wv, which, c);
+            atomicAdd(a.stats + ((int64_t)n_all * Np + c) * 3 + which, (double)acc);
+          }
+        }
+      } else if (cur_n >= 0) {
+        for (int i = lane; i < 3 * Np; i += 64) {
+          const int which = i / Np, c = i - which * Np;
+          atomicAdd(a.stats + ((int64_t)cur_n * Np + c) * 3 + which, (double)wave_value(wave, which, c));
+        }
       }
     }
   }
