@@ -1471,6 +1471,12 @@ int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, doubl
   }
   const int ntiles = ((g.W + V2_TW - 1) / V2_TW) * ((g.H + V2_TH - 1) / V2_TH);
   int tpw = 16;  // swept on MI355X: 1:427us 4:255 8:240 16:233 32:250 (stage-1 shape)
+  // ...but a walk is a serial chain (~5.5 us per tile): keep ~2 workgroups per CU in the grid
+  // (the 64x64 / 32x32 stages launched 256 / 224 workgroups of 16 / 8 tiles: one per CU, 98 / 52 us)
+  const int chunks_ = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
+  // measured best: 16 / 8 / 4 tiles for the 128x128 / 64x64 / 32x32 stages = ~2 workgroups per CU, and
+  // never fewer than 4 tiles (the prefetch pipeline needs a walk)
+  while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks_ * g.B < 2L * device_cus()) tpw >>= 1;
   if (const char* e = getenv("C3D_DW_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;  // tuning knob
   if (tpw > ntiles) tpw = ntiles;
   dim3 grid(chunk_order_grid((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), (long)((ntiles + tpw - 1) / tpw) * g.B));

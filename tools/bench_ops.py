@@ -10,11 +10,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from change3d_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
-B, T = 32, 3
+B, T = int(os.environ.get("C3D_BENCH_B", "32")), 3   # C3D_BENCH_B=1 C3D_BENCH_DIV=16: tiny launches (fixed costs, under rocprofv3)
+DIV = int(os.environ.get("C3D_BENCH_DIV", "1"))
 DT = torch.bfloat16
 dt = ops.dt_code(DT)
 # (stage, H(in), Cin, Ci, Co) for identity blocks; block 0 has stride 2 from H*2
-STAGES = [(1, 128, 24, 54, 24), (2, 64, 48, 108, 48), (3, 32, 96, 216, 96)]
+STAGES = [(1, 128 // DIV, 24, 54, 24), (2, 64 // DIV, 48, 108, 48), (3, 32 // DIV, 96, 216, 96)]
 
 
 def timeit(fn, iters=20):
