@@ -1531,10 +1531,11 @@ int launch_bwd_data_t(const void* t1, const void* bb, const float* cA, const flo
   }
   const int ntiles = ((g.W + TW - 1) / TW) * ((g.H + TH - 1) / TH);
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
-  // walk length: enough workgroups to fill the chip a few times over, tiles to amortise the prologue
+  // walk length: long enough to amortise the prologue and pipeline the loads, short enough for ~2 workgroups per CU
   static const int env_tpw = getenv("C3D_DWBD_TPW") ? atoi(getenv("C3D_DWBD_TPW")) : 0;
-  int tpw = env_tpw > 0 ? env_tpw : 16;
-  while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 4L * device_cus()) tpw >>= 1;
+  int tpw = 16;   // measured best: 16 / 16 / 8 tiles for the 128x128 / 64x64 / 32x32 stages (~2 workgroups per CU)
+  while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 7L * device_cus() / 4) tpw >>= 1;
+  if (env_tpw > 0) tpw = env_tpw;
   if (tpw > ntiles) tpw = ntiles;
   dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
   dw_bwd_data_kernel<T, S, TH, TW, TT><<<grid, dim3(NTHR), lds, stream>>>(
