@@ -240,6 +240,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    t_enqueued = time.perf_counter() - t0   # host time to launch everything (includes the loss read-backs)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -266,7 +267,8 @@ def main():
                                f"pairs, T={5 if scd else 3}, train step (fwd+{'0.5*CE+BCE/Dice+ChangeSimilarity' if scd else 'BCE/Dice'}"
                                f"+bwd+Adam)",
                    "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                   "hip_graph": graph is not None, "final_loss": round(final_loss, 5)},
+                   "hip_graph": graph is not None, "final_loss": round(final_loss, 5),
+                   "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3)},
         "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_sample": bytes_per_sample,
                           "achieved": round(value / world * bytes_per_sample / 1e9, 1), "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": round(value / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4)},

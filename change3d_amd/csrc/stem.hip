@@ -86,26 +86,35 @@ template <typename T>
 __global__ __launch_bounds__(ST_THREADS) void stem_fwd_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ w_t,
                                                               const float* __restrict__ w_xy, T* __restrict__ u,
-                                                              double* __restrict__ sums, const StemGeom g) {
+                                                              double* __restrict__ sums, const StemGeom g,
+                                                              const int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* wt = sm;                    // [27][24]
   float* wxy = wt + 27 * ST_C;       // [5][24]
   float* red = wxy + 5 * ST_C;       // [6 waves][3][16]
   float* xt = red + 6 * 3 * 16;      // [3][T][IH][IW]
   const int tid = threadIdx.x;
-  const int tiles_x = (g.W + ST_TW - 1) / ST_TW;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int tiles_x = (g.W + ST_TW - 1) / ST_TW, tiles_y = (g.H + ST_TH - 1) / ST_TH;
+  const int ntiles = tiles_x * tiles_y;
+  const int b = blockIdx.y;
   stage_weights(wt, wxy, w_t, w_xy, tid, ST_THREADS);
-  load_x_tile(xt, x, g, b, ty * ST_TH, tx * ST_TW, tid, ST_THREADS);
-  __syncthreads();
   const int cv = tid % 3, pix = tid / 3;
   const int px = pix % ST_TW, py = pix / ST_TW;
-  const int gy = ty * ST_TH + py, gx = tx * ST_TW + px;
-  float v[ST_MAXT][8];
-  spatial_conv(v, xt, wt, g.T, py, px, cv);
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  // a workgroup walks `tiles_per_wg` tiles and flushes the BN statistics once (one tile per workgroup
+  // meant 16 k workgroups x 48 same-address f64 atomics per step)
+  const int tl0 = blockIdx.x * tiles_per_wg;
+  const int tl1 = tl0 + tiles_per_wg < ntiles ? tl0 + tiles_per_wg : ntiles;
+  for (int tl = tl0; tl < tl1; ++tl) {
+  const int tx = tl % tiles_x, ty = tl / tiles_x;
+  __syncthreads();   // the previous tile's x rows are no longer read (and the weights are staged)
+  load_x_tile(xt, x, g, b, ty * ST_TH, tx * ST_TW, tid, ST_THREADS);
+  __syncthreads();
+  const int gy = ty * ST_TH + py, gx = tx * ST_TW + px;
+  float v[ST_MAXT][8];
+  spatial_conv(v, xt, wt, g.T, py, px, cv);
   const bool ok = gy < g.H && gx < g.W;
 #pragma unroll
   for (int t = 0; t < ST_MAXT; ++t) {
@@ -128,6 +137,7 @@ __global__ __launch_bounds__(ST_THREADS) void stem_fwd_kernel(const float* __res
       }
     }
   }
+  }  // tile walk
   if (!sums) return;
   // cv = tid % 3 is not lane-periodic in a wave (64 % 3 != 0): reduce through LDS atomics.  The
   // partial sums go in as 2^-40 fixed point: integer adds are associative, so the result does not
@@ -399,12 +409,15 @@ extern "C" int c3d_stem_fwd(const float* x, const float* w_t, const float* w_xy,
   if (!x || !w_t || !w_xy || !u || B <= 0 || T <= 0 || T > ST_MAXT || H <= 0 || W <= 0) return C3D_E_BADARG;
   StemGeom g{B, T, H, W};
   const size_t lds = (27 * ST_C + 5 * ST_C + 6 * 3 * 16 + (size_t)ST_CI * T * ST_IH * ST_IW) * sizeof(float);
-  dim3 grid(((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH), B);
+  const int ntiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
+  int tpw = 16;
+  while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * B < 1024) tpw >>= 1;   // keep ~4 workgroups per CU
+  dim3 grid((ntiles + tpw - 1) / tpw, B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == C3D_DT_F32)
-    stem_fwd_kernel<float><<<grid, ST_THREADS, lds, s>>>(x, w_t, w_xy, (float*)u, sums, g);
+    stem_fwd_kernel<float><<<grid, ST_THREADS, lds, s>>>(x, w_t, w_xy, (float*)u, sums, g, tpw);
   else if (dtype == C3D_DT_BF16)
-    stem_fwd_kernel<bf16_t><<<grid, ST_THREADS, lds, s>>>(x, w_t, w_xy, (bf16_t*)u, sums, g);
+    stem_fwd_kernel<bf16_t><<<grid, ST_THREADS, lds, s>>>(x, w_t, w_xy, (bf16_t*)u, sums, g, tpw);
   else return C3D_E_BADARG;
   C3D_CHECK_LAUNCH();
   return 0;
