@@ -749,9 +749,10 @@ template <int S, int TH, int TW, int TT> struct WgDma {
   static constexpr int A_BYTES = NA_I * 1024, D_BYTES = ND_I * 1024;
   static constexpr int SINK_OFF = A_BYTES + 2 * D_BYTES;
   static constexpr int SLOT_BYTES = SINK_OFF + 1024;
-  static constexpr int NSLOT = 3;
   static constexpr int MAXB = 8;  // samples one workgroup walk may touch (their coefB rows sit in LDS)
   static constexpr int FIXED_BYTES = (27 * 32 + MAXB * 32) * 4;
+  // three slots (two tiles in flight ahead of the consumers) when they fit, else two (T = 5: 73 KB slots)
+  static constexpr int NSLOT = FIXED_BYTES + 3 * SLOT_BYTES <= 160 * 1024 ? 3 : 2;
   static constexpr int LDS_BYTES = FIXED_BYTES + NSLOT * SLOT_BYTES;
   static_assert(NI <= 63, "vmcnt is a 6-bit counter");
 };
@@ -914,18 +915,20 @@ __global__ __launch_bounds__(TH * TW * DW_CV * 3 + DW_LOADERS) void dw_wgrad_dma
       }
     };
 
+    constexpr int AH = G::NSLOT - 1;   // tiles whose DMA is issued ahead of the tile being consumed
     if (nit > 0) issue(item0, 0);
-    if (nit > 1) issue(item0 + 1, 1);
+    if (AH > 1 && nit > 1) issue(item0 + 1, 1);
     if (nit > 0) {
-      if (nit > 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::NI) : "memory");
+      if (AH > 1 && nit > 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::NI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       convert(item0, 0);
     }
     wg_barrier_raw();
     for (int it = 0; it < nit; ++it) {
-      if (it + 2 < nit) issue(item0 + it + 2, (it + 2) % G::NSLOT);
+      // slot (it + AH) % NSLOT was consumed in pass it - 1
+      if (it + AH < nit) issue(item0 + it + AH, (it + AH) % G::NSLOT);
       if (it + 1 < nit) {
-        if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::NI) : "memory");
+        if (AH > 1 && it + AH < nit) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::NI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         convert(item0 + it + 1, (it + 1) % G::NSLOT);
       }
@@ -1589,14 +1592,14 @@ int launch_wgrad(const void* t1, const void* bb, const float* cA, const float* c
   return 0;
 }
 
-// bf16, T = 3: LDS-DMA producer.  Returns C3D_E_UNSUPPORTED when the geometry does not fit (the
-// caller then uses the register-staged kernel).
-template <int S>
-int launch_wgrad_dma(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const void* a,
-                     const float* ss_a, float* dw, const DwGeom& g, hipStream_t stream) {
+// bf16, T = 3 (three slots) or T = 5 (two slots): LDS-DMA producer.  Returns C3D_E_UNSUPPORTED when the
+// geometry does not fit (the caller then uses the register-staged kernel).
+template <int S, int TT>
+int launch_wgrad_dma_t(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const void* a,
+                       const float* ss_a, float* dw, const DwGeom& g, hipStream_t stream) {
   constexpr int TH = DwTile<bf16_t, S>::TH, TW = DwTile<bf16_t, S>::TW;
-  typedef WgDma<S, TH, TW, 3> G;
-  if (g.T != 3 || G::LDS_BYTES > 160 * 1024) return C3D_E_UNSUPPORTED;
+  typedef WgDma<S, TH, TW, TT> G;
+  if (g.T != TT || G::LDS_BYTES > 160 * 1024) return C3D_E_UNSUPPORTED;
   const int ntiles = ((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH);
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
   const long items = (long)g.B * ntiles;
@@ -1609,17 +1612,25 @@ int launch_wgrad_dma(const void* t1, const void* bb, const float* cA, const floa
   if ((ipw + ntiles - 2) / ntiles + 1 > G::MAXB) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_dma_kernel<S, TH, TW, 3>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_dma_kernel<S, TH, TW, TT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   dim3 grid(chunk_order_grid(chunks, (items + ipw - 1) / ipw));
-  dw_wgrad_dma_kernel<S, TH, TW, 3><<<grid, dim3(G::NCOMP + DW_LOADERS), G::LDS_BYTES, stream>>>(
+  dw_wgrad_dma_kernel<S, TH, TW, TT><<<grid, dim3(G::NCOMP + DW_LOADERS), G::LDS_BYTES, stream>>>(
       reinterpret_cast<const bf16_t*>(t1), reinterpret_cast<const bf16_t*>(bb), cA, cB, cC,
       reinterpret_cast<const bf16_t*>(a), ss_a, dw, g, (int)ipw);
   C3D_CHECK_LAUNCH();
   return 0;
+}
+
+template <int S>
+int launch_wgrad_dma(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const void* a,
+                     const float* ss_a, float* dw, const DwGeom& g, hipStream_t stream) {
+  if (g.T == 3) return launch_wgrad_dma_t<S, 3>(t1, bb, cA, cB, cC, a, ss_a, dw, g, stream);
+  if (g.T == 5) return launch_wgrad_dma_t<S, 5>(t1, bb, cA, cB, cC, a, ss_a, dw, g, stream);
+  return C3D_E_UNSUPPORTED;
 }
 
 bool geom_ok(const DwGeom& g) {
