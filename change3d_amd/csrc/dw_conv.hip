@@ -274,9 +274,11 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
     }
     cf[i] = v;
   }
-  float s1[8], s2[8];
+  // BN_a-backward sums (sum t2, sum t2*ahat): f32 within a tile, f64 across the walk -- the two terms
+  // nearly cancel on some channels and a long f32 chain cost 1-2 digits of d gamma there
+  double S1[8], S2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) { S1[j] = 0.0; S2[j] = 0.0; }
 
   typename RW::type r1[SL], r2[SL];
   unsigned vmask = 0;
@@ -388,6 +390,9 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
       }
     }
     if (p_ok) {
+      float s1[8], s2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
       float sa[8], sb[8], ma[8], ra[8];
       lds_ld8(cf + 3 * 32 + cv * 8, sa);
       lds_ld8(cf + 4 * 32 + cv * 8, sb);
@@ -409,32 +414,36 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
           Vec8<T>::store(t2 + off, o);
         }
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { S1[j] += (double)s1[j]; S2[j] += (double)s2[j]; }
     }
   }
 #undef BD_ISSUE
   const int lane = tid & 63, wave = tid >> 6;
+  double* red64 = reinterpret_cast<double*>(tile);   // [waves][DW_CV][16]; the tile is dead now
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
 #pragma unroll
     for (int o = DW_CV; o < 64; o <<= 1) {
-      s1[j] += __shfl_xor(s1[j], o, 64);
-      s2[j] += __shfl_xor(s2[j], o, 64);
+      S1[j] += __shfl_xor(S1[j], o, 64);
+      S2[j] += __shfl_xor(S2[j], o, 64);
     }
   }
   if (lane < DW_CV) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      red[(wave * DW_CV + lane) * 16 + j] = s1[j];
-      red[(wave * DW_CV + lane) * 16 + 8 + j] = s2[j];
+      red64[(wave * DW_CV + lane) * 16 + j] = S1[j];
+      red64[(wave * DW_CV + lane) * 16 + 8 + j] = S2[j];
     }
   }
   __syncthreads();
   if (tid < DW_CV * 16) {
     const int v = tid / 16, k = tid & 15;
-    float s = 0.f;
-    for (int wv = 0; wv < NTHR / 64; ++wv) s += red[(wv * DW_CV + v) * 16 + k];
+    double sacc = 0.0;
+    for (int wv = 0; wv < NTHR / 64; ++wv) sacc += red64[(wv * DW_CV + v) * 16 + k];
     const int c = c0 + v * 8 + (k & 7);
-    if (c < g.C) atomicAdd(dsums + (size_t)(k >> 3) * g.C + c, (double)s);
+    if (c < g.C) atomicAdd(dsums + (size_t)(k >> 3) * g.C + c, sacc);
   }
 }
 
