@@ -99,25 +99,21 @@ PROFILE_DETAIL = False  # profile keys carry the GEMM shape/mode (tools/profile_
 SIDE_STREAM = os.environ.get("C3D_WGRAD_SIDE", "1") != "0"
 _side_streams = {}
 _side_pending = []      # (seq, done_event, tensors kept alive until the event has been waited for)
-_side_state = {"seq": 0, "cb": False}
-
-
-def _side_end_of_backward():
-    _side_state["cb"] = False
-    side_join()
+_side_state = {"seq": 0}
 
 
 def side_run(fn, *tensors):
     """Run `fn` (kernel launches) on the side stream after everything issued so far on the current
-    stream.  Only inside an autograd backward pass (that is where the join callback can be queued);
-    anywhere else `fn` runs inline."""
-    if SIDE_STREAM and not _side_state["cb"]:
+    stream.  Only inside an autograd backward pass (that is where the join callback can be queued: one
+    per call, joining is idempotent); anywhere else `fn` runs inline."""
+    in_backward = False
+    if SIDE_STREAM:
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(_side_end_of_backward)
-            _side_state["cb"] = True
+            torch.autograd.Variable._execution_engine.queue_callback(side_join)
+            in_backward = True
         except RuntimeError:
             pass
-    if not (SIDE_STREAM and _side_state["cb"]):
+    if not in_backward:
         fn()
         return
     dev = torch.cuda.current_device()
