@@ -82,10 +82,10 @@ __device__ __forceinline__ void lds_ld8(const float* p, float (&f)[8]) {
 
 // ----------------------------------------------------------------------------------------------
 // Forward.  grid = (tiles_x*tiles_y, channel chunks, B); block = TH*TW*DW_CV threads.
-template <typename T, int S, int TH, int TW>
+template <typename T, int S, int TH, int TW, int TT>
 __global__ __launch_bounds__(TH * TW * DW_CV) void dw_fwd_kernel(
     const T* __restrict__ x, const float* __restrict__ ss, const float* __restrict__ w, T* __restrict__ y,
-    double* __restrict__ nc, const DwGeom g) {
+    double* __restrict__ nc, const DwGeom g, const int tiles_per_wg) {
   typedef typename LdsStore<T>::type L;
   constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
   constexpr int NTHR = TH * TW * DW_CV;
@@ -95,9 +95,12 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_fwd_kernel(
   L* tile = reinterpret_cast<L*>(red + (NTHR / 64) * DW_CV * 16);     // [T][IH][IW][32]
 
   const int tid = threadIdx.x;
-  const int tiles_x = (g.Wo + TW - 1) / TW;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int tiles_x = (g.Wo + TW - 1) / TW, tiles_y = (g.Ho + TH - 1) / TH;
+  const int ntiles = tiles_x * tiles_y;
+  const int gx_ = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
+  const ChunkOrder co = chunk_order((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), gx_ * g.B);
+  if (co.group < 0) return;
+  const int chunk = co.chunk, b = co.group / gx_, tg = co.group % gx_;
   const int c0 = chunk * DW_CV * 8;
   const int cv = tid % DW_CV;
   const int cbase = c0 + cv * 8;
@@ -112,6 +115,17 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_fwd_kernel(
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sc[j] = c_ok ? ss[cbase + j] : 0.f; sh[j] = c_ok ? ss[g.Cp + cbase + j] : 0.f; }
 
+  // a workgroup walks `tiles_per_wg` tiles (one statistics flush; TT sizes the accumulators)
+  const int pix = tid / DW_CV;
+  const int px = pix % TW, py = pix / TW;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const int tl0 = tg * tiles_per_wg;
+  const int tl1 = tl0 + tiles_per_wg < ntiles ? tl0 + tiles_per_wg : ntiles;
+  for (int tl = tl0; tl < tl1; ++tl) {
+  const int tx = tl % tiles_x, ty = tl / tiles_x;
+  __syncthreads();   // previous tile consumed (and the weights are staged)
   // input tile (all T frames) with the BN+ReLU prologue; zero outside the image
   const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
   const int items = g.T * IH * IW * DW_CV;
@@ -134,14 +148,12 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_fwd_kernel(
   }
   __syncthreads();
 
-  const int pix = tid / DW_CV;
-  const int px = pix % TW, py = pix / TW;
   const int oy = ty * TH + py, ox = tx * TW + px;
   const bool p_ok = c_ok && oy < g.Ho && ox < g.Wo;
 
-  float acc[DW_MAXT][8];
+  float acc[TT][8];
 #pragma unroll
-  for (int t = 0; t < DW_MAXT; ++t)
+  for (int t = 0; t < TT; ++t)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
 
@@ -158,14 +170,14 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_fwd_kernel(
         wk[kt][4] = w1.x; wk[kt][5] = w1.y; wk[kt][6] = w1.z; wk[kt][7] = w1.w;
       }
 #pragma unroll
-      for (int ti = 0; ti < DW_MAXT; ++ti) {
+      for (int ti = 0; ti < TT; ++ti) {
         if (ti < g.T) {
           float v[8];
           Vec8<L>::load(tile + ((size_t)(ti * IH + py * S + ky) * IW + px * S + kx) * 32 + cv * 8, v);
 #pragma unroll
           for (int kt = 0; kt < 3; ++kt) {
             const int to = ti - kt + 1;  // out[to] += in[to + kt - 1] * w[kt]
-            if (to >= 0 && to < DW_MAXT && to < g.T) {
+            if (to >= 0 && to < TT && to < g.T) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) acc[to][j] = fmaf(v[j], wk[kt][j], acc[to][j]);
             }
@@ -175,12 +187,9 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_fwd_kernel(
     }
   }
 
-  float s1[8], s2[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   if (p_ok) {
 #pragma unroll
-    for (int t = 0; t < DW_MAXT; ++t) {
+    for (int t = 0; t < TT; ++t) {
       if (t < g.T) {
         Vec8<T>::store(y + ((((size_t)b * g.T + t) * g.Ho + oy) * g.Wo + ox) * g.Cp + cbase, acc[t]);
 #pragma unroll
@@ -191,6 +200,7 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_fwd_kernel(
       }
     }
   }
+  }  // tile walk
   if (nc == nullptr) return;
   // reduce over the pixels of the workgroup: lanes with equal cv inside a wave, then across waves
   const int lane = tid & 63, wave = tid >> 6;
@@ -1502,9 +1512,9 @@ template <typename T, int S> struct DwTile;  // forward / wgrad output tile per 
 template <typename T> struct DwTile<T, 1> { static constexpr int TH = 8, TW = 8; };
 template <typename T> struct DwTile<T, 2> { static constexpr int TH = 4, TW = 8; };
 
-template <typename T, int S>
-int launch_fwd(const void* x, const float* ss, const float* w, void* y, double* nc, const DwGeom& g,
-               hipStream_t stream) {
+template <typename T, int S, int TT>
+int launch_fwd_t(const void* x, const float* ss, const float* w, void* y, double* nc, const DwGeom& g,
+                 hipStream_t stream) {
   constexpr int TH = DwTile<T, S>::TH, TW = DwTile<T, S>::TW;
   constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, NTHR = TH * TW * DW_CV;
   const size_t lds = (27 * 32 + (NTHR / 64) * DW_CV * 16) * sizeof(float) +
@@ -1512,16 +1522,30 @@ int launch_fwd(const void* x, const float* ss, const float* w, void* y, double* 
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_kernel<T, S, TH, TW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_kernel<T, S, TH, TW, TT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  dim3 grid(((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH), (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), g.B);
-  dw_fwd_kernel<T, S, TH, TW><<<grid, dim3(NTHR), lds, stream>>>(
-      reinterpret_cast<const T*>(x), ss, w, reinterpret_cast<T*>(y), nc, g);
+  const int ntiles = ((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH);
+  const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
+  static const int env_tpw = getenv("C3D_DWF1_TPW") ? atoi(getenv("C3D_DWF1_TPW")) : 0;
+  int tpw = 8;   // no prefetch in this kernel: the walk only amortises the weight staging and the statistics flush
+  while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 2L * device_cus()) tpw >>= 1;   // swept: 8 is best
+  if (env_tpw > 0) tpw = env_tpw;
+  if (tpw > ntiles) tpw = ntiles;
+  dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
+  dw_fwd_kernel<T, S, TH, TW, TT><<<grid, dim3(NTHR), lds, stream>>>(
+      reinterpret_cast<const T*>(x), ss, w, reinterpret_cast<T*>(y), nc, g, tpw);
   C3D_CHECK_LAUNCH();
   return 0;
+}
+
+template <typename T, int S>
+int launch_fwd(const void* x, const float* ss, const float* w, void* y, double* nc, const DwGeom& g,
+               hipStream_t stream) {
+  if (g.T <= 3) return launch_fwd_t<T, S, 3>(x, ss, w, y, nc, g, stream);
+  return launch_fwd_t<T, S, 5>(x, ss, w, y, nc, g, stream);
 }
 
 template <typename T, int S, int TT>

@@ -100,3 +100,20 @@ if __name__ == "__main__":
         pw_family()
     if "dw" in fams:
         dw_family()
+
+
+def dw_stride2_family():
+    """First block of each stage: stride-2 depthwise conv on the previous stage's resolution."""
+    for st, H, Ci in [(1, 256 // DIV, 54), (2, 128 // DIV, 108), (3, 64 // DIV, 216)]:
+        Cip = ops.cpad(Ci)
+        a_ = rt(B, T, H, H, Cip)
+        b_ = rt(B, T, H // 2, H // 2, Cip)
+        w = torch.randn(Ci, 27, device=DEV) * 0.1
+        ss = torch.rand(2 * Cip, device=DEV)
+        nc = torch.zeros(B * Cip * 2, dtype=torch.float64, device=DEV)
+        us = timeit(lambda: ops.dw_fwd(a_, ss, w, b_, nc, B, T, H, H, Ci, 2, dt), iters=10)
+        report(f"s{st} dw fwd stride 2 C={Ci} {H}x{H}", us, (a_.numel() + b_.numel()) * 2)
+
+
+if "dws2" in sys.argv[1:]:
+    dw_stride2_family()
