@@ -460,6 +460,7 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
 // Asynchronous LDS vector read of 8 tile elements with an explicit wait, for hand-pipelined
 // inner loops (inline asm: the wait names the destination so its consumers cannot move above it).
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 template <typename P> __device__ __forceinline__ uint32_t lds_addr(const P* p) {
   return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));
 }
@@ -973,6 +974,330 @@ __global__ __launch_bounds__(TH * TW * DW_CV * 3 + DW_LOADERS) void dw_wgrad_dma
       wg_barrier_raw();
     }
     wgrad_reduce_to_lds(acc, red, kt, tid & 63);
+    wg_barrier_raw();
+    for (int i = tid; i < 27 * 32; i += NCOMP) {
+      const int tap = i / 32, c = c0 + (i & 31);
+      if (c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, red[i]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Weight gradient, bf16, stride 1, T = 3: LDS-DMA producer + v_dot2c consumer.
+// In the kernel above 53 % of the consumer's VALU time is bf16->f32 unpacking (integer ops run at half
+// the f32 FMA rate).  The reduction of this kernel runs over PIXELS, so two output pixels (y, y+4) of a
+// tile are paired: with (db[y], db[y+4]) and (a[r], a[r+4]) packed per channel as bf16 pairs,
+//     acc[tap][c] = v_dot2c_f32_bf16(acc, dpair[c], apair[c])      -- two MACs, no conversion --
+// and the consumer needs half the threads (6 waves).  The DMA makes the pairing free: lane L < 32 of a
+// wave-instruction loads the vector of row r, lane L + 32 the vector of row r + 4 of the SAME item, so
+// both partners are landed by one wave (its own vmcnt covers them) 512 B apart; the in-place pass
+// converts 4 channels of both rows per lane and writes the packed pairs over its own raw vector.
+// Item = (frame, row r < 6 | y < 4, column, channel vector); an item occupies 16 B in each half
+// of its wave-instruction's KB:  [instr][half][32 items] -- consecutive items are 16 B apart, so the
+// consumer's two b128 reads per operand are conflict free.
+constexpr int D2_TH = 8, D2_TW = 8, D2_IW = D2_TW + 2, D2_AR = D2_TH / 2 + 2, D2_DR = D2_TH / 2;   // 6 a-rows, 4 d-rows
+constexpr int D2_LOADERS = 512;   // 8 producer waves: with 6 consumer waves the in-place conversion is the longer job
+template <int TT> struct WgDot2 {
+  static constexpr int NCOMP = D2_DR * D2_TW * DW_CV * 3;                 // 384 consumer threads
+  static constexpr int NLW = D2_LOADERS / 64;
+  static constexpr int NA_IT = TT * D2_AR * D2_IW * DW_CV, ND_IT = TT * D2_DR * D2_TW * DW_CV;   // items
+  static constexpr int NA_I = (NA_IT + 31) / 32, ND_I = (ND_IT + 31) / 32;                      // wave-instructions
+  static constexpr int NA_W = (NA_I + NLW - 1) / NLW, ND_W = (ND_I + NLW - 1) / NLW;
+  static constexpr int NI = NA_W + 2 * ND_W;
+  static constexpr int A_BYTES = NA_I * 1024, D_BYTES = ND_I * 1024;
+  static constexpr int SINK_OFF = A_BYTES + 2 * D_BYTES;
+  static constexpr int SLOT_BYTES = SINK_OFF + 1024;
+  static constexpr int NSLOT = 3;
+  static constexpr int MAXB = 8;
+  static constexpr int FIXED_BYTES = (27 * 32 + MAXB * 32) * 4;
+  static constexpr int LDS_BYTES = FIXED_BYTES + NSLOT * SLOT_BYTES;
+  static_assert(NI <= 63, "vmcnt is a 6-bit counter");
+};
+
+__device__ __forceinline__ uint32_t d2_item_off(const int item) {   // byte offset of an item's half 0 in its region
+  return (uint32_t)((item >> 5) * 1024 + (item & 31) * 16);
+}
+
+template <int TT>
+__global__ __launch_bounds__(WgDot2<TT>::NCOMP + D2_LOADERS) void dw_wgrad_dot2_kernel(
+    const bf16_t* __restrict__ t1, const bf16_t* __restrict__ bb, const float* __restrict__ coefA,
+    const float* __restrict__ coefB, const float* __restrict__ coefC, const bf16_t* __restrict__ a,
+    const float* __restrict__ ss_a, float* __restrict__ dw, const DwGeom g, const int items_per_wg) {
+  typedef WgDot2<TT> G;
+  constexpr int NCOMP = G::NCOMP;
+  typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);   // [27][32] workgroup accumulator
+  float* cbs = red + 27 * 32;                    // [MAXB][32] per-sample coefB rows of this chunk
+  unsigned char* slots = smem + G::FIXED_BYTES;
+
+  const int tid = threadIdx.x;
+  const int tiles_x = (g.Wo + D2_TW - 1) / D2_TW, tiles_y = (g.Ho + D2_TH - 1) / D2_TH;
+  const int ntiles = tiles_x * tiles_y;
+  const int n_wg_items = (g.B * ntiles + items_per_wg - 1) / items_per_wg;
+  const ChunkOrder co = chunk_order((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), n_wg_items);
+  if (co.group < 0) return;
+  const int c0 = co.chunk * DW_CV * 8;
+  const int item0 = co.group * items_per_wg;
+  int item1 = item0 + items_per_wg;
+  if (item1 > g.B * ntiles) item1 = g.B * ntiles;
+  const int nit = item1 - item0;
+  const int b0 = item0 / ntiles;
+  const int nb = nit > 0 ? (item1 - 1) / ntiles - b0 + 1 : 0;
+  for (int i = tid; i < 27 * 32; i += NCOMP + D2_LOADERS) red[i] = 0.f;
+  for (int i = tid; i < nb * 32; i += NCOMP + D2_LOADERS) {
+    const int c = c0 + (i & 31);
+    cbs[i] = c < g.Cp ? coefB[(size_t)(b0 + (i >> 5)) * g.Cp + c] : 0.f;
+  }
+  wg_barrier_raw();
+
+  if (tid >= NCOMP) {
+    // ------------------------------- producer waves -------------------------------------------
+    const int lane = tid & 63;
+    const int lw = (tid - NCOMP) >> 6;
+    const int hl = lane >> 5, li = lane & 31;     // half (row r / row r+4 partner), item within the instruction
+    const int cv = li & (DW_CV - 1);              // item = instr*32 + li, so cv = li % 4
+    const int cbase = c0 + cv * 8;
+    const bool c_ok = cbase < g.Cp;
+    const int cb_ld = c_ok ? cbase : c0;
+    const int ch0 = hl * 4;                       // this lane converts channels [ch0, ch0+4) of both rows
+    float sa[4], sb[4], cA[4], cC[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sa[j] = c_ok ? ss_a[cbase + ch0 + j] : 0.f; sb[j] = c_ok ? ss_a[g.Cp + cbase + ch0 + j] : 0.f;
+      cA[j] = c_ok ? coefA[cbase + ch0 + j] : 0.f; cC[j] = c_ok ? coefC[cbase + ch0 + j] : 0.f;
+    }
+    float cB[4];
+    int cur_b = -1;
+
+    // Tile-independent part of this lane's units, decoded ONCE: pixel offset relative to the tile origin
+    // (frame, row incl. the +4 of the partner half, column) and a packed (row, column, real) word for
+    // the conversion's in-image tests.  Per tile the DMA source is then one add and ONE clamp of the
+    // pixel index: halo positions outside the image may be fetched from any valid address, the
+    // conversion overwrites them with zeros.  (Decoding per tile cost ~40 integer VALU per unit and the
+    // eight producer waves, not the six consumer waves, set the pace.)
+    int relA[G::NA_W], codeA[G::NA_W], relD[G::ND_W], codeD[G::ND_W];
+#pragma unroll
+    for (int r_ = 0; r_ < G::NA_W; ++r_) {
+      const int q = lw + G::NLW * r_;
+      int it = q * 32 + li;
+      const bool real = q < G::NA_I && it < G::NA_IT;
+      if (it > G::NA_IT - 1) it = G::NA_IT - 1;
+      const int p = it / DW_CV;
+      const int ix = p % D2_IW, qq = p / D2_IW;
+      const int rr = qq % D2_AR, t = qq / D2_AR;
+      relA[r_] = (t * g.H + rr + 4 * hl) * g.W + ix;
+      codeA[r_] = rr | (ix << 8) | (real ? (1 << 30) : 0);
+    }
+#pragma unroll
+    for (int r_ = 0; r_ < G::ND_W; ++r_) {
+      const int q = lw + G::NLW * r_;
+      int it = q * 32 + li;
+      const bool real = q < G::ND_I && it < G::ND_IT;
+      if (it > G::ND_IT - 1) it = G::ND_IT - 1;
+      const int p = it / DW_CV;
+      const int ox = p % D2_TW, qq = p / D2_TW;
+      const int yy = qq % D2_DR, t = qq / D2_DR;
+      relD[r_] = (t * g.Ho + yy + 4 * hl) * g.Wo + ox;
+      codeD[r_] = yy | (ox << 8) | (real ? (1 << 30) : 0);
+    }
+    const int npix_a = g.B * g.T * g.H * g.W - 1, npix_d = g.B * g.T * g.Ho * g.Wo - 1;
+
+    auto issue = [&](const int item, const int slot) {
+      unsigned char* sl = slots + slot * G::SLOT_BYTES;
+      const int b = item / ntiles, tl = item - b * ntiles;
+      const int tx = tl % tiles_x, ty = tl / tiles_x;
+      const int oA = (b * g.T * g.H + ty * D2_TH - 1) * g.W + tx * D2_TW - 1;
+      const int oD = (b * g.T * g.Ho + ty * D2_TH) * g.Wo + tx * D2_TW;
+#pragma unroll
+      for (int r_ = 0; r_ < G::NA_W; ++r_) {
+        const int q = lw + G::NLW * r_;
+        unsigned char* dst = sl + (q < G::NA_I ? q * 1024 : G::SINK_OFF);
+        int rel = relA[r_];
+        asm volatile("" : "+v"(rel));
+        int pix = oA + rel;
+        pix = pix < 0 ? 0 : (pix > npix_a ? npix_a : pix);
+        const bf16_t* src = a + (size_t)pix * g.Cp + cb_ld;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+      }
+#pragma unroll
+      for (int r_ = 0; r_ < G::ND_W; ++r_) {
+        const int q = lw + G::NLW * r_;
+        unsigned char* dst = sl + (q < G::ND_I ? G::A_BYTES + q * 1024 : G::SINK_OFF);
+        unsigned char* dst2 = sl + (q < G::ND_I ? G::A_BYTES + G::D_BYTES + q * 1024 : G::SINK_OFF);
+        int rel = relD[r_];
+        asm volatile("" : "+v"(rel));
+        int pix = oD + rel;
+        pix = pix < 0 ? 0 : (pix > npix_d ? npix_d : pix);
+        const size_t off = (size_t)pix * g.Cp + cb_ld;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(t1 + off), (lds_ptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(bb + off), (lds_ptr_t)dst2, 16, 0, 0);
+      }
+    };
+
+    // 4 channels [ch0, ch0+4) of a raw 8-channel bf16 vector
+    auto up4 = [&](const u32x2_t v, float (&f)[4]) {
+      f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
+      f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
+    };
+
+    auto convert = [&](const int item, const int slot) {
+      const uint32_t sl = lds_addr(slots + slot * G::SLOT_BYTES);
+      const int b = item / ntiles, tl = item - b * ntiles;
+      const int tx = tl % tiles_x, ty = tl / tiles_x;
+      const int iy0 = ty * D2_TH - 1, ix0 = tx * D2_TW - 1;
+      if (b != cur_b) {  // wave-uniform
+        LdsVec<float>::raw_t r;
+        LdsVec<float>::issue(r, lds_addr(cbs + (b - b0) * 32 + cv * 8));
+        LdsVec<float>::template wait<0>(r);
+        float c8[8];
+        LdsVec<float>::cvt(r, c8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cB[j] = hl ? c8[4 + j] : c8[j];
+        cur_b = b;
+      }
+#pragma unroll
+      for (int r_ = 0; r_ < G::NA_W; ++r_) {
+        const int q = lw + G::NLW * r_;
+        int cd = codeA[r_];
+        asm volatile("" : "+v"(cd));
+        if (cd & (1 << 30)) {
+          const int rr = cd & 255, ix = (cd >> 8) & 255;
+          const int gx = ix0 + ix, gy0 = iy0 + rr, gy1 = gy0 + 4;
+          const bool okx = c_ok && gx >= 0 && gx < g.W;
+          const bool ok0 = okx && gy0 >= 0 && gy0 < g.H, ok1 = okx && gy1 >= 0 && gy1 < g.H;
+          const uint32_t base = sl + (uint32_t)(q * 1024 + li * 16);   // half 0 (row r); half 1 (row r+4) at +512
+          u32x2_t w0, w1;   // row r, row r+4 (both landed by this wave)
+          asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(w0), "=&v"(w1) : "v"(base + (uint32_t)(ch0 * 2)));
+          float f0[4], f1[4];
+          up4(w0, f0);
+          up4(w1, f1);
+          u32x4_t out;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            out[j] = pack_bf16x2(ok0 ? fmaxf(fmaf(f0[j], sa[j], sb[j]), 0.f) : 0.f,
+                                 ok1 ? fmaxf(fmaf(f1[j], sa[j], sb[j]), 0.f) : 0.f);
+          asm volatile("ds_write_b128 %0, %1" : : "v"(base + (uint32_t)(hl * 512)), "v"(out) : "memory");
+        }
+      }
+#pragma unroll
+      for (int r_ = 0; r_ < G::ND_W; ++r_) {
+        const int q = lw + G::NLW * r_;
+        int cd = codeD[r_];
+        asm volatile("" : "+v"(cd));
+        if (cd & (1 << 30)) {
+          const int yy = cd & 255, ox = (cd >> 8) & 255;
+          const int gx = tx * D2_TW + ox, gy0 = ty * D2_TH + yy, gy1 = gy0 + 4;
+          const bool okx = c_ok && gx < g.Wo;
+          const bool ok0 = okx && gy0 < g.Ho, ok1 = okx && gy1 < g.Ho;
+          const uint32_t base = sl + (uint32_t)(G::A_BYTES + q * 1024 + li * 16);
+          u32x2_t w0, w1, w2, w3;   // t1 row y, t1 row y+4, b row y, b row y+4
+          asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %5\n\t"
+                       "ds_read_b64 %3, %5 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+                       : "v"(base + (uint32_t)(ch0 * 2)), "v"(base + (uint32_t)(G::D_BYTES + ch0 * 2)));
+          float u0[4], u1[4], v0[4], v1[4];
+          up4(w0, u0);
+          up4(w1, u1);
+          up4(w2, v0);
+          up4(w3, v1);
+          u32x4_t out;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            out[j] = pack_bf16x2(ok0 ? fmaf(cA[j], u0[j], fmaf(cC[j], v0[j], cB[j])) : 0.f,
+                                 ok1 ? fmaf(cA[j], u1[j], fmaf(cC[j], v1[j], cB[j])) : 0.f);
+          asm volatile("ds_write_b128 %0, %1" : : "v"(base + (uint32_t)(hl * 512)), "v"(out) : "memory");
+        }
+      }
+    };
+
+    if (nit > 0) issue(item0, 0);
+    if (nit > 1) issue(item0 + 1, 1);
+    if (nit > 0) {
+      if (nit > 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::NI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      convert(item0, 0);
+    }
+    wg_barrier_raw();
+    for (int it = 0; it < nit; ++it) {
+      if (it + 2 < nit) issue(item0 + it + 2, (it + 2) % G::NSLOT);
+      if (it + 1 < nit) {
+        if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        convert(item0 + it + 1, (it + 1) % G::NSLOT);
+      }
+      wg_barrier_raw();
+    }
+    wg_barrier_raw();  // matches the consumers' flush barrier
+  } else {
+    // ------------------------------- consumer waves -------------------------------------------
+    // thread = (pixel pair (y, y+4; x), channel vector, temporal tap kt); acc[ky*3+kx][channel]
+    const int cv = tid % DW_CV;
+    const int pp = (tid / DW_CV) % (D2_DR * D2_TW);
+    const int kt = tid / (DW_CV * D2_DR * D2_TW);
+    const int px = pp % D2_TW, py = pp / D2_TW;
+    float acc[9][8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    wg_barrier_raw();
+    for (int it = 0; it < nit; ++it) {
+      const uint32_t sl = lds_addr(slots + (it % G::NSLOT) * G::SLOT_BYTES);
+#pragma unroll 1
+      for (int to = 0; to < TT; ++to) {
+        const int ti = to + kt - 1;
+        if (ti < 0 || ti >= TT) continue;
+        const uint32_t d_addr = sl + (uint32_t)G::A_BYTES + d2_item_off(((to * D2_DR + py) * D2_TW + px) * DW_CV + cv);
+        u32x4_t d0, d1;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(d0), "=&v"(d1) : "v"(d_addr));
+        u32x4_t r0[2], r1[2];
+        auto a_addr = [&](const int k) {
+          return sl + d2_item_off(((ti * D2_AR + py + k / 3) * D2_IW + px + k % 3) * DW_CV + cv);
+        };
+        {
+          const uint32_t ad = a_addr(0);
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:512" : "=&v"(r0[0]), "=&v"(r1[0]) : "v"(ad));
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          if (k < 8) {
+            const uint32_t ad = a_addr(k + 1);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:512"
+                         : "=&v"(r0[(k + 1) & 1]), "=&v"(r1[(k + 1) & 1]) : "v"(ad));
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r0[k & 1]), "+v"(r1[k & 1]));
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0[k & 1]), "+v"(r1[k & 1]));
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // (copy the elements out first: __builtin_bit_cast of a vector-element lvalue reads element 0)
+            const uint32_t dl = d0[j], dh = d1[j], al = r0[k & 1][j], ah = r1[k & 1][j];
+            acc[k][j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, dl), __builtin_bit_cast(bf2_t, al),
+                                                        acc[k][j], false);
+            acc[k][4 + j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, dh), __builtin_bit_cast(bf2_t, ah),
+                                                            acc[k][4 + j], false);
+          }
+          asm volatile("" : "+v"(acc[k][0]), "+v"(acc[k][1]), "+v"(acc[k][2]), "+v"(acc[k][3]),
+                       "+v"(acc[k][4]), "+v"(acc[k][5]), "+v"(acc[k][6]), "+v"(acc[k][7]));
+        }
+      }
+      wg_barrier_raw();
+    }
+    // reduce across the pixel pairs of each wave (lanes with equal cv; kt is wave-uniform: 128 threads per kt)
+    const int lane = tid & 63;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = acc[k][j];
+#pragma unroll
+        for (int o = DW_CV; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        if (lane < DW_CV) atomicAdd(&red[(kt * 9 + k) * 32 + lane * 8 + j], v);
+      }
+    }
     wg_barrier_raw();
     for (int i = tid; i < 27 * 32; i += NCOMP) {
       const int tap = i / 32, c = c0 + (i & 31);
@@ -1666,6 +1991,36 @@ int launch_wgrad_dma(const void* t1, const void* bb, const float* cA, const floa
   return C3D_E_UNSUPPORTED;
 }
 
+// bf16, stride 1, T = 3: pixel-paired v_dot2c consumer (see dw_wgrad_dot2_kernel).
+int launch_wgrad_dot2(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const void* a,
+                      const float* ss_a, float* dw, const DwGeom& g, hipStream_t stream) {
+  typedef WgDot2<3> G;
+  if (g.T != 3 || g.stride != 1 || G::LDS_BYTES > 160 * 1024) return C3D_E_UNSUPPORTED;
+  const int ntiles = ((g.Wo + D2_TW - 1) / D2_TW) * ((g.Ho + D2_TH - 1) / D2_TH);
+  const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
+  const long items = (long)g.B * ntiles;
+  static const int env_wgs = getenv("C3D_DWWG_WGS") ? atoi(getenv("C3D_DWWG_WGS")) : 0;
+  const long target = env_wgs > 0 ? env_wgs : device_cus();
+  long gx = target / chunks;
+  if (gx >= N_XCD) gx = gx / N_XCD * N_XCD;
+  if (gx < 1) gx = 1;
+  const long ipw = (items + gx - 1) / gx;
+  if ((ipw + ntiles - 2) / ntiles + 1 > G::MAXB) return C3D_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_dot2_kernel<3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(chunk_order_grid(chunks, (items + ipw - 1) / ipw));
+  dw_wgrad_dot2_kernel<3><<<grid, dim3(G::NCOMP + D2_LOADERS), G::LDS_BYTES, stream>>>(
+      reinterpret_cast<const bf16_t*>(t1), reinterpret_cast<const bf16_t*>(bb), cA, cB, cC,
+      reinterpret_cast<const bf16_t*>(a), ss_a, dw, g, (int)ipw);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
 bool geom_ok(const DwGeom& g) {
   if (g.B <= 0 || g.T <= 0 || g.T > DW_MAXT || g.H <= 0 || g.W <= 0 || g.C <= 0 || g.Cp < g.C || (g.Cp & 7))
     return false;
@@ -1728,6 +2083,11 @@ extern "C" int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA
                        : launch_wgrad<float, 2>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
   if (dtype == C3D_DT_BF16) {
     static const bool no_dma = getenv("C3D_DWWG_NODMA") != nullptr;
+    static const bool no_dot2 = getenv("C3D_DWWG_NODOT2") != nullptr;
+    if (!no_dma && !no_dot2 && stride == 1) {
+      const int rc = launch_wgrad_dot2(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
+      if (rc != C3D_E_UNSUPPORTED) return rc;
+    }
     if (!no_dma) {
       const int rc = stride == 1 ? launch_wgrad_dma<1>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s)
                                  : launch_wgrad_dma<2>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
