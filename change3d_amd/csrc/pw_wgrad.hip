@@ -119,8 +119,13 @@ template <> struct ColBuf<float> {
 
 // HASP2: the P operand carries the AFFINE2 prologue (second tensor + coefficients)
 template <typename T, bool HASP2>
-__global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad_args a, const int tiles_per_wg,
+__global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad_args a_in, const int tiles_per_wg,
                                                               const int WN, const int WK, const int MT) {
+  c3d_pw_wgrad_args a = a_in;
+  if (a.taps > 1) {   // batched ConvTranspose taps: blockIdx.y selects the (dy, dx) shift of the q rows
+    a.dy = (int)blockIdx.y / 4 - 1;
+    a.dx = (int)blockIdx.y % 4 - 1;
+  }
   typedef MmaT<T> MM;
   typedef typename MM::lds_t lds_t;
   typedef RawW<T> RW;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
 #undef WG_ISSUE
 
   // partials -> workspace [grid][N][K]
-  float* wsb = a.ws + (size_t)blockIdx.x * a.N * a.K;
+  float* wsb = a.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.N * a.K;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int nt = wn_i + i * WN;
@@ -297,8 +302,10 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
 // dW += sum over per-workgroup partials.  32 outputs per block x 8 part-groups: each thread adds at
 // most parts/8 coalesced values with 4 loads in flight (the serial 256-deep walk cost 55 us/call).
 __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __restrict__ ws, float* dw, int N, int K,
-                                                              int parts, int sn, int sk) {
+                                                              int parts, int sn, int sk, int tap_stride) {
   __shared__ float red[8][32];
+  ws += (size_t)blockIdx.y * parts * N * K;   // batched taps: one slab of partials per tap
+  dw += (size_t)blockIdx.y * tap_stride;
   const int e = threadIdx.x & 31, pg = threadIdx.x >> 5;
   const int idx = blockIdx.x * 32 + e;
   const int NK = N * K;
@@ -369,18 +376,20 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   static const int cap_env = getenv("C3D_WG_BLOCKS") ? atoi(getenv("C3D_WG_BLOCKS")) : 0;  // tuning knob
   int64_t cap = device_cus() < WGRAD_MAX_PARTS ? device_cus() : WGRAD_MAX_PARTS;
   if (cap_env > 0 && cap_env <= WGRAD_MAX_PARTS) cap = cap_env;
+  const int taps = a.taps > 1 ? a.taps : 1;
+  if (taps > 1 && cap > WGRAD_MAX_PARTS / taps) cap = WGRAD_MAX_PARTS / taps;   // the workspace holds MAX_PARTS slabs
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   const int tpw = (int)((tiles + blocks - 1) / blocks);
   blocks = (tiles + tpw - 1) / tpw;
   if (a.p_coef)
-    pw_wgrad_kernel<T, true><<<dim3((unsigned)blocks), dim3(WG_THREADS), lds, stream>>>(a, tpw, WN, WK, MT);
+    pw_wgrad_kernel<T, true><<<dim3((unsigned)blocks, taps), dim3(WG_THREADS), lds, stream>>>(a, tpw, WN, WK, MT);
   else
-    pw_wgrad_kernel<T, false><<<dim3((unsigned)blocks), dim3(WG_THREADS), lds, stream>>>(a, tpw, WN, WK, MT);
+    pw_wgrad_kernel<T, false><<<dim3((unsigned)blocks, taps), dim3(WG_THREADS), lds, stream>>>(a, tpw, WN, WK, MT);
   C3D_CHECK_LAUNCH();
   const int nk = a.N * a.K;
-  pw_wgrad_reduce_kernel<<<dim3((nk + 31) / 32), dim3(256), 0, stream>>>(a.ws, a.dw, a.N, a.K, (int)blocks,
-                                                                            a.dw_sn, a.dw_sk);
+  pw_wgrad_reduce_kernel<<<dim3((nk + 31) / 32, taps), dim3(256), 0, stream>>>(a.ws, a.dw, a.N, a.K, (int)blocks,
+                                                                                  a.dw_sn, a.dw_sk, a.dw_tap_stride);
   C3D_CHECK_LAUNCH();
   return 0;
 }

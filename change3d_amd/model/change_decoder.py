@@ -93,11 +93,10 @@ class _DecoderFn(torch.autograd.Function):
 
             def convt_param_grads(dcur=dcur, t=t, gb=gb, gw=gw, M=M, h=h, w=w, Cout=Cout):
                 ops.col_sum(dcur, gb, B * 4 * h * w, Cout, dt)
-                for ky in range(4):
-                    for kx in range(4):
-                        ops.pw_wgrad(t, dcur, None, M=M, K=Cout, N=Cout, dw_sn=Cout * 16, dw_sk=16, dtype=dt,
-                                     row_mode=ops.ROWS_S2SHIFT, H=2 * h, W=2 * w, dy=ky - 1, dx=kx - 1,
-                                     dw_ptr=gw.data_ptr() + (ky * 4 + kx) * 4)
+                # the 4x4 taps (ky, kx) in ONE launch: tap t reads dcur at (2i + ky - 1, 2j + kx - 1) and
+                # accumulates at gw[ci][co][ky][kx] (16 launches of ~20-50 us each before)
+                ops.pw_wgrad(t, dcur, gw, M=M, K=Cout, N=Cout, dw_sn=Cout * 16, dw_sk=16, dtype=dt,
+                             row_mode=ops.ROWS_S2SHIFT, H=2 * h, W=2 * w, taps=16, dw_tap_stride=1)
 
             ops.side_run(convt_param_grads, dcur, t)   # leaves of the backward graph: side stream
             dx = torch.empty((B, h, w, cpad(Cin)), dtype=act, device=dev)

@@ -217,7 +217,7 @@ def _ws(device, n_floats):
 
 def pw_wgrad(p, q, dw, *, M, K, N, dw_sn, dw_sk, dtype, p2=None, p_coef=None, q_mode=PRO_NONE, q_ss=None,
              q_gate=None, rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, dy=0, dx=0,
-             q_ptr=None, dw_ptr=None):
+             q_ptr=None, dw_ptr=None, taps=0, dw_tap_stride=0):
     a = L.PwWgradArgs()
     a.p, a.p2 = _p(p), _p(p2)
     a.q = q_ptr if q_ptr is not None else _p(q)
@@ -230,6 +230,7 @@ def pw_wgrad(p, q, dw, *, M, K, N, dw_sn, dw_sk, dtype, p2=None, p_coef=None, q_
     a.dw_sn, a.dw_sk = dw_sn, dw_sk
     a.row_mode, a.rpg, a.H, a.W, a.dy, a.dx = row_mode, rpg, H, W, dy, dx
     a.q_mode, a.dtype = q_mode, dtype
+    a.taps, a.dw_tap_stride = taps, dw_tap_stride
     _launch(_detail("c3d_pw_wgrad", a), a.M * (a.Np * (2 if p2 is not None else 1) + a.Kp) * _es(dtype), L.lib().c3d_pw_wgrad, C.byref(a), _stream())
 
 

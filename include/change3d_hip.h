@@ -106,6 +106,9 @@ typedef struct c3d_pw_wgrad_args {
   int32_t dy, dx;                   /* C3D_ROWS_S2SHIFT: row m=(b,i,j) reads pixel (2i+dy, 2j+dx) */
   int32_t q_mode;                   /* C3D_PRO_NONE | C3D_PRO_BN_SE_SWISH                    */
   int32_t dtype;
+  int32_t taps;                     /* C3D_ROWS_S2SHIFT: 16 = ONE launch covers the 4x4 taps of a ConvTranspose2d   */
+  int32_t dw_tap_stride;            /* k4s2p1 weight gradient, (dy,dx) = (tap/4-1, tap%4-1), tap t accumulates at   */
+                                    /* dw + t*dw_tap_stride (reference model/change_decoder.py:30-45); 0/1 = dy,dx */
 } c3d_pw_wgrad_args;
 
 int64_t c3d_pw_wgrad_ws_floats(int32_t N, int32_t K);
