@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libchange3d_hip.so")
+LIB_PATH = os.environ.get("C3D_LIB") or os.path.join(_HERE, "lib", "libchange3d_hip.so")  # C3D_LIB: instrumented builds (tools/)
 
 DT_F32, DT_BF16 = 0, 1
 PRO_NONE, PRO_BN_SE_SWISH, PRO_AFFINE2 = 0, 1, 2

@@ -22,6 +22,21 @@
 #include "pw_common.h"
 #include <cstdlib>
 
+#ifdef C3D_PW_CLOCK
+// Debug build only (tools/pw_phase_clock.py): per-phase shader-clock sums over all waves.
+constexpr int CLK_WAVES = 8192;
+__device__ unsigned long long c3d_pw_clk[CLK_WAVES][16];   // per-wave slots (atomics on shared slots stall the launch)
+#define CLK_DECL unsigned long long clk_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long clk_last_ = __builtin_amdgcn_s_memtime();
+#define CLK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); clk_[i] += t_ - clk_last_; clk_last_ = t_; }
+#define CLK_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define CLK_FLUSH if (lane == 0) { const int w_ = (blockIdx.x * WAVES + wave) % CLK_WAVES; for (int i_ = 0; i_ < 15; ++i_) c3d_pw_clk[w_][i_] += clk_[i_]; c3d_pw_clk[w_][15] += 1ull; }
+#else
+#define CLK_DECL
+#define CLK(i)
+#define CLK_WAITVM
+#define CLK_FLUSH
+#endif
+
 namespace {
 
 constexpr bool PROis(int pro) { return pro == C3D_PRO_AFFINE2; }
@@ -104,6 +119,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  CLK_DECL
   const int Kp = a.Kp, Np = a.Np;
   const int Kpad = (Kp + MM::KSTEP - 1) / MM::KSTEP * MM::KSTEP;
   const int KL = Kpad + MM::KPAD;
@@ -186,6 +202,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
   }
 
   if (t0 < t1) { PW_ISSUE(t0) }
+  CLK(9)
 
   // ---- stage weights: zero fill, then vectorised fill along W's contiguous dimension -------
   {
@@ -198,7 +215,9 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
       const int np = (PRO == C3D_PRO_AFFINE2 ? 3 : 2) * Kp;
       for (int i = tid; i < np; i += WAVES * 64) Pp[i] = a.pro_p[i];
     }
+    CLK(10)
     __syncthreads();
+    CLK(11)
     const bool kc = (a.w_sk == 1);
     const int CL = kc ? a.K : a.N, OLn = kc ? a.N : a.K;
     const int ostride = kc ? a.w_sn : a.w_sk;
@@ -235,7 +254,9 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
         }
       }
     }
+    CLK(12)
     __syncthreads();
+    CLK(13)
   }
 
   // each wave zeroes its X region once: the K-padding columns [Kp, Kpad) are never written later
@@ -244,7 +265,10 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
     MM::store8(Xs + i, z);
   }
 
+  CLK(0)
   for (int64_t it0 = t0; it0 < t1; it0 += L.tpi) {
+    CLK_WAITVM
+    CLK(1)
     // ---------------- convert + prologue -> LDS (all sub-tiles of this iteration) ------------
 #pragma unroll
     for (int j = 0; j < PW_SLOTS; ++j) {
@@ -291,8 +315,10 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
         }
       }
     }
+    CLK(2)
     // ---------------- prefetch the next iteration's rows -------------------------------------
     if (it0 + L.tpi < t1) { PW_ISSUE(it0 + L.tpi) }
+    CLK(3)
 
     for (int sub = 0; sub < L.tpi; ++sub) {
       const int64_t tile = it0 + sub;
@@ -311,6 +337,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
           acc[nt] = MM::mma(wa, xb, acc[nt]);
         }
       }
+      CLK(4)
       // ---------------- stage result tile: Os[row = lane&15][channel] -------------------------
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -321,6 +348,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
           *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(acc[nt][0], acc[nt][1]), pack_bf16x2(acc[nt][2], acc[nt][3]));
         }
       }
+      CLK(5)
       // ---------------- epilogue + store ---------------------------------------------------
       if (EPI == C3D_EPI_SWISH_SE_BWD) {
         const int64_t n_tile = (uint32_t)row0 / rps32;
@@ -399,9 +427,11 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
           Vec8<T>::store(Y + yoff, f);
         }
       }
+      CLK(6)
     }
   }
 #undef PW_ISSUE
+  CLK(7)
 
   // ---- final flush of per-lane partial sums -------------------------------------------------
   // lanes -> LDS ([value][lane] per wave, the X regions are dead now) -> one thread per output sums the
@@ -482,6 +512,8 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
       }
     }
   }
+  CLK(8)
+  CLK_FLUSH
 }
 
 inline size_t al16(size_t v) { return (v + 15) / 16 * 16; }
@@ -534,7 +566,12 @@ int launch_pw_w(const c3d_pw_args& a, hipStream_t stream) {
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks < 1) blocks = 1;
   int64_t tpw = (tiles + blocks * WAVES - 1) / (blocks * WAVES);
-  tpw = (tpw + L.tpi - 1) / L.tpi * L.tpi;  // whole iterations
+  // Whole iterations only when that does not idle CUs: 6144 tiles over 2048 waves is 3 per wave; rounding
+  // to 4 (tpi = 2) left 64 of 256 CUs without a workgroup (stage-3 K=96 layers, -20 % per launch).
+  static const int round_iters = getenv("C3D_PW_ROUND") ? atoi(getenv("C3D_PW_ROUND")) : 0;
+  const int64_t tpw_r = (tpw + L.tpi - 1) / L.tpi * L.tpi;
+  const int64_t blocks_r = (tiles + tpw_r * WAVES - 1) / (tpw_r * WAVES);
+  if (round_iters || blocks_r * 16 >= blocks * 15) tpw = tpw_r;
   blocks = (tiles + tpw * WAVES - 1) / (tpw * WAVES);
   L.tiles_per_wave = (int)tpw;
   pw_gemm_kernel<T, NT, PRO, EPI, WAVES><<<dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream>>>(a, L);
@@ -549,7 +586,7 @@ int launch_pw(const c3d_pw_args& a, hipStream_t stream) {
   size_t lds = 0;
   static const int force8 = getenv("C3D_PW_FORCE8") ? atoi(getenv("C3D_PW_FORCE8")) : 0;  // tuning knob
   const bool e1_epi = EPI == C3D_EPI_SWISH_SE_BWD || EPI == C3D_EPI_ADD;  // epilogues with exposed companion loads
-  if (plan_pw<T, NT, PRO, EPI, 8>(a, L, lds) &&
+  if (force8 >= 0 && plan_pw<T, NT, PRO, EPI, 8>(a, L, lds) &&
       (L.tpi * ((((a.Kp >> 3) + 3) >> 2)) >= 4 || lds <= 80 * 1024 || force8 == 2 || (force8 == 1 && e1_epi)))
     return launch_pw_w<T, NT, PRO, EPI, 8>(a, stream);
   if (plan_pw<T, NT, PRO, EPI, 4>(a, L, lds)) return launch_pw_w<T, NT, PRO, EPI, 4>(a, stream);
@@ -584,6 +621,19 @@ int dispatch_mode(const c3d_pw_args& a, hipStream_t s) {
 }  // namespace
 
 extern "C" int c3d_device_cus(void) { return device_cus(); }
+
+#ifdef C3D_PW_CLOCK
+extern "C" int c3d_debug_pw_clock(unsigned long long* out, int reset) {   // out[CLK_WAVES][16]
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(c3d_pw_clk), sizeof(unsigned long long) * CLK_WAVES * 16);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(c3d_pw_clk));
+    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * CLK_WAVES * 16);
+  }
+  return (int)e;
+}
+#endif
 
 extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   if (!args || !args->x || !args->y || !args->w) return C3D_E_BADARG;

@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""Where does a pointwise GEMM launch spend its time?  Builds libchange3d_hip_clk.so (pw_gemm.hip with
+-DC3D_PW_CLOCK: s_memtime stamps around every phase of the wave loop, summed over waves) and prints the
+per-wave average of each phase for the stage-1..3 layer shapes.
+
+  python tools/pw_phase_clock.py --build        (CPU container: cross-compile, the .so travels with gpurun)
+  python tools/pw_phase_clock.py                (GPU box)
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CLK_LIB = os.path.join(ROOT, "change3d_amd", "lib", "libchange3d_hip_clk.so")
+PHASES = ["zero X region", "wait loads", "convert+prologue", "issue prefetch", "mfma", "stage Os", "epilogue+store",
+          "loop exit", "stats flush", "params+first issue", "zero W, Pp", "barrier 1", "W load+scatter", "barrier 2"]
+NP = len(PHASES)
+
+
+def build():
+    import __graft_entry__ as g
+    g.build(verbose=False)
+    objdir = os.path.join(g.LIBDIR, "obj")
+    o = os.path.join(objdir, "pw_gemm_clk.o")
+    subprocess.check_call([g.HIPCC] + g.FLAGS + ["-DC3D_PW_CLOCK", "-c", os.path.join(g.CSRC, "pw_gemm.hip"), "-o", o])
+    objs = [o] + [os.path.join(objdir, s.replace(".hip", ".o")) for s in g.SOURCES if s != "pw_gemm.hip"]
+    subprocess.check_call([g.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", CLK_LIB] + objs)
+    print("built", CLK_LIB)
+
+
+def main():
+    os.environ["C3D_LIB"] = CLK_LIB
+    import torch
+    from change3d_amd import _lib, ops
+    h = _lib.lib()
+    h.c3d_debug_pw_clock.restype = C.c_int
+    h.c3d_debug_pw_clock.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    buf = (C.c_ulonglong * (8192 * 16))()
+
+    def read(reset=True):
+        torch.cuda.synchronize()
+        assert h.c3d_debug_pw_clock(buf, 1 if reset else 0) == 0
+        import numpy as np
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 16).astype(np.float64)
+        a = a[a[:, 15] > 0]
+        v = list(a[:, :15].sum(0)) + [a[:, 15].sum()]
+        per = a[:, :15].sum(1) / a[:, 15]
+        return v, (per.min(), per.mean(), per.max()) if len(per) else (0, 0, 0)
+
+    DEV, DT, B, T = "cuda:0", torch.bfloat16, int(os.environ.get("C3D_BENCH_B", "32")), 3
+    dt = ops.dt_code(DT)
+    rt = lambda *s: torch.randn(*s, device=DEV).to(DT)  # noqa: E731
+    only = sys.argv[1:]
+    for st, H, Cin, Ci, Co in [(1, 128, 24, 54, 24), (2, 64, 48, 108, 48), (3, 32, 96, 216, 96)]:
+        M = B * T * H * H
+        Cip = ops.cpad(Ci)
+        x, a_, b_, c_ = rt(M, Cin), rt(M, Cip), rt(M, Cip), rt(M, Co)
+        wa, wc = torch.randn(Ci, Cin, device=DEV) * 0.1, torch.randn(Co, Ci, device=DEV) * 0.1
+        stats = torch.zeros(16 * 2 * 256, dtype=torch.float64, device=DEV)
+        ss, gate = torch.rand(2 * Cip, device=DEV), torch.rand(B * Cip, device=DEV)
+        coef3, coefo = torch.rand(3 * Cip, device=DEV), torch.rand(3 * Co, device=DEV)
+        nc3 = torch.zeros(B * Cip * 3, dtype=torch.float64, device=DEV)
+        rps = T * H * H
+        cases = {
+            "conv_a fwd   NONE+STATS": lambda: ops.pw_gemm(x, wa, a_, M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt,
+                                                           epi_mode=ops.EPI_STATS, stats=stats),
+            "conv_c fwd   SWISH+STATS": lambda: ops.pw_gemm(b_, wc, c_, M=M, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt,
+                                                            pro_mode=ops.PRO_BN_SE_SWISH, pro_p=ss, pro_gate=gate,
+                                                            rows_per_sample=rps, epi_mode=ops.EPI_STATS, stats=stats),
+            "conv_c bwd-d AFFINE2+SWISH_SE_BWD": lambda: ops.pw_gemm(
+                c_, wc, a_, M=M, K=Co, N=Ci, w_sn=1, w_sk=Ci, dtype=dt, x2=c_, pro_mode=ops.PRO_AFFINE2, pro_p=coefo,
+                epi_mode=ops.EPI_SWISH_SE_BWD, e1=b_, epi_p=ss, epi_gate=gate, epi_q=ss, stats=nc3, rows_per_sample=rps),
+            "conv_a bwd-d AFFINE2+ADD": lambda: ops.pw_gemm(a_, wa, x, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=b_,
+                                                            pro_mode=ops.PRO_AFFINE2, pro_p=coef3, epi_mode=ops.EPI_ADD,
+                                                            e1=c_, res_mode=0),
+        }
+        for name, fn in cases.items():
+            if only and not any(o in f"s{st} {name}" for o in only):
+                continue
+            for _ in range(3):
+                fn()
+            read()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            iters = 10
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            v, (pmin, pmean, pmax) = read()
+            us = e0.elapsed_time(e1) / iters * 1e3
+            waves = v[15] / iters
+            tot = sum(v[:15]) / v[15]
+            print(f"s{st} {name}: {us:.1f} us/launch, {waves:.0f} waves, clk per wave mean {tot:.0f} min {pmin:.0f} "
+                  f"max {pmax:.0f} ({pmax / us:.0f} clk/us if the longest wave spans the launch)")
+            for i, ph in enumerate(PHASES):
+                print(f"    {ph:18s} {v[i] / v[15]:10.0f} clk  {100.0 * v[i] / sum(v[:15]):5.1f} %")
+
+
+if __name__ == "__main__":
+    if "--build" in sys.argv:
+        build()
+    else:
+        main()
