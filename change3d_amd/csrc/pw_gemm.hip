@@ -94,7 +94,61 @@ __device__ __forceinline__ void lds_ld8(const float* p, float (&f)[8]) {
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
-constexpr int PW_SLOTS = 8;  // raw 8-channel vectors per lane per iteration (~8 KB per wave in flight)
+// Weight matrix (f32, any strides) -> LDS image Ws[n][k] in the MFMA operand type.  VW = floats per global load
+// along the contiguous dimension, KC = that dimension is K (then the VW elements are adjacent in LDS too: one
+// 8-byte / 16-byte write).  All of a thread's loads are issued before the first LDS write: one round trip.
+template <typename T, int VW, bool KC, int WAVES>
+__device__ __forceinline__ void stage_weights(const float* __restrict__ w, typename Mma<T>::lds_t* Ws, int CL, int OLn,
+                                              int ostride, int KL, int tid) {
+  typedef Mma<T> MM;
+  typedef typename MM::lds_t lds_t;
+  constexpr int WB = 8;
+  const int vpr = CL / VW, total = OLn * vpr;
+  const float inv = 1.0f / (float)vpr;
+  for (int base = tid; base < total; base += WAVES * 64 * WB) {
+    float v[WB][VW];
+    int oo[WB], ii[WB];
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+      const int idx = base + u * WAVES * 64;
+      oo[u] = -1;
+      if (idx < total) {
+        const int o = __float2int_rz(((float)idx + 0.5f) * inv);
+        const int i = idx - o * vpr;
+        oo[u] = o; ii[u] = i * VW;
+        const float* src = w + (size_t)o * ostride + i * VW;
+        if (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][VW > 2 ? 2 : 0] = t.z; v[u][VW > 3 ? 3 : 0] = t.w; }
+        else if (VW == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[u][0] = t.x; v[u][VW > 1 ? 1 : 0] = t.y; }
+        else v[u][0] = src[0];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+      if (oo[u] >= 0) {
+        if (KC && VW == 4) {
+          lds_t* dst = Ws + oo[u] * KL + ii[u];
+          if (sizeof(lds_t) == 2) {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[u][0], v[u][VW > 1 ? 1 : 0]), pack_bf16x2(v[u][VW > 2 ? 2 : 0], v[u][VW > 3 ? 3 : 0]));
+          } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[u][0], v[u][VW > 1 ? 1 : 0], v[u][VW > 2 ? 2 : 0], v[u][VW > 3 ? 3 : 0]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VW; ++e) {
+            const int n = KC ? oo[u] : ii[u] + e;
+            const int k = KC ? ii[u] + e : oo[u];
+            Ws[n * KL + k] = MM::cvt(v[u][e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// raw 8-channel vectors per lane per iteration (~8 KB per wave in flight).  The widest data-gradient variant
+// (N > 112 with the two-tensor prologue: only K = 96 in this network, 2 sub-tiles x 3 vectors) gets 6 so that its
+// 8-wave form fits 256 VGPRs without spilling.
+template <int NT, int PRO, int WAVES> struct PwSlots { static constexpr int value = (NT == 14 && PRO == C3D_PRO_AFFINE2 && WAVES == 8) ? 6 : 8; };
 
 // Output staging type: plain-store / statistics epilogues round once to the storage type anyway,
 // the arithmetic epilogues (Swish/SE backward, residual add) keep the f32 accumulator.
@@ -108,17 +162,21 @@ struct PwLaunch {
   int w_off, p_off, wave_off, wave_bytes, os_off, gs_off;  // byte offsets in dynamic LDS
 };
 
-template <typename T, int NT, int PRO, int EPI, int WAVES>
+// DENSE = rows are consecutive in memory (row_mode C3D_ROWS_DENSE): a 16-row tile is one contiguous span, so
+// every lane's load address is (wave-uniform tile base) + lane*16 B + constant -- no per-slot index arithmetic,
+// no 64-bit vector multiplies (the generic path's row_offset() code cost ~50 VGPRs and spilled).
+template <typename T, int NT, int PRO, int EPI, int WAVES, bool DENSE>
 __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a, const PwLaunch L) {
   typedef Mma<T> MM;
   typedef typename MM::lds_t lds_t;
   typedef Raw<T> RW;
   typedef typename OutStage<T, EPI>::type os_t;
+  constexpr int PW_SLOTS = PwSlots<NT, PRO, WAVES>::value;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile indices stay in SGPRs
   CLK_DECL
   const int Kp = a.Kp, Np = a.Np;
   const int Kpad = (Kp + MM::KSTEP - 1) / MM::KSTEP * MM::KSTEP;
@@ -164,15 +222,17 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
     }
   }
 
-  const int64_t tiles = (a.M + 15) >> 4;
-  const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
-  const int64_t t0 = gw * L.tiles_per_wave;
-  int64_t t1 = t0 + L.tiles_per_wave;
+  const int M32 = (int)a.M;                    // M < 2^31 (checked by the entry point)
+  const int tiles = (M32 + 15) >> 4;
+  const int gw = (int)blockIdx.x * WAVES + wave;
+  int t0 = gw * L.tiles_per_wave;
+  if (t0 > tiles) t0 = tiles;
+  int t1 = t0 + L.tiles_per_wave;
   if (t1 > tiles) t1 = tiles;
   const uint32_t rps32 = a.rows_per_sample > 0 ? (uint32_t)a.rows_per_sample : 1u;
   const int64_t nmax = (int64_t)(((uint32_t)a.M - 1u) / rps32);
-  int64_t cur_n = -1;   // sample whose partial sums are accumulated (SWISH_SE_BWD epilogue)
-  int64_t gate_n = -1;  // sample whose gate is cached in Gs (BN_SE_SWISH prologue)
+  int cur_n = -1;       // sample whose partial sums are accumulated (SWISH_SE_BWD epilogue)
+  int gate_n = -1;      // sample whose gate is cached in Gs (BN_SE_SWISH prologue)
 
   const T* X = reinterpret_cast<const T*>(a.x);
   const T* X2 = reinterpret_cast<const T*>(a.x2);
@@ -182,7 +242,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
   typename RW::type xr[PW_SLOTS];
   typename RW::type x2r[PROis(PRO) ? PW_SLOTS : 1];
 
-#define PW_ISSUE(TILE0)                                                                        \
+#define PW_ISSUE_GENERIC(TILE0)                                                                \
   _Pragma("unroll") for (int j = 0; j < PW_SLOTS; ++j) {                                       \
     if (j < nslots) {                                                                          \
       const int i_ = lane + 64 * slot_q[j];                                                    \
@@ -200,6 +260,27 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
       }                                                                                        \
     }                                                                                          \
   }
+  // rows of tile tl that exist (0 beyond this wave's range), times Gi = number of valid flat vectors
+#define PW_LIM(TL) (((TL) < t1 ? (M32 - ((TL) << 4) > 16 ? 16 : M32 - ((TL) << 4)) : 0) * Gi)
+#define PW_ISSUE_DENSE(TILE0)                                                                  \
+  {                                                                                            \
+    const T* xb_ = X + (int64_t)(TILE0) * 16 * Kp + lane * 8;                                  \
+    const T* x2b_ = PRO == C3D_PRO_AFFINE2 ? X2 + (int64_t)(TILE0) * 16 * Kp + lane * 8 : X;   \
+    _Pragma("unroll") for (int j = 0; j < PW_SLOTS; ++j) {                                     \
+      if (j < nslots) {                                                                        \
+        const int i_ = lane + 64 * slot_q[j];                                                  \
+        const int o_ = slot_s[j] * 16 * Kp + 512 * slot_q[j];                                  \
+        if (i_ < PW_LIM((TILE0) + slot_s[j])) {                                                \
+          xr[j] = RW::load(xb_ + o_);                                                          \
+          if (PRO == C3D_PRO_AFFINE2) x2r[PROis(PRO) ? j : 0] = RW::load(x2b_ + o_);           \
+        } else {                                                                               \
+          xr[j] = RW::zero();                                                                  \
+          if (PRO == C3D_PRO_AFFINE2) x2r[PROis(PRO) ? j : 0] = RW::zero();                    \
+        }                                                                                      \
+      }                                                                                        \
+    }                                                                                          \
+  }
+#define PW_ISSUE(TILE0) if constexpr (DENSE) PW_ISSUE_DENSE(TILE0) else { PW_ISSUE_GENERIC(TILE0) }
 
   if (t0 < t1) { PW_ISSUE(t0) }
   CLK(9)
@@ -221,38 +302,15 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
     const bool kc = (a.w_sk == 1);
     const int CL = kc ? a.K : a.N, OLn = kc ? a.N : a.K;
     const int ostride = kc ? a.w_sn : a.w_sk;
-    int VW = 1;
-    if ((CL & 3) == 0 && (ostride & 3) == 0 && ((uintptr_t)a.w & 15) == 0) VW = 4;
-    else if ((CL & 1) == 0 && (ostride & 1) == 0 && ((uintptr_t)a.w & 7) == 0) VW = 2;
-    const int vpr = CL / VW, total = OLn * vpr;
-    const float inv = 1.0f / (float)vpr;
-    for (int base = tid; base < total; base += WAVES * 64 * 4) {
-      float v[4][4];
-      int oo[4], ii[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = base + u * WAVES * 64;
-        oo[u] = -1;
-        if (idx < total) {
-          const int o = __float2int_rz(((float)idx + 0.5f) * inv);
-          const int i = idx - o * vpr;
-          oo[u] = o; ii[u] = i * VW;
-          const float* src = a.w + (size_t)o * ostride + i * VW;
-          if (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
-          else if (VW == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
-          else v[u][0] = src[0];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (oo[u] >= 0) {
-          for (int e = 0; e < VW; ++e) {
-            const int n = kc ? oo[u] : ii[u] + e;
-            const int k = kc ? ii[u] + e : oo[u];
-            Ws[n * KL + k] = MM::cvt(v[u][e]);
-          }
-        }
-      }
+    if ((CL & 3) == 0 && (ostride & 3) == 0 && ((uintptr_t)a.w & 15) == 0) {
+      if (kc) stage_weights<T, 4, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+      else stage_weights<T, 4, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+    } else if ((CL & 1) == 0 && (ostride & 1) == 0 && ((uintptr_t)a.w & 7) == 0) {
+      if (kc) stage_weights<T, 2, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+      else stage_weights<T, 2, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+    } else {
+      if (kc) stage_weights<T, 1, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+      else stage_weights<T, 1, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
     }
     CLK(12)
     __syncthreads();
@@ -265,8 +323,20 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
     MM::store8(Xs + i, z);
   }
 
+  // Companion rows (E1) of the arithmetic epilogues are requested ONE PASS AHEAD, the first pass of a tile before
+  // its MFMAs (and before the next iteration's prefetch burst: vmcnt retires in order).  The pass loop used to
+  // issue load -> s_waitcnt vmcnt(0) -> ~140 VALU per pass: one exposed memory round trip per pass, 8 per tile.
+  constexpr bool E1_PIPE = EPI == C3D_EPI_SWISH_SE_BWD || EPI == C3D_EPI_ADD;
+  const bool e1_rows = E1_PIPE && (EPI == C3D_EPI_SWISH_SE_BWD || a.res_mode == 0);   // E1 has Y's row layout
+  const int npass = (16 + RPo - 1) / RPo;
+  const int v_oc = act_o ? v_o : 0;             // clamped: inactive lanes load a valid address (result unused)
+  typename RW::type e1n = RW::zero();
+  // address of this lane's E1 vector for pass p of the tile starting at row0 (clamped into the tensor)
+#define PW_E1_PTR(ROW0, P)                                                                           \
+  (E1 + (int64_t)((ROW0) + ((P) * RPo + rr_o < 16 && (ROW0) + (P) * RPo + rr_o < M32 ? (P) * RPo + rr_o : 0)) * Np + v_oc * 8)
+
   CLK(0)
-  for (int64_t it0 = t0; it0 < t1; it0 += L.tpi) {
+  for (int it0 = t0; it0 < t1; it0 += L.tpi) {
     CLK_WAITVM
     CLK(1)
     // ---------------- convert + prologue -> LDS (all sub-tiles of this iteration) ------------
@@ -277,7 +347,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
         const int row_ = __float2int_rz(((float)i_ + 0.5f) * invGi);
         const int v_ = i_ - row_ * Gi;
         if (row_ < 16) {
-          const int64_t tl_ = it0 + slot_s[j];
+          const int tl_ = it0 + slot_s[j];
           float f[8];
           RW::cvt(xr[j], f);
           if (PRO == C3D_PRO_BN_SE_SWISH) {
@@ -285,10 +355,10 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
             lds_ld8(Pp + v_ * 8, sc);
             lds_ld8(Pp + Kp + v_ * 8, sh);
             if (a.pro_gate) {
-              int64_t n_ = (uint32_t)(tl_ << 4) / rps32;
-              if (n_ > nmax) n_ = nmax;
+              int n_ = (int)((uint32_t)(tl_ << 4) / rps32);
+              if (n_ > (int)nmax) n_ = (int)nmax;
               if (n_ != gate_n) {  // wave-uniform: a sub-tile never straddles two samples
-                for (int c = lane; c < Kp; c += 64) Gs[c] = a.pro_gate[n_ * Kp + c];
+                for (int c = lane; c < Kp; c += 64) Gs[c] = a.pro_gate[(int64_t)n_ * Kp + c];
                 gate_n = n_;
               }
               lds_ld8(Gs + v_ * 8, g);
@@ -307,7 +377,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
             lds_ld8(Pp + v_ * 8, cA);
             lds_ld8(Pp + Kp + v_ * 8, cB);
             lds_ld8(Pp + 2 * Kp + v_ * 8, cC);
-            const bool real = tl_ < t1 && ((tl_ << 4) + row_) < a.M;
+            const bool real = tl_ < t1 && ((tl_ << 4) + row_) < M32;
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = real ? fmaf(cA[e], f[e], fmaf(cC[e], f2[e], cB[e])) : 0.f;
           }
@@ -316,15 +386,17 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
       }
     }
     CLK(2)
+    if (e1_rows) e1n = RW::load(PW_E1_PTR(it0 << 4, 0));
     // ---------------- prefetch the next iteration's rows -------------------------------------
     if (it0 + L.tpi < t1) { PW_ISSUE(it0 + L.tpi) }
     CLK(3)
 
     for (int sub = 0; sub < L.tpi; ++sub) {
-      const int64_t tile = it0 + sub;
+      const int tile = it0 + sub;
       if (tile >= t1) break;
-      const int64_t row0 = tile << 4;
+      const int row0 = tile << 4;
       const lds_t* Xt = Xs + sub * 16 * KL;
+      if (e1_rows && sub > 0) e1n = RW::load(PW_E1_PTR(row0, 0));
       // ---------------- MFMA ---------------------------------------------------------------
       f32x4_t acc[NT];
 #pragma unroll
@@ -351,7 +423,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
       CLK(5)
       // ---------------- epilogue + store ---------------------------------------------------
       if (EPI == C3D_EPI_SWISH_SE_BWD) {
-        const int64_t n_tile = (uint32_t)row0 / rps32;
+        const int n_tile = (int)((uint32_t)row0 / rps32);
         if (n_tile != cur_n) {
           if (cur_n >= 0) {
 #pragma unroll
@@ -368,20 +440,22 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
           }
           cur_n = n_tile;
           if (a.epi_gate && act_o) {
-            const float* gp = a.epi_gate + cur_n * Np + v_o * 8;
+            const float* gp = a.epi_gate + (int64_t)cur_n * Np + v_o * 8;
             const float4 g0 = *reinterpret_cast<const float4*>(gp);
             const float4 g1 = *reinterpret_cast<const float4*>(gp + 4);
             eG[0] = g0.x; eG[1] = g0.y; eG[2] = g0.z; eG[3] = g0.w; eG[4] = g1.x; eG[5] = g1.y; eG[6] = g1.z; eG[7] = g1.w;
           }
         }
       }
-      for (int p = 0; p * RPo < 16; ++p) {
+      for (int p = 0; p < npass; ++p) {
         const int row = p * RPo + rr_o;
-        const int64_t m = row0 + row;
-        if (act_o && row < 16 && m < a.M) {
+        const int m = row0 + row;
+        typename RW::type e1c = e1n;
+        if (e1_rows && p + 1 < npass) e1n = RW::load(PW_E1_PTR(row0, p + 1));
+        if (act_o && row < 16 && m < M32) {
           float f[8];
           Vec8<os_t>::load(Os + row * NL + v_o * 8, f);
-          const int64_t yoff = m * Np + v_o * 8;
+          const int64_t yoff = (int64_t)m * Np + v_o * 8;
           if (EPI == C3D_EPI_STATS) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -390,7 +464,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
             }
           } else if (EPI == C3D_EPI_SWISH_SE_BWD) {
             float bv[8];
-            Vec8<T>::load(E1 + yoff, bv);
+            RW::cvt(e1c, bv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const float pb = fmaf(bv[j], eS[j], eB[j]);
@@ -406,7 +480,7 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
           } else if (EPI == C3D_EPI_ADD) {
             if (a.res_mode == 0) {
               float rv[8];
-              Vec8<T>::load(E1 + yoff, rv);
+              RW::cvt(e1c, rv);
 #pragma unroll
               for (int j = 0; j < 8; ++j) f[j] += rv[j];
             } else {
@@ -430,7 +504,11 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
       CLK(6)
     }
   }
+#undef PW_E1_PTR
 #undef PW_ISSUE
+#undef PW_ISSUE_DENSE
+#undef PW_ISSUE_GENERIC
+#undef PW_LIM
   CLK(7)
 
   // ---- final flush of per-lane partial sums -------------------------------------------------
@@ -522,6 +600,7 @@ template <typename T, int NT, int PRO, int EPI, int WAVES>
 bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   typedef Mma<T> MM;
   typedef typename OutStage<T, EPI>::type os_t;
+  constexpr int PW_SLOTS = PwSlots<NT, PRO, WAVES>::value;
   const int Kpad = (a.Kp + MM::KSTEP - 1) / MM::KSTEP * MM::KSTEP;
   const int KL = Kpad + MM::KPAD;
   const int NL = NT * 16 + (sizeof(os_t) == 4 ? 4 : 8);
@@ -545,14 +624,14 @@ bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   return false;
 }
 
-template <typename T, int NT, int PRO, int EPI, int WAVES>
-int launch_pw_w(const c3d_pw_args& a, hipStream_t stream) {
+template <typename T, int NT, int PRO, int EPI, int WAVES, bool DENSE>
+int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
   PwLaunch L;
   size_t lds = 0;
   if (!plan_pw<T, NT, PRO, EPI, WAVES>(a, L, lds)) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, NT, PRO, EPI, WAVES>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -574,9 +653,16 @@ int launch_pw_w(const c3d_pw_args& a, hipStream_t stream) {
   if (round_iters || blocks_r * 16 >= blocks * 15) tpw = tpw_r;
   blocks = (tiles + tpw * WAVES - 1) / (tpw * WAVES);
   L.tiles_per_wave = (int)tpw;
-  pw_gemm_kernel<T, NT, PRO, EPI, WAVES><<<dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream>>>(a, L);
+  pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE><<<dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream>>>(a, L);
   C3D_CHECK_LAUNCH();
   return 0;
+}
+
+template <typename T, int NT, int PRO, int EPI, int WAVES>
+int launch_pw_w(const c3d_pw_args& a, hipStream_t stream) {
+  // the dense-row specialisation exists for the throughput (bf16) path only; f32 (parity) uses the generic code
+  if (sizeof(T) == 2 && a.row_mode == C3D_ROWS_DENSE) return launch_pw_d<T, NT, PRO, EPI, WAVES, sizeof(T) == 2>(a, stream);
+  return launch_pw_d<T, NT, PRO, EPI, WAVES, false>(a, stream);
 }
 
 template <typename T, int NT, int PRO, int EPI>
