@@ -39,6 +39,135 @@ __device__ unsigned long long c3d_pw_clk[CLK_WAVES][16];   // per-wave slots (at
 
 namespace {
 
+// ---- hand-scheduled weight-fragment pipeline (bf16) ------------------------------------------------------
+// U ds_read_b128 in flight, then the U (or 2U) MFMAs behind counted lgkmcnt waits, in ONE asm statement: the
+// compiler interleaves read -> wait -> MFMA with at most two reads in flight (LDS latency ~130 clk against 16-32
+// clk of MFMA per fragment), and nothing (in particular no scalar load, which shares lgkmcnt and returns out of
+// order) can be scheduled into the counted region.  Operand A = weight fragment, B = data rows.  The trailing
+// s_nop covers the MFMA -> VALU read hazard the compiler cannot see through inline asm.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int U, bool PAIR> struct MfmaBatch;
+template <> struct MfmaBatch<1, false> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %1, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "=&v"(b0), "+v"(addr)
+                 : "s"(str), "v"(xb));
+  }
+};
+template <> struct MfmaBatch<1, true> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %2, %3\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %5, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %2, %6, %1\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a2[0]), "=&v"(b0), "+v"(addr)
+                 : "s"(str), "v"(xb), "v"(xb2));
+  }
+};
+template <> struct MfmaBatch<2, false> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %2, %4\n\tv_add_u32 %4, %5, %4\n\tds_read_b128 %3, %4\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %6, %1\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "=&v"(b0), "=&v"(b1), "+v"(addr)
+                 : "s"(str), "v"(xb));
+  }
+};
+template <> struct MfmaBatch<2, true> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %4, %6\n\tv_add_u32 %6, %7, %6\n\tds_read_b128 %5, %6\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\tv_mfma_f32_16x16x32_bf16 %2, %4, %9, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\tv_mfma_f32_16x16x32_bf16 %3, %5, %9, %3\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a2[0]), "+v"(a2[1]), "=&v"(b0), "=&v"(b1), "+v"(addr)
+                 : "s"(str), "v"(xb), "v"(xb2));
+  }
+};
+template <> struct MfmaBatch<3, false> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1; u32x4_t b2;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %3, %6\n\tv_add_u32 %6, %7, %6\n\tds_read_b128 %4, %6\n\tv_add_u32 %6, %7, %6\n\tds_read_b128 %5, %6\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %0, %3, %8, %0\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %1, %4, %8, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %2, %5, %8, %2\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "+v"(addr)
+                 : "s"(str), "v"(xb));
+  }
+};
+template <> struct MfmaBatch<3, true> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1; u32x4_t b2;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %6, %9\n\tv_add_u32 %9, %10, %9\n\tds_read_b128 %7, %9\n\tv_add_u32 %9, %10, %9\n\tds_read_b128 %8, %9\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %0, %6, %11, %0\n\tv_mfma_f32_16x16x32_bf16 %3, %6, %12, %3\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %1, %7, %11, %1\n\tv_mfma_f32_16x16x32_bf16 %4, %7, %12, %4\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %2, %8, %11, %2\n\tv_mfma_f32_16x16x32_bf16 %5, %8, %12, %5\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "+v"(addr)
+                 : "s"(str), "v"(xb), "v"(xb2));
+  }
+};
+template <> struct MfmaBatch<4, false> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %4, %8\n\tv_add_u32 %8, %9, %8\n\tds_read_b128 %5, %8\n\tv_add_u32 %8, %9, %8\n\tds_read_b128 %6, %8\n\tv_add_u32 %8, %9, %8\n\tds_read_b128 %7, %8\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %0, %4, %10, %0\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %10, %1\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %2, %6, %10, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %3, %7, %10, %3\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "+v"(addr)
+                 : "s"(str), "v"(xb));
+  }
+};
+template <> struct MfmaBatch<4, true> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %8, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %9, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %10, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %11, %12\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %0, %8, %14, %0\n\tv_mfma_f32_16x16x32_bf16 %4, %8, %15, %4\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %1, %9, %14, %1\n\tv_mfma_f32_16x16x32_bf16 %5, %9, %15, %5\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %2, %10, %14, %2\n\tv_mfma_f32_16x16x32_bf16 %6, %10, %15, %6\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %3, %11, %14, %3\n\tv_mfma_f32_16x16x32_bf16 %7, %11, %15, %7\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(a2[3]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "+v"(addr)
+                 : "s"(str), "v"(xb), "v"(xb2));
+  }
+};
+template <> struct MfmaBatch<5, false> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %5, %10\n\tv_add_u32 %10, %11, %10\n\tds_read_b128 %6, %10\n\tv_add_u32 %10, %11, %10\n\tds_read_b128 %7, %10\n\tv_add_u32 %10, %11, %10\n\tds_read_b128 %8, %10\n\tv_add_u32 %10, %11, %10\n\tds_read_b128 %9, %10\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %0, %5, %12, %0\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %1, %6, %12, %1\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %2, %7, %12, %2\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %3, %8, %12, %3\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %4, %9, %12, %4\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "+v"(addr)
+                 : "s"(str), "v"(xb));
+  }
+};
+template <> struct MfmaBatch<5, true> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %10, %15\n\tv_add_u32 %15, %16, %15\n\tds_read_b128 %11, %15\n\tv_add_u32 %15, %16, %15\n\tds_read_b128 %12, %15\n\tv_add_u32 %15, %16, %15\n\tds_read_b128 %13, %15\n\tv_add_u32 %15, %16, %15\n\tds_read_b128 %14, %15\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %0, %10, %17, %0\n\tv_mfma_f32_16x16x32_bf16 %5, %10, %18, %5\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %1, %11, %17, %1\n\tv_mfma_f32_16x16x32_bf16 %6, %11, %18, %6\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %2, %12, %17, %2\n\tv_mfma_f32_16x16x32_bf16 %7, %12, %18, %7\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %3, %13, %17, %3\n\tv_mfma_f32_16x16x32_bf16 %8, %13, %18, %8\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %4, %14, %17, %4\n\tv_mfma_f32_16x16x32_bf16 %9, %14, %18, %9\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(a2[3]), "+v"(a2[4]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "+v"(addr)
+                 : "s"(str), "v"(xb), "v"(xb2));
+  }
+};
+template <> struct MfmaBatch<6, false> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4; u32x4_t b5;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %6, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %7, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %8, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %9, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %10, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %11, %12\n\ts_waitcnt lgkmcnt(5)\n\tv_mfma_f32_16x16x32_bf16 %0, %6, %14, %0\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %1, %7, %14, %1\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %2, %8, %14, %2\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %3, %9, %14, %3\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %4, %10, %14, %4\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %5, %11, %14, %5\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "+v"(addr)
+                 : "s"(str), "v"(xb));
+  }
+};
+template <> struct MfmaBatch<6, true> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4; u32x4_t b5;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %12, %18\n\tv_add_u32 %18, %19, %18\n\tds_read_b128 %13, %18\n\tv_add_u32 %18, %19, %18\n\tds_read_b128 %14, %18\n\tv_add_u32 %18, %19, %18\n\tds_read_b128 %15, %18\n\tv_add_u32 %18, %19, %18\n\tds_read_b128 %16, %18\n\tv_add_u32 %18, %19, %18\n\tds_read_b128 %17, %18\n\ts_waitcnt lgkmcnt(5)\n\tv_mfma_f32_16x16x32_bf16 %0, %12, %20, %0\n\tv_mfma_f32_16x16x32_bf16 %6, %12, %21, %6\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %1, %13, %20, %1\n\tv_mfma_f32_16x16x32_bf16 %7, %13, %21, %7\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %2, %14, %20, %2\n\tv_mfma_f32_16x16x32_bf16 %8, %14, %21, %8\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %3, %15, %20, %3\n\tv_mfma_f32_16x16x32_bf16 %9, %15, %21, %9\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %4, %16, %20, %4\n\tv_mfma_f32_16x16x32_bf16 %10, %16, %21, %10\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %5, %17, %20, %5\n\tv_mfma_f32_16x16x32_bf16 %11, %17, %21, %11\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(a2[3]), "+v"(a2[4]), "+v"(a2[5]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "+v"(addr)
+                 : "s"(str), "v"(xb), "v"(xb2));
+  }
+};
+template <> struct MfmaBatch<7, false> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4; u32x4_t b5; u32x4_t b6;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %7, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %8, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %9, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %10, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %11, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %12, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %13, %14\n\ts_waitcnt lgkmcnt(6)\n\tv_mfma_f32_16x16x32_bf16 %0, %7, %16, %0\n\ts_waitcnt lgkmcnt(5)\n\tv_mfma_f32_16x16x32_bf16 %1, %8, %16, %1\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %2, %9, %16, %2\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %3, %10, %16, %3\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %4, %11, %16, %4\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %5, %12, %16, %5\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %6, %13, %16, %6\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "+v"(addr)
+                 : "s"(str), "v"(xb));
+  }
+};
+template <> struct MfmaBatch<7, true> {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4; u32x4_t b5; u32x4_t b6;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %14, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %15, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %16, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %17, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %18, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %19, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %20, %21\n\ts_waitcnt lgkmcnt(6)\n\tv_mfma_f32_16x16x32_bf16 %0, %14, %23, %0\n\tv_mfma_f32_16x16x32_bf16 %7, %14, %24, %7\n\ts_waitcnt lgkmcnt(5)\n\tv_mfma_f32_16x16x32_bf16 %1, %15, %23, %1\n\tv_mfma_f32_16x16x32_bf16 %8, %15, %24, %8\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %2, %16, %23, %2\n\tv_mfma_f32_16x16x32_bf16 %9, %16, %24, %9\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %3, %17, %23, %3\n\tv_mfma_f32_16x16x32_bf16 %10, %17, %24, %10\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %4, %18, %23, %4\n\tv_mfma_f32_16x16x32_bf16 %11, %18, %24, %11\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %5, %19, %23, %5\n\tv_mfma_f32_16x16x32_bf16 %12, %19, %24, %12\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %6, %20, %23, %6\n\tv_mfma_f32_16x16x32_bf16 %13, %20, %24, %13\n\ts_nop 15\n\ts_nop 2"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(a2[3]), "+v"(a2[4]), "+v"(a2[5]), "+v"(a2[6]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "+v"(addr)
+                 : "s"(str), "v"(xb), "v"(xb2));
+  }
+};
+// all NT output tiles of one K step, UB fragments per batch
+template <int NT, int UB, int N0, bool PAIR> struct MfmaSeq {
+  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, const uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
+    constexpr int U = NT - N0 < UB ? NT - N0 : UB;
+    MfmaBatch<U, PAIR>::run(a + N0, a2 + N0, addr + N0 * str, str, xb, xb2);
+    if constexpr (N0 + U < NT) MfmaSeq<NT, UB, N0 + U, PAIR>::run(a, a2, addr, str, xb, xb2);
+  }
+};
+
 constexpr bool PROis(int pro) { return pro == C3D_PRO_AFFINE2; }
 
 __device__ __forceinline__ int64_t row_offset(const c3d_pw_args& a, uint32_t um) {
@@ -117,20 +246,20 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ w, typen
         const int i = idx - o * vpr;
         oo[u] = o; ii[u] = i * VW;
         const float* src = w + (size_t)o * ostride + i * VW;
-        if (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][VW > 2 ? 2 : 0] = t.z; v[u][VW > 3 ? 3 : 0] = t.w; }
-        else if (VW == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[u][0] = t.x; v[u][VW > 1 ? 1 : 0] = t.y; }
+        if constexpr (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
+        else if constexpr (VW == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
         else v[u][0] = src[0];
       }
     }
 #pragma unroll
     for (int u = 0; u < WB; ++u) {
       if (oo[u] >= 0) {
-        if (KC && VW == 4) {
+        if constexpr (KC && VW == 4) {
           lds_t* dst = Ws + oo[u] * KL + ii[u];
           if (sizeof(lds_t) == 2) {
-            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[u][0], v[u][VW > 1 ? 1 : 0]), pack_bf16x2(v[u][VW > 2 ? 2 : 0], v[u][VW > 3 ? 3 : 0]));
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[u][0], v[u][1]), pack_bf16x2(v[u][2], v[u][3]));
           } else {
-            *reinterpret_cast<float4*>(dst) = make_float4(v[u][0], v[u][VW > 1 ? 1 : 0], v[u][VW > 2 ? 2 : 0], v[u][VW > 3 ? 3 : 0]);
+            *reinterpret_cast<float4*>(dst) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
           }
         } else {
 #pragma unroll
@@ -145,10 +274,22 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ w, typen
   }
 }
 
-// raw 8-channel vectors per lane per iteration (~8 KB per wave in flight).  The widest data-gradient variant
-// (N > 112 with the two-tensor prologue: only K = 96 in this network, 2 sub-tiles x 3 vectors) gets 6 so that its
-// 8-wave form fits 256 VGPRs without spilling.
-template <int NT, int PRO, int WAVES> struct PwSlots { static constexpr int value = (NT == 14 && PRO == C3D_PRO_AFFINE2 && WAVES == 8) ? 6 : 8; };
+// raw 8-channel vectors per lane per iteration (~8 KB per wave in flight).  The two-tensor prologue doubles the
+// registers per slot; its heaviest forms (the Swish/SE-backward epilogue's 64 per-lane parameters and sums, or
+// 14 accumulator tiles) get 6 slots so that 8 waves per CU fit 256 VGPRs without spilling.
+// sub-tiles per weight-fragment read (2 where acc[2][NT] fits next to the prefetch and epilogue registers)
+template <typename T, int NT, int PRO, int EPI> struct PwPair {
+  static constexpr int value = (sizeof(T) == 2 && ((NT == 7 && !(PRO == C3D_PRO_AFFINE2 && EPI == C3D_EPI_SWISH_SE_BWD)) ||
+                                                   (NT == 14 && PRO == C3D_PRO_NONE))) ? 2 : 1;
+};
+// weight fragments in flight per batch of the hand-scheduled MFMA pipeline (4 VGPRs each); 0 = leave the loop to
+// the compiler (the widest Swish/SE-backward variant sits at 256 VGPRs already)
+template <int NT, int PRO, int EPI> struct PwFragBatch {
+  static constexpr int value = (NT == 14 && PRO == C3D_PRO_AFFINE2 && EPI == C3D_EPI_SWISH_SE_BWD) ? 0 : (NT < 7 ? NT : 7);
+};
+template <int NT, int PRO, int EPI, int WAVES> struct PwSlots {
+  static constexpr int value = (PRO == C3D_PRO_AFFINE2 && WAVES == 8 && (NT == 14 || EPI == C3D_EPI_SWISH_SE_BWD)) ? 6 : 8;
+};
 
 // Output staging type: plain-store / statistics epilogues round once to the storage type anyway,
 // the arithmetic epilogues (Swish/SE backward, residual add) keep the f32 accumulator.
@@ -166,12 +307,12 @@ struct PwLaunch {
 // every lane's load address is (wave-uniform tile base) + lane*16 B + constant -- no per-slot index arithmetic,
 // no 64-bit vector multiplies (the generic path's row_offset() code cost ~50 VGPRs and spilled).
 template <typename T, int NT, int PRO, int EPI, int WAVES, bool DENSE>
-__global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a, const PwLaunch L) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES == 8 ? 2 : 1, 2))) void pw_gemm_kernel(const c3d_pw_args a, const PwLaunch L) {
   typedef Mma<T> MM;
   typedef typename MM::lds_t lds_t;
   typedef Raw<T> RW;
   typedef typename OutStage<T, EPI>::type os_t;
-  constexpr int PW_SLOTS = PwSlots<NT, PRO, WAVES>::value;
+  constexpr int PW_SLOTS = PwSlots<NT, PRO, EPI, WAVES>::value;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -264,12 +405,14 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
 #define PW_LIM(TL) (((TL) < t1 ? (M32 - ((TL) << 4) > 16 ? 16 : M32 - ((TL) << 4)) : 0) * Gi)
 #define PW_ISSUE_DENSE(TILE0)                                                                  \
   {                                                                                            \
-    const T* xb_ = X + (int64_t)(TILE0) * 16 * Kp + lane * 8;                                  \
-    const T* x2b_ = PRO == C3D_PRO_AFFINE2 ? X2 + (int64_t)(TILE0) * 16 * Kp + lane * 8 : X;   \
+    const T* xb_ = X + (int64_t)(TILE0) * 16 * Kp;               /* wave-uniform: SGPR pair */  \
+    const T* x2b_ = PRO == C3D_PRO_AFFINE2 ? X2 + (int64_t)(TILE0) * 16 * Kp : X;              \
+    int lo_ = lane * 8;                                                                        \
+    asm volatile("" : "+v"(lo_));   /* keeps (X + lane*8), (X2 + lane*8) from living in 4 VGPRs across the loop */ \
     _Pragma("unroll") for (int j = 0; j < PW_SLOTS; ++j) {                                     \
       if (j < nslots) {                                                                        \
         const int i_ = lane + 64 * slot_q[j];                                                  \
-        const int o_ = slot_s[j] * 16 * Kp + 512 * slot_q[j];                                  \
+        const int o_ = slot_s[j] * 16 * Kp + 512 * slot_q[j] + lo_;                            \
         if (i_ < PW_LIM((TILE0) + slot_s[j])) {                                                \
           xr[j] = RW::load(xb_ + o_);                                                          \
           if (PRO == C3D_PRO_AFFINE2) x2r[PROis(PRO) ? j : 0] = RW::load(x2b_ + o_);           \
@@ -331,9 +474,27 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
   const int npass = (16 + RPo - 1) / RPo;
   const int v_oc = act_o ? v_o : 0;             // clamped: inactive lanes load a valid address (result unused)
   typename RW::type e1n = RW::zero();
-  // address of this lane's E1 vector for pass p of the tile starting at row0 (clamped into the tensor)
-#define PW_E1_PTR(ROW0, P)                                                                           \
-  (E1 + (int64_t)((ROW0) + ((P) * RPo + rr_o < 16 && (ROW0) + (P) * RPo + rr_o < M32 ? (P) * RPo + rr_o : 0)) * Np + v_oc * 8)
+  // this lane's E1 vector for pass P of the tile starting at ROW0: wave-uniform row base (scalar registers) + a
+  // loop-invariant 32-bit lane offset; lanes without a row in this pass read the pass's first row (result unused)
+  const int e1_lane = rr_o * Np + v_oc * 8;
+#define PW_E1_PTR(ROW0, P)                                                                                          \
+  (E1 + (int64_t)((ROW0) + (P) * RPo < M32 ? (ROW0) + (P) * RPo : M32 - 1) * Np +                                   \
+   (((P) * RPo + rr_o < 16 && (ROW0) + (P) * RPo + rr_o < M32) ? e1_lane : v_oc * 8))
+
+  // Weight fragments: narrow outputs (NT <= 4) with K <= 64 keep ALL of them in registers (the per-tile MFMA phase
+  // was LDS-read latency: X fragment, then each weight fragment, serially); wide outputs run two sub-tiles per
+  // weight-fragment read when the register budget allows (the stage-3 MFMA phase was LDS-bandwidth bound: 8 waves
+  // x 1 KB per MFMA).
+  constexpr bool WREG = NT <= 4 && sizeof(T) == 2 && !(PRO == C3D_PRO_AFFINE2 && EPI == C3D_EPI_SWISH_SE_BWD);
+  constexpr int MT = PwPair<T, NT, PRO, EPI>::value;
+  typename MM::frag_t wr[WREG ? 2 * NT : 1];
+  if (WREG && KS <= 2) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      wr[WREG ? nt : 0] = MM::load(Ws, nt * 16 + (lane & 15), 0, KL, lane);
+      wr[WREG ? NT + nt : 0] = MM::load(Ws, nt * 16 + (lane & 15), KS == 2 ? 1 : 0, KL, lane);
+    }
+  }
 
   CLK(0)
   for (int it0 = t0; it0 < t1; it0 += L.tpi) {
@@ -391,25 +552,8 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
     if (it0 + L.tpi < t1) { PW_ISSUE(it0 + L.tpi) }
     CLK(3)
 
-    for (int sub = 0; sub < L.tpi; ++sub) {
-      const int tile = it0 + sub;
-      if (tile >= t1) break;
-      const int row0 = tile << 4;
-      const lds_t* Xt = Xs + sub * 16 * KL;
-      if (e1_rows && sub > 0) e1n = RW::load(PW_E1_PTR(row0, 0));
-      // ---------------- MFMA ---------------------------------------------------------------
-      f32x4_t acc[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      for (int ks = 0; ks < KS; ++ks) {
-        const typename MM::frag_t xb = MM::load(Xt, lane & 15, ks, KL, lane);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const typename MM::frag_t wa = MM::load(Ws, nt * 16 + (lane & 15), ks, KL, lane);
-          acc[nt] = MM::mma(wa, xb, acc[nt]);
-        }
-      }
-      CLK(4)
+    // stage one 16-row result tile to Os, run the fused epilogue over it, store
+    auto finish_tile = [&](const f32x4_t (&acc)[NT], const int row0, const bool has_next) {
       // ---------------- stage result tile: Os[row = lane&15][channel] -------------------------
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -451,7 +595,10 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
         const int row = p * RPo + rr_o;
         const int m = row0 + row;
         typename RW::type e1c = e1n;
-        if (e1_rows && p + 1 < npass) e1n = RW::load(PW_E1_PTR(row0, p + 1));
+        if (e1_rows) {
+          if (p + 1 < npass) e1n = RW::load(PW_E1_PTR(row0, p + 1));
+          else if (has_next) e1n = RW::load(PW_E1_PTR(row0 + 16, 0));   // first pass of the next tile of this iteration
+        }
         if (act_o && row < 16 && m < M32) {
           float f[8];
           Vec8<os_t>::load(Os + row * NL + v_o * 8, f);
@@ -501,6 +648,71 @@ __global__ __launch_bounds__(WAVES * 64) void pw_gemm_kernel(const c3d_pw_args a
           Vec8<T>::store(Y + yoff, f);
         }
       }
+    };
+
+    for (int sub = 0; sub < L.tpi; sub += MT) {
+      const int tile = it0 + sub;
+      if (tile >= t1) break;
+      const int row0 = tile << 4;
+      const lds_t* Xt = Xs + sub * 16 * KL;
+      const bool two = MT == 2 && sub + 1 < L.tpi && tile + 1 < t1;          // wave-uniform
+      // ---------------- MFMA: MT sub-tiles share every weight fragment read -----------------
+      f32x4_t acc[NT], acc2[NT];   // acc2 is dead code (no registers) when MT == 1
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (MT == 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc2[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      if (WREG && KS <= 2) {
+        const typename MM::frag_t xb0 = MM::load(Xt, lane & 15, 0, KL, lane);
+        typename MM::frag_t xb1 = xb0;
+        if (KS == 2) xb1 = MM::load(Xt, lane & 15, 1, KL, lane);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = MM::mma(wr[WREG ? nt : 0], xb0, acc[nt]);
+        if (KS == 2) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = MM::mma(wr[WREG ? NT + nt : 0], xb1, acc[nt]);
+        }
+      } else {
+        const uint32_t wstr = (uint32_t)(16 * KL * sizeof(lds_t));                       // bytes between output tiles
+        const uint32_t wlane = (uint32_t)(uintptr_t)Ws + (uint32_t)(((lane & 15) * KL + (lane >> 4) * 8) * sizeof(lds_t));
+        constexpr int UB = PwFragBatch<NT, PRO, EPI>::value;
+        if (MT == 2 && two) {
+          for (int ks = 0; ks < KS; ++ks) {
+            const typename MM::frag_t xb = MM::load(Xt, lane & 15, ks, KL, lane);
+            const typename MM::frag_t xb2 = MM::load(Xt + 16 * KL, lane & 15, ks, KL, lane);
+            if constexpr (sizeof(T) == 2 && UB > 0) {
+              const u32x4_t xv = __builtin_bit_cast(u32x4_t, xb), xv2 = __builtin_bit_cast(u32x4_t, xb2);
+              MfmaSeq<NT, (UB > 0 ? UB : 1), 0, true>::run(acc, acc2, wlane + ks * 64, wstr, xv, xv2);
+            } else {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                const typename MM::frag_t wa = MM::load(Ws, nt * 16 + (lane & 15), ks, KL, lane);
+                acc[nt] = MM::mma(wa, xb, acc[nt]);
+                acc2[nt] = MM::mma(wa, xb2, acc2[nt]);
+              }
+            }
+          }
+        } else {
+          for (int ks = 0; ks < KS; ++ks) {
+            const typename MM::frag_t xb = MM::load(Xt, lane & 15, ks, KL, lane);
+            if constexpr (sizeof(T) == 2 && UB > 0) {
+              const u32x4_t xv = __builtin_bit_cast(u32x4_t, xb);
+              MfmaSeq<NT, (UB > 0 ? UB : 1), 0, false>::run(acc, acc, wlane + ks * 64, wstr, xv, xv);
+            } else {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                const typename MM::frag_t wa = MM::load(Ws, nt * 16 + (lane & 15), ks, KL, lane);
+                acc[nt] = MM::mma(wa, xb, acc[nt]);
+              }
+            }
+          }
+        }
+      }
+      CLK(4)
+      finish_tile(acc, row0, MT == 2 ? two : (sub + 1 < L.tpi && tile + 1 < t1));
+      if (MT == 2 && two) finish_tile(acc2, row0 + 16, sub + 2 < L.tpi && tile + 2 < t1);
       CLK(6)
     }
   }
@@ -600,7 +812,7 @@ template <typename T, int NT, int PRO, int EPI, int WAVES>
 bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   typedef Mma<T> MM;
   typedef typename OutStage<T, EPI>::type os_t;
-  constexpr int PW_SLOTS = PwSlots<NT, PRO, WAVES>::value;
+  constexpr int PW_SLOTS = PwSlots<NT, PRO, EPI, WAVES>::value;
   const int Kpad = (a.Kp + MM::KSTEP - 1) / MM::KSTEP * MM::KSTEP;
   const int KL = Kpad + MM::KPAD;
   const int NL = NT * 16 + (sizeof(os_t) == 4 ? 4 : 8);
