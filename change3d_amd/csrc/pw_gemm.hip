@@ -301,6 +301,7 @@ struct PwLaunch {
   int tpi;             // sub-tiles per iteration (prefetch batch)
   int xs_rows;         // rows of the wave's X region (= tpi*16)
   int w_off, p_off, wave_off, wave_bytes, os_off, gs_off;  // byte offsets in dynamic LDS
+  int flush_shuffle_max;  // row-lanes per channel vector up to which the final sums are shuffled instead of dumped
 };
 
 // DENSE = rows are consecutive in memory (row_mode C3D_ROWS_DENSE): a 16-row tile is one contiguous span, so
@@ -728,8 +729,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   // RPo row-lanes of every wave -> ONE f64 atomic per value and workgroup.  (The lane step used to be
   // RPo dependent ds_bpermute shuffles per value: 7-14 us per launch on the narrow layers, Go = 3..7.)
   constexpr int NV = EPI == C3D_EPI_SWISH_SE_BWD ? 24 : 16;   // partial sums per lane
+  const int flush_shuffle_max = L.flush_shuffle_max;
   if (EPI == C3D_EPI_STATS || EPI == C3D_EPI_SWISH_SE_BWD) {
-    const bool dump = (size_t)L.wave_bytes >= (size_t)64 * NV * sizeof(float) + WAVES * sizeof(int);
+    // wide layers (2-3 row-lanes per channel vector): one or two shuffles per value beat the [NV][64] lane dump and
+    // leave the cross-wave sum 8 reads per value instead of 16-24
+    const bool dump = RPo > flush_shuffle_max && (size_t)L.wave_bytes >= (size_t)64 * NV * sizeof(float) + WAVES * sizeof(int);
     float* mine = reinterpret_cast<float*>(smem + L.wave_off + (size_t)wave * L.wave_bytes);   // [NV][64]
     int* ncur = reinterpret_cast<int*>(smem + L.wave_off + (size_t)WAVES * L.wave_bytes - WAVES * sizeof(int));
     __syncthreads();
@@ -865,6 +869,8 @@ int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
   if (round_iters || blocks_r * 16 >= blocks * 15) tpw = tpw_r;
   blocks = (tiles + tpw * WAVES - 1) / (tpw * WAVES);
   L.tiles_per_wave = (int)tpw;
+  static const int fsm = getenv("C3D_PW_FLUSH_SHFL") ? atoi(getenv("C3D_PW_FLUSH_SHFL")) : 0;   // tuning knob (measured: no gain)
+  L.flush_shuffle_max = fsm;
   pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE><<<dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream>>>(a, L);
   C3D_CHECK_LAUNCH();
   return 0;

@@ -4,6 +4,21 @@
 #include "pw_common.h"
 #include <cstdlib>
 
+#ifdef C3D_PW_CLOCK
+// Debug build only (tools/pw_phase_clock.py --wgrad): per-phase shader-clock sums, one slot per (workgroup, wave).
+constexpr int WCLK_WAVES = 8192;
+__device__ unsigned long long c3d_wg_clk[WCLK_WAVES][8];
+#define WCLK_DECL unsigned long long wclk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long wclk_last_ = __builtin_amdgcn_s_memtime();
+#define WCLK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); wclk_[i] += t_ - wclk_last_; wclk_last_ = t_; }
+#define WCLK_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define WCLK_FLUSH if (lane == 0) { const int w_ = ((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) % WCLK_WAVES; for (int i_ = 0; i_ < 7; ++i_) c3d_wg_clk[w_][i_] += wclk_[i_]; c3d_wg_clk[w_][7] += 1ull; }
+#else
+#define WCLK_DECL
+#define WCLK(i)
+#define WCLK_WAITVM
+#define WCLK_FLUSH
+#endif
+
 namespace {
 
 // =============================================================================================
@@ -118,7 +133,10 @@ template <> struct ColBuf<float> {
 };
 
 // HASP2: the P operand carries the AFFINE2 prologue (second tensor + coefficients)
-template <typename T, bool HASP2>
+// QD: the Q rows are dense and unshifted (row m at m * Kp) -- tile base in scalar registers + a 32-bit lane offset
+// instead of q_row_offset()'s mode switch and 64-bit multiplies per row ("issue next tile" was 18-25 % of a wave's
+// time in this VALU-bound kernel).
+template <typename T, bool HASP2, bool QD>
 __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad_args a_in, const int tiles_per_wg,
                                                               const int WN, const int WK, const int MT) {
   c3d_pw_wgrad_args a = a_in;
@@ -131,6 +149,7 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
   typedef RawW<T> RW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WCLK_DECL
   const int Kp = a.Kp, Np = a.Np;
   const int NT = (Np + 15) >> 4, KT = (Kp + 15) >> 4;
   const int ML = MT + MM::MPAD;
@@ -182,39 +201,80 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
   typename RW::type r2[HASP2 ? WG_RPT : 1];
   unsigned vmask = 0;  // which of the WG_RPT rows were real
 
+  const int lane_row0 = rg * WG_RPT;                              // first tile row of this thread
+  const int p_lane = lane_row0 * Np + vv * 8, q_lane = lane_row0 * Kp + vv * 8;
 #define WG_ISSUE(TILE)                                                                          \
   {                                                                                             \
-    const int64_t rbase_ = (TILE) * MT + rg * WG_RPT;                                           \
+    const int64_t tb_ = (int64_t)(TILE) * MT;                     /* wave-uniform */             \
+    const int64_t left64_ = a.M - tb_;                                                          \
+    const int left_ = left64_ > MT ? MT : (int)left64_;           /* rows of this tile that exist */ \
+    const T* Pt_ = P + tb_ * Np;                                                                \
+    const T* P2t_ = HASP2 ? P2 + tb_ * Np : P;                                                  \
+    const T* Qt_ = Q + tb_ * Kp;                                                                \
     vmask = 0;                                                                                  \
     _Pragma("unroll") for (int r = 0; r < WG_RPT; ++r) {                                        \
-      const int64_t m_ = rbase_ + r;                                                            \
       r1[r] = RW::zero();                                                                       \
       if (HASP2) r2[HASP2 ? r : 0] = RW::zero();                                                \
-      if (m_ < a.M) {                                                                           \
+      if (lane_row0 + r < left_) {                                                              \
         if (p_act) {                                                                            \
-          r1[r] = RW::load(P + m_ * Np + vv * 8);                                               \
-          if (HASP2) r2[HASP2 ? r : 0] = RW::load(P2 + m_ * Np + vv * 8);                       \
+          r1[r] = RW::load(Pt_ + (p_lane + r * Np));                                            \
+          if (HASP2) r2[HASP2 ? r : 0] = RW::load(P2t_ + (p_lane + r * Np));                    \
           vmask |= 1u << r;                                                                     \
         } else if (q_act) {                                                                     \
-          const int64_t qo_ = q_row_offset(a, m_);                                              \
-          if (qo_ >= 0) { r1[r] = RW::load(Q + qo_ + vv * 8); vmask |= 1u << r; }               \
+          if constexpr (QD) {                                                                   \
+            r1[r] = RW::load(Qt_ + (q_lane + r * Kp)); vmask |= 1u << r;                        \
+          } else {                                                                              \
+            const int64_t qo_ = q_row_offset(a, tb_ + lane_row0 + r);                           \
+            if (qo_ >= 0) { r1[r] = RW::load(Q + qo_ + vv * 8); vmask |= 1u << r; }             \
+          }                                                                                     \
         }                                                                                       \
       }                                                                                         \
     }                                                                                           \
   }
 
+  // Swish/SE gate of the sample this thread is in: cached across tiles (it used to be re-read, behind an
+  // s_waitcnt vmcnt(0), for every tile -- a global round trip on the critical Q-staging waves)
+  const bool swish = q_act && a.q_mode == C3D_PRO_BN_SE_SWISH;
+  float g[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g[j] = 1.f;
+  int gn = -1;
+
   __syncthreads();  // zero fill complete
   if (t0 < t1) WG_ISSUE(t0)
   int cur = 0;
+  WCLK(0)
   for (int64_t tile = t0; tile < t1; ++tile, cur ^= 1) {
+    WCLK_WAITVM
+    WCLK(1)
     lds_t* PT = base + (size_t)cur * buf_elems;
     lds_t* QT = PT + (size_t)NT * 16 * ML;
     // ---- convert + prologue + transpose (register naming) -> LDS -------------------------------
     if (p_act || q_act) {
       ColBuf<T> cb;
-      float g[8];
-      const bool swish = q_act && a.q_mode == C3D_PRO_BN_SE_SWISH;
-      int64_t gn = -1;
+      const bool all_real = vmask == (1u << WG_RPT) - 1u;
+      int rows_n[WG_RPT];    // sample of each row (swish gate); the thread's rows are consecutive
+      bool one_sample = true;
+      if (swish && a.q_gate) {
+        const int64_t m0 = tile * MT + rg * WG_RPT;
+        const int64_t rps = a.rows_per_sample;
+        if (gn < 0 || m0 < (int64_t)gn * rps || m0 >= (int64_t)(gn + 1) * rps) {   // rarely: the cached sample moved on
+          const int n0 = (int)((uint32_t)m0 / (uint32_t)rps);
+          one_sample = m0 + WG_RPT - 1 < (int64_t)(n0 + 1) * rps;
+          if (one_sample) {
+            const float* gp = a.q_gate + (int64_t)n0 * Kp + vv * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = gp[j];
+            gn = n0;
+          }
+        } else {
+          one_sample = m0 + WG_RPT - 1 < (int64_t)(gn + 1) * rps;
+        }
+        if (!one_sample) {
+#pragma unroll
+          for (int r = 0; r < WG_RPT; ++r) rows_n[r] = (int)((uint32_t)(m0 + r) / (uint32_t)rps);
+        }
+      }
 #pragma unroll
       for (int rp = 0; rp < WG_RPT / 2; ++rp) {
         float fr[2][8];
@@ -223,26 +283,27 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
           const int r = 2 * rp + h;
           float (&f)[8] = fr[h];
           RW::cvt(r1[r], f);
-          const bool real = (vmask >> r) & 1u;
           if (HASP2 && p_act) {
             float f2[8];
             RW::cvt(r2[HASP2 ? r : 0], f2);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = real ? fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j])) : 0.f;
+            for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j]));
           } else if (swish) {
-            const int64_t m = tile * MT + rg * WG_RPT + r;
-            const int64_t n = real ? (int64_t)((uint32_t)m / (uint32_t)a.rows_per_sample) : gn;
-            if (a.q_gate && real && n != gn) {
-              const float* gp = a.q_gate + n * Kp + vv * 8;
+            if (!one_sample && ((vmask >> r) & 1u) && rows_n[r] != gn) {   // a row group that straddles two samples
+              const float* gp = a.q_gate + (int64_t)rows_n[r] * Kp + vv * 8;
 #pragma unroll
               for (int j = 0; j < 8; ++j) g[j] = gp[j];
-              gn = n;
+              gn = rows_n[r];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float qv = (a.q_gate ? g[j] : 1.f) * fmaf(f[j], cA[j], cB[j]);
-              f[j] = real ? qv * sigmoid_t<T>(qv) : 0.f;
+              const float qv = g[j] * fmaf(f[j], cA[j], cB[j]);
+              f[j] = qv * sigmoid_t<T>(qv);
             }
+          }
+          if (!all_real && !((vmask >> r) & 1u)) {   // rows past the end of the tensor (last tile) / outside the image
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.f;
           }
         }
         cb.put2(rp, fr[0], fr[1]);
@@ -251,9 +312,12 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
 #pragma unroll
       for (int j = 0; j < 8; ++j) cb.store(dst + (size_t)j * ML, j);
     }
+    WCLK(2)
     // ---- prefetch the next tile while this one is multiplied -----------------------------------
     if (tile + 1 < t1) WG_ISSUE(tile + 1)
+    WCLK(3)
     __syncthreads();  // the only barrier per tile (LDS tiles are double buffered)
+    WCLK(4)
     for (int ks = 0; ks < MT / MM::KSTEP; ++ks) {
       typename MM::frag_t pa[4], qb[4];
 #pragma unroll
@@ -276,6 +340,7 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
         }
       }
     }
+    WCLK(5)
   }
 #undef WG_ISSUE
 
@@ -297,6 +362,8 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
       }
     }
   }
+  WCLK(6)
+  WCLK_FLUSH
 }
 
 // dW += sum over per-workgroup partials.  32 outputs per block x 8 part-groups: each thread adds at
@@ -363,12 +430,14 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   if (WN == 0) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_kernel<T, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_kernel<T, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e1 != hipSuccess) return (int)e1;
-    if (e2 != hipSuccess) return (int)e2;
+    const void* fns[4] = {reinterpret_cast<const void*>(&pw_wgrad_kernel<T, true, true>),
+                          reinterpret_cast<const void*>(&pw_wgrad_kernel<T, true, false>),
+                          reinterpret_cast<const void*>(&pw_wgrad_kernel<T, false, true>),
+                          reinterpret_cast<const void*>(&pw_wgrad_kernel<T, false, false>)};
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_set = true;
   }
   const int64_t tiles = (a.M + MT - 1) / MT;
@@ -382,10 +451,15 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   if (blocks < 1) blocks = 1;
   const int tpw = (int)((tiles + blocks - 1) / blocks);
   blocks = (tiles + tpw - 1) / tpw;
-  if (a.p_coef)
-    pw_wgrad_kernel<T, true><<<dim3((unsigned)blocks, taps), dim3(WG_THREADS), lds, stream>>>(a, tpw, WN, WK, MT);
-  else
-    pw_wgrad_kernel<T, false><<<dim3((unsigned)blocks, taps), dim3(WG_THREADS), lds, stream>>>(a, tpw, WN, WK, MT);
+  const bool qd = a.row_mode == C3D_ROWS_DENSE && taps == 1;
+  const dim3 grid((unsigned)blocks, taps), blk(WG_THREADS);
+  if (a.p_coef) {
+    if (qd) pw_wgrad_kernel<T, true, true><<<grid, blk, lds, stream>>>(a, tpw, WN, WK, MT);
+    else pw_wgrad_kernel<T, true, false><<<grid, blk, lds, stream>>>(a, tpw, WN, WK, MT);
+  } else {
+    if (qd) pw_wgrad_kernel<T, false, true><<<grid, blk, lds, stream>>>(a, tpw, WN, WK, MT);
+    else pw_wgrad_kernel<T, false, false><<<grid, blk, lds, stream>>>(a, tpw, WN, WK, MT);
+  }
   C3D_CHECK_LAUNCH();
   const int nk = a.N * a.K;
   pw_wgrad_reduce_kernel<<<dim3((nk + 31) / 32, taps), dim3(256), 0, stream>>>(a.ws, a.dw, a.N, a.K, (int)blocks,
@@ -411,3 +485,16 @@ extern "C" int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream) {
   if (a.dtype == C3D_DT_BF16) return launch_wgrad<bf16_t>(a, s);
   return C3D_E_BADARG;
 }
+
+#ifdef C3D_PW_CLOCK
+extern "C" int c3d_debug_wgrad_clock(unsigned long long* out, int reset) {   // out[WCLK_WAVES][8]
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(c3d_wg_clk), sizeof(unsigned long long) * WCLK_WAVES * 8);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(c3d_wg_clk));
+    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * WCLK_WAVES * 8);
+  }
+  return (int)e;
+}
+#endif

@@ -23,9 +23,14 @@ def build():
     import __graft_entry__ as g
     g.build(verbose=False)
     objdir = os.path.join(g.LIBDIR, "obj")
-    o = os.path.join(objdir, "pw_gemm_clk.o")
-    subprocess.check_call([g.HIPCC] + g.FLAGS + ["-DC3D_PW_CLOCK", "-c", os.path.join(g.CSRC, "pw_gemm.hip"), "-o", o])
-    objs = [o] + [os.path.join(objdir, s.replace(".hip", ".o")) for s in g.SOURCES if s != "pw_gemm.hip"]
+    clk = ["pw_gemm.hip", "pw_wgrad.hip"]
+    procs = []
+    for src in clk:
+        o = os.path.join(objdir, src.replace(".hip", "_clk.o"))
+        procs.append(subprocess.Popen([g.HIPCC] + g.FLAGS + ["-DC3D_PW_CLOCK", "-c", os.path.join(g.CSRC, src), "-o", o]))
+    for p_ in procs:
+        assert p_.wait() == 0
+    objs = [os.path.join(objdir, s.replace(".hip", "_clk.o" if s in clk else ".o")) for s in g.SOURCES]
     subprocess.check_call([g.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", CLK_LIB] + objs)
     print("built", CLK_LIB)
 
@@ -98,8 +103,67 @@ def main():
                 print(f"    {ph:18s} {v[i] / v[15]:10.0f} clk  {100.0 * v[i] / sum(v[:15]):5.1f} %")
 
 
+WG_PHASES = ["setup", "wait loads", "convert -> LDS", "issue next tile", "barrier", "mfma", "partials store"]
+
+
+def main_wgrad():
+    os.environ["C3D_LIB"] = CLK_LIB
+    import numpy as np
+    import torch
+    from change3d_amd import _lib, ops
+    h = _lib.lib()
+    h.c3d_debug_wgrad_clock.restype = C.c_int
+    h.c3d_debug_wgrad_clock.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    buf = (C.c_ulonglong * (8192 * 8))()
+
+    def read():
+        torch.cuda.synchronize()
+        assert h.c3d_debug_wgrad_clock(buf, 1) == 0
+        return np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.float64)
+
+    DEV, DT, B, T = "cuda:0", torch.bfloat16, 32, 3
+    dt = ops.dt_code(DT)
+    rt = lambda *s: torch.randn(*s, device=DEV).to(DT)  # noqa: E731
+    for st, H, Cin, Ci, Co in [(1, 128, 24, 54, 24), (2, 64, 48, 108, 48), (3, 32, 96, 216, 96)]:
+        M = B * T * H * H
+        Cip = ops.cpad(Ci)
+        x, a_, b_, c_ = rt(M, Cin), rt(M, Cip), rt(M, Cip), rt(M, Co)
+        ss, gate = torch.rand(2 * Cip, device=DEV), torch.rand(B * Cip, device=DEV)
+        coef3, coefo = torch.rand(3 * Cip, device=DEV), torch.rand(3 * Co, device=DEV)
+        dwc, dwa = torch.zeros(Co, Ci, device=DEV), torch.zeros(Ci, Cin, device=DEV)
+        cases = {
+            f"conv_c wgrad N={Co} K={Ci} (P affine2, Q swish)": lambda: ops.pw_wgrad(
+                c_, b_, dwc, M=M, K=Ci, N=Co, dw_sn=Ci, dw_sk=1, dtype=dt, p2=c_, p_coef=coefo,
+                q_mode=ops.PRO_BN_SE_SWISH, q_ss=ss, q_gate=gate, rows_per_sample=T * H * H),
+            f"conv_a wgrad N={Ci} K={Cin} (P affine2)": lambda: ops.pw_wgrad(
+                a_, x, dwa, M=M, K=Cin, N=Ci, dw_sn=Cin, dw_sk=1, dtype=dt, p2=b_, p_coef=coef3),
+        }
+        for name, fn in cases.items():
+            for _ in range(3):
+                fn()
+            read()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            iters = 10
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            a = read()
+            us = e0.elapsed_time(e1) / iters * 1e3
+            a = a[a[:, 7] > 0]
+            print(f"s{st} {name}: {us:.1f} us/launch (incl. reduce kernel), {len(a)} wave slots")
+            for grp, sel in (("waves 0-3 (stage P)", np.arange(len(a)) % 8 < 4), ("waves 4-7 (stage Q)", np.arange(len(a)) % 8 >= 4)):
+                v = a[sel]
+                tot = v[:, :7].sum() / v[:, 7].sum()
+                print(f"  {grp}: {tot:.0f} clk per wave")
+                for i, ph in enumerate(WG_PHASES):
+                    print(f"    {ph:18s} {v[:, i].sum() / v[:, 7].sum():10.0f} clk  {100.0 * v[:, i].sum() / v[:, :7].sum():5.1f} %")
+
+
 if __name__ == "__main__":
     if "--build" in sys.argv:
         build()
+    elif "--wgrad" in sys.argv:
+        main_wgrad()
     else:
         main()
