@@ -14,6 +14,7 @@ Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed,
 bytes) and `cpu_baseline` (the CPU oracle = port of the reference path, timed on host cores).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -72,7 +73,8 @@ def cpu_baseline(size, batch=2, timed=6, budget_s=20.0):
     from oracle import model as om, synth
     cores = usable_cores()
     torch.set_num_threads(cores)
-    net = om.Trainer(om.make_args(size=size))
+    with contextlib.redirect_stdout(sys.stderr):   # the mirror prints the reference's "pretrained weights" notice
+        net = om.Trainer(om.make_args(size=size))
     net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25))
     net.train()
     opt = om.make_adam(net)
@@ -156,7 +158,8 @@ def main():
     margs = make_args(num_perception_frame=3, size=a.size, dataset="SECOND", num_class=7) if scd else make_args(size=a.size)
     margs.act_dtype = act
     margs.lr_mode, margs.lr, margs.max_epochs, margs.step_loss = "poly", 2e-4, 1, 100
-    net = Trainer(margs)
+    with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
+        net = Trainer(margs)
     net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25))
     net = net.to(dev).train()
     broadcast_module_state(net)
