@@ -16,6 +16,21 @@
 #include "../../include/change3d_hip.h"
 #include <cstdlib>
 
+#ifdef C3D_PW_CLOCK
+// Debug build only (tools/pw_phase_clock.py --dw): per-phase shader-clock sums of the data-gradient kernel.
+constexpr int DCLK_WAVES = 16384;
+__device__ unsigned long long c3d_dw_clk[DCLK_WAVES][10];
+#define DCLK_DECL unsigned long long dclk_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dclk_last_ = __builtin_amdgcn_s_memtime();
+#define DCLK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); dclk_[i] += t_ - dclk_last_; dclk_last_ = t_; }
+#define DCLK_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define DCLK_FLUSH if ((threadIdx.x & 63) == 0) { const int w_ = (blockIdx.x * 4 + (threadIdx.x >> 6)) % DCLK_WAVES; for (int i_ = 0; i_ < 9; ++i_) c3d_dw_clk[w_][i_] += dclk_[i_]; c3d_dw_clk[w_][9] += 1ull; }
+#else
+#define DCLK_DECL
+#define DCLK(i)
+#define DCLK_WAITVM
+#define DCLK_FLUSH
+#endif
+
 namespace {
 
 constexpr int DW_CV = 4;    // channel vectors (of 8) per workgroup pass = 32 channels
@@ -260,6 +275,7 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
   constexpr int plane = NI;                       // float4 units per half-vector plane
 
   const int tid = threadIdx.x;
+  DCLK_DECL
   const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y;
   const int gx = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
@@ -292,22 +308,36 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
 
   typename RW::type r1[SL], r2[SL];
   unsigned vmask = 0;
+  // Per-slot staging descriptors, computed once: the kernel is VALU-bound (4 waves per SIMD, in-kernel clocks), and
+  // the per-tile decode of (frame, row, column) with its 64-bit offset multiplies was ~70 quarter-rate integer
+  // instructions per tile and thread.  rel = offset of the slot's element relative to the tile origin, yx = its
+  // (row, column) inside the staged tile (0x7fff: slot not in use).
+  int rel[SL], yx[SL];
+#pragma unroll
+  for (int sl = 0; sl < SL; ++sl) {
+    const int i_ = tid + sl * NTHR;
+    const int p_ = i_ / DW_CV;
+    const int ix_ = p_ % DW_, q_ = p_ / DW_;
+    const int iy_ = q_ % DH, t_ = q_ / DH;
+    const bool use_ = i_ < NI && c_ok && t_ < g.T;
+    rel[sl] = ((t_ * g.Ho + iy_) * g.Wo + ix_) * g.Cp + cbase;
+    yx[sl] = use_ ? (iy_ | (ix_ << 16)) : 0x7fff7fff;
+  }
 #define BD_ISSUE(TL)                                                                             \
   {                                                                                              \
     const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                        \
     const int dy0_ = (S == 1) ? ty_ * TH - 1 : ((ty_ * TH) >> 1) - 1;                            \
     const int dx0_ = (S == 1) ? tx_ * TW - 1 : ((tx_ * TW) >> 1) - 1;                            \
+    const int64_t tb_ = ((((int64_t)b * g.T) * g.Ho + dy0_) * g.Wo + dx0_) * g.Cp;  /* wave-uniform */ \
+    const T* t1b_ = t1 + tb_;                                                                    \
+    const T* bbb_ = bb + tb_;                                                                    \
     vmask = 0;                                                                                   \
     _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                          \
-      const int i_ = tid + sl * NTHR;                                                            \
-      const int p_ = i_ / DW_CV;                                                                 \
-      const int ix_ = p_ % DW_, q_ = p_ / DW_;                                                   \
-      const int iy_ = q_ % DH, t_ = q_ / DH;                                                     \
-      const int gy_ = dy0_ + iy_, gx_ = dx0_ + ix_;                                              \
-      if (i_ < NI && c_ok && t_ < g.T && gy_ >= 0 && gy_ < g.Ho && gx_ >= 0 && gx_ < g.Wo) {    \
-        const size_t off_ = ((((size_t)b * g.T + t_) * g.Ho + gy_) * g.Wo + gx_) * g.Cp + cbase; \
-        r1[sl] = RW::load(t1 + off_);                                                            \
-        r2[sl] = RW::load(bb + off_);                                                            \
+      const unsigned gy_ = (unsigned)(dy0_ + (yx[sl] & 0xffff));                                 \
+      const unsigned gx_ = (unsigned)(dx0_ + (yx[sl] >> 16));                                    \
+      if (gy_ < (unsigned)g.Ho && gx_ < (unsigned)g.Wo) {                                        \
+        r1[sl] = RW::load(t1b_ + rel[sl]);                                                       \
+        r2[sl] = RW::load(bbb_ + rel[sl]);                                                       \
         vmask |= 1u << sl;                                                                       \
       }                                                                                          \
     }                                                                                            \
@@ -319,12 +349,16 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
   int tl1 = tl0 + tiles_per_wg;
   if (tl1 > ntiles) tl1 = ntiles;
   if (tl0 < tl1) BD_ISSUE(tl0)
+  DCLK(0)
   for (int tl = tl0; tl < tl1; ++tl) {
     const int tx = tl % tiles_x, ty = tl / tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
     const int dy0 = (S == 1) ? y0 - 1 : (y0 >> 1) - 1;   // first db row/col held in the tile
     const int dx0 = (S == 1) ? x0 - 1 : (x0 >> 1) - 1;
     __syncthreads();   // the previous tile's taps are done (and wl/cf are visible on the first pass)
+    DCLK(1)
+    DCLK_WAITVM
+    DCLK(2)
     {
       float cA[8], cB[8], cC[8];
       lds_ld8(cf + 0 * 32 + cv * 8, cA);
@@ -350,18 +384,23 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
         }
       }
     }
+    DCLK(3)
     // this tile's `a` rows (epilogue operands) first, then the next tile's raw rows: vmcnt is in
     // order, so the epilogue waits only for what it needs
     const int iy = y0 + py, ix = x0 + px;
     const bool p_ok = c_ok && iy < g.H && ix < g.W;
+    const int64_t ob = ((((int64_t)b * g.T) * g.H + y0) * g.W + x0) * g.Cp;   // wave-uniform tile origin (a, t2)
+    const int orel = (py * g.W + px) * g.Cp + cbase, ofr = g.H * g.W * g.Cp;   // lane offset, frame stride
     typename RW::type ar[TT];
     if (p_ok) {
 #pragma unroll
       for (int t = 0; t < TT; ++t)
-        if (t < g.T) ar[t] = RW::load(a + ((((size_t)b * g.T + t) * g.H + iy) * g.W + ix) * g.Cp + cbase);
+        if (t < g.T) ar[t] = RW::load(a + ob + (orel + t * ofr));
     }
     if (tl + 1 < tl1) BD_ISSUE(tl + 1)
+    DCLK(4)
     __syncthreads();
+    DCLK(5)
 
     float acc[TT][8];
 #pragma unroll
@@ -399,6 +438,7 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
         }
       }
     }
+    DCLK(6)
     if (p_ok) {
       float s1[8], s2[8];
 #pragma unroll
@@ -411,7 +451,6 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         if (t < g.T) {
-          const size_t off = ((((size_t)b * g.T + t) * g.H + iy) * g.W + ix) * g.Cp + cbase;
           float av[8], o[8];
           RW::cvt(ar[t], av);
 #pragma unroll
@@ -421,12 +460,13 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
             o[j] = d;
             s1[j] += d; s2[j] += d * ((av[j] - ma[j]) * ra[j]);
           }
-          Vec8<T>::store(t2 + off, o);
+          Vec8<T>::store(t2 + ob + (orel + t * ofr), o);
         }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) { S1[j] += (double)s1[j]; S2[j] += (double)s2[j]; }
     }
+    DCLK(7)
   }
 #undef BD_ISSUE
   const int lane = tid & 63, wave = tid >> 6;
@@ -455,6 +495,8 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
     const int c = c0 + v * 8 + (k & 7);
     if (c < g.C) atomicAdd(dsums + (size_t)(k >> 3) * g.C + c, sacc);
   }
+  DCLK(8)
+  DCLK_FLUSH
 }
 
 // Asynchronous LDS vector read of 8 tile elements with an explicit wait, for hand-pipelined
@@ -2117,3 +2159,16 @@ extern "C" int c3d_dw333_bwd(const void* t1, const void* b, const float* coefA, 
                        : launch_bwd_fused_t<bf16_t, 2>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s);
   return C3D_E_BADARG;
 }
+
+#ifdef C3D_PW_CLOCK
+extern "C" int c3d_debug_dw_clock(unsigned long long* out, int reset) {   // out[DCLK_WAVES][10]
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(c3d_dw_clk), sizeof(unsigned long long) * DCLK_WAVES * 10);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(c3d_dw_clk));
+    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * DCLK_WAVES * 10);
+  }
+  return (int)e;
+}
+#endif
