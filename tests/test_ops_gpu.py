@@ -184,6 +184,89 @@ def test_pw_gemm_swish_se_bwd_epilogue(dtype):
     assert torch.allclose(s[..., 2], ref2, rtol=1e-4, atol=1e-3), "sum t1*bhat"
 
 
+# Long walks: many tiles per wave, several iterations of 1-8 sub-tiles, a partial last iteration and a ragged last
+# tile.  The small cases above give every wave at most one tile, so the prefetch ring, the paired sub-tiles, the
+# hand-scheduled fragment batches across K steps and the companion-row prefetch chain are only exercised here.
+@pytest.mark.parametrize("K,N", [(24, 54), (54, 24), (48, 108), (108, 48), (96, 216), (216, 96)])
+@pytest.mark.parametrize("mode", ["stats", "swish_stats", "affine2_add", "affine2_swish_se_bwd"])
+def test_pw_gemm_long_walks(K, N, mode):
+    _need_gpu()
+    from change3d_amd import ops
+    dtype = torch.bfloat16
+    from change3d_amd import _lib
+    cus = _lib.lib().c3d_device_cus()
+    B = 5
+    rows = 16 * ((7 * 8 * cus) // B + 3)               # ~7 tiles per wave at 8 waves per CU, odd tile count per sample
+    M = B * rows - 11                                   # ragged last tile (not for the per-sample epilogue)
+    if mode in ("swish_stats", "affine2_swish_se_bwd"):
+        M = B * rows
+    Kp, Np = ops.cpad(K), ops.cpad(N)
+    x = q(rnd((M, K), 31), dtype)
+    y = torch.full((M, Np), float("nan"), dtype=dtype, device=DEV)
+    dt = ops.dt_code(dtype)
+    xd = padc(x, Kp).to(DEV, dtype).contiguous()
+    if mode == "stats":
+        w = rnd((N, K), 32, 0.2)
+        ref = x @ w.t()
+        stats = torch.zeros(ops.STAT_STRIPES * 2 * N, dtype=torch.float64, device=DEV)
+        ops.pw_gemm(xd, w.to(DEV), y, M=M, K=K, N=N, w_sn=K, w_sk=1, dtype=dt, epi_mode=ops.EPI_STATS, stats=stats)
+    elif mode == "swish_stats":
+        w = rnd((N, K), 33, 0.2)
+        scale, shift = rnd((K,), 34).abs() + 0.5, rnd((K,), 35, 0.3)
+        gate = torch.sigmoid(rnd((B, K), 36))
+        v = (x * scale + shift).view(B, rows, K) * gate[:, None, :]
+        ref = (v * torch.sigmoid(v)).view(M, K) @ w.t()
+        stats = torch.zeros(ops.STAT_STRIPES * 2 * N, dtype=torch.float64, device=DEV)
+        ops.pw_gemm(xd, w.to(DEV), y, M=M, K=K, N=N, w_sn=K, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH,
+                    pro_p=torch.cat([padc(scale, Kp), padc(shift, Kp)]).to(DEV),
+                    pro_gate=padc(gate, Kp).to(DEV).contiguous(), rows_per_sample=rows, epi_mode=ops.EPI_STATS, stats=stats)
+    else:
+        a2 = q(rnd((M, K), 37), dtype)
+        A, Bc, Cc = rnd((K,), 38), rnd((K,), 39, 0.1), rnd((K,), 40, 0.1)
+        wt = rnd((K, N), 41, 0.2)                       # conv weight [out=K][in=N]: transposed use
+        pre = (A * x + Bc + Cc * a2) @ wt
+        coef = torch.cat([padc(A, Kp), padc(Bc, Kp), padc(Cc, Kp)]).to(DEV)
+        a2d = padc(a2, Kp).to(DEV, dtype).contiguous()
+        if mode == "affine2_add":
+            res = q(rnd((M, N), 42), dtype)
+            ref = pre + res
+            ops.pw_gemm(xd, wt.to(DEV), y, M=M, K=K, N=N, w_sn=1, w_sk=N, dtype=dt, x2=a2d, pro_mode=ops.PRO_AFFINE2,
+                        pro_p=coef, epi_mode=ops.EPI_ADD, e1=padc(res, Np).to(DEV, dtype).contiguous(), res_mode=0)
+        else:
+            b = q(rnd((M, N), 43), dtype)
+            scale, shift = rnd((N,), 44).abs() + 0.5, rnd((N,), 45, 0.3)
+            gate = torch.sigmoid(rnd((B, N), 46))
+            mean, rstd = rnd((N,), 47, 0.5), rnd((N,), 48).abs() + 0.5
+            pb = b * scale + shift
+            gg = gate.repeat_interleave(rows, 0)
+            qv = gg * pb
+            sg = torch.sigmoid(qv)
+            dq = pre * sg * (1 + qv * (1 - sg))
+            ref = dq * gg
+            nc3 = torch.zeros(B * Np * 3, dtype=torch.float64, device=DEV)
+            ops.pw_gemm(xd, wt.to(DEV), y, M=M, K=K, N=N, w_sn=1, w_sk=N, dtype=dt, x2=a2d, pro_mode=ops.PRO_AFFINE2,
+                        pro_p=coef, epi_mode=ops.EPI_SWISH_SE_BWD, e1=padc(b, Np).to(DEV, dtype).contiguous(),
+                        epi_p=torch.cat([padc(scale, Np), padc(shift, Np)]).to(DEV),
+                        epi_gate=padc(gate, Np).to(DEV).contiguous(),
+                        epi_q=torch.cat([padc(mean, Np), padc(rstd, Np)]).to(DEV), stats=nc3, rows_per_sample=rows)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all(), "every row must be written"
+    close(y[:, :N], ref, dtype, "y", scale=ref.abs().max().item())
+    yq = y[:, :N].float().cpu().double()
+    if mode in ("stats", "swish_stats"):
+        s = stats.cpu().view(ops.STAT_STRIPES, 2 * N).sum(0)
+        assert torch.allclose(s[:N], yq.sum(0), rtol=1e-5, atol=1e-2), "column sums"
+        assert torch.allclose(s[N:], (yq * yq).sum(0), rtol=1e-5, atol=1e-2), "column sums of squares"
+    if mode == "affine2_swish_se_bwd":
+        s = nc3.cpu().view(B, Np, 3)[:, :N]
+        ref1 = yq.view(B, rows, N).sum(1)
+        ref2 = (yq * ((b - mean) * rstd).double()).view(B, rows, N).sum(1)
+        ref0 = (dq * pb).view(B, rows, N).sum(1).double()
+        assert torch.allclose(s[..., 1], ref1, rtol=1e-4, atol=1e-2), "sum t1"
+        assert torch.allclose(s[..., 2], ref2, rtol=1e-4, atol=1e-2), "sum t1*bhat"
+        assert torch.allclose(s[..., 0], ref0, rtol=3e-2, atol=3e-2 * ref0.abs().max().item()), "sum dq*pb"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("K,N", [(24, 54), (216, 96), (96, 216), (48, 48)])
 def test_pw_wgrad(dtype, K, N):
@@ -208,6 +291,37 @@ def test_pw_wgrad(dtype, K, N):
                  q_ss=torch.cat([padc(scale, Kp), padc(shift, Kp)]).to(DEV),
                  q_gate=padc(gate, Kp).to(DEV).contiguous(), rows_per_sample=rows)
     close(dw, ref, dtype, "dW", scale=ref.abs().max().item())
+
+
+# Many tiles per workgroup with the per-sample Swish gate cached across tiles: samples that end inside a tile, inside
+# a thread's 4-row group (rows_per_sample % 4 != 0) and a ragged last tile.
+@pytest.mark.parametrize("K,N,rows", [(216, 96, 148), (216, 96, 150), (108, 48, 301), (54, 24, 1027)])
+def test_pw_wgrad_long_walks(K, N, rows):
+    _need_gpu()
+    from change3d_amd import ops
+    dtype = torch.bfloat16
+    B = 400000 // rows
+    M = B * rows - 5
+    Kp, Np = ops.cpad(K), ops.cpad(N)
+    # all-positive operands (the sum is coherent, ~M terms of one sign) and gates that alternate between 0.1 and 0.9
+    # from sample to sample: a row converted with a neighbouring sample's gate shifts the result by percent
+    p, p2 = q(rnd((M, N), 50).abs(), dtype), q(rnd((M, N), 51).abs(), dtype)
+    A, Bc, Cc = rnd((N,), 52).abs() + 0.5, torch.zeros(N), rnd((N,), 54, 0.1).abs()
+    x = q(rnd((M, K), 55).abs(), dtype)
+    scale, shift = rnd((K,), 56).abs() + 0.5, rnd((K,), 57, 0.3).abs()
+    gate = torch.where(torch.arange(B)[:, None] % 2 == 0, torch.full((B, K), 0.1), torch.full((B, K), 0.9))
+    P = (A * p + Bc + Cc * p2).double()
+    v = (x * scale + shift) * gate.repeat_interleave(rows, 0)[:M]
+    Q = (v * torch.sigmoid(v)).double()
+    ref = (P.t() @ Q).float()
+    dw = torch.zeros((N, K), dtype=torch.float32, device=DEV)
+    ops.pw_wgrad(padc(p, Np).to(DEV, dtype).contiguous(), padc(x, Kp).to(DEV, dtype).contiguous(), dw, M=M, K=K, N=N,
+                 dw_sn=K, dw_sk=1, dtype=ops.dt_code(dtype), p2=padc(p2, Np).to(DEV, dtype).contiguous(),
+                 p_coef=torch.cat([padc(A, Np), padc(Bc, Np), padc(Cc, Np)]).to(DEV), q_mode=ops.PRO_BN_SE_SWISH,
+                 q_ss=torch.cat([padc(scale, Kp), padc(shift, Kp)]).to(DEV),
+                 q_gate=padc(gate, Kp).to(DEV).contiguous(), rows_per_sample=rows)
+    rel = ((dw.cpu() - ref).abs() / ref.abs()).max().item()
+    assert rel < 4e-3, rel      # bf16 operand rounding is 2^-9 per term and averages out over ~4e5 coherent terms
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
