@@ -1,928 +1,9 @@
-// Pointwise-convolution row GEMM on MFMA (gfx950), forward and data-gradient.
-//
-//   Y[m, n] = epilogue( sum_k prologue(X)[m, k] * Wt[n, k] ),   M ~ 1e5..6e6, K,N <= 224.
-//
-// Design (HBM-bound op: ~10-40 flop/B, far under the MFMA ridge):
-//  * every WAVE owns whole 16-row tiles end to end (load -> MFMA -> store); waves of a
-//    workgroup share only the weight matrix, staged once into LDS, so the tile loop has no
-//    workgroup barrier;
-//  * a 16-row tile of a channels-last tensor is ONE contiguous 16*Kp-element span: it is
-//    loaded with 16-byte lane vectors (lane <-> (row, 8-channel vector), the vector index
-//    fixed per lane so the per-channel prologue parameters live in registers);
-//  * MFMA roles are swapped (A = weights, B = data rows) so each lane ends up holding 4
-//    consecutive output channels of one data row -> one 16-byte LDS write per 16x16 tile;
-//  * the result tile is read back row-contiguous and stored with 16/32-byte lane vectors,
-//    again with a fixed 8-channel vector per lane, which is where the fused epilogues
-//    (BN statistics, Swish/SE backward, residual add) run and accumulate per-lane partial
-//    sums that are flushed with f64 atomics once per wave (or per batch sample).
-//  * bf16 storage -> v_mfma_f32_16x16x32_bf16; f32 storage -> v_mfma_f32_16x16x4_f32
-//    (exact f32 fma chain, used by the parity path).
-#include "common.h"
-#include "../../include/change3d_hip.h"
-#include "pw_common.h"
-#include <cstdlib>
+// Pointwise-convolution row GEMM: C entry point and the bf16 (throughput) instantiations.  The kernel lives in
+// pw_gemm_impl.h; the f32 (parity) instantiations are compiled in pw_gemm_f32.hip.
+#include "pw_gemm_impl.h"
 
-#ifdef C3D_PW_CLOCK
-// Debug build only (tools/pw_phase_clock.py): per-phase shader-clock sums over all waves.
-constexpr int CLK_WAVES = 8192;
-__device__ unsigned long long c3d_pw_clk[CLK_WAVES][16];   // per-wave slots (atomics on shared slots stall the launch)
-#define CLK_DECL unsigned long long clk_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long clk_last_ = __builtin_amdgcn_s_memtime();
-#define CLK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); clk_[i] += t_ - clk_last_; clk_last_ = t_; }
-#define CLK_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#define CLK_FLUSH if (lane == 0) { const int w_ = (blockIdx.x * WAVES + wave) % CLK_WAVES; for (int i_ = 0; i_ < 15; ++i_) c3d_pw_clk[w_][i_] += clk_[i_]; c3d_pw_clk[w_][15] += 1ull; }
-#else
-#define CLK_DECL
-#define CLK(i)
-#define CLK_WAITVM
-#define CLK_FLUSH
-#endif
-
-namespace {
-
-// ---- hand-scheduled weight-fragment pipeline (bf16) ------------------------------------------------------
-// U ds_read_b128 in flight, then the U (or 2U) MFMAs behind counted lgkmcnt waits, in ONE asm statement: the
-// compiler interleaves read -> wait -> MFMA with at most two reads in flight (LDS latency ~130 clk against 16-32
-// clk of MFMA per fragment), and nothing (in particular no scalar load, which shares lgkmcnt and returns out of
-// order) can be scheduled into the counted region.  Operand A = weight fragment, B = data rows.  The trailing
-// s_nop covers the MFMA -> VALU read hazard the compiler cannot see through inline asm.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-template <int U, bool PAIR> struct MfmaBatch;
-template <> struct MfmaBatch<1, false> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %1, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "=&v"(b0), "+v"(addr)
-                 : "s"(str), "v"(xb));
-  }
-};
-template <> struct MfmaBatch<1, true> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %2, %3\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %5, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %2, %6, %1\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a2[0]), "=&v"(b0), "+v"(addr)
-                 : "s"(str), "v"(xb), "v"(xb2));
-  }
-};
-template <> struct MfmaBatch<2, false> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %2, %4\n\tv_add_u32 %4, %5, %4\n\tds_read_b128 %3, %4\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %6, %1\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "=&v"(b0), "=&v"(b1), "+v"(addr)
-                 : "s"(str), "v"(xb));
-  }
-};
-template <> struct MfmaBatch<2, true> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %4, %6\n\tv_add_u32 %6, %7, %6\n\tds_read_b128 %5, %6\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\tv_mfma_f32_16x16x32_bf16 %2, %4, %9, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\tv_mfma_f32_16x16x32_bf16 %3, %5, %9, %3\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a2[0]), "+v"(a2[1]), "=&v"(b0), "=&v"(b1), "+v"(addr)
-                 : "s"(str), "v"(xb), "v"(xb2));
-  }
-};
-template <> struct MfmaBatch<3, false> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1; u32x4_t b2;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %3, %6\n\tv_add_u32 %6, %7, %6\n\tds_read_b128 %4, %6\n\tv_add_u32 %6, %7, %6\n\tds_read_b128 %5, %6\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %0, %3, %8, %0\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %1, %4, %8, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %2, %5, %8, %2\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "+v"(addr)
-                 : "s"(str), "v"(xb));
-  }
-};
-template <> struct MfmaBatch<3, true> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1; u32x4_t b2;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %6, %9\n\tv_add_u32 %9, %10, %9\n\tds_read_b128 %7, %9\n\tv_add_u32 %9, %10, %9\n\tds_read_b128 %8, %9\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %0, %6, %11, %0\n\tv_mfma_f32_16x16x32_bf16 %3, %6, %12, %3\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %1, %7, %11, %1\n\tv_mfma_f32_16x16x32_bf16 %4, %7, %12, %4\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %2, %8, %11, %2\n\tv_mfma_f32_16x16x32_bf16 %5, %8, %12, %5\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "+v"(addr)
-                 : "s"(str), "v"(xb), "v"(xb2));
-  }
-};
-template <> struct MfmaBatch<4, false> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %4, %8\n\tv_add_u32 %8, %9, %8\n\tds_read_b128 %5, %8\n\tv_add_u32 %8, %9, %8\n\tds_read_b128 %6, %8\n\tv_add_u32 %8, %9, %8\n\tds_read_b128 %7, %8\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %0, %4, %10, %0\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %10, %1\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %2, %6, %10, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %3, %7, %10, %3\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "+v"(addr)
-                 : "s"(str), "v"(xb));
-  }
-};
-template <> struct MfmaBatch<4, true> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %8, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %9, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %10, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %11, %12\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %0, %8, %14, %0\n\tv_mfma_f32_16x16x32_bf16 %4, %8, %15, %4\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %1, %9, %14, %1\n\tv_mfma_f32_16x16x32_bf16 %5, %9, %15, %5\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %2, %10, %14, %2\n\tv_mfma_f32_16x16x32_bf16 %6, %10, %15, %6\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %3, %11, %14, %3\n\tv_mfma_f32_16x16x32_bf16 %7, %11, %15, %7\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(a2[3]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "+v"(addr)
-                 : "s"(str), "v"(xb), "v"(xb2));
-  }
-};
-template <> struct MfmaBatch<5, false> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %5, %10\n\tv_add_u32 %10, %11, %10\n\tds_read_b128 %6, %10\n\tv_add_u32 %10, %11, %10\n\tds_read_b128 %7, %10\n\tv_add_u32 %10, %11, %10\n\tds_read_b128 %8, %10\n\tv_add_u32 %10, %11, %10\n\tds_read_b128 %9, %10\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %0, %5, %12, %0\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %1, %6, %12, %1\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %2, %7, %12, %2\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %3, %8, %12, %3\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %4, %9, %12, %4\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "+v"(addr)
-                 : "s"(str), "v"(xb));
-  }
-};
-template <> struct MfmaBatch<5, true> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %10, %15\n\tv_add_u32 %15, %16, %15\n\tds_read_b128 %11, %15\n\tv_add_u32 %15, %16, %15\n\tds_read_b128 %12, %15\n\tv_add_u32 %15, %16, %15\n\tds_read_b128 %13, %15\n\tv_add_u32 %15, %16, %15\n\tds_read_b128 %14, %15\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %0, %10, %17, %0\n\tv_mfma_f32_16x16x32_bf16 %5, %10, %18, %5\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %1, %11, %17, %1\n\tv_mfma_f32_16x16x32_bf16 %6, %11, %18, %6\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %2, %12, %17, %2\n\tv_mfma_f32_16x16x32_bf16 %7, %12, %18, %7\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %3, %13, %17, %3\n\tv_mfma_f32_16x16x32_bf16 %8, %13, %18, %8\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %4, %14, %17, %4\n\tv_mfma_f32_16x16x32_bf16 %9, %14, %18, %9\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(a2[3]), "+v"(a2[4]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "+v"(addr)
-                 : "s"(str), "v"(xb), "v"(xb2));
-  }
-};
-template <> struct MfmaBatch<6, false> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4; u32x4_t b5;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %6, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %7, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %8, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %9, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %10, %12\n\tv_add_u32 %12, %13, %12\n\tds_read_b128 %11, %12\n\ts_waitcnt lgkmcnt(5)\n\tv_mfma_f32_16x16x32_bf16 %0, %6, %14, %0\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %1, %7, %14, %1\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %2, %8, %14, %2\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %3, %9, %14, %3\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %4, %10, %14, %4\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %5, %11, %14, %5\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "+v"(addr)
-                 : "s"(str), "v"(xb));
-  }
-};
-template <> struct MfmaBatch<6, true> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4; u32x4_t b5;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %12, %18\n\tv_add_u32 %18, %19, %18\n\tds_read_b128 %13, %18\n\tv_add_u32 %18, %19, %18\n\tds_read_b128 %14, %18\n\tv_add_u32 %18, %19, %18\n\tds_read_b128 %15, %18\n\tv_add_u32 %18, %19, %18\n\tds_read_b128 %16, %18\n\tv_add_u32 %18, %19, %18\n\tds_read_b128 %17, %18\n\ts_waitcnt lgkmcnt(5)\n\tv_mfma_f32_16x16x32_bf16 %0, %12, %20, %0\n\tv_mfma_f32_16x16x32_bf16 %6, %12, %21, %6\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %1, %13, %20, %1\n\tv_mfma_f32_16x16x32_bf16 %7, %13, %21, %7\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %2, %14, %20, %2\n\tv_mfma_f32_16x16x32_bf16 %8, %14, %21, %8\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %3, %15, %20, %3\n\tv_mfma_f32_16x16x32_bf16 %9, %15, %21, %9\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %4, %16, %20, %4\n\tv_mfma_f32_16x16x32_bf16 %10, %16, %21, %10\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %5, %17, %20, %5\n\tv_mfma_f32_16x16x32_bf16 %11, %17, %21, %11\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(a2[3]), "+v"(a2[4]), "+v"(a2[5]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "+v"(addr)
-                 : "s"(str), "v"(xb), "v"(xb2));
-  }
-};
-template <> struct MfmaBatch<7, false> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4; u32x4_t b5; u32x4_t b6;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %7, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %8, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %9, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %10, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %11, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %12, %14\n\tv_add_u32 %14, %15, %14\n\tds_read_b128 %13, %14\n\ts_waitcnt lgkmcnt(6)\n\tv_mfma_f32_16x16x32_bf16 %0, %7, %16, %0\n\ts_waitcnt lgkmcnt(5)\n\tv_mfma_f32_16x16x32_bf16 %1, %8, %16, %1\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %2, %9, %16, %2\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %3, %10, %16, %3\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %4, %11, %16, %4\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %5, %12, %16, %5\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %6, %13, %16, %6\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "+v"(addr)
-                 : "s"(str), "v"(xb));
-  }
-};
-template <> struct MfmaBatch<7, true> {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    u32x4_t b0; u32x4_t b1; u32x4_t b2; u32x4_t b3; u32x4_t b4; u32x4_t b5; u32x4_t b6;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %14, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %15, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %16, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %17, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %18, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %19, %21\n\tv_add_u32 %21, %22, %21\n\tds_read_b128 %20, %21\n\ts_waitcnt lgkmcnt(6)\n\tv_mfma_f32_16x16x32_bf16 %0, %14, %23, %0\n\tv_mfma_f32_16x16x32_bf16 %7, %14, %24, %7\n\ts_waitcnt lgkmcnt(5)\n\tv_mfma_f32_16x16x32_bf16 %1, %15, %23, %1\n\tv_mfma_f32_16x16x32_bf16 %8, %15, %24, %8\n\ts_waitcnt lgkmcnt(4)\n\tv_mfma_f32_16x16x32_bf16 %2, %16, %23, %2\n\tv_mfma_f32_16x16x32_bf16 %9, %16, %24, %9\n\ts_waitcnt lgkmcnt(3)\n\tv_mfma_f32_16x16x32_bf16 %3, %17, %23, %3\n\tv_mfma_f32_16x16x32_bf16 %10, %17, %24, %10\n\ts_waitcnt lgkmcnt(2)\n\tv_mfma_f32_16x16x32_bf16 %4, %18, %23, %4\n\tv_mfma_f32_16x16x32_bf16 %11, %18, %24, %11\n\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 %5, %19, %23, %5\n\tv_mfma_f32_16x16x32_bf16 %12, %19, %24, %12\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 %6, %20, %23, %6\n\tv_mfma_f32_16x16x32_bf16 %13, %20, %24, %13\n\ts_nop 15\n\ts_nop 2"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(a2[3]), "+v"(a2[4]), "+v"(a2[5]), "+v"(a2[6]), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "+v"(addr)
-                 : "s"(str), "v"(xb), "v"(xb2));
-  }
-};
-// all NT output tiles of one K step, UB fragments per batch
-template <int NT, int UB, int N0, bool PAIR> struct MfmaSeq {
-  static __device__ __forceinline__ void run(f32x4_t* a, f32x4_t* a2, const uint32_t addr, const uint32_t str, const u32x4_t xb, const u32x4_t xb2) {
-    constexpr int U = NT - N0 < UB ? NT - N0 : UB;
-    MfmaBatch<U, PAIR>::run(a + N0, a2 + N0, addr + N0 * str, str, xb, xb2);
-    if constexpr (N0 + U < NT) MfmaSeq<NT, UB, N0 + U, PAIR>::run(a, a2, addr, str, xb, xb2);
-  }
-};
-
-constexpr bool PROis(int pro) { return pro == C3D_PRO_AFFINE2; }
-
-__device__ __forceinline__ int64_t row_offset(const c3d_pw_args& a, uint32_t um) {
-  if (a.row_mode == C3D_ROWS_DENSE) return (int64_t)um * a.Kp;
-  if (a.row_mode == C3D_ROWS_FRAME) {
-    const uint32_t g = um / (uint32_t)a.rpg;
-    const uint32_t r = um - g * (uint32_t)a.rpg;
-    return (int64_t)g * a.gstride + (int64_t)r * a.Kp;
-  }
-  // STRIDE2: m = (bt, ho, wo) over output [BT][H/2][W/2]
-  const uint32_t Wo = (uint32_t)a.W >> 1, Ho = (uint32_t)a.H >> 1;
-  const uint32_t wo = um % Wo;
-  const uint32_t t = um / Wo;
-  const uint32_t ho = t % Ho;
-  const uint32_t bt = t / Ho;
-  return (((int64_t)bt * a.H + 2 * ho) * a.W + 2 * wo) * a.Kp;
-}
-
-// Sum `v` over the lanes {lane, lane+G, lane+2G, ...} (result valid in lanes < G).
-__device__ __forceinline__ float strided_lane_sum(float v, int lane, int G, int RP) {
-  float s = v;
-  for (int k = 1; k < RP; ++k) s += __shfl(v, lane + k * G, 64);
-  return s;
-}
-
-// raw (unconverted) 8-element vectors kept in registers while a prefetch is in flight
-template <typename T> struct Raw;
-template <> struct Raw<bf16_t> {
-  typedef uint4 type;
-  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
-  static __device__ __forceinline__ type zero() { return make_uint4(0, 0, 0, 0); }
-  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-  }
-};
-template <> struct Raw<float> {
-  struct type { float4 a, b; };
-  static __device__ __forceinline__ type load(const float* p) {
-    type t; t.a = *reinterpret_cast<const float4*>(p); t.b = *reinterpret_cast<const float4*>(p + 4); return t;
-  }
-  static __device__ __forceinline__ type zero() { type t; t.a = make_float4(0, 0, 0, 0); t.b = t.a; return t; }
-  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
-    f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w; f[4] = v.b.x; f[5] = v.b.y; f[6] = v.b.z; f[7] = v.b.w;
-  }
-};
-
-__device__ __forceinline__ void lds_ld8(const float* p, float (&f)[8]) {
-  const float4 a = *reinterpret_cast<const float4*>(p);
-  const float4 b = *reinterpret_cast<const float4*>(p + 4);
-  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-}
-
-// Weight matrix (f32, any strides) -> LDS image Ws[n][k] in the MFMA operand type.  VW = floats per global load
-// along the contiguous dimension, KC = that dimension is K (then the VW elements are adjacent in LDS too: one
-// 8-byte / 16-byte write).  All of a thread's loads are issued before the first LDS write: one round trip.
-template <typename T, int VW, bool KC, int WAVES>
-__device__ __forceinline__ void stage_weights(const float* __restrict__ w, typename Mma<T>::lds_t* Ws, int CL, int OLn,
-                                              int ostride, int KL, int tid) {
-  typedef Mma<T> MM;
-  typedef typename MM::lds_t lds_t;
-  constexpr int WB = 8;
-  const int vpr = CL / VW, total = OLn * vpr;
-  const float inv = 1.0f / (float)vpr;
-  for (int base = tid; base < total; base += WAVES * 64 * WB) {
-    float v[WB][VW];
-    int oo[WB], ii[WB];
-#pragma unroll
-    for (int u = 0; u < WB; ++u) {
-      const int idx = base + u * WAVES * 64;
-      oo[u] = -1;
-      if (idx < total) {
-        const int o = __float2int_rz(((float)idx + 0.5f) * inv);
-        const int i = idx - o * vpr;
-        oo[u] = o; ii[u] = i * VW;
-        const float* src = w + (size_t)o * ostride + i * VW;
-        if constexpr (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
-        else if constexpr (VW == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
-        else v[u][0] = src[0];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < WB; ++u) {
-      if (oo[u] >= 0) {
-        if constexpr (KC && VW == 4) {
-          lds_t* dst = Ws + oo[u] * KL + ii[u];
-          if (sizeof(lds_t) == 2) {
-            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[u][0], v[u][1]), pack_bf16x2(v[u][2], v[u][3]));
-          } else {
-            *reinterpret_cast<float4*>(dst) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < VW; ++e) {
-            const int n = KC ? oo[u] : ii[u] + e;
-            const int k = KC ? ii[u] + e : oo[u];
-            Ws[n * KL + k] = MM::cvt(v[u][e]);
-          }
-        }
-      }
-    }
-  }
-}
-
-// raw 8-channel vectors per lane per iteration (~8 KB per wave in flight).  The two-tensor prologue doubles the
-// registers per slot; its heaviest forms (the Swish/SE-backward epilogue's 64 per-lane parameters and sums, or
-// 14 accumulator tiles) get 6 slots so that 8 waves per CU fit 256 VGPRs without spilling.
-// sub-tiles per weight-fragment read (2 where acc[2][NT] fits next to the prefetch and epilogue registers)
-template <typename T, int NT, int PRO, int EPI> struct PwPair {
-  static constexpr int value = (sizeof(T) == 2 && ((NT == 7 && !(PRO == C3D_PRO_AFFINE2 && EPI == C3D_EPI_SWISH_SE_BWD)) ||
-                                                   (NT == 14 && PRO == C3D_PRO_NONE))) ? 2 : 1;
-};
-// weight fragments in flight per batch of the hand-scheduled MFMA pipeline (4 VGPRs each); 0 = leave the loop to
-// the compiler (the widest Swish/SE-backward variant sits at 256 VGPRs already)
-template <int NT, int PRO, int EPI> struct PwFragBatch {
-  static constexpr int value = (NT == 14 && PRO == C3D_PRO_AFFINE2 && EPI == C3D_EPI_SWISH_SE_BWD) ? 0 : (NT < 7 ? NT : 7);
-};
-template <int NT, int PRO, int EPI, int WAVES> struct PwSlots {
-  static constexpr int value = (PRO == C3D_PRO_AFFINE2 && WAVES == 8 && (NT == 14 || EPI == C3D_EPI_SWISH_SE_BWD)) ? 6 : 8;
-};
-
-// Output staging type: plain-store / statistics epilogues round once to the storage type anyway,
-// the arithmetic epilogues (Swish/SE backward, residual add) keep the f32 accumulator.
-template <typename T, int EPI> struct OutStage { typedef float type; };
-template <int EPI> struct OutStage<bf16_t, EPI> { typedef bf16_t type; };  // halves the result tile: 8 waves/CU fit
-
-struct PwLaunch {
-  int tiles_per_wave;  // 16-row sub-tiles per wave (contiguous range)
-  int tpi;             // sub-tiles per iteration (prefetch batch)
-  int xs_rows;         // rows of the wave's X region (= tpi*16)
-  int w_off, p_off, wave_off, wave_bytes, os_off, gs_off;  // byte offsets in dynamic LDS
-  int flush_shuffle_max;  // row-lanes per channel vector up to which the final sums are shuffled instead of dumped
-};
-
-// DENSE = rows are consecutive in memory (row_mode C3D_ROWS_DENSE): a 16-row tile is one contiguous span, so
-// every lane's load address is (wave-uniform tile base) + lane*16 B + constant -- no per-slot index arithmetic,
-// no 64-bit vector multiplies (the generic path's row_offset() code cost ~50 VGPRs and spilled).
-template <typename T, int NT, int PRO, int EPI, int WAVES, bool DENSE>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES == 8 ? 2 : 1, 2))) void pw_gemm_kernel(const c3d_pw_args a, const PwLaunch L) {
-  typedef Mma<T> MM;
-  typedef typename MM::lds_t lds_t;
-  typedef Raw<T> RW;
-  typedef typename OutStage<T, EPI>::type os_t;
-  constexpr int PW_SLOTS = PwSlots<NT, PRO, EPI, WAVES>::value;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile indices stay in SGPRs
-  CLK_DECL
-  const int Kp = a.Kp, Np = a.Np;
-  const int Kpad = (Kp + MM::KSTEP - 1) / MM::KSTEP * MM::KSTEP;
-  const int KL = Kpad + MM::KPAD;
-  constexpr int NL = NT * 16 + (sizeof(os_t) == 4 ? 4 : 8);
-  const int KS = Kpad / MM::KSTEP;
-
-  lds_t* Ws = reinterpret_cast<lds_t*>(smem + L.w_off);
-  float* Pp = reinterpret_cast<float*>(smem + L.p_off);  // prologue parameters [3][Kp]
-  unsigned char* wreg = smem + L.wave_off + (size_t)wave * L.wave_bytes;
-  lds_t* Xs = reinterpret_cast<lds_t*>(wreg);
-  os_t* Os = reinterpret_cast<os_t*>(wreg + L.os_off);
-  float* Gs = reinterpret_cast<float*>(wreg + L.gs_off);  // gate of the current sample [Kp]
-
-  // The first tile's rows (and the per-lane epilogue parameters) are requested BEFORE the weights are
-  // staged: a launch is a chain of dependent global round trips (parameters, weights, first tile,
-  // epilogue operands: ~16 us even for a 4-workgroup grid), so the independent ones must overlap.
-  // ---- lane maps -----------------------------------------------------------------------------
-  const int Gi = Kp >> 3;                       // input: flat map, slot i = lane + 64*q over 16*Gi vectors
-  const int Q = (Gi + 3) >> 2;                  // vector slots per lane per 16-row sub-tile
-  const float invGi = 1.0f / (float)Gi;
-  const int Go = Np >> 3, RPo = 64 / Go;        // output: (row-in-pass, fixed channel vector) map
-  const bool act_o = lane < Go * RPo;
-  const int rr_o = lane / Go, v_o = lane - rr_o * Go;
-  int slot_s[PW_SLOTS], slot_q[PW_SLOTS];
-  {
-    int s_ = 0, q_ = 0;
-#pragma unroll
-    for (int j = 0; j < PW_SLOTS; ++j) { slot_s[j] = s_; slot_q[j] = q_; if (++q_ == Q) { q_ = 0; ++s_; } }
-  }
-  const int nslots = L.tpi * Q;
-
-  // per-lane epilogue parameters / accumulators
-  float eS[8], eB[8], eM[8], eR[8], eG[8];
-  float s0[8], s1[8], s2[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { eS[j] = 1.f; eB[j] = 0.f; eM[j] = 0.f; eR[j] = 0.f; eG[j] = 1.f; s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
-  if (EPI == C3D_EPI_SWISH_SE_BWD && act_o) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      eS[j] = a.epi_p[v_o * 8 + j]; eB[j] = a.epi_p[Np + v_o * 8 + j];
-      eM[j] = a.epi_q[v_o * 8 + j]; eR[j] = a.epi_q[Np + v_o * 8 + j];
-    }
-  }
-
-  const int M32 = (int)a.M;                    // M < 2^31 (checked by the entry point)
-  const int tiles = (M32 + 15) >> 4;
-  const int gw = (int)blockIdx.x * WAVES + wave;
-  int t0 = gw * L.tiles_per_wave;
-  if (t0 > tiles) t0 = tiles;
-  int t1 = t0 + L.tiles_per_wave;
-  if (t1 > tiles) t1 = tiles;
-  const uint32_t rps32 = a.rows_per_sample > 0 ? (uint32_t)a.rows_per_sample : 1u;
-  const int64_t nmax = (int64_t)(((uint32_t)a.M - 1u) / rps32);
-  int cur_n = -1;       // sample whose partial sums are accumulated (SWISH_SE_BWD epilogue)
-  int gate_n = -1;      // sample whose gate is cached in Gs (BN_SE_SWISH prologue)
-
-  const T* X = reinterpret_cast<const T*>(a.x);
-  const T* X2 = reinterpret_cast<const T*>(a.x2);
-  const T* E1 = reinterpret_cast<const T*>(a.e1);
-  T* Y = reinterpret_cast<T*>(a.y);
-
-  typename RW::type xr[PW_SLOTS];
-  typename RW::type x2r[PROis(PRO) ? PW_SLOTS : 1];
-
-#define PW_ISSUE_GENERIC(TILE0)                                                                \
-  _Pragma("unroll") for (int j = 0; j < PW_SLOTS; ++j) {                                       \
-    if (j < nslots) {                                                                          \
-      const int i_ = lane + 64 * slot_q[j];                                                    \
-      const int row_ = __float2int_rz(((float)i_ + 0.5f) * invGi);                             \
-      const int v_ = i_ - row_ * Gi;                                                           \
-      const int64_t tl_ = (TILE0) + slot_s[j];                                                 \
-      const int64_t m_ = (tl_ << 4) + row_;                                                    \
-      if (row_ < 16 && tl_ < t1 && m_ < a.M) {                                                 \
-        const int64_t off_ = row_offset(a, (uint32_t)m_) + v_ * 8;                             \
-        xr[j] = RW::load(X + off_);                                                            \
-        if (PRO == C3D_PRO_AFFINE2) x2r[PROis(PRO) ? j : 0] = RW::load(X2 + off_);             \
-      } else {                                                                                 \
-        xr[j] = RW::zero();                                                                    \
-        if (PRO == C3D_PRO_AFFINE2) x2r[PROis(PRO) ? j : 0] = RW::zero();                      \
-      }                                                                                        \
-    }                                                                                          \
-  }
-  // rows of tile tl that exist (0 beyond this wave's range), times Gi = number of valid flat vectors
-#define PW_LIM(TL) (((TL) < t1 ? (M32 - ((TL) << 4) > 16 ? 16 : M32 - ((TL) << 4)) : 0) * Gi)
-#define PW_ISSUE_DENSE(TILE0)                                                                  \
-  {                                                                                            \
-    const T* xb_ = X + (int64_t)(TILE0) * 16 * Kp;               /* wave-uniform: SGPR pair */  \
-    const T* x2b_ = PRO == C3D_PRO_AFFINE2 ? X2 + (int64_t)(TILE0) * 16 * Kp : X;              \
-    int lo_ = lane * 8;                                                                        \
-    asm volatile("" : "+v"(lo_));   /* keeps (X + lane*8), (X2 + lane*8) from living in 4 VGPRs across the loop */ \
-    _Pragma("unroll") for (int j = 0; j < PW_SLOTS; ++j) {                                     \
-      if (j < nslots) {                                                                        \
-        const int i_ = lane + 64 * slot_q[j];                                                  \
-        const int o_ = slot_s[j] * 16 * Kp + 512 * slot_q[j] + lo_;                            \
-        if (i_ < PW_LIM((TILE0) + slot_s[j])) {                                                \
-          xr[j] = RW::load(xb_ + o_);                                                          \
-          if (PRO == C3D_PRO_AFFINE2) x2r[PROis(PRO) ? j : 0] = RW::load(x2b_ + o_);           \
-        } else {                                                                               \
-          xr[j] = RW::zero();                                                                  \
-          if (PRO == C3D_PRO_AFFINE2) x2r[PROis(PRO) ? j : 0] = RW::zero();                    \
-        }                                                                                      \
-      }                                                                                        \
-    }                                                                                          \
-  }
-#define PW_ISSUE(TILE0) if constexpr (DENSE) PW_ISSUE_DENSE(TILE0) else { PW_ISSUE_GENERIC(TILE0) }
-
-  if (t0 < t1) { PW_ISSUE(t0) }
-  CLK(9)
-
-  // ---- stage weights: zero fill, then vectorised fill along W's contiguous dimension -------
-  {
-    const int wtot = NT * 16 * KL;  // elements, multiple of 8
-    for (int i = tid * 8; i < wtot; i += WAVES * 64 * 8) {
-      float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      MM::store8(Ws + i, z);
-    }
-    if (PRO != C3D_PRO_NONE) {
-      const int np = (PRO == C3D_PRO_AFFINE2 ? 3 : 2) * Kp;
-      for (int i = tid; i < np; i += WAVES * 64) Pp[i] = a.pro_p[i];
-    }
-    CLK(10)
-    __syncthreads();
-    CLK(11)
-    const bool kc = (a.w_sk == 1);
-    const int CL = kc ? a.K : a.N, OLn = kc ? a.N : a.K;
-    const int ostride = kc ? a.w_sn : a.w_sk;
-    if ((CL & 3) == 0 && (ostride & 3) == 0 && ((uintptr_t)a.w & 15) == 0) {
-      if (kc) stage_weights<T, 4, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-      else stage_weights<T, 4, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-    } else if ((CL & 1) == 0 && (ostride & 1) == 0 && ((uintptr_t)a.w & 7) == 0) {
-      if (kc) stage_weights<T, 2, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-      else stage_weights<T, 2, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-    } else {
-      if (kc) stage_weights<T, 1, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-      else stage_weights<T, 1, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-    }
-    CLK(12)
-    __syncthreads();
-    CLK(13)
-  }
-
-  // each wave zeroes its X region once: the K-padding columns [Kp, Kpad) are never written later
-  for (int i = lane * 8; i < L.xs_rows * KL; i += 64 * 8) {
-    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    MM::store8(Xs + i, z);
-  }
-
-  // Companion rows (E1) of the arithmetic epilogues are requested ONE PASS AHEAD, the first pass of a tile before
-  // its MFMAs (and before the next iteration's prefetch burst: vmcnt retires in order).  The pass loop used to
-  // issue load -> s_waitcnt vmcnt(0) -> ~140 VALU per pass: one exposed memory round trip per pass, 8 per tile.
-  constexpr bool E1_PIPE = EPI == C3D_EPI_SWISH_SE_BWD || EPI == C3D_EPI_ADD;
-  const bool e1_rows = E1_PIPE && (EPI == C3D_EPI_SWISH_SE_BWD || a.res_mode == 0);   // E1 has Y's row layout
-  const int npass = (16 + RPo - 1) / RPo;
-  const int v_oc = act_o ? v_o : 0;             // clamped: inactive lanes load a valid address (result unused)
-  typename RW::type e1n = RW::zero();
-  // this lane's E1 vector for pass P of the tile starting at ROW0: wave-uniform row base (scalar registers) + a
-  // loop-invariant 32-bit lane offset; lanes without a row in this pass read the pass's first row (result unused)
-  const int e1_lane = rr_o * Np + v_oc * 8;
-#define PW_E1_PTR(ROW0, P)                                                                                          \
-  (E1 + (int64_t)((ROW0) + (P) * RPo < M32 ? (ROW0) + (P) * RPo : M32 - 1) * Np +                                   \
-   (((P) * RPo + rr_o < 16 && (ROW0) + (P) * RPo + rr_o < M32) ? e1_lane : v_oc * 8))
-
-  // Weight fragments: narrow outputs (NT <= 4) with K <= 64 keep ALL of them in registers (the per-tile MFMA phase
-  // was LDS-read latency: X fragment, then each weight fragment, serially); wide outputs run two sub-tiles per
-  // weight-fragment read when the register budget allows (the stage-3 MFMA phase was LDS-bandwidth bound: 8 waves
-  // x 1 KB per MFMA).
-  constexpr bool WREG = NT <= 4 && sizeof(T) == 2 && !(PRO == C3D_PRO_AFFINE2 && EPI == C3D_EPI_SWISH_SE_BWD);
-  constexpr int MT = PwPair<T, NT, PRO, EPI>::value;
-  typename MM::frag_t wr[WREG ? 2 * NT : 1];
-  if (WREG && KS <= 2) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      wr[WREG ? nt : 0] = MM::load(Ws, nt * 16 + (lane & 15), 0, KL, lane);
-      wr[WREG ? NT + nt : 0] = MM::load(Ws, nt * 16 + (lane & 15), KS == 2 ? 1 : 0, KL, lane);
-    }
-  }
-
-  CLK(0)
-  for (int it0 = t0; it0 < t1; it0 += L.tpi) {
-    CLK_WAITVM
-    CLK(1)
-    // ---------------- convert + prologue -> LDS (all sub-tiles of this iteration) ------------
-#pragma unroll
-    for (int j = 0; j < PW_SLOTS; ++j) {
-      if (j < nslots) {
-        const int i_ = lane + 64 * slot_q[j];
-        const int row_ = __float2int_rz(((float)i_ + 0.5f) * invGi);
-        const int v_ = i_ - row_ * Gi;
-        if (row_ < 16) {
-          const int tl_ = it0 + slot_s[j];
-          float f[8];
-          RW::cvt(xr[j], f);
-          if (PRO == C3D_PRO_BN_SE_SWISH) {
-            float sc[8], sh[8], g[8];
-            lds_ld8(Pp + v_ * 8, sc);
-            lds_ld8(Pp + Kp + v_ * 8, sh);
-            if (a.pro_gate) {
-              int n_ = (int)((uint32_t)(tl_ << 4) / rps32);
-              if (n_ > (int)nmax) n_ = (int)nmax;
-              if (n_ != gate_n) {  // wave-uniform: a sub-tile never straddles two samples
-                for (int c = lane; c < Kp; c += 64) Gs[c] = a.pro_gate[(int64_t)n_ * Kp + c];
-                gate_n = n_;
-              }
-              lds_ld8(Gs + v_ * 8, g);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) g[e] = 1.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float q = g[e] * fmaf(f[e], sc[e], sh[e]);
-              f[e] = q * sigmoid_t<T>(q);
-            }
-          } else if (PRO == C3D_PRO_AFFINE2) {
-            float f2[8], cA[8], cB[8], cC[8];
-            RW::cvt(x2r[PROis(PRO) ? j : 0], f2);
-            lds_ld8(Pp + v_ * 8, cA);
-            lds_ld8(Pp + Kp + v_ * 8, cB);
-            lds_ld8(Pp + 2 * Kp + v_ * 8, cC);
-            const bool real = tl_ < t1 && ((tl_ << 4) + row_) < M32;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = real ? fmaf(cA[e], f[e], fmaf(cC[e], f2[e], cB[e])) : 0.f;
-          }
-          MM::store8(Xs + (slot_s[j] * 16 + row_) * KL + v_ * 8, f);
-        }
-      }
-    }
-    CLK(2)
-    if (e1_rows) e1n = RW::load(PW_E1_PTR(it0 << 4, 0));
-    // ---------------- prefetch the next iteration's rows -------------------------------------
-    if (it0 + L.tpi < t1) { PW_ISSUE(it0 + L.tpi) }
-    CLK(3)
-
-    // stage one 16-row result tile to Os, run the fused epilogue over it, store
-    auto finish_tile = [&](const f32x4_t (&acc)[NT], const int row0, const bool has_next) {
-      // ---------------- stage result tile: Os[row = lane&15][channel] -------------------------
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        os_t* dst = Os + (lane & 15) * NL + nt * 16 + (lane >> 4) * 4;
-        if (sizeof(os_t) == 4) {
-          *reinterpret_cast<float4*>(dst) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
-        } else {
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(acc[nt][0], acc[nt][1]), pack_bf16x2(acc[nt][2], acc[nt][3]));
-        }
-      }
-      CLK(5)
-      // ---------------- epilogue + store ---------------------------------------------------
-      if (EPI == C3D_EPI_SWISH_SE_BWD) {
-        const int n_tile = (int)((uint32_t)row0 / rps32);
-        if (n_tile != cur_n) {
-          if (cur_n >= 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float r0 = strided_lane_sum(s0[j], lane, Go, RPo);
-              const float r1 = strided_lane_sum(s1[j], lane, Go, RPo);
-              const float r2 = strided_lane_sum(s2[j], lane, Go, RPo);
-              if (lane < Go) {
-                double* d = a.stats + ((int64_t)cur_n * Np + v_o * 8 + j) * 3;
-                atomicAdd(d, (double)r0); atomicAdd(d + 1, (double)r1); atomicAdd(d + 2, (double)r2);
-              }
-              s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f;
-            }
-          }
-          cur_n = n_tile;
-          if (a.epi_gate && act_o) {
-            const float* gp = a.epi_gate + (int64_t)cur_n * Np + v_o * 8;
-            const float4 g0 = *reinterpret_cast<const float4*>(gp);
-            const float4 g1 = *reinterpret_cast<const float4*>(gp + 4);
-            eG[0] = g0.x; eG[1] = g0.y; eG[2] = g0.z; eG[3] = g0.w; eG[4] = g1.x; eG[5] = g1.y; eG[6] = g1.z; eG[7] = g1.w;
-          }
-        }
-      }
-      for (int p = 0; p < npass; ++p) {
-        const int row = p * RPo + rr_o;
-        const int m = row0 + row;
-        typename RW::type e1c = e1n;
-        if (e1_rows) {
-          if (p + 1 < npass) e1n = RW::load(PW_E1_PTR(row0, p + 1));
-          else if (has_next) e1n = RW::load(PW_E1_PTR(row0 + 16, 0));   // first pass of the next tile of this iteration
-        }
-        if (act_o && row < 16 && m < M32) {
-          float f[8];
-          Vec8<os_t>::load(Os + row * NL + v_o * 8, f);
-          const int64_t yoff = (int64_t)m * Np + v_o * 8;
-          if (EPI == C3D_EPI_STATS) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float r = round_as<T>(f[j]);
-              s0[j] += r; s1[j] += r * r;
-            }
-          } else if (EPI == C3D_EPI_SWISH_SE_BWD) {
-            float bv[8];
-            RW::cvt(e1c, bv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float pb = fmaf(bv[j], eS[j], eB[j]);
-              const float q = eG[j] * pb;
-              const float sg = sigmoid_t<T>(q);
-              const float dq = f[j] * sg * (1.f + q * (1.f - sg));
-              const float t = round_as<T>(dq * eG[j]);
-              s0[j] += dq * pb;                        // d gate
-              s1[j] += t;                              // sum t1
-              s2[j] += t * ((bv[j] - eM[j]) * eR[j]);  // sum t1*bhat (centred)
-              f[j] = t;
-            }
-          } else if (EPI == C3D_EPI_ADD) {
-            if (a.res_mode == 0) {
-              float rv[8];
-              RW::cvt(e1c, rv);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) f[j] += rv[j];
-            } else {
-              const uint32_t um = (uint32_t)m;
-              const uint32_t w = um % (uint32_t)a.W;
-              const uint32_t t = um / (uint32_t)a.W;
-              const uint32_t h = t % (uint32_t)a.H;
-              const uint32_t bt = t / (uint32_t)a.H;
-              if (((w | h) & 1u) == 0u) {
-                const int64_t roff = (((int64_t)bt * (a.H >> 1) + (h >> 1)) * (a.W >> 1) + (w >> 1)) * Np + v_o * 8;
-                float rv[8];
-                Vec8<T>::load(E1 + roff, rv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] += rv[j];
-              }
-            }
-          }
-          Vec8<T>::store(Y + yoff, f);
-        }
-      }
-    };
-
-    for (int sub = 0; sub < L.tpi; sub += MT) {
-      const int tile = it0 + sub;
-      if (tile >= t1) break;
-      const int row0 = tile << 4;
-      const lds_t* Xt = Xs + sub * 16 * KL;
-      const bool two = MT == 2 && sub + 1 < L.tpi && tile + 1 < t1;          // wave-uniform
-      // ---------------- MFMA: MT sub-tiles share every weight fragment read -----------------
-      f32x4_t acc[NT], acc2[NT];   // acc2 is dead code (no registers) when MT == 1
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (MT == 2) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc2[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      }
-      if (WREG && KS <= 2) {
-        const typename MM::frag_t xb0 = MM::load(Xt, lane & 15, 0, KL, lane);
-        typename MM::frag_t xb1 = xb0;
-        if (KS == 2) xb1 = MM::load(Xt, lane & 15, 1, KL, lane);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = MM::mma(wr[WREG ? nt : 0], xb0, acc[nt]);
-        if (KS == 2) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt] = MM::mma(wr[WREG ? NT + nt : 0], xb1, acc[nt]);
-        }
-      } else {
-        const uint32_t wstr = (uint32_t)(16 * KL * sizeof(lds_t));                       // bytes between output tiles
-        const uint32_t wlane = (uint32_t)(uintptr_t)Ws + (uint32_t)(((lane & 15) * KL + (lane >> 4) * 8) * sizeof(lds_t));
-        constexpr int UB = PwFragBatch<NT, PRO, EPI>::value;
-        if (MT == 2 && two) {
-          for (int ks = 0; ks < KS; ++ks) {
-            const typename MM::frag_t xb = MM::load(Xt, lane & 15, ks, KL, lane);
-            const typename MM::frag_t xb2 = MM::load(Xt + 16 * KL, lane & 15, ks, KL, lane);
-            if constexpr (sizeof(T) == 2 && UB > 0) {
-              const u32x4_t xv = __builtin_bit_cast(u32x4_t, xb), xv2 = __builtin_bit_cast(u32x4_t, xb2);
-              MfmaSeq<NT, (UB > 0 ? UB : 1), 0, true>::run(acc, acc2, wlane + ks * 64, wstr, xv, xv2);
-            } else {
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                const typename MM::frag_t wa = MM::load(Ws, nt * 16 + (lane & 15), ks, KL, lane);
-                acc[nt] = MM::mma(wa, xb, acc[nt]);
-                acc2[nt] = MM::mma(wa, xb2, acc2[nt]);
-              }
-            }
-          }
-        } else {
-          for (int ks = 0; ks < KS; ++ks) {
-            const typename MM::frag_t xb = MM::load(Xt, lane & 15, ks, KL, lane);
-            if constexpr (sizeof(T) == 2 && UB > 0) {
-              const u32x4_t xv = __builtin_bit_cast(u32x4_t, xb);
-              MfmaSeq<NT, (UB > 0 ? UB : 1), 0, false>::run(acc, acc, wlane + ks * 64, wstr, xv, xv);
-            } else {
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                const typename MM::frag_t wa = MM::load(Ws, nt * 16 + (lane & 15), ks, KL, lane);
-                acc[nt] = MM::mma(wa, xb, acc[nt]);
-              }
-            }
-          }
-        }
-      }
-      CLK(4)
-      finish_tile(acc, row0, MT == 2 ? two : (sub + 1 < L.tpi && tile + 1 < t1));
-      if (MT == 2 && two) finish_tile(acc2, row0 + 16, sub + 2 < L.tpi && tile + 2 < t1);
-      CLK(6)
-    }
-  }
-#undef PW_E1_PTR
-#undef PW_ISSUE
-#undef PW_ISSUE_DENSE
-#undef PW_ISSUE_GENERIC
-#undef PW_LIM
-  CLK(7)
-
-  // ---- final flush of per-lane partial sums -------------------------------------------------
-  // lanes -> LDS ([value][lane] per wave, the X regions are dead now) -> one thread per output sums the
-  // RPo row-lanes of every wave -> ONE f64 atomic per value and workgroup.  (The lane step used to be
-  // RPo dependent ds_bpermute shuffles per value: 7-14 us per launch on the narrow layers, Go = 3..7.)
-  constexpr int NV = EPI == C3D_EPI_SWISH_SE_BWD ? 24 : 16;   // partial sums per lane
-  const int flush_shuffle_max = L.flush_shuffle_max;
-  if (EPI == C3D_EPI_STATS || EPI == C3D_EPI_SWISH_SE_BWD) {
-    // wide layers (2-3 row-lanes per channel vector): one or two shuffles per value beat the [NV][64] lane dump and
-    // leave the cross-wave sum 8 reads per value instead of 16-24
-    const bool dump = RPo > flush_shuffle_max && (size_t)L.wave_bytes >= (size_t)64 * NV * sizeof(float) + WAVES * sizeof(int);
-    float* mine = reinterpret_cast<float*>(smem + L.wave_off + (size_t)wave * L.wave_bytes);   // [NV][64]
-    int* ncur = reinterpret_cast<int*>(smem + L.wave_off + (size_t)WAVES * L.wave_bytes - WAVES * sizeof(int));
-    __syncthreads();
-    if (dump) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        mine[j * 64 + lane] = s0[j];
-        mine[(8 + j) * 64 + lane] = s1[j];
-        if (EPI == C3D_EPI_SWISH_SE_BWD) mine[(16 + j) * 64 + lane] = s2[j];
-      }
-    } else {   // tiny LDS regions: shuffle the row-lanes together, result in lanes < Go, stored at [value][v_o]
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float r0 = strided_lane_sum(s0[j], lane, Go, RPo);
-        const float r1 = strided_lane_sum(s1[j], lane, Go, RPo);
-        const float r2 = EPI == C3D_EPI_SWISH_SE_BWD ? strided_lane_sum(s2[j], lane, Go, RPo) : 0.f;
-        if (lane < Go) {
-          mine[j * Go + lane] = r0;
-          mine[(8 + j) * Go + lane] = r1;
-          if (EPI == C3D_EPI_SWISH_SE_BWD) mine[(16 + j) * Go + lane] = r2;
-        }
-      }
-    }
-    if (EPI == C3D_EPI_SWISH_SE_BWD && lane == 0) ncur[wave] = (int)cur_n;
-    __syncthreads();
-    // value (which, channel c = v*8 + j) of wave wv
-    auto wave_value = [&](const int wv, const int which, const int c) -> float {
-      const float* base = reinterpret_cast<const float*>(smem + L.wave_off + (size_t)wv * L.wave_bytes);
-      const int v = c >> 3, j = c & 7;
-      if (!dump) return base[(which * 8 + j) * Go + v];
-      float acc = 0.f;
-      for (int rr = 0; rr < RPo; ++rr) acc += base[(which * 8 + j) * 64 + rr * Go + v];
-      return acc;
-    };
-    if (EPI == C3D_EPI_STATS) {
-      // into one of C3D_STAT_STRIPES accumulator sets (keeps same-address atomic contention low)
-      double* dst = a.stats + (size_t)(blockIdx.x % C3D_STAT_STRIPES) * 2 * a.N;
-      for (int i = tid; i < 2 * a.N; i += WAVES * 64) {
-        const int which = i / a.N, c = i - which * a.N;
-        float acc = 0.f;
-        for (int wv = 0; wv < WAVES; ++wv) acc += wave_value(wv, which, c);
-        atomicAdd(dst + which * a.N + c, (double)acc);
-      }
-    } else {
-      // Per-(sample, channel) sums.  The waves of a workgroup almost always end inside the same sample:
-      // combine them (the per-wave flush was 660 k same-address atomics = 40 % of the stage-3 kernel).
-      int n_all = -1;
-      bool uniform = true;
-      for (int wv = 0; wv < WAVES; ++wv) {
-        const int nw = ncur[wv];
-        if (nw < 0) continue;          // a wave without tiles contributes nothing
-        if (n_all < 0) n_all = nw;
-        else if (nw != n_all) uniform = false;
-      }
-      if (uniform) {
-        if (n_all >= 0) {
-          for (int i = tid; i < 3 * Np; i += WAVES * 64) {
-            const int which = i / Np, c = i - which * Np;
-            float acc = 0.f;
-            for (int wv = 0; wv < WAVES; ++wv)
-              if (ncur[wv] >= 0) acc += wave_value(wv, which, c);
-            atomicAdd(a.stats + ((int64_t)n_all * Np + c) * 3 + which, (double)acc);
-          }
-        }
-      } else if (cur_n >= 0) {
-        for (int i = lane; i < 3 * Np; i += 64) {
-          const int which = i / Np, c = i - which * Np;
-          atomicAdd(a.stats + ((int64_t)cur_n * Np + c) * 3 + which, (double)wave_value(wave, which, c));
-        }
-      }
-    }
-  }
-  CLK(8)
-  CLK_FLUSH
-}
-
-inline size_t al16(size_t v) { return (v + 15) / 16 * 16; }
-
-template <typename T, int NT, int PRO, int EPI, int WAVES>
-bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
-  typedef Mma<T> MM;
-  typedef typename OutStage<T, EPI>::type os_t;
-  constexpr int PW_SLOTS = PwSlots<NT, PRO, EPI, WAVES>::value;
-  const int Kpad = (a.Kp + MM::KSTEP - 1) / MM::KSTEP * MM::KSTEP;
-  const int KL = Kpad + MM::KPAD;
-  const int NL = NT * 16 + (sizeof(os_t) == 4 ? 4 : 8);
-  const int Q = ((a.Kp >> 3) + 3) >> 2;
-  const size_t w_bytes = al16((size_t)NT * 16 * KL * sizeof(typename MM::lds_t));
-  const size_t p_bytes = al16((size_t)3 * a.Kp * sizeof(float));
-  const size_t os_bytes = al16((size_t)16 * NL * sizeof(os_t));
-  const size_t gs_bytes = al16((size_t)a.Kp * sizeof(float));
-  for (int tpi = PW_SLOTS / Q; tpi >= 1; --tpi) {
-    const size_t xs_bytes = al16((size_t)tpi * 16 * KL * sizeof(typename MM::lds_t));
-    const size_t wave_bytes = xs_bytes + os_bytes + gs_bytes;
-    const size_t total = w_bytes + p_bytes + WAVES * wave_bytes;
-    if (total <= 160 * 1024) {
-      L.tpi = tpi; L.xs_rows = tpi * 16;
-      L.w_off = 0; L.p_off = (int)w_bytes; L.wave_off = (int)(w_bytes + p_bytes);
-      L.wave_bytes = (int)wave_bytes; L.os_off = (int)xs_bytes; L.gs_off = (int)(xs_bytes + os_bytes);
-      lds = total;
-      return true;
-    }
-  }
-  return false;
-}
-
-template <typename T, int NT, int PRO, int EPI, int WAVES, bool DENSE>
-int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
-  PwLaunch L;
-  size_t lds = 0;
-  if (!plan_pw<T, NT, PRO, EPI, WAVES>(a, L, lds)) return C3D_E_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const int64_t tiles = (a.M + 15) >> 4;
-  int occ = (int)((160 * 1024) / lds);
-  if (occ > 32 / WAVES) occ = 32 / WAVES;
-  if (occ < 1) occ = 1;
-  const int64_t max_blocks = (int64_t)device_cus() * occ;
-  int64_t blocks = (tiles + (int64_t)WAVES * L.tpi - 1) / ((int64_t)WAVES * L.tpi);  // >= one iteration per wave
-  if (blocks > max_blocks) blocks = max_blocks;
-  if (blocks < 1) blocks = 1;
-  int64_t tpw = (tiles + blocks * WAVES - 1) / (blocks * WAVES);
-  // Whole iterations only when that does not idle CUs: 6144 tiles over 2048 waves is 3 per wave; rounding
-  // to 4 (tpi = 2) left 64 of 256 CUs without a workgroup (stage-3 K=96 layers, -20 % per launch).
-  static const int round_iters = getenv("C3D_PW_ROUND") ? atoi(getenv("C3D_PW_ROUND")) : 0;
-  const int64_t tpw_r = (tpw + L.tpi - 1) / L.tpi * L.tpi;
-  const int64_t blocks_r = (tiles + tpw_r * WAVES - 1) / (tpw_r * WAVES);
-  if (round_iters || blocks_r * 16 >= blocks * 15) tpw = tpw_r;
-  blocks = (tiles + tpw * WAVES - 1) / (tpw * WAVES);
-  L.tiles_per_wave = (int)tpw;
-  static const int fsm = getenv("C3D_PW_FLUSH_SHFL") ? atoi(getenv("C3D_PW_FLUSH_SHFL")) : 0;   // tuning knob (measured: no gain)
-  L.flush_shuffle_max = fsm;
-  pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE><<<dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream>>>(a, L);
-  C3D_CHECK_LAUNCH();
-  return 0;
-}
-
-template <typename T, int NT, int PRO, int EPI, int WAVES>
-int launch_pw_w(const c3d_pw_args& a, hipStream_t stream) {
-  // the dense-row specialisation exists for the throughput (bf16) path only; f32 (parity) uses the generic code
-  if (sizeof(T) == 2 && a.row_mode == C3D_ROWS_DENSE) return launch_pw_d<T, NT, PRO, EPI, WAVES, sizeof(T) == 2>(a, stream);
-  return launch_pw_d<T, NT, PRO, EPI, WAVES, false>(a, stream);
-}
-
-template <typename T, int NT, int PRO, int EPI>
-int launch_pw(const c3d_pw_args& a, hipStream_t stream) {
-  // prefer 8 waves per workgroup (one weight copy per 8 waves) when LDS allows it
-  PwLaunch L;
-  size_t lds = 0;
-  static const int force8 = getenv("C3D_PW_FORCE8") ? atoi(getenv("C3D_PW_FORCE8")) : 0;  // tuning knob
-  const bool e1_epi = EPI == C3D_EPI_SWISH_SE_BWD || EPI == C3D_EPI_ADD;  // epilogues with exposed companion loads
-  if (force8 >= 0 && plan_pw<T, NT, PRO, EPI, 8>(a, L, lds) &&
-      (L.tpi * ((((a.Kp >> 3) + 3) >> 2)) >= 4 || lds <= 80 * 1024 || force8 == 2 || (force8 == 1 && e1_epi)))
-    return launch_pw_w<T, NT, PRO, EPI, 8>(a, stream);
-  if (plan_pw<T, NT, PRO, EPI, 4>(a, L, lds)) return launch_pw_w<T, NT, PRO, EPI, 4>(a, stream);
-  if (sizeof(T) == 4) return launch_pw_w<float, NT, PRO, EPI, 2>(a, stream);  // f32 parity path only
-  return C3D_E_UNSUPPORTED;
-}
-
-template <typename T, int PRO, int EPI>
-int dispatch_nt(const c3d_pw_args& a, hipStream_t stream) {
-  const int nt = (a.Np + 15) / 16;
-  if (nt <= 2) return launch_pw<T, 2, PRO, EPI>(a, stream);
-  if (nt <= 4) return launch_pw<T, 4, PRO, EPI>(a, stream);
-  if (nt <= 7) return launch_pw<T, 7, PRO, EPI>(a, stream);
-  if (nt <= 14) return launch_pw<T, 14, PRO, EPI>(a, stream);
-  return C3D_E_UNSUPPORTED;
-}
-
-template <typename T>
-int dispatch_mode(const c3d_pw_args& a, hipStream_t s) {
-  const int pro = a.pro_mode, epi = a.epi_mode;
-  if (pro == C3D_PRO_NONE && epi == C3D_EPI_STORE) return dispatch_nt<T, C3D_PRO_NONE, C3D_EPI_STORE>(a, s);
-  if (pro == C3D_PRO_NONE && epi == C3D_EPI_STATS) return dispatch_nt<T, C3D_PRO_NONE, C3D_EPI_STATS>(a, s);
-  if (pro == C3D_PRO_BN_SE_SWISH && epi == C3D_EPI_STORE) return dispatch_nt<T, C3D_PRO_BN_SE_SWISH, C3D_EPI_STORE>(a, s);
-  if (pro == C3D_PRO_BN_SE_SWISH && epi == C3D_EPI_STATS) return dispatch_nt<T, C3D_PRO_BN_SE_SWISH, C3D_EPI_STATS>(a, s);
-  if (pro == C3D_PRO_AFFINE2 && epi == C3D_EPI_STORE) return dispatch_nt<T, C3D_PRO_AFFINE2, C3D_EPI_STORE>(a, s);
-  if (pro == C3D_PRO_AFFINE2 && epi == C3D_EPI_SWISH_SE_BWD) return dispatch_nt<T, C3D_PRO_AFFINE2, C3D_EPI_SWISH_SE_BWD>(a, s);
-  if (pro == C3D_PRO_AFFINE2 && epi == C3D_EPI_ADD) return dispatch_nt<T, C3D_PRO_AFFINE2, C3D_EPI_ADD>(a, s);
-  if (pro == C3D_PRO_NONE && epi == C3D_EPI_ADD) return dispatch_nt<T, C3D_PRO_NONE, C3D_EPI_ADD>(a, s);
-  return C3D_E_UNSUPPORTED;
-}
-
-}  // namespace
+// f32 instantiations (pw_gemm_f32.hip); library-internal
+__attribute__((visibility("hidden"))) int c3d_detail_pw_gemm_f32(const c3d_pw_args* args, void* stream);
 
 extern "C" int c3d_device_cus(void) { return device_cus(); }
 
@@ -955,7 +36,7 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   if (a.pro_mode == C3D_PRO_BN_SE_SWISH && a.pro_gate && (a.rows_per_sample & 15)) return C3D_E_BADARG;
   if (a.M >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (a.dtype == C3D_DT_F32) return dispatch_mode<float>(a, s);
+  if (a.dtype == C3D_DT_F32) return c3d_detail_pw_gemm_f32(args, stream);
   if (a.dtype == C3D_DT_BF16) return dispatch_mode<bf16_t>(a, s);
   return C3D_E_BADARG;
 }
