@@ -24,5 +24,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   C3D_WGRAD_SIDE=0 timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- \
       python bench.py --no-cpu-baseline --no-graph --no-kernel-profile --steps 1 --warmup 1 > $d.log 2>&1
 done
+# MFMA utilisation of the pointwise kernels (own pass; summarised by hand into profiles/r01_pmc_mfma.json)
+rm -rf gpurun_out/pmc_mfma
+C3D_WGRAD_SIDE=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
+    -d gpurun_out/pmc_mfma -- python bench.py --no-cpu-baseline --no-graph --no-kernel-profile --steps 1 --warmup 1 > gpurun_out/pmc_mfma.log 2>&1
 python tools/summarize_rocprof.py gpurun_out r01
 ls -la gpurun_out/*.json
