@@ -9,6 +9,7 @@
 // The weight gradient of the transposed conv runs on the MFMA weight-gradient kernel
 // (c3d_pw_wgrad with C3D_ROWS_S2SHIFT addressing), the bias gradient on c3d_col_sum.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/change3d_hip.h"
 
 namespace {
@@ -258,12 +259,18 @@ __global__ __launch_bounds__(HD_TH * HD_TW) void head_bwd_kernel(
   const int tiles_x = (W + HD_TW - 1) / HD_TW, tiles_y = (H + HD_TH - 1) / HD_TH;
   const int ntiles = tiles_x * tiles_y;
   const int b = blockIdx.y;
-  // weight-gradient ownership: thread < 27*NC owns (n, tap, cvec)
-  const int wn = tid / 27, wtap = (tid % 27) / 3, wcv = tid % 3;
+  // Weight gradient: thread = (pixel slice of 9, tap, channel vector) keeps dW[n][tap][8 channels] for every class n.
+  // (It used to be 27*NC threads each walking all 256 pixels of a tile while the other waves idled, and 216 global
+  // atomics per 4-tile workgroup onto the same 216 addresses.)
+  constexpr int HD_NSL = 9;
+  const int wown = tid % 27, wsl = tid / 27;      // wsl < 9 for tid < 243
+  const int wtap = wown / 3, wcv = wown % 3;
   const int wky = wtap / 3, wkx = wtap % 3;
-  float dwacc[8];
+  float dwacc[HD_MAXNC][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) dwacc[j] = 0.f;
+  for (int n = 0; n < HD_MAXNC; ++n)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwacc[n][j] = 0.f;
   int tl0 = blockIdx.x * tiles_per_wg, tl1 = tl0 + tiles_per_wg;
   if (tl1 > ntiles) tl1 = ntiles;
   for (int tl = tl0; tl < tl1; ++tl) {
@@ -325,20 +332,41 @@ __global__ __launch_bounds__(HD_TH * HD_TW) void head_bwd_kernel(
       }
     }
     // ---- dW ----------------------------------------------------------------------------------
-    if (tid < 27 * NC) {
-      for (int qy = 0; qy < HD_TH; ++qy) {
-        for (int qx = 0; qx < HD_TW; ++qx) {
-          const float d = dl[wn][qy + 1][qx + 1];
-          const float* xp = &xt[qy + wky][qx + wkx][wcv * 8];
+    if (tid < 27 * HD_NSL) {
+      for (int pi = wsl; pi < HD_TH * HD_TW; pi += HD_NSL) {
+        const int qy = pi / HD_TW, qx = pi % HD_TW;
+        const float* xp = &xt[qy + wky][qx + wkx][wcv * 8];
+        float xv[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dwacc[j] = fmaf(d, xp[j], dwacc[j]);
+        for (int j = 0; j < 8; ++j) xv[j] = xp[j];
+#pragma unroll
+        for (int n = 0; n < HD_MAXNC; ++n) {
+          if (n < NC) {
+            const float d = dl[n][qy + 1][qx + 1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dwacc[n][j] = fmaf(d, xv[j], dwacc[n][j]);
+          }
         }
       }
     }
   }
-  if (tid < 27 * NC) {
+  // slices -> LDS (the weight copy is dead now and has exactly 27 x 8 x 8 floats) -> one global atomic per value
+  __syncthreads();
+  for (int i = tid; i < 27 * HD_MAXNC * 8; i += NTHR) wl[i] = 0.f;
+  __syncthreads();
+  if (tid < 27 * HD_NSL) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(dw + ((size_t)wn * HD_C + wcv * 8 + j) * 9 + wtap, dwacc[j]);
+    for (int n = 0; n < HD_MAXNC; ++n) {
+      if (n < NC) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&wl[(wown * HD_MAXNC + n) * 8 + j], dwacc[n][j]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 27 * HD_MAXNC * 8; i += NTHR) {
+    const int j = i & 7, n = (i >> 3) % HD_MAXNC, own = i / (8 * HD_MAXNC);
+    if (n < NC) atomicAdd(dw + ((size_t)n * HD_C + (own % 3) * 8 + j) * 9 + own / 3, wl[i]);
   }
 }
 
@@ -434,7 +462,10 @@ extern "C" int c3d_head3x3_bwd(const float* dout, const float* prob, const void*
   if (!dout || !x || !w || !dx || !dw || B <= 0 || C != HD_C || NC <= 0 || NC > HD_MAXNC) return C3D_E_BADARG;
   if (has_sigmoid && !prob) return C3D_E_BADARG;
   const int ntiles = ((W + HD_TW - 1) / HD_TW) * ((H + HD_TH - 1) / HD_TH);
-  const int tpw = ntiles >= 4 ? 4 : ntiles;
+  static const int env_tpw = getenv("C3D_HEAD_TPW") ? atoi(getenv("C3D_HEAD_TPW")) : 0;   // tuning knob
+  int tpw = env_tpw > 0 ? env_tpw : 16;    // long walks: every workgroup ends with 216*NC same-address global atomics
+  while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * B < 2L * 256) tpw >>= 1;            // ... but keep >= 2 per CU
+  if (tpw > ntiles) tpw = ntiles;
   dim3 grid((ntiles + tpw - 1) / tpw, B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == C3D_DT_F32)
