@@ -10,6 +10,7 @@
 //                          the batch (the only input frames that are parameters,
 //                          reference model/trainer.py:51-54,155).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/change3d_hip.h"
 
 namespace {
@@ -18,6 +19,28 @@ constexpr int ST_C = 24;      // stem output channels (X3D-L as used by Change3D
 constexpr int ST_CI = 3;
 constexpr int ST_TH = 8, ST_TW = 16;
 constexpr int ST_MAXT = 5;
+
+// unconverted 8-channel vectors (kept raw while the loads are in flight)
+template <typename T> struct RawS;
+template <> struct RawS<bf16_t> {
+  typedef uint4 type;
+  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+};
+template <> struct RawS<float> {
+  struct type { float4 a, b; };
+  static __device__ __forceinline__ type load(const float* p) {
+    type t; t.a = *reinterpret_cast<const float4*>(p); t.b = *reinterpret_cast<const float4*>(p + 4); return t;
+  }
+  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
+    f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w; f[4] = v.b.x; f[5] = v.b.y; f[6] = v.b.z; f[7] = v.b.w;
+  }
+};
 constexpr int ST_IH = ST_TH + 2, ST_IW = ST_TW + 2;
 
 struct StemGeom { int B, T, H, W; };
@@ -193,21 +216,34 @@ __global__ __launch_bounds__(ST_THREADS) void stem_bwd_dv_kernel(
   if (tl1 > ntiles) tl1 = ntiles;
   for (int tl = tl0; tl < tl1; ++tl) {
     const int tx = tl % tiles_x, ty = tl / tiles_x;
+    const int gy = ty * ST_TH + py, gx = tx * ST_TW + px;
+    const bool in_img = gy < g.H && gx < g.W;
+    // this pixel's (g0, u) rows are requested BEFORE the x tile is staged: the two global round trips of a tile
+    // used to run back to back (one workgroup of 6 waves per CU, nothing else to hide them)
+    typename RawS<T>::type gr[ST_MAXT], ur[ST_MAXT];
+    if (in_img) {
+#pragma unroll
+      for (int t = 0; t < ST_MAXT; ++t) {
+        if (t < g.T) {
+          const size_t off = ((((size_t)b * g.T + t) * g.H + gy) * g.W + gx) * ST_C + cv * 8;
+          gr[t] = RawS<T>::load(g0 + off);
+          ur[t] = RawS<T>::load(u + off);
+        }
+      }
+    }
     __syncthreads();
     load_x_tile(xt, x, g, b, ty * ST_TH, tx * ST_TW, tid, ST_THREADS);
     __syncthreads();
-    const int gy = ty * ST_TH + py, gx = tx * ST_TW + px;
-    if (gy >= g.H || gx >= g.W) continue;
+    if (!in_img) continue;
     float v[ST_MAXT][8];
     spatial_conv(v, xt, wt, g.T, py, px, cv);
     float du[ST_MAXT][8];
 #pragma unroll
     for (int t = 0; t < ST_MAXT; ++t) {
       if (t < g.T) {
-        const size_t off = ((((size_t)b * g.T + t) * g.H + gy) * g.W + gx) * ST_C + cv * 8;
         float gg[8], uu[8];
-        Vec8<T>::load(g0 + off, gg);
-        Vec8<T>::load(u + off, uu);
+        RawS<T>::cvt(gr[t], gg);
+        RawS<T>::cvt(ur[t], uu);
 #pragma unroll
         for (int j = 0; j < 8; ++j) du[t][j] = fmaf(cA[j], gg[j], fmaf(cC[j], uu[j], cB[j]));
       } else {
@@ -431,7 +467,13 @@ extern "C" int c3d_stem_bwd_dv(const float* x, const float* w_t, const float* w_
   StemGeom g{B, T, H, W};
   const size_t lds = (27 * ST_C + 5 * ST_C + 5 * ST_C + (size_t)ST_CI * T * ST_IH * ST_IW) * sizeof(float);
   const int ntiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
-  const int tpw = ntiles >= 16 ? 16 : ntiles;
+  // one workgroup (6 waves, ~216 VGPRs) fits per CU and each ends with 120 same-address atomics: walks as long as
+  // 2 workgroups per CU allow
+  static const int env_tpw = getenv("C3D_STEM_DV_TPW") ? atoi(getenv("C3D_STEM_DV_TPW")) : 0;   // tuning knob
+  int tpw = 64;
+  while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * B < 2L * 256) tpw >>= 1;
+  if (env_tpw > 0) tpw = env_tpw;
+  if (tpw > ntiles) tpw = ntiles;
   dim3 grid((ntiles + tpw - 1) / tpw, B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == C3D_DT_F32)
