@@ -62,7 +62,12 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
   extern __shared__ float sm[];  // z[B][C] then h[B][Cr]
   float* z = sm;
   float* h = sm + (size_t)B * C;
+  float* w1s = h + (size_t)B * Cr;      // [Cr][C]  FC weights staged once, coalesced (the FC loops read them
+  float* w2s = w1s + (size_t)Cr * C;    // [C][Cr]   element by element from global memory before)
   const int tid = threadIdx.x;
+  if (w1) {
+    for (int i = tid; i < Cr * C; i += blockDim.x) { w1s[i] = w1[i]; w2s[i] = w2[i]; }
+  }
   const double count = cnt_per_sample * B;
   // gridDim.x workgroups each recompute the cheap whole-layer parts (statistics, FC1) and OWN a
   // channel slice [c_lo, c_hi) of everything that is written (running statistics, scale/shift, gate)
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
     const int i = idx >> 3, q = idx & 7;
     const int n = i / Cr, r = i - n * Cr;
     float a = 0.f;
-    for (int c = q; c < C; c += 8) a = fmaf(w1[(size_t)r * C + c], z[(size_t)n * C + c], a);
+    for (int c = q; c < C; c += 8) a = fmaf(w1s[(size_t)r * C + c], z[(size_t)n * C + c], a);
     a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
     a += b1[r];
     a = a > 0.f ? a : 0.f;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
     float g = 0.f;
     if (c < C) {
       float a = b2[c];
-      for (int r = 0; r < Cr; ++r) a = fmaf(w2[(size_t)c * Cr + r], h[(size_t)n * Cr + r], a);
+      for (int r = 0; r < Cr; ++r) a = fmaf(w2s[(size_t)c * Cr + r], h[(size_t)n * Cr + r], a);
       g = 1.0f / (1.0f + expf(-a));
     }
     gate[(size_t)n * Cp + c] = g;
@@ -174,6 +179,11 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
   float* dh = du + (size_t)B * C;      // [B][Cr]
   float* dz = dh + (size_t)B * Cr;     // [B][C]
   float* zz = dz + (size_t)B * C;      // [B][C]  forward z (input of the SE FCs)
+  // FC weights and the hidden activations are staged once, coalesced: the FC loops below used to read them from
+  // global memory element by element (chains of dependent L2 round trips in a single-digit-workgroup kernel)
+  float* w1s = zz + (size_t)B * C;     // [Cr][C]
+  float* w2s = w1s + (size_t)Cr * C;   // [C][Cr]
+  float* hids = w2s + (size_t)C * Cr;  // [B][Cr]
   const int tid = threadIdx.x;
   const double count = cnt_per_sample * B;
   const bool se = w1 != nullptr;
@@ -183,6 +193,8 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
   const int c_lo = (int)blockIdx.x * cs, c_hi = c_lo + cs < Cp ? c_lo + cs : Cp;
   const int cw = c_hi - c_lo;
   if (se) {
+    for (int i = tid; i < Cr * C; i += blockDim.x) { w1s[i] = w1[i]; w2s[i] = w2[i]; }
+    for (int i = tid; i < B * Cr; i += blockDim.x) hids[i] = hid[i];
 #pragma unroll 4
     for (int i = tid; i < B * C; i += blockDim.x) {
       const int n = i / C, c = i - n * C;
@@ -195,16 +207,16 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
       const int i = idx >> 3, q = idx & 7;
       const int n = i / Cr, r = i - n * Cr;
       float a = 0.f;
-      for (int c = q; c < C; c += 8) a = fmaf(w2[(size_t)c * Cr + r], du[(size_t)n * C + c], a);
+      for (int c = q; c < C; c += 8) a = fmaf(w2s[(size_t)c * Cr + r], du[(size_t)n * C + c], a);
       a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
-      if (q == 0) dh[i] = hid[i] > 0.f ? a : 0.f;
+      if (q == 0) dh[i] = hids[i] > 0.f ? a : 0.f;
     }
     __syncthreads();
     for (int i = tid; i < B * cw; i += blockDim.x) {
       const int n = i / cw, c = c_lo + (i - n * cw);
       if (c >= C) continue;
       float a = 0.f;
-      for (int r = 0; r < Cr; ++r) a = fmaf(w1[(size_t)r * C + c], dh[(size_t)n * Cr + r], a);
+      for (int r = 0; r < Cr; ++r) a = fmaf(w1s[(size_t)r * C + c], dh[(size_t)n * Cr + r], a);
       dz[(size_t)n * C + c] = a;
     }
     // parameter gradients of the two FCs
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
       if (c >= C) continue;
       float a = 0.f, b = 0.f;
       for (int n = 0; n < B; ++n) {
-        a = fmaf(du[(size_t)n * C + c], hid[(size_t)n * Cr + r], a);
+        a = fmaf(du[(size_t)n * C + c], hids[(size_t)n * Cr + r], a);
         b = fmaf(dh[(size_t)n * Cr + r], zz[(size_t)n * C + c], b);
       }
       dw2[(size_t)c * Cr + r] += a;
@@ -290,8 +302,17 @@ extern "C" int c3d_bn_se_finalize(const double* nc, int32_t B, double cnt_per_sa
                                   void* stream) {
   if (!nc || !gamma || !beta || !ss || C <= 0 || Cp < C || B <= 0) return C3D_E_BADARG;
   if (w1 && (!b1 || !w2 || !b2 || !gate || Cr <= 0)) return C3D_E_BADARG;
-  const size_t lds = w1 ? ((size_t)B * C + (size_t)B * Cr) * sizeof(float) : 0;
-  if (lds > 64 * 1024) return C3D_E_UNSUPPORTED;
+  const size_t lds = w1 ? ((size_t)B * C + (size_t)B * Cr + (size_t)2 * C * Cr) * sizeof(float) : 0;
+  if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_se_finalize_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+  }
   bn_se_finalize_kernel<<<dim3(w1 ? SE_SLICES : 1), dim3(SE_THREADS), lds, reinterpret_cast<hipStream_t>(stream)>>>(
       nc, B, cnt_per_sample, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, C, Cp,
       training, w1, b1, w2, b2, Cr, ss, mr, gate, hid);
@@ -316,7 +337,7 @@ extern "C" int c3d_se_bn_bwd_coef(const double* nc3, const double* ncf, int32_t 
   if (!nc3 || !ncf || !gamma || !mr || !ss || !coefA || !coefC || !coefB || C <= 0 || Cp < C || B <= 0)
     return C3D_E_BADARG;
   if (w1 && (!w2 || !gate || !hid || !dw1 || !db1 || !dw2 || !db2 || Cr <= 0)) return C3D_E_BADARG;
-  const size_t lds = w1 ? ((size_t)3 * B * C + (size_t)B * Cr) * sizeof(float) : 0;
+  const size_t lds = w1 ? ((size_t)3 * B * C + (size_t)2 * B * Cr + (size_t)2 * C * Cr) * sizeof(float) : 0;
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
