@@ -19,14 +19,22 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int stripes,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    int64_t* nbt, float momentum, float eps, int C, int Cp, int training,
                                    float* __restrict__ ss, float* __restrict__ mr) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && training && nbt) *nbt += 1;
-  if (c >= Cp) return;
+  // 16 lanes per channel: each reads one stripe, fixed-order butterfly (the one-thread-per-channel loop was 16
+  // dependent L2 round trips -- 9.6 us for a kernel on the critical path of every BN layer)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gid >> 4, kq = gid & 15;
+  if (gid == 0 && training && nbt) *nbt += 1;
+  const bool live = c < C;
+  double s1 = 0, s2 = 0;
+  if (training && live) {
+    for (int k = kq; k < stripes; k += 16) { s1 += sums[(size_t)k * 2 * C + c]; s2 += sums[(size_t)k * 2 * C + C + c]; }
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (kq != 0 || c >= Cp) return;
   if (c >= C) { ss[c] = 0.f; ss[Cp + c] = 0.f; if (mr) { mr[c] = 0.f; mr[Cp + c] = 0.f; } return; }
   double mean, var;
   if (training) {
-    double s1 = 0, s2 = 0;
-    for (int k = 0; k < stripes; ++k) { s1 += sums[(size_t)k * 2 * C + c]; s2 += sums[(size_t)k * 2 * C + C + c]; }
     mean = s1 / count;
     var = s2 / count - mean * mean;
     if (var < 0) var = 0;
@@ -147,12 +155,17 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
 __global__ void bn_bwd_coef_kernel(const double* __restrict__ dsums, int stripes, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ mr, int C, int Cp, float* __restrict__ coef,
                                    float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cp) return;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;   // 16 lanes per channel, one stripe each
+  const int c = gid >> 4, kq = gid & 15;
+  double s1 = 0, s2 = 0;  // sum g, sum g * xhat (over the striped accumulator sets)
+  if (c < C) {
+    for (int k = kq; k < stripes; k += 16) { s1 += dsums[(size_t)k * 2 * C + c]; s2 += dsums[(size_t)k * 2 * C + C + c]; }
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (kq != 0 || c >= Cp) return;
   if (c >= C) { coef[c] = 0.f; coef[Cp + c] = 0.f; coef[2 * Cp + c] = 0.f; return; }
   const double mean = mr[c], rstd = mr[Cp + c];
-  double s1 = 0, s2 = 0;  // sum g, sum g * xhat (over the striped accumulator sets)
-  for (int k = 0; k < stripes; ++k) { s1 += dsums[(size_t)k * 2 * C + c]; s2 += dsums[(size_t)k * 2 * C + C + c]; }
   const double A = (double)gamma[c] * rstd;
   const double Cc = -A * rstd * s2 / count;
   const double Bc = -A * s1 / count - Cc * mean;
@@ -287,7 +300,7 @@ extern "C" int c3d_bn_finalize(const double* sums, int32_t stripes, double count
   if (!gamma || !beta || !ss || C <= 0 || Cp < C) return C3D_E_BADARG;
   if (training && (!sums || stripes < 1)) return C3D_E_BADARG;
   if (!training && (!running_mean || !running_var)) return C3D_E_BADARG;
-  bn_finalize_kernel<<<dim3((Cp + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+  bn_finalize_kernel<<<dim3((Cp * 16 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
       sums, stripes, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, C, Cp,
       training, ss, mr);
   C3D_CHECK_LAUNCH();
@@ -323,7 +336,7 @@ extern "C" int c3d_bn_se_finalize(const double* nc, int32_t B, double cnt_per_sa
 extern "C" int c3d_bn_bwd_coef(const double* dsums, int32_t stripes, double count, const float* gamma, const float* mr, int32_t C,
                                int32_t Cp, float* coef, float* dgamma, float* dbeta, void* stream) {
   if (!dsums || stripes < 1 || !gamma || !mr || !coef || C <= 0 || Cp < C) return C3D_E_BADARG;
-  bn_bwd_coef_kernel<<<dim3((Cp + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+  bn_bwd_coef_kernel<<<dim3((Cp * 16 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
       dsums, stripes, count, gamma, mr, C, Cp, coef, dgamma, dbeta);
   C3D_CHECK_LAUNCH();
   return 0;
