@@ -66,42 +66,68 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(size, batch=2, timed=6, budget_s=20.0):
-    """Reference arithmetic (oracle = torch-CPU fp32 eager NCDHW port of the reference path),
-    same loss / Adam, on the usable host cores.  Bounded sample: 1 warm-up + up to `timed` steps
-    of B=`batch`, stopping early once `budget_s` seconds of timed work are spent."""
-    from oracle import model as om, synth
+def _mem_available_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(size, budget_s=45.0):
+    """Reference arithmetic (oracle = torch-CPU fp32 eager NCDHW port of the reference path), same loss /
+    Adam, on the usable host cores.  SURVEY.md 8(d) config 1: 32 synthetic pairs as 4 micro-batches of 8
+    (fp32 autograd needs ~2.2 GB RSS per sample), one train step per micro-batch, phases timed as the
+    reference's own timer does (scripts/train_BCD.py:187-217).  Bounded sample: 1 warm-up micro-batch, then
+    micro-batches until the pass of 32 pairs is done or `budget_s` seconds are spent; hosts with < 40 GB of
+    free RAM fall back to micro-batches of 2."""
+    from oracle import model as om
+    from change3d_amd import synthetic as synth
     cores = usable_cores()
     torch.set_num_threads(cores)
+    micro = 8 if _mem_available_gb() >= 40.0 else 2
     with contextlib.redirect_stdout(sys.stderr):   # the mirror prints the reference's "pretrained weights" notice
         net = om.Trainer(om.make_args(size=size))
     net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25))
     net.train()
     opt = om.make_adam(net)
-    pre, post, tgt = synth.synth_batch(batch, size, seed=0)
+    pre, post, tgt = synth.synth_batch(32, size, seed=0)
+    phase = [0.0, 0.0, 0.0]
 
-    def one():
-        prob = net.update_bcd(pre, post)
-        loss = om.bce_dice_loss(prob, tgt)
+    def one(i, timed=True):
+        sl = slice((i * micro) % 32, (i * micro) % 32 + micro)
+        t0 = time.time()
+        prob = net.update_bcd(pre[sl], post[sl])
+        loss = om.bce_dice_loss(prob, tgt[sl])
+        t1 = time.time()
         opt.zero_grad()
         loss.backward()
+        t2 = time.time()
         opt.step()
+        t3 = time.time()
+        if timed:
+            phase[0] += t1 - t0; phase[1] += t2 - t1; phase[2] += t3 - t2
         return loss.item()
 
     t0 = time.time()
-    one()
+    one(0, timed=False)
     warm = time.time() - t0
     done, t0 = 0, time.time()
+    n_pass = 32 // micro
     if warm > budget_s:  # very slow host: the warm-up step is the sample
         done, dt = 1, warm
     else:
-        while done < timed and time.time() - t0 < budget_s:
-            one()
+        while done < n_pass and time.time() - t0 < budget_s:
+            one(done)
             done += 1
         dt = time.time() - t0
-    return {"value": round(batch * done / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{done} timed steps of B={batch} {size}x{size} pairs (1 warm-up, {warm:.1f}s), fp32, torch-CPU "
-                      f"eager NCDHW, {cores} threads"}
+    return {"value": round(micro * done / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "phases_s": {"fwd_loss": round(phase[0], 2), "bwd": round(phase[1], 2), "optimizer": round(phase[2], 3)},
+            "sample": f"{done} of the {n_pass} micro-batches of {micro} that make SURVEY 8(d) config 1 (32 {size}x{size} pairs), "
+                      f"one train step each (1 warm-up micro-batch, {warm:.1f}s), fp32, torch-CPU eager NCDHW, {cores} threads"}
 
 
 def pmc_traffic(entry):
@@ -122,13 +148,30 @@ def pmc_traffic(entry):
         return {}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
+    (the driver's own multi-GPU command line is exactly this)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a line for a different job size")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
     # (test hooks: C3D_DIST_DEVICE / C3D_DIST_BACKEND let a 1-GPU box run the N>1 code path with gloo)
@@ -143,8 +186,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from oracle import synth  # deterministic synthetic weights / batches only (not the checker here)
-    from oracle.model import make_args
+    from change3d_amd import synthetic as synth   # deterministic synthetic weights / batches (no oracle in the product leg)
+    from change3d_amd.synthetic import make_args
     from change3d_amd import ops
     from change3d_amd.model.trainer import Trainer
     from change3d_amd.model.utils import BCEDiceLoss, FusedAdam, adjust_learning_rate
@@ -164,6 +207,9 @@ def main():
     net = net.to(dev).train()
     broadcast_module_state(net)
     arena, sync = setup_data_parallel(net, dev, overlap=True)
+    dist_world = dist.get_world_size() if world > 1 else 1
+    if dist_world != a.gpus or sync.world != a.gpus:
+        raise SystemExit(f"process group has {dist_world} ranks (GradSync {sync.world}) but --gpus {a.gpus}")
     opt = FusedAdam(arena, lr=margs.lr, capturable=True)
     meter = ConfuseMatrixMeter(2)
     pre, post, tgt = (t.to(dev) for t in synth.synth_batch(a.batch, a.size, seed=rank))
@@ -222,6 +268,7 @@ def main():
         torch.cuda.synchronize()
 
     def step():
+        h0 = time.perf_counter()
         adjust_learning_rate(margs, opt, 0, state["it"], MAX_ITER)
         opt.prepare_step()
         if graph is not None:
@@ -230,6 +277,7 @@ def main():
             state["loss"], state["prob"] = fwd_bwd()
             sync.finish()
             opt.launch()
+        state["host_s"] = state.get("host_s", 0.0) + time.perf_counter() - h0   # enqueue only (no read-back)
         state["it"] += 1
         if state["it"] % 5 == 0:  # reference prints (and syncs on) the loss every 5 iterations
             state["last_loss"] = float(state["loss"])
@@ -240,10 +288,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    state["host_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    t_enqueued = time.perf_counter() - t0   # host time to launch everything (includes the loss read-backs)
+    t_enqueued = state["host_s"]   # host time spent enqueueing the steps (loss read-backs excluded)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -269,7 +318,8 @@ def main():
                                f"{'SECOND' if scd else 'LEVIR-CD'}-shaped "
                                f"pairs, T={5 if scd else 3}, train step (fwd+{'0.5*CE+BCE/Dice+ChangeSimilarity' if scd else 'BCE/Dice'}"
                                f"+bwd+Adam)",
-                   "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "dist_world_size": dist_world,
+                   "dist_backend": (dist.get_backend() if world > 1 else None),
                    "hip_graph": graph is not None, "final_loss": round(final_loss, 5),
                    "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3)},
         "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_sample": bytes_per_sample,

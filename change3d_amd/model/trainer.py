@@ -60,28 +60,55 @@ class _EnhanceFn(torch.autograd.Function):
         return to_logical(dx), None, None
 
 
+def _ndhwc_storage(t):
+    """[B,T,H,W,C] contiguous view of a logical NCDHW tensor whose memory already is channels-last
+    (None otherwise)."""
+    p = t.permute(0, 2, 3, 4, 1)
+    return p if p.is_contiguous() else None
+
+
 class _TapFrames(torch.autograd.Function):
-    """x -> (x, x[:, :, k0], ..., x[:, :, k0+n-1]) with the frame gradients added IN PLACE into the
-    gradient that arrives for x.  The plain `x[:, :, k]` of reference model/trainer.py:136-139 costs a
-    full-size zero fill, a scatter and a full-size add per stage in backward (1.3 GB of traffic for
-    the 256x256 stem output); here it is one strided add over the tapped frames."""
+    """x -> (x, x[:, :, k0], ..., x[:, :, k0+n-1]) with the frame gradients accumulated by ONE strided
+    HIP pass per tapped frame (`c3d_frame_scatter`, accumulate=1) into the gradient that arrives for x.
+    The plain `x[:, :, k]` of reference model/trainer.py:136-139 costs a full-size zero fill, a scatter
+    and a full-size add per stage in backward (1.3 GB of traffic for the 256x256 stem output).
+
+    Ownership: the gradient arriving for x is the tensor the NEXT stage's backward allocated for exactly
+    this edge (x has one other consumer), so it is accumulated into in place; anything else (a gradient
+    in a foreign layout / dtype) is first copied into a buffer this function owns.  For the last stage x
+    has no other consumer: the gradient buffer is created here (materialize_grads is off)."""
 
     @staticmethod
     def forward(ctx, x, k0, n):
-        ctx.k0, ctx.n, ctx.T_total = k0, n, x.shape[2]
+        ctx.set_materialize_grads(False)
+        ctx.k0, ctx.n, ctx.x_meta = k0, n, (tuple(x.shape), x.dtype)
         return (x.view_as(x),) + tuple(x[:, :, k0 + i] for i in range(n))
 
     @staticmethod
     def backward(ctx, gx, *gf):
-        if gx is None:   # x has no other consumer (last stage): the frames are the whole gradient
-            ref = next(g for g in gf if g is not None)
-            B, C, H, W = ref.shape
-            T = ctx.T_total
-            gx = torch.zeros((B, T, H, W, C), dtype=ref.dtype, device=ref.device).permute(0, 4, 1, 2, 3)
-        for i, g in enumerate(gf):
-            if g is not None:
-                gx[:, :, ctx.k0 + i].add_(g)
-        return gx, None, None
+        (B, C, T, H, W), act = ctx.x_meta
+        live = [(i, g) for i, g in enumerate(gf) if g is not None]
+        if gx is None and not live:
+            return None, None, None
+        dev = (gx if gx is not None else live[0][1]).device
+        dt = ops.dt_code(act)
+        fresh = gx is None
+        buf = None if fresh else (_ndhwc_storage(gx) if gx.dtype == act else None)
+        if buf is None:
+            buf = torch.empty((B, T, H, W, C), dtype=act, device=dev)
+            if fresh:   # frames nobody tapped carry no gradient
+                tapped = {ctx.k0 + i for i, _ in live}
+                for t in range(T):
+                    if t not in tapped:
+                        buf[:, t].zero_()
+            else:
+                buf.copy_(gx.permute(0, 2, 3, 4, 1))
+        for i, g in live:
+            gc = g.permute(0, 2, 3, 1)
+            if g.dtype != act or not gc.is_contiguous():
+                gc = gc.to(act).contiguous()
+            ops.frame_scatter(gc, buf, B, T, H * W, C, ctx.k0 + i, 0 if fresh else 1, dt)
+        return buf.permute(0, 4, 1, 2, 3), None, None
 
 
 def tap_frames(x, k0, n):

@@ -5,6 +5,7 @@ data-parallel train step needs that the reference gets from torch.optim: a flat 
 gradient arena and a fused Adam (`scripts/train_BCD.py:284-290` hyper-parameters).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -49,8 +50,12 @@ def adjust_learning_rate(args, optimizer, epoch=None, iter=None, max_batches=Non
     if shrink_factor is not None:
         if not 0 < shrink_factor < 1:
             raise ValueError(f"Shrink factor must be between 0 and 1, got {shrink_factor}")
+        if verbose:
+            print("\nDECAYING learning rate.")
         for group in optimizer.param_groups:
             group["lr"] = group["lr"] * shrink_factor
+        if verbose:
+            print(f"The new learning rate is {optimizer.param_groups[0]['lr']:.6f}\n")
         return optimizer.param_groups[0]["lr"]
     if args.lr_mode == "step":
         if epoch is None:
@@ -69,6 +74,53 @@ def adjust_learning_rate(args, optimizer, epoch=None, iter=None, max_batches=Non
     for group in optimizer.param_groups:
         group["lr"] = lr
     return lr
+
+
+def load_checkpoint(args, model, save_path, max_batches):
+    """Resume contract of reference model/utils.py:205-232: `<save_path>/checkpoint.pth.tar` holds
+    {'epoch', 'state_dict', ...}; only the weights and the epoch are restored (never the optimizer state).
+    Returns (start_epoch, cur_iter).  `map_location='cpu'`: `load_state_dict` copies into the parameters'
+    own (arena) storage, so views held by ParamArena / kernels stay valid."""
+    start_epoch, cur_iter = 0, 0
+    if args.resume is not None:
+        checkpoint_path = os.path.join(save_path, "checkpoint.pth.tar")
+        if os.path.isfile(checkpoint_path):
+            print(f"=> loading checkpoint '{checkpoint_path}'")
+            checkpoint = torch.load(checkpoint_path, map_location="cpu")
+            start_epoch = checkpoint["epoch"]
+            cur_iter = start_epoch * max_batches
+            model.load_state_dict(checkpoint["state_dict"])
+            print(f"=> loaded checkpoint '{checkpoint_path}' (epoch {checkpoint['epoch']})")
+        else:
+            print(f"=> no checkpoint found at '{checkpoint_path}'")
+    return start_epoch, cur_iter
+
+
+_LOG_HEADERS = {
+    ("LEVIR-CD", "WHU-CD", "CLCD"): ("Epoch", "Kappa (val)", "IoU (val)", "F1 (val)", "R (val)", "P (val)"),
+    ("HRSCD", "SECOND"): ("epoch", "train_loss", "train_acc", "val_Fscd", "val_IoU_mean", "val_Sek", "val_loss", "val_acc"),
+    ("xBD",): ("epoch", "loss_val", "loc_f1_score", "harmonic_mean_f1", "oa_f1", "damage_f1_scores"),
+    ("LEVIR-CC", "DUBAI-CC"): ("epoch", "loss_val", "loc_f1_score", "harmonic_mean_f1", "oa_f1", "damage_f1_scores"),
+}
+
+
+def setup_logger(args, save_path):
+    """Log-file contract of reference model/utils.py:235-276: append the argument dump and the per-dataset
+    column header to `<save_path>/<args.log_file>`, return the open handle."""
+    logger = open(os.path.join(save_path, args.log_file), "a+")
+    logger.write("Model Configurations:\n")
+    for arg, value in vars(args).items():
+        logger.write(f"{arg}: {value}\n")
+        print(f"{arg}: {value}")
+    logger.write("\n" + "-" * 60)
+    for names, cols in _LOG_HEADERS.items():
+        if args.dataset in names:
+            logger.write("\n" + "\t".join(cols))
+            break
+    else:
+        assert False, r"setup_logger error, please check the input dataset!"
+    logger.flush()
+    return logger
 
 
 class _BCEDiceFn(torch.autograd.Function):
@@ -210,6 +262,18 @@ class ParamArena:
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
 
+    def check_grads_attached(self):
+        """Raise if a parameter's `.grad` is no longer the arena view.  `model.zero_grad()` / `p.grad = None`
+        (torch's set_to_none default) detach it: the kernels would then accumulate into a fresh tensor while
+        Adam and the all-reduce read the stale flat buffer, and training would silently do nothing.  Clear
+        gradients with `optimizer.zero_grad()` (FusedAdam) or `arena.zero_grad()`."""
+        base = self.flat_grad.data_ptr()
+        for n, p, o in zip(self.names, self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != base + 4 * o:
+                raise RuntimeError(
+                    f"gradient of '{n}' is not a view of the flat gradient arena (was model.zero_grad() or "
+                    f"p.grad = None used?): clear gradients with FusedAdam.zero_grad() / ParamArena.zero_grad()")
+
     def zero_grad(self):
         self.flat_grad.zero_()
         self.attach_grads()
@@ -241,6 +305,7 @@ class FusedAdam:
 
     def prepare_step(self):
         """Host-side part of a step (call OUTSIDE a captured graph, before replay)."""
+        self.arena.check_grads_attached()
         self.step_count += 1
         lr, bc1, bc2s = self.hparams(self.step_count)
         if self.capturable:

@@ -368,7 +368,6 @@ class _StageFn(torch.autograd.Function):
             prev_mark = ops.side_mark()
         if stage.post_backward is not None:  # data-parallel hook: this stage's grads must be final
             ops.side_join()
-        if stage.post_backward is not None:  # data-parallel hook: this stage's grads are final
             stage.post_backward()
         return to_logical(cur).to(ctx.x_dtype), None, None
 
@@ -443,22 +442,97 @@ def _init_net_weights(model, fc_init_std=0.01):
             m.bias.data.zero_()
 
 
+class Swish(nn.Module):
+    """`pytorchvideo.layers.swish.Swish` as the reference imports it (reference model/x3d.py:13-20): the
+    default `inner_act` of the bottleneck.  Inside `create_x3d*` it is a MARKER (Swish is fused into the
+    pointwise-GEMM prologue/epilogue kernels); standalone it evaluates x * sigmoid(x)."""
+
+    def forward(self, x):
+        return x * torch.sigmoid(x)
+
+
+def _check_norm_act(norm, norm_eps, norm_momentum, activation, what):
+    if norm is not nn.BatchNorm3d or activation is not nn.ReLU or norm_eps != BN_EPS or norm_momentum != BN_MOM:
+        raise NotImplementedError(f"{what}: only BatchNorm3d(eps=1e-5, momentum=0.1) + ReLU is implemented as HIP kernels")
+
+
+def create_x3d_stem(*, in_channels, out_channels, conv_kernel_size=(5, 3, 3), conv_stride=(1, 2, 2),
+                    conv_padding=(2, 1, 1), norm=nn.BatchNorm3d, norm_eps=1e-5, norm_momentum=0.1,
+                    activation=nn.ReLU, act_dtype=torch.float32):
+    """reference model/x3d.py:23-106 (same keywords).  Change3D calls it with stride (1,1,1)
+    (reference model/x3d.py:564); that is the configuration the stem kernels implement."""
+    _check_norm_act(norm, norm_eps, norm_momentum, activation, "create_x3d_stem")
+    if tuple(conv_padding) != tuple(k // 2 for k in conv_kernel_size):
+        raise NotImplementedError("stem kernels use 'same' padding")
+    return X3DStem(in_channels, out_channels, conv_kernel_size, conv_stride, act_dtype)
+
+
+def create_x3d_bottleneck_block(*, dim_in, dim_inner, dim_out, conv_kernel_size=(3, 3, 3), conv_stride=(1, 2, 2),
+                                norm=nn.BatchNorm3d, norm_eps=1e-5, norm_momentum=0.1, se_ratio=0.0625,
+                                activation=nn.ReLU, inner_act=Swish):
+    """reference model/x3d.py:109-232.  Returns the `branch2` PARAMETER HOLDER (conv_a/norm_a/conv_b/norm_b/
+    conv_c/norm_c with the reference's key names); it is executed only as part of a residual stage
+    (`create_x3d_res_stage`), whose kernels fuse across the block.  `se_ratio > 0` puts an SE block here, as
+    the reference does (the stage passes 0 for odd block indices)."""
+    _check_norm_act(norm, norm_eps, norm_momentum, activation, "create_x3d_bottleneck_block")
+    if inner_act is not Swish or tuple(conv_kernel_size) != (3, 3, 3) or conv_stride[0] != 1 or conv_stride[1] != conv_stride[2]:
+        raise NotImplementedError("bottleneck kernels: 3x3x3 depthwise, spatial stride 1 or 2, Swish inner activation")
+    blk = X3DResBlock(dim_in, dim_inner, dim_out, conv_stride[1], use_se=se_ratio > 0.0, se_ratio=se_ratio)
+    return blk.branch2
+
+
+def create_x3d_res_block(*, dim_in, dim_inner, dim_out, bottleneck=create_x3d_bottleneck_block, use_shortcut=True,
+                         conv_kernel_size=(3, 3, 3), conv_stride=(1, 2, 2), norm=nn.BatchNorm3d, norm_eps=1e-5,
+                         norm_momentum=0.1, se_ratio=0.0625, activation=nn.ReLU, inner_act=Swish):
+    """reference model/x3d.py:235-328: parameter holder for one residual block (branch1_conv / branch1_norm /
+    branch2); executed inside a stage."""
+    _check_norm_act(norm, norm_eps, norm_momentum, activation, "create_x3d_res_block")
+    if bottleneck is not create_x3d_bottleneck_block or inner_act is not Swish or not use_shortcut \
+            or tuple(conv_kernel_size) != (3, 3, 3) or conv_stride[0] != 1 or conv_stride[1] != conv_stride[2]:
+        raise NotImplementedError("only the X3D residual block Change3D uses is implemented as HIP kernels")
+    return X3DResBlock(dim_in, dim_inner, dim_out, conv_stride[1], use_se=se_ratio > 0.0, se_ratio=se_ratio)
+
+
+def create_x3d_res_stage(*, depth, dim_in, dim_inner, dim_out, bottleneck=create_x3d_bottleneck_block,
+                         conv_kernel_size=(3, 3, 3), conv_stride=(1, 2, 2), norm=nn.BatchNorm3d, norm_eps=1e-5,
+                         norm_momentum=0.1, se_ratio=0.0625, activation=nn.ReLU, inner_act=Swish,
+                         act_dtype=torch.float32):
+    """reference model/x3d.py:331-412: `depth` blocks, stride on block 0 only, SE on even block indices."""
+    _check_norm_act(norm, norm_eps, norm_momentum, activation, "create_x3d_res_stage")
+    if bottleneck is not create_x3d_bottleneck_block or inner_act is not Swish \
+            or tuple(conv_kernel_size) != (3, 3, 3) or conv_stride[0] != 1 or conv_stride[1] != conv_stride[2]:
+        raise NotImplementedError("only the X3D residual stage Change3D uses is implemented as HIP kernels")
+    return X3DResStage(depth, dim_in, dim_inner, dim_out, conv_stride[1], se_ratio, act_dtype)
+
+
+def create_x3d_head(*, dim_in, dim_inner, dim_out, num_classes, pool_act=nn.ReLU, pool_kernel_size=(13, 5, 5),
+                    norm=nn.BatchNorm3d, norm_eps=1e-5, norm_momentum=0.1, bn_lin5_on=False, dropout_rate=0.5,
+                    activation=nn.Softmax, output_with_global_average=True):
+    """reference model/x3d.py:415-540: parameter holder (never executed by any Change3D path)."""
+    if bn_lin5_on:
+        raise NotImplementedError("head_bn_lin5_on is not used by Change3D")
+    return X3DHead(dim_in, dim_inner, dim_out, num_classes, dropout_rate)
+
+
 def create_x3d(*, input_channel=3, input_clip_length=13, input_crop_size=160, model_num_class=400,
                dropout_rate=0.5, width_factor=2.0, depth_factor=2.2, norm=nn.BatchNorm3d, norm_eps=1e-5,
                norm_momentum=0.1, activation=nn.ReLU, stem_dim_in=12, stem_conv_kernel_size=(5, 3, 3),
                stem_conv_stride=(1, 1, 1), stage_conv_kernel_size=((3, 3, 3),) * 4,
-               stage_spatial_stride=(2, 2, 2, 2), stage_temporal_stride=(1, 1, 1, 1), bottleneck=None,
-               bottleneck_factor=2.25, se_ratio=0.0625, inner_act=None, head_dim_out=2048,
-               head_pool_act=nn.ReLU, head_bn_lin5_on=False, head_activation=None,
+               stage_spatial_stride=(2, 2, 2, 2), stage_temporal_stride=(1, 1, 1, 1),
+               bottleneck=create_x3d_bottleneck_block, bottleneck_factor=2.25, se_ratio=0.0625, inner_act=Swish,
+               head_dim_out=2048, head_pool_act=nn.ReLU, head_bn_lin5_on=False, head_activation=None,
                head_output_with_global_average=True, act_dtype=torch.float32):
-    """Same keyword surface as reference model/x3d.py:543-584 (+ `act_dtype`)."""
+    """Same keyword surface and defaults as reference model/x3d.py:543-584 (+ `act_dtype`, the activation
+    storage type of the HIP path)."""
     if (norm is not nn.BatchNorm3d or activation is not nn.ReLU or norm_eps != BN_EPS or norm_momentum != BN_MOM
             or tuple(stage_spatial_stride) != (2, 2, 2, 2) or tuple(stage_temporal_stride) != (1, 1, 1, 1)
             or any(tuple(k) != (3, 3, 3) for k in stage_conv_kernel_size) or head_bn_lin5_on
-            or head_activation is not None or bottleneck is not None or inner_act is not None):
+            or head_activation is not None or bottleneck is not create_x3d_bottleneck_block or inner_act is not Swish):
         raise NotImplementedError("only the X3D configuration Change3D uses is implemented as HIP kernels")
     stem_out = round_width(stem_dim_in, width_factor)
-    blocks = [X3DStem(input_channel, stem_out, stem_conv_kernel_size, stem_conv_stride, act_dtype)]
+    blocks = [create_x3d_stem(in_channels=input_channel, out_channels=stem_out, conv_kernel_size=stem_conv_kernel_size,
+                              conv_stride=stem_conv_stride,
+                              conv_padding=tuple(k // 2 for k in stem_conv_kernel_size), act_dtype=act_dtype)]
     dims = [stem_dim_in]
     for _ in range(3):
         dims.append(round_width(dims[-1], 2.0, divisor=8))
@@ -466,8 +540,31 @@ def create_x3d(*, input_channel=3, input_clip_length=13, input_crop_size=160, mo
     for i, d in enumerate((1, 2, 5, 3)):
         cout = round_width(dims[i], width_factor)
         cinner = int(bottleneck_factor * cout)
-        blocks.append(X3DResStage(round_repeats(d, depth_factor), cin, cinner, cout, stage_spatial_stride[i],
-                                  se_ratio, act_dtype))
+        blocks.append(create_x3d_res_stage(depth=round_repeats(d, depth_factor), dim_in=cin, dim_inner=cinner,
+                                           dim_out=cout, conv_stride=(stage_temporal_stride[i], stage_spatial_stride[i],
+                                                                      stage_spatial_stride[i]),
+                                           se_ratio=se_ratio, act_dtype=act_dtype))
         cin = cout
-    blocks.append(X3DHead(cin, cinner, head_dim_out, model_num_class, dropout_rate))
+    blocks.append(create_x3d_head(dim_in=cin, dim_inner=cinner, dim_out=head_dim_out, num_classes=model_num_class,
+                                  dropout_rate=dropout_rate))
     return X3DNet(blocks, act_dtype)
+
+
+def stage_saved_activations(y):
+    """Debug / test access to what a residual stage kept for backward: for the stage output `y` (logical
+    NCDHW tensor returned by `X3DResStage.forward` with grad enabled) a list with one dict per block holding the
+    stored activation tensors `a`, `b`, `c`, `sc` ([rows, Cp] in the activation dtype; `sc` only where the
+    shortcut has a BatchNorm), their BatchNorm (mean | rstd) vectors `mr_a`, `mr_b`, `mr_c`, `mr_sc` (f32
+    [2][Cp]) and the real channel counts `C_a` ... -- tests recompute the statistics in f64 from these
+    (tests/test_bf16_fullsize_gpu.py)."""
+    fn = y.grad_fn
+    if fn is None or not hasattr(fn, "stage") or not hasattr(fn, "saved"):
+        raise ValueError("not the output of a residual stage evaluated with grad enabled")
+    out = []
+    for blk, sv in zip(fn.stage.res_blocks, fn.saved):
+        rec = dict(a=sv["a"], b=sv["b"], c=sv["c"], mr_a=sv["mr_a"], mr_b=sv["mr_b"], mr_c=sv["mr_c"],
+                   C_a=blk.cinner, C_b=blk.cinner, C_c=blk.cout)
+        if sv["mr_1"] is not None:
+            rec.update(sc=sv["sc"], mr_sc=sv["mr_1"], C_sc=blk.cout)
+        out.append(rec)
+    return out

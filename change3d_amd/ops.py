@@ -325,6 +325,12 @@ def enhance_bwd_apply(dout, y, dd, dy, B, T, HW, Cp, t_pre, t_post, dtype):
                                           _stream())
 
 
+def frame_scatter(src, dst, B, T, HW, Cp, t_dst, accumulate, dtype):
+    """dst[:, t_dst] (+)= src for channels-last src [B][HW][Cp], dst [B][T][HW][Cp]."""
+    _launch("c3d_frame_scatter", B * HW * Cp * (3 if accumulate else 2) * _es(dtype), L.lib().c3d_frame_scatter, _p(src), _p(dst), B, T, HW, Cp,
+            t_dst, 1 if accumulate else 0, dtype, _stream())
+
+
 # ------------------------------------------------------------------------------------ stem
 def stem_fwd(x, w_t, w_xy, u, sums, B, T, H, W, dtype):
     _launch("c3d_stem_fwd", x.numel() * 4 + u.numel() * _es(dtype), L.lib().c3d_stem_fwd, _p(x), _p(w_t), _p(w_xy), _p(u), _p(sums), B, T, H, W, dtype, _stream())

@@ -59,6 +59,7 @@ class GradSync:
         """After backward: reduce what is left, average, and fence the compute stream."""
         if self.world == 1:
             return
+        self.arena.check_grads_attached()   # a detached p.grad would leave its real gradient out of the exchange
         g = self.arena.flat_grad
         if self._tail_launched:
             head = g[:self.split]

@@ -350,9 +350,7 @@ def cm2score(cm):
             "precision": precision, "Pre": pre}
 
 
-def make_args(num_perception_frame=1, size=256, dataset="LEVIR-CD", num_class=1):
-    return SimpleNamespace(pretrained="/nonexistent", num_perception_frame=num_perception_frame,
-                           in_height=size, in_width=size, dataset=dataset, num_class=num_class)
+from change3d_amd.synthetic import make_args  # noqa: E402,F401  (one definition, shared with bench/scripts)
 
 
 def make_adam(model, lr=2e-4):

@@ -1,78 +1,7 @@
 """ORACLE — test infrastructure only.
 
-Deterministic synthetic weights / inputs / targets, generated with numpy's PCG64
-(`np.random.default_rng`) so the same seed yields the same tensors in the build
-container and on the GPU box (no dependence on torch's RNG stream).
-
-Input contract mirrors the reference data pipeline (reference data/transforms.py:127-154,
-LEVIR normalisation mean=std=0.5): image = (u8/255 - 0.5)/0.5 with u8 ~ U{0..255};
-target in {0,1} made of 1-3 axis-aligned rectangles (~5 % of pixels).
-`X3D_L.pyth` is not available offline, so weights are synthetic per key.
-"""
-import numpy as np
-import torch
-
-
-def synth_state_dict(model, seed=16, mask_margin=1.0):
-    """Fill every tensor of `model.state_dict()` from a key-ordered PCG64 stream.
-
-    conv / linear weights: N(0, sqrt(2/fan_in)); BN weight U(0.5,1.5), bias N(0,0.1),
-    running_mean N(0,0.1), running_var U(0.5,1.5); conv biases N(0,0.1);
-    perception_frames N(0,1).  `mask_margin` scales `*.up_c1.0.weight` so sigmoid
-    outputs move away from 0.5 (SURVEY.md §7 'mask parity is fragile')."""
-    rng = np.random.default_rng(seed)
-    out = {}
-    for key, ref in model.state_dict().items():
-        shape = tuple(ref.shape)
-        if key.endswith("num_batches_tracked"):
-            val = np.zeros(shape, dtype=np.int64)
-        elif key.endswith("running_mean"):
-            val = rng.normal(0.0, 0.1, shape)
-        elif key.endswith("running_var"):
-            val = rng.uniform(0.5, 1.5, shape)
-        elif key.endswith("perception_frames"):
-            val = rng.normal(0.0, 1.0, shape)
-        elif len(shape) == 1:
-            is_norm_w = key.endswith("weight")
-            val = rng.uniform(0.5, 1.5, shape) if is_norm_w else rng.normal(0.0, 0.1, shape)
-        else:
-            fan_in = int(np.prod(shape[1:]))
-            val = rng.normal(0.0, np.sqrt(2.0 / fan_in), shape)
-            if key.endswith("up_c1.0.weight"):
-                val = val * mask_margin
-        dtype = torch.int64 if key.endswith("num_batches_tracked") else torch.float32
-        out[key] = torch.from_numpy(np.ascontiguousarray(val)).to(dtype)
-    return out
-
-
-def synth_batch(batch, size=256, seed=0):
-    """(pre, post, target): (B,3,S,S) fp32 x2 in [-1,1], (B,1,S,S) fp32 in {0,1}."""
-    rng = np.random.default_rng(1000 + seed)
-    u8 = rng.integers(0, 256, size=(2, batch, 3, size, size), dtype=np.uint8)
-    imgs = (u8.astype(np.float32) / 255.0 - 0.5) / 0.5
-    tgt = np.zeros((batch, 1, size, size), dtype=np.float32)
-    for b in range(batch):
-        for _ in range(int(rng.integers(1, 4))):
-            h = int(rng.integers(size // 16, size // 4))
-            w = int(rng.integers(size // 16, size // 4))
-            y0 = int(rng.integers(0, size - h))
-            x0 = int(rng.integers(0, size - w))
-            tgt[b, 0, y0:y0 + h, x0:x0 + w] = 1.0
-    return torch.from_numpy(imgs[0]), torch.from_numpy(imgs[1]), torch.from_numpy(tgt)
-
-
-def synth_scd_labels(batch, size=256, seed=0, num_class=7):
-    """SCD labels as `scripts/train_SCD.py:209-217` sees them after the loader: (B,3,S,S) int64 =
-    [pre class map in 0..num_class-1, post class map, change mask in {0,1}] (blocky class maps, the
-    change mask of `synth_batch` with the same seed)."""
-    rng = np.random.default_rng(2000 + seed)
-    cell = max(size // 8, 1)
-    grid = rng.integers(0, num_class, size=(2, batch, (size + cell - 1) // cell, (size + cell - 1) // cell))
-    maps = np.repeat(np.repeat(grid, cell, axis=2), cell, axis=3)[:, :, :size, :size]
-    change = synth_batch(batch, size, seed)[2].numpy()[:, 0].astype(np.int64)
-    return torch.from_numpy(np.stack([maps[0], maps[1], change], axis=1).astype(np.int64))
-
-
-def synth_tensor(shape, seed, scale=1.0):
-    rng = np.random.default_rng(seed)
-    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+The deterministic synthetic-data generator lives in `change3d_amd/synthetic.py` (a neutral module:
+benchmarks and scripts need seeded tensors without importing the oracle); re-exported here so
+oracle-side code and tests keep one definition."""
+from change3d_amd.synthetic import (make_args, synth_batch, synth_scd_labels, synth_state_dict,  # noqa: F401
+                                    synth_tensor)

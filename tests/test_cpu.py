@@ -255,3 +255,88 @@ def test_two_rank_gloo_gradient_allreduce_is_mean_of_local_grads():
     for o, n in zip(offs, sizes):
         assert np.allclose(f0[o:o + n], mean[pos:pos + n], rtol=1e-6, atol=1e-9)
         pos += n
+
+
+# ------------------------------------------------------------- round-2 boundary / hygiene checks
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under change3d_amd/ (nor bench.py's product leg) may import it."""
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "change3d_amd")):
+        for f in files:
+            if f.endswith(".py") and pat.search(open(os.path.join(dp, f)).read()):
+                bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    hits = [m.start() for m in pat.finditer(bench)]
+    lo, hi = bench.index("def cpu_baseline("), bench.index("def pmc_traffic(")
+    assert hits and all(lo < h < hi for h in hits), "bench.py may touch oracle/ only inside its cpu_baseline leg"
+
+
+def test_create_x3d_accepts_the_reference_default_callables_and_exports_creators():
+    import torch.nn as nn
+    from change3d_amd.model import x3d
+    net = x3d.create_x3d(input_clip_length=3, depth_factor=5.0, bottleneck=x3d.create_x3d_bottleneck_block,
+                         inner_act=x3d.Swish, norm=nn.BatchNorm3d, activation=nn.ReLU)
+    assert len(net.state_dict()) == 1141
+    import inspect
+    sig = inspect.signature(x3d.create_x3d).parameters
+    assert sig["bottleneck"].default is x3d.create_x3d_bottleneck_block and sig["inner_act"].default is x3d.Swish
+    stage = x3d.create_x3d_res_stage(depth=3, dim_in=24, dim_inner=54, dim_out=24)
+    assert [b.use_se for b in stage.res_blocks] == [True, False, True] and stage.res_blocks[0].stride == 2
+    blk = x3d.create_x3d_res_block(dim_in=24, dim_inner=108, dim_out=48)
+    assert blk.branch1_conv is not None and blk.branch1_norm is not None
+    b2 = x3d.create_x3d_bottleneck_block(dim_in=48, dim_inner=108, dim_out=48, conv_stride=(1, 1, 1), se_ratio=0.0)
+    assert isinstance(b2.norm_b[1], nn.Identity) and b2.conv_b.groups == 108
+    assert x3d.create_x3d_stem(in_channels=3, out_channels=24, conv_stride=(1, 1, 1)).conv.conv_xy.groups == 24
+    head = x3d.create_x3d_head(dim_in=192, dim_inner=432, dim_out=2048, num_classes=400)
+    assert head.proj.weight.shape == (400, 2048)
+    with pytest.raises(NotImplementedError):
+        x3d.create_x3d(input_clip_length=3, depth_factor=5.0, inner_act=nn.ReLU)
+
+
+def test_dropin_import_paths_resolve_to_the_mirrors():
+    """`PYTHONPATH=change3d_amd/dropin` makes the reference's own import lines (scripts/train_BCD.py:20-28,
+    model/trainer.py:14-17) resolve to this package."""
+    import subprocess
+    code = ("from model.trainer import Trainer, Encoder; from model.x3d import create_x3d; "
+            "from model.change_decoder import ChangeDecoder; "
+            "from model.utils import adjust_learning_rate, BCEDiceLoss, load_checkpoint, setup_logger, weight_init; "
+            "from utils.metric_tool import ConfuseMatrixMeter; import change3d_amd.model.trainer as t; "
+            "assert Trainer is t.Trainer; print('ok')")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "change3d_amd", "dropin") + os.pathsep + ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/")
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_arena_refuses_detached_gradients():
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.utils import FusedAdam, ParamArena, hot_path_named_params
+    from change3d_amd.synthetic import make_args
+    net = Trainer(make_args(size=32))
+    arena = ParamArena(hot_path_named_params(net), torch.device("cpu"))
+    opt = FusedAdam(arena, lr=1e-3)
+    arena.check_grads_attached()
+    net.zero_grad()                      # torch default set_to_none=True detaches p.grad from the arena
+    with pytest.raises(RuntimeError, match="not a view of the flat gradient arena"):
+        opt.prepare_step()
+    opt.zero_grad()                      # the supported way re-attaches
+    arena.check_grads_attached()
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr and not out.stdout.strip()
+
+
+def test_shrink_lr_prints_like_the_reference(capsys):
+    from types import SimpleNamespace
+    from change3d_amd.model.utils import adjust_learning_rate
+    opt = SimpleNamespace(param_groups=[{"lr": 1e-3}])
+    assert abs(adjust_learning_rate(None, opt, shrink_factor=0.5) - 5e-4) < 1e-18
+    assert "DECAYING learning rate" in capsys.readouterr().out
+    adjust_learning_rate(None, opt, shrink_factor=0.5, verbose=False)
+    assert capsys.readouterr().out == ""

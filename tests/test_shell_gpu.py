@@ -1,0 +1,156 @@
+"""Step-shell pieces on the GPU (SURVEY.md 8(f).3 and the rows the round-1 review found untested): the frame tap
+(`c3d_frame_scatter`), checkpoint round trip between the HIP mirror and the oracle, `update_bda` (T=4)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).norm().item() / (b.norm().item() + 1e-30)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_frame_scatter_op(dtype, accumulate):
+    _need_gpu()
+    from change3d_amd import ops, synthetic as synth
+    B, T, H, W, C = 3, 5, 9, 7, 48
+    src = synth.synth_tensor((B, H, W, C), 1).to(DEV).to(dtype)
+    dst = synth.synth_tensor((B, T, H, W, C), 2).to(DEV).to(dtype)
+    want = dst.clone()
+    want[:, 3] = (want[:, 3].float() + src.float()).to(dtype) if accumulate else src
+    ops.frame_scatter(src, dst, B, T, H * W, C, 3, accumulate, ops.dt_code(dtype))
+    torch.cuda.synchronize()
+    assert torch.equal(dst, want)
+
+
+@pytest.mark.parametrize("last", [False, True])
+def test_tap_frames_backward_matches_plain_indexing(last):
+    """`tap_frames` against the reference's plain `x[:, :, k]` (model/trainer.py:136-139) under autograd;
+    `last`: x has no other consumer (the res4 case: the gradient buffer is created inside the tap)."""
+    _need_gpu()
+    from change3d_amd import synthetic as synth
+    from change3d_amd.model.trainer import tap_frames
+    B, C, T, H, W = 2, 24, 5, 8, 8
+    base = synth.synth_tensor((B, T, H, W, C), 3).to(DEV).permute(0, 4, 1, 2, 3)   # channels-last storage
+    gy = synth.synth_tensor((B, T, H, W, C), 4).to(DEV).permute(0, 4, 1, 2, 3)
+    gfs = [synth.synth_tensor((B, H, W, C), 5 + i).to(DEV).permute(0, 3, 1, 2) for i in range(3)]
+    xr = base.clone().requires_grad_(True)
+    fr = [xr[:, :, 1 + i] for i in range(3)]
+    tot = sum((f * g).sum() for f, g in zip(fr, gfs)) + (0 if last else (xr * 2.0 * gy).sum())
+    tot.backward()
+    xd = base.clone().requires_grad_(True)
+    y, fd = tap_frames(xd * 1.0, 1, 3)
+    tot = sum((f * g).sum() for f, g in zip(fd, gfs)) + (0 if last else (y * 2.0 * gy).sum())
+    tot.backward()
+    assert torch.allclose(xd.grad, xr.grad, rtol=1e-6, atol=1e-6)
+
+
+def test_checkpoint_round_trip_mirror_oracle_mirror(tmp_path):
+    """reference scripts/train_BCD.py:333-349 (checkpoint layout) / model/utils.py:205-232 (resume): a checkpoint
+    written from the HIP mirror after a train step strict-loads into the oracle (= the reference module tree) and
+    the oracle's eval output agrees; loaded back through the mirror's `load_checkpoint` into a fresh HIP model
+    WITH a parameter arena the eval output is bit-identical."""
+    _need_gpu()
+    from types import SimpleNamespace
+    from oracle import model as om
+    from change3d_amd import synthetic as synth
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.utils import (BCEDiceLoss, FusedAdam, ParamArena, hot_path_named_params,
+                                          load_checkpoint)
+    S, B = 64, 2
+    args = synth.make_args(size=S)
+    net = Trainer(args)
+    net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25))
+    net = net.to(DEV).train()
+    arena = ParamArena(hot_path_named_params(net), torch.device(DEV))
+    opt = FusedAdam(arena, lr=2e-4)
+    pre, post, tgt = (t.to(DEV) for t in synth.synth_batch(B, S, seed=0))
+    for _ in range(2):
+        opt.zero_grad()
+        loss = BCEDiceLoss(net.update_bcd(pre, post), tgt)
+        loss.backward()
+        opt.step()
+    net.eval()
+    with torch.no_grad():
+        p_hip = net.update_bcd(pre, post).clone()
+    ckpt = {"epoch": 3, "arch": str(net), "state_dict": net.state_dict(), "optimizer": opt.state_dict(),
+            "loss_train": float(loss), "loss_val": 0.0, "F_train": 0.0, "F_val": 0.0, "lr": 2e-4}
+    torch.save(ckpt, os.path.join(tmp_path, "checkpoint.pth.tar"))
+    # ---- into the oracle (reference module tree), strict
+    state = torch.load(os.path.join(tmp_path, "checkpoint.pth.tar"), map_location="cpu")
+    ora = om.Trainer(args)
+    ora.load_state_dict(state["state_dict"], strict=True)
+    ora.eval()
+    with torch.no_grad():
+        p_ora = ora.update_bcd(pre.cpu(), post.cpu())
+    assert (p_hip.cpu() - p_ora).abs().max().item() < 2e-4
+    assert state["optimizer"]["step"] == 2 and state["epoch"] == 3
+    # ---- oracle-written checkpoint back into a fresh mirror through load_checkpoint (resume path)
+    torch.save({"epoch": 3, "state_dict": ora.state_dict()}, os.path.join(tmp_path, "checkpoint.pth.tar"))
+    net2 = Trainer(args).to(DEV)
+    arena2 = ParamArena(hot_path_named_params(net2), torch.device(DEV))
+    start_epoch, cur_iter = load_checkpoint(SimpleNamespace(resume=True), net2, str(tmp_path), 100)
+    assert (start_epoch, cur_iter) == (3, 300)
+    arena2.check_grads_attached()
+    for p, o in zip(arena2.params, arena2.offsets):   # parameters still live in the arena after the load
+        assert p.data_ptr() == arena2.flat_param.data_ptr() + 4 * o
+    net2.eval()
+    with torch.no_grad():
+        p_back = net2.update_bcd(pre, post)
+    assert torch.equal(p_back, p_hip)
+    assert load_checkpoint(SimpleNamespace(resume=None), net2, str(tmp_path), 100) == (0, 0)
+
+
+def test_e2e_bda_forward_backward_vs_oracle_size64():
+    """`Trainer.update_bda` (reference model/trainer.py:268-290): K=2 perception frames, T=4, two decoders."""
+    _need_gpu()
+    from oracle import model as om
+    from change3d_amd import synthetic as synth
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.utils import hot_path_named_params
+    from test_model_gpu import K_NOISE, _grad_check
+    S, B = 64, 2
+    mk = lambda: om.make_args(num_perception_frame=2, size=S, dataset="xBD", num_class=5)  # noqa: E731
+    ref = om.Trainer(mk())
+    sd = synth.synth_state_dict(ref, seed=16, mask_margin=0.25)
+    ref.load_state_dict(sd)
+    ref64 = om.Trainer(mk())
+    ref64.load_state_dict(sd)
+    ref64 = ref64.double()
+    mine = Trainer(mk())
+    mine.load_state_dict(sd)
+    mine = mine.to(DEV)
+    pre, post, _ = synth.synth_batch(B, S, seed=7)
+    ref.train(); mine.train(); ref64.train()
+    outs_r, outs_64 = ref.update_bda(pre, post), ref64.update_bda(pre.double(), post.double())
+    outs_d = mine.update_bda(pre.to(DEV), post.to(DEV))
+    probes = [synth.synth_tensor(tuple(o.shape), 60 + i, 1.0 / o[0].numel()) for i, o in enumerate(outs_r)]
+    sum((o * p).sum() for o, p in zip(outs_r, probes)).backward()
+    sum((o * p.double()).sum() for o, p in zip(outs_64, probes)).backward()
+    sum((o * p.to(DEV)).sum() for o, p in zip(outs_d, probes)).backward()
+    torch.cuda.synchronize()
+    for name, o_d, o_r, o_64 in zip(("cls", "loc"), outs_d, outs_r, outs_64):
+        assert o_d.shape == o_r.shape
+        scale = max(1.0, o_64.detach().abs().max().item())
+        e_hip = (o_d.detach().cpu().double() - o_64.detach()).abs().max().item() / scale
+        e_ref = (o_r.detach().double() - o_64.detach()).abs().max().item() / scale
+        print(f"BDA {name}: max rel err vs fp64: hip {e_hip:.3e}  fp32 reference {e_ref:.3e}")
+        assert e_hip <= K_NOISE * e_ref + 1e-6, (name, e_hip, e_ref)
+    names = [n for n, _ in hot_path_named_params(mine)]
+    g_hip = {n: p.grad for n, p in hot_path_named_params(mine)}
+    g32 = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+    g64 = {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
+    assert set(names) == set(g32.keys())
+    _grad_check(names, g_hip, g32, g64)

@@ -1,8 +1,8 @@
 import faulthandler, sys, os, torch
 faulthandler.enable()
 sys.path.insert(0, os.getcwd())
-from oracle import synth
-from oracle.model import make_args
+from change3d_amd import synthetic as synth  # deterministic synthetic weights / batches (neutral module)
+from change3d_amd.synthetic import make_args
 from change3d_amd.model.trainer import Trainer
 from change3d_amd.model.utils import BCEDiceLoss, FusedAdam, ParamArena, hot_path_named_params
 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)

@@ -12,8 +12,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from change3d_amd.model.trainer import Trainer  # noqa: E402
 from change3d_amd.utils.metric_tool import ConfuseMatrixMeter  # noqa: E402
-from oracle import synth  # noqa: E402  (deterministic synthetic weights / batches only)
-from oracle.model import make_args  # noqa: E402
+from change3d_amd import synthetic as synth  # deterministic synthetic weights / batches (neutral module)
+from change3d_amd.synthetic import make_args
 
 
 def main():
