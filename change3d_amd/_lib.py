@@ -37,6 +37,27 @@ class PwWgradArgs(C.Structure):
                 ("q_mode", i32), ("dtype", i32), ("taps", i32), ("dw_tap_stride", i32)]
 
 
+class BnPtrs(C.Structure):
+    _fields_ = [("gamma", vp), ("beta", vp), ("running_mean", vp), ("running_var", vp), ("num_batches_tracked", vp),
+                ("dgamma", vp), ("dbeta", vp)]
+
+
+class BlockDesc(C.Structure):
+    _fields_ = [("cin", i32), ("cinner", i32), ("cout", i32), ("stride", i32), ("se_width", i32),
+                ("has_sc_conv", i32), ("has_sc_bn", i32), ("reserved", i32),
+                ("w_a", vp), ("w_b", vp), ("w_c", vp), ("w_sc", vp),
+                ("dw_a", vp), ("dw_b", vp), ("dw_c", vp), ("dw_sc", vp),
+                ("bn_a", BnPtrs), ("bn_b", BnPtrs), ("bn_c", BnPtrs), ("bn_sc", BnPtrs),
+                ("se_w1", vp), ("se_b1", vp), ("se_w2", vp), ("se_b2", vp),
+                ("dse_w1", vp), ("dse_b1", vp), ("dse_w2", vp), ("dse_b2", vp)]
+
+
+class StageDesc(C.Structure):
+    _fields_ = [("n_blocks", i32), ("B", i32), ("T", i32), ("H", i32), ("W", i32), ("dtype", i32),
+                ("training", i32), ("reserved", i32), ("momentum", f32), ("eps", f32),
+                ("blocks", C.POINTER(BlockDesc))]
+
+
 # name -> (restype, argtypes); every function declared in include/change3d_hip.h
 SIGNATURES = {
     "c3d_abi_version": (i32, []),
@@ -80,6 +101,11 @@ SIGNATURES = {
     "c3d_cossim_bwd": (i32, [vp, vp, vp, vp, i64, i32, i64, i64, i64, i64, i64, vp, vp, vp]),
     "c3d_adam_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
     "c3d_confusion2": (i32, [vp, vp, i64, vp, vp]),
+    "c3d_stage_ws_bytes": (i32, [C.POINTER(StageDesc), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "c3d_stage_fwd": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp]),
+    "c3d_stage_bwd": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp, vp, vp, vp]),
+    "c3d_side_join": (i32, [vp]),
+    "c3d_stage_saved": (i32, [C.POINTER(StageDesc), i32, C.c_char_p, C.POINTER(i64), C.POINTER(i64)]),
 }
 
 _lib = None

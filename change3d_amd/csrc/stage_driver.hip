@@ -1,0 +1,487 @@
+// Residual-stage step driver (host code): enqueues every kernel of one X3D residual stage, forward or backward,
+// from ONE C call (reference model/x3d.py:331-412 ResStage / ResBlock / BottleneckBlock, driven by
+// `self.x3d.blocks[i](x)` at reference model/trainer.py:126-139).
+//
+// Why it exists: a B=32 BCD step is ~1000 kernel launches; issued one by one through Python + ctypes they cost
+// 19-22 ms of host time per step (round-1 measurement), a floor the kernels had almost reached.  Here the
+// per-block launch sequence runs in C++ (sub-microsecond argument marshalling), the activations of a whole stage
+// live in ONE workspace carved by a deterministic plan (no allocator calls between kernels), the f64 statistics
+// accumulators of the stage are zeroed by one memset, and the leaf gradients (weight gradients) go to an internal
+// side stream forked / joined with events.
+#include "../../include/change3d_hip.h"
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+inline int cpad(int c) { return (c + 7) / 8 * 8; }
+inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
+inline size_t es(int dtype) { return dtype == C3D_DT_F32 ? 4 : 2; }
+constexpr int S = C3D_STAT_STRIPES;
+enum { SC_NONE = 0, SC_IDENTITY = 1, SC_BN = 2, SC_RAW = 3 };
+
+#define RC(call)              \
+  do {                        \
+    const int rc_ = (call);   \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+#define HIPRC(call)                            \
+  do {                                         \
+    const hipError_t e_ = (call);              \
+    if (e_ != hipSuccess) return (int)e_;      \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------ workspace plan
+struct BlkGeom {
+  int H, W, Ho, Wo;
+  int64_t M, Mo;   // rows in / out
+  int Cin, Ci, Co, Cinp, Cip, Cop, s, Cr;
+  bool se, sc_conv, sc_bn;
+};
+
+struct BlkFwd {   // byte offsets into ws_fwd
+  size_t a, b, c, sc, y;                                        // activations (y: SIZE_MAX for the last block)
+  size_t ss_a, mr_a, ss_b, mr_b, gate, hid, ss_c, mr_c, ss_1, mr_1;   // f32 vectors
+  size_t sums_a, nc_b, sums_c, sums_1;                          // f64 accumulators
+};
+
+struct BlkBwd {   // byte offsets into ws_bwd (ring slot for the big tensors)
+  size_t g, t1, t2, dxs, dx;
+  size_t coef_c, coef_1, coef_a, cA, cC, cB;                   // f32 vectors
+  size_t dsums_c, dsums_1, nc3, dsums_a;                        // f64 accumulators
+};
+
+struct Plan {
+  std::vector<BlkGeom> g;
+  std::vector<BlkFwd> f;
+  std::vector<BlkBwd> b;
+  size_t fwd_acc_off = 0, fwd_acc_bytes = 0, fwd_total = 0;
+  size_t bwd_acc_off = 0, bwd_acc_bytes = 0, bwd_total = 0, wgrad_ws = 0;
+  size_t y_bytes = 0, dx_bytes = 0;
+};
+
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) { const size_t o = off; off += al(bytes); return o; }
+};
+
+int make_plan(const c3d_stage_desc* d, Plan& P) {
+  if (!d || d->n_blocks <= 0 || !d->blocks || d->B <= 0 || d->T <= 0 || d->H <= 0 || d->W <= 0) return C3D_E_BADARG;
+  if (d->dtype != C3D_DT_F32 && d->dtype != C3D_DT_BF16) return C3D_E_BADARG;
+  const size_t e = es(d->dtype);
+  const int n = d->n_blocks;
+  P.g.resize(n); P.f.resize(n); P.b.resize(n);
+  int H = d->H, W = d->W;
+  for (int i = 0; i < n; ++i) {
+    const c3d_block_desc& k = d->blocks[i];
+    if (k.cin <= 0 || k.cinner <= 0 || k.cout <= 0 || (k.stride != 1 && k.stride != 2)) return C3D_E_BADARG;
+    if (i > 0 && k.cin != d->blocks[i - 1].cout) return C3D_E_BADARG;
+    if (!k.has_sc_conv && (k.cin != k.cout || k.stride != 1)) return C3D_E_BADARG;
+    if (k.has_sc_bn && !k.has_sc_conv) return C3D_E_BADARG;
+    BlkGeom& G = P.g[i];
+    G.H = H; G.W = W; G.s = k.stride;
+    G.Ho = (H - 1) / k.stride + 1; G.Wo = (W - 1) / k.stride + 1;
+    G.M = (int64_t)d->B * d->T * H * W; G.Mo = (int64_t)d->B * d->T * G.Ho * G.Wo;
+    G.Cin = k.cin; G.Ci = k.cinner; G.Co = k.cout;
+    G.Cinp = cpad(k.cin); G.Cip = cpad(k.cinner); G.Cop = cpad(k.cout);
+    G.se = k.se_width > 0; G.Cr = k.se_width; G.sc_conv = k.has_sc_conv != 0; G.sc_bn = k.has_sc_bn != 0;
+    H = G.Ho; W = G.Wo;
+  }
+  // ---- forward workspace: activations, then f32 vectors, then ONE contiguous f64 accumulator region
+  Carver cf;
+  for (int i = 0; i < n; ++i) {
+    const BlkGeom& G = P.g[i];
+    BlkFwd& F = P.f[i];
+    F.a = cf.take((size_t)G.M * G.Cip * e);
+    F.b = cf.take((size_t)G.Mo * G.Cip * e);
+    F.c = cf.take((size_t)G.Mo * G.Cop * e);
+    F.sc = G.sc_conv ? cf.take((size_t)G.Mo * G.Cop * e) : SIZE_MAX;
+    F.y = i + 1 < n ? cf.take((size_t)G.Mo * G.Cop * e) : SIZE_MAX;
+  }
+  for (int i = 0; i < n; ++i) {
+    const BlkGeom& G = P.g[i];
+    BlkFwd& F = P.f[i];
+    F.ss_a = cf.take(2 * G.Cip * 4); F.mr_a = cf.take(2 * G.Cip * 4);
+    F.ss_b = cf.take(2 * G.Cip * 4); F.mr_b = cf.take(2 * G.Cip * 4);
+    F.gate = G.se ? cf.take((size_t)d->B * G.Cip * 4) : SIZE_MAX;
+    F.hid = G.se ? cf.take((size_t)d->B * G.Cr * 4) : SIZE_MAX;
+    F.ss_c = cf.take(2 * G.Cop * 4); F.mr_c = cf.take(2 * G.Cop * 4);
+    F.ss_1 = G.sc_bn ? cf.take(2 * G.Cop * 4) : SIZE_MAX;
+    F.mr_1 = G.sc_bn ? cf.take(2 * G.Cop * 4) : SIZE_MAX;
+  }
+  P.fwd_acc_off = cf.off;
+  for (int i = 0; i < n; ++i) {
+    const BlkGeom& G = P.g[i];
+    BlkFwd& F = P.f[i];
+    F.sums_a = cf.take((size_t)S * 2 * G.Ci * 8);
+    F.nc_b = cf.take((size_t)d->B * G.Cip * 2 * 8);
+    F.sums_c = cf.take((size_t)S * 2 * G.Co * 8);
+    F.sums_1 = G.sc_bn ? cf.take((size_t)S * 2 * G.Co * 8) : SIZE_MAX;
+  }
+  P.fwd_acc_bytes = cf.off - P.fwd_acc_off;
+  P.fwd_total = cf.off;
+  // ---- backward workspace: two ring slots of big temporaries (the side stream lags the data-gradient chain by at
+  //      most one block), per-block f32 coefficient vectors, one f64 accumulator region, the split-K scratch of
+  //      the pointwise weight gradient
+  size_t mx_g = 0, mx_t1 = 0, mx_t2 = 0, mx_dxs = 0, mx_dx = 0;
+  int64_t wsf = 0;
+  for (int i = 0; i < n; ++i) {
+    const BlkGeom& G = P.g[i];
+    mx_g = std::max(mx_g, (size_t)G.Mo * G.Cop * e);
+    mx_t1 = std::max(mx_t1, (size_t)G.Mo * G.Cip * e);
+    mx_t2 = std::max(mx_t2, (size_t)G.M * G.Cip * e);
+    if (G.sc_conv) mx_dxs = std::max(mx_dxs, (size_t)G.Mo * G.Cinp * e);
+    if (i > 0) mx_dx = std::max(mx_dx, (size_t)G.M * G.Cinp * e);
+    wsf = std::max(wsf, c3d_pw_wgrad_ws_floats(G.Co, G.Ci));
+    wsf = std::max(wsf, c3d_pw_wgrad_ws_floats(G.Ci, G.Cin));
+    wsf = std::max(wsf, c3d_pw_wgrad_ws_floats(G.Co, G.Cin));
+  }
+  Carver cb;
+  size_t ring[2][5];
+  for (int r = 0; r < 2; ++r) {
+    ring[r][0] = cb.take(mx_g); ring[r][1] = cb.take(mx_t1); ring[r][2] = cb.take(mx_t2);
+    ring[r][3] = mx_dxs ? cb.take(mx_dxs) : SIZE_MAX; ring[r][4] = mx_dx ? cb.take(mx_dx) : SIZE_MAX;
+  }
+  P.wgrad_ws = cb.take((size_t)wsf * 4);
+  for (int i = 0; i < n; ++i) {
+    const BlkGeom& G = P.g[i];
+    BlkBwd& Bk = P.b[i];
+    const int r = i & 1;
+    Bk.g = ring[r][0]; Bk.t1 = ring[r][1]; Bk.t2 = ring[r][2]; Bk.dxs = ring[r][3];
+    Bk.dx = i > 0 ? ring[r][4] : SIZE_MAX;
+    Bk.coef_c = cb.take(3 * G.Cop * 4);
+    Bk.coef_1 = G.sc_bn ? cb.take(3 * G.Cop * 4) : SIZE_MAX;
+    Bk.coef_a = cb.take(3 * G.Cip * 4);
+    Bk.cA = cb.take(G.Cip * 4); Bk.cC = cb.take(G.Cip * 4); Bk.cB = cb.take((size_t)d->B * G.Cip * 4);
+  }
+  P.bwd_acc_off = cb.off;
+  for (int i = 0; i < n; ++i) {
+    const BlkGeom& G = P.g[i];
+    BlkBwd& Bk = P.b[i];
+    Bk.dsums_c = cb.take(2 * G.Co * 8);
+    Bk.dsums_1 = G.sc_bn ? cb.take(2 * G.Co * 8) : SIZE_MAX;
+    Bk.nc3 = cb.take((size_t)d->B * G.Cip * 3 * 8);
+    Bk.dsums_a = cb.take(2 * G.Ci * 8);
+  }
+  P.bwd_acc_bytes = cb.off - P.bwd_acc_off;
+  P.bwd_total = cb.off;
+  P.y_bytes = (size_t)P.g[n - 1].Mo * P.g[n - 1].Cop * e;
+  P.dx_bytes = (size_t)P.g[0].M * P.g[0].Cinp * e;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ side stream
+struct SideCtx {
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> pool;
+  size_t next = 0;
+  std::deque<std::pair<uint64_t, hipEvent_t>> marks;   // (sequence, done event) of side work not yet joined
+  uint64_t seq = 0;
+  hipEvent_t ev() {
+    if (pool.size() < 256) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      pool.push_back(e);
+      return e;
+    }
+    next = (next + 1) % pool.size();
+    return pool[next];
+  }
+};
+
+std::mutex g_mu;
+SideCtx g_side[16];
+
+bool side_enabled() {
+  static const bool on = !(getenv("C3D_WGRAD_SIDE") && atoi(getenv("C3D_WGRAD_SIDE")) == 0);
+  return on;
+}
+
+SideCtx* side_ctx() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideCtx& c = g_side[dev];
+  if (!c.side && hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return &c;
+}
+
+// Run `fn(stream)` on the side stream after everything issued so far on `main` (inline when disabled).
+template <typename F>
+int side_run(hipStream_t main, F&& fn) {
+  if (!side_enabled()) return fn(main);
+  std::lock_guard<std::mutex> lk(g_mu);
+  SideCtx* c = side_ctx();
+  if (!c) return fn(main);
+  hipEvent_t fork = c->ev();
+  if (!fork) return fn(main);
+  HIPRC(hipEventRecord(fork, main));
+  HIPRC(hipStreamWaitEvent(c->side, fork, 0));
+  RC(fn(c->side));
+  hipEvent_t done = c->ev();
+  if (!done) return (int)hipErrorOutOfMemory;
+  HIPRC(hipEventRecord(done, c->side));
+  c->marks.emplace_back(++c->seq, done);
+  while (c->marks.size() > 64) c->marks.pop_front();   // older work is ordered before the newer marks on the side stream
+  return 0;
+}
+
+uint64_t side_mark() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  SideCtx* c = side_ctx();
+  return c ? c->seq : 0;
+}
+
+// `main` waits for the side work issued up to sequence `upto` (everything if upto == UINT64_MAX).
+int side_join(hipStream_t main, uint64_t upto) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  SideCtx* c = side_ctx();
+  if (!c) return 0;
+  hipEvent_t last = nullptr;
+  while (!c->marks.empty() && c->marks.front().first <= upto) {
+    last = c->marks.front().second;
+    c->marks.pop_front();
+  }
+  if (last) HIPRC(hipStreamWaitEvent(main, last, 0));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ launch helpers
+struct PwCall {
+  c3d_pw_args a;
+  PwCall(const void* x, const float* w, void* y, int64_t M, int K, int N, int w_sn, int w_sk, int dtype) {
+    std::memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w; a.y = y; a.M = M; a.K = K; a.Kp = cpad(K); a.N = N; a.Np = cpad(N);
+    a.w_sn = w_sn; a.w_sk = w_sk; a.dtype = dtype;
+    a.pro_mode = C3D_PRO_NONE; a.epi_mode = C3D_EPI_STORE; a.row_mode = C3D_ROWS_DENSE;
+  }
+};
+
+struct WgCall {
+  c3d_pw_wgrad_args a;
+  WgCall(const void* p, const void* q, float* dw, float* ws, int64_t M, int K, int N, int dw_sn, int dw_sk, int dtype) {
+    std::memset(&a, 0, sizeof(a));
+    a.p = p; a.q = q; a.dw = dw; a.ws = ws; a.M = M; a.K = K; a.Kp = cpad(K); a.N = N; a.Np = cpad(N);
+    a.dw_sn = dw_sn; a.dw_sk = dw_sk; a.dtype = dtype; a.q_mode = C3D_PRO_NONE; a.row_mode = C3D_ROWS_DENSE;
+  }
+};
+
+inline char* at(void* base, size_t off) { return off == SIZE_MAX ? nullptr : reinterpret_cast<char*>(base) + off; }
+template <typename T> inline T* atT(void* base, size_t off) { return reinterpret_cast<T*>(at(base, off)); }
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" int c3d_stage_ws_bytes(const c3d_stage_desc* d, int64_t* ws_fwd_bytes, int64_t* ws_bwd_bytes, int64_t* y_bytes,
+                                  int64_t* dx_bytes) {
+  Plan P;
+  RC(make_plan(d, P));
+  if (ws_fwd_bytes) *ws_fwd_bytes = (int64_t)P.fwd_total;
+  if (ws_bwd_bytes) *ws_bwd_bytes = (int64_t)P.bwd_total;
+  if (y_bytes) *y_bytes = (int64_t)P.y_bytes;
+  if (dx_bytes) *dx_bytes = (int64_t)P.dx_bytes;
+  return 0;
+}
+
+extern "C" int c3d_stage_saved(const c3d_stage_desc* d, int32_t blk, const char* name, int64_t* offset, int64_t* bytes) {
+  Plan P;
+  RC(make_plan(d, P));
+  if (blk < 0 || blk >= d->n_blocks || !name || !offset || !bytes) return C3D_E_BADARG;
+  const BlkGeom& G = P.g[blk];
+  const BlkFwd& F = P.f[blk];
+  const size_t e = es(d->dtype);
+  size_t off = SIZE_MAX, n = 0;
+  if (!strcmp(name, "a")) { off = F.a; n = (size_t)G.M * G.Cip * e; }
+  else if (!strcmp(name, "b")) { off = F.b; n = (size_t)G.Mo * G.Cip * e; }
+  else if (!strcmp(name, "c")) { off = F.c; n = (size_t)G.Mo * G.Cop * e; }
+  else if (!strcmp(name, "sc")) { off = F.sc; n = (size_t)G.Mo * G.Cop * e; }
+  else if (!strcmp(name, "mr_a")) { off = F.mr_a; n = 2 * G.Cip * 4; }
+  else if (!strcmp(name, "mr_b")) { off = F.mr_b; n = 2 * G.Cip * 4; }
+  else if (!strcmp(name, "mr_c")) { off = F.mr_c; n = 2 * G.Cop * 4; }
+  else if (!strcmp(name, "mr_sc")) { off = F.mr_1; n = 2 * G.Cop * 4; }
+  else if (!strcmp(name, "ss_a")) { off = F.ss_a; n = 2 * G.Cip * 4; }
+  else if (!strcmp(name, "ss_b")) { off = F.ss_b; n = 2 * G.Cip * 4; }
+  else if (!strcmp(name, "ss_c")) { off = F.ss_c; n = 2 * G.Cop * 4; }
+  else if (!strcmp(name, "ss_sc")) { off = F.ss_1; n = 2 * G.Cop * 4; }
+  else if (!strcmp(name, "gate")) { off = F.gate; n = (size_t)d->B * G.Cip * 4; }
+  if (off == SIZE_MAX) return C3D_E_BADARG;
+  *offset = (int64_t)off; *bytes = (int64_t)n;
+  return 0;
+}
+
+extern "C" int c3d_side_join(void* stream) { return side_join(reinterpret_cast<hipStream_t>(stream), UINT64_MAX); }
+
+extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, void* y_out, void* stream) {
+  Plan P;
+  RC(make_plan(d, P));
+  if (!x || !ws || !y_out) return C3D_E_BADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int dt = d->dtype, tr = d->training ? 1 : 0, B = d->B, T = d->T;
+  HIPRC(hipMemsetAsync(at(ws, P.fwd_acc_off), 0, P.fwd_acc_bytes, st));
+  const int epi = tr ? C3D_EPI_STATS : C3D_EPI_STORE;
+  const void* cur = x;
+  for (int i = 0; i < d->n_blocks; ++i) {
+    const c3d_block_desc& k = d->blocks[i];
+    const BlkGeom& G = P.g[i];
+    const BlkFwd& F = P.f[i];
+    void* a = at(ws, F.a); void* b = at(ws, F.b); void* c = at(ws, F.c); void* sc = at(ws, F.sc);
+    void* y = F.y == SIZE_MAX ? y_out : at(ws, F.y);
+    float* ss_a = atT<float>(ws, F.ss_a); float* mr_a = atT<float>(ws, F.mr_a);
+    float* ss_b = atT<float>(ws, F.ss_b); float* mr_b = atT<float>(ws, F.mr_b);
+    float* ss_c = atT<float>(ws, F.ss_c); float* mr_c = atT<float>(ws, F.mr_c);
+    float* ss_1 = atT<float>(ws, F.ss_1); float* mr_1 = atT<float>(ws, F.mr_1);
+    float* gate = atT<float>(ws, F.gate); float* hid = atT<float>(ws, F.hid);
+    double* sums_a = atT<double>(ws, F.sums_a); double* nc_b = atT<double>(ws, F.nc_b);
+    double* sums_c = atT<double>(ws, F.sums_c); double* sums_1 = atT<double>(ws, F.sums_1);
+    const int64_t rps = (int64_t)T * G.Ho * G.Wo;
+    // conv_a (1x1x1) + BN_a statistics
+    {
+      PwCall p(cur, k.w_a, a, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
+      p.a.epi_mode = epi; p.a.stats = sums_a;
+      RC(c3d_pw_gemm(&p.a, st));
+    }
+    RC(c3d_bn_finalize(sums_a, S, (double)G.M, k.bn_a.gamma, k.bn_a.beta, k.bn_a.running_mean, k.bn_a.running_var,
+                       tr ? k.bn_a.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr, ss_a, mr_a, st));
+    // conv_b (depthwise 3x3x3, BN_a + ReLU on load) + per-sample statistics; BN_b + SE
+    RC(c3d_dw333_fwd(a, ss_a, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+    RC(c3d_bn_se_finalize(nc_b, B, (double)rps, k.bn_b.gamma, k.bn_b.beta, k.bn_b.running_mean, k.bn_b.running_var,
+                          tr ? k.bn_b.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr,
+                          G.se ? k.se_w1 : nullptr, k.se_b1, k.se_w2, k.se_b2, G.Cr, ss_b, mr_b, gate, hid, st));
+    // conv_c (BN_b * SE gate, Swish on load) + BN_c statistics
+    {
+      PwCall p(b, k.w_c, c, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
+      p.a.pro_mode = C3D_PRO_BN_SE_SWISH; p.a.pro_p = ss_b; p.a.pro_gate = gate; p.a.rows_per_sample = rps;
+      p.a.epi_mode = epi; p.a.stats = sums_c;
+      RC(c3d_pw_gemm(&p.a, st));
+    }
+    RC(c3d_bn_finalize(sums_c, S, (double)G.Mo, k.bn_c.gamma, k.bn_c.beta, k.bn_c.running_mean, k.bn_c.running_var,
+                       tr ? k.bn_c.num_batches_tracked : nullptr, d->momentum, d->eps, G.Co, G.Cop, tr, ss_c, mr_c, st));
+    // shortcut
+    int mode = SC_IDENTITY;
+    const void* scp = cur;
+    if (G.sc_conv) {
+      PwCall p(cur, k.w_sc, sc, G.Mo, G.Cin, G.Co, G.Cin, 1, dt);
+      p.a.row_mode = G.s == 2 ? C3D_ROWS_STRIDE2 : C3D_ROWS_DENSE; p.a.H = G.H; p.a.W = G.W;
+      p.a.epi_mode = G.sc_bn ? epi : C3D_EPI_STORE; p.a.stats = sums_1;
+      RC(c3d_pw_gemm(&p.a, st));
+      if (G.sc_bn) {
+        RC(c3d_bn_finalize(sums_1, S, (double)G.Mo, k.bn_sc.gamma, k.bn_sc.beta, k.bn_sc.running_mean,
+                           k.bn_sc.running_var, tr ? k.bn_sc.num_batches_tracked : nullptr, d->momentum, d->eps,
+                           G.Co, G.Cop, tr, ss_1, mr_1, st));
+        mode = SC_BN;
+      } else {
+        mode = SC_RAW;
+      }
+      scp = sc;
+    }
+    RC(c3d_block_out_fwd(c, ss_c, scp, ss_1, mode, y, G.Mo, G.Cop, dt, st));
+    cur = y;
+  }
+  return 0;
+}
+
+extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void* y_out, const void* dy, void* ws,
+                             void* wb, void* dx_out, void* stream) {
+  Plan P;
+  RC(make_plan(d, P));
+  if (!x || !y_out || !dy || !ws || !wb || !dx_out) return C3D_E_BADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int dt = d->dtype, B = d->B, T = d->T;
+  HIPRC(hipMemsetAsync(at(wb, P.bwd_acc_off), 0, P.bwd_acc_bytes, st));
+  float* wgws = atT<float>(wb, P.wgrad_ws);
+  const void* cur_dy = dy;
+  uint64_t prev_mark = 0;
+  bool have_prev = false;
+  for (int i = d->n_blocks - 1; i >= 0; --i) {
+    const c3d_block_desc& k = d->blocks[i];
+    const BlkGeom& G = P.g[i];
+    const BlkFwd& F = P.f[i];
+    const BlkBwd& Bk = P.b[i];
+    const void* xin = i == 0 ? x : (P.f[i - 1].y == SIZE_MAX ? y_out : at(ws, P.f[i - 1].y));
+    const void* a = at(ws, F.a); const void* b = at(ws, F.b); const void* c = at(ws, F.c); const void* sc = at(ws, F.sc);
+    const void* y = F.y == SIZE_MAX ? y_out : at(ws, F.y);
+    const float* ss_a = atT<float>(ws, F.ss_a); const float* mr_a = atT<float>(ws, F.mr_a);
+    const float* ss_b = atT<float>(ws, F.ss_b); const float* mr_b = atT<float>(ws, F.mr_b);
+    const float* mr_c = atT<float>(ws, F.mr_c); const float* mr_1 = atT<float>(ws, F.mr_1);
+    const float* gate = atT<float>(ws, F.gate); const float* hid = atT<float>(ws, F.hid);
+    const double* nc_b = atT<double>(ws, F.nc_b);
+    void* g = at(wb, Bk.g); void* t1 = at(wb, Bk.t1); void* t2 = at(wb, Bk.t2); void* dxs = at(wb, Bk.dxs);
+    void* dx = i == 0 ? dx_out : at(wb, Bk.dx);
+    float* coef_c = atT<float>(wb, Bk.coef_c); float* coef_1 = atT<float>(wb, Bk.coef_1);
+    float* coef_a = atT<float>(wb, Bk.coef_a);
+    float* cA = atT<float>(wb, Bk.cA); float* cC = atT<float>(wb, Bk.cC); float* cB = atT<float>(wb, Bk.cB);
+    double* dsums_c = atT<double>(wb, Bk.dsums_c); double* dsums_1 = atT<double>(wb, Bk.dsums_1);
+    double* nc3 = atT<double>(wb, Bk.nc3); double* dsums_a = atT<double>(wb, Bk.dsums_a);
+    const int64_t rps = (int64_t)T * G.Ho * G.Wo;
+    const bool scbn = G.sc_bn;
+    // ---- y = relu(bn_c(c) + shortcut)
+    RC(c3d_block_out_bwd(cur_dy, y, c, scbn ? sc : nullptr, g, mr_c, scbn ? mr_1 : nullptr, dsums_c,
+                         scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, st));
+    RC(c3d_bn_bwd_coef(dsums_c, 1, (double)G.Mo, k.bn_c.gamma, mr_c, G.Co, G.Cop, coef_c, k.bn_c.dgamma, k.bn_c.dbeta, st));
+    // ---- conv_c data gradient, Swish / SE backward in the epilogue; weight gradient on the side stream
+    {
+      PwCall p(g, k.w_c, t1, G.Mo, G.Co, G.Ci, 1, G.Ci, dt);
+      p.a.x2 = c; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_c;
+      p.a.epi_mode = C3D_EPI_SWISH_SE_BWD; p.a.e1 = b; p.a.epi_p = ss_b; p.a.epi_gate = gate; p.a.epi_q = mr_b;
+      p.a.stats = nc3; p.a.rows_per_sample = rps;
+      RC(c3d_pw_gemm(&p.a, st));
+    }
+    RC(side_run(st, [&](hipStream_t s2) {
+      WgCall w(g, b, k.dw_c, wgws, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
+      w.a.p2 = c; w.a.p_coef = coef_c; w.a.q_mode = C3D_PRO_BN_SE_SWISH; w.a.q_ss = ss_b; w.a.q_gate = gate;
+      w.a.rows_per_sample = rps;
+      return c3d_pw_wgrad(&w.a, s2);
+    }));
+    RC(c3d_se_bn_bwd_coef(nc3, nc_b, B, (double)rps, k.bn_b.gamma, mr_b, ss_b, G.Ci, G.Cip, G.se ? k.se_w1 : nullptr,
+                          k.se_w2, gate, hid, G.Cr, cA, cC, cB, k.bn_b.dgamma, k.bn_b.dbeta, k.dse_w1, k.dse_b1,
+                          k.dse_w2, k.dse_b2, st));
+    // ---- depthwise conv_b
+    RC(c3d_dw333_bwd_data(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+    RC(side_run(st, [&](hipStream_t s2) {
+      return c3d_dw333_wgrad(t1, b, cA, cB, cC, a, ss_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, s2);
+    }));
+    RC(c3d_bn_bwd_coef(dsums_a, 1, (double)G.M, k.bn_a.gamma, mr_a, G.Ci, G.Cip, coef_a, k.bn_a.dgamma, k.bn_a.dbeta, st));
+    // ---- shortcut branch
+    const void* res = g;
+    int res_mode = 0;
+    if (G.sc_conv) {
+      const int rm = G.s == 2 ? C3D_ROWS_STRIDE2 : C3D_ROWS_DENSE;
+      PwCall p(g, k.w_sc, dxs, G.Mo, G.Co, G.Cin, 1, G.Cin, dt);
+      if (scbn) {
+        RC(c3d_bn_bwd_coef(dsums_1, 1, (double)G.Mo, k.bn_sc.gamma, mr_1, G.Co, G.Cop, coef_1, k.bn_sc.dgamma,
+                           k.bn_sc.dbeta, st));
+        p.a.x2 = sc; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_1;
+      }
+      RC(c3d_pw_gemm(&p.a, st));
+      RC(side_run(st, [&](hipStream_t s2) {
+        WgCall w(g, xin, k.dw_sc, wgws, G.Mo, G.Cin, G.Co, G.Cin, 1, dt);
+        if (scbn) { w.a.p2 = sc; w.a.p_coef = coef_1; }
+        w.a.row_mode = rm; w.a.H = G.H; w.a.W = G.W;
+        return c3d_pw_wgrad(&w.a, s2);
+      }));
+      res = dxs;
+      res_mode = G.s == 2 ? 1 : 0;
+    }
+    // ---- conv_a data gradient (+ shortcut gradient in the epilogue) and weight gradient
+    {
+      PwCall p(t2, k.w_a, dx, G.M, G.Ci, G.Cin, 1, G.Cin, dt);
+      p.a.x2 = a; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_a;
+      p.a.epi_mode = C3D_EPI_ADD; p.a.e1 = res; p.a.res_mode = res_mode; p.a.H = G.H; p.a.W = G.W;
+      RC(c3d_pw_gemm(&p.a, st));
+    }
+    RC(side_run(st, [&](hipStream_t s2) {
+      WgCall w(t2, xin, k.dw_a, wgws, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
+      w.a.p2 = a; w.a.p_coef = coef_a;
+      return c3d_pw_wgrad(&w.a, s2);
+    }));
+    // the side stream may lag by ONE block: block i-1 reuses the ring slot of block i+1
+    if (have_prev) RC(side_join(st, prev_mark));
+    prev_mark = side_mark();
+    have_prev = true;
+    cur_dy = dx;
+  }
+  return 0;
+}

@@ -336,7 +336,10 @@ def _block_backward(blk, dy, sv, act_dtype, pool=None):
     return dx
 
 
-class _StageFn(torch.autograd.Function):
+class _StageFnPy(torch.autograd.Function):
+    """Per-kernel launch path (one ctypes call per kernel): used when per-kernel profiling / tracing is on
+    (`ops.PROFILE`, `ops.TRACE`) or `C3D_PY_STAGE=1`; the product path is `_StageFn` (C++ stage driver)."""
+
     @staticmethod
     def forward(ctx, x, anchor, stage):
         ops.require_gpu(x, "stage input")
@@ -372,6 +375,62 @@ class _StageFn(torch.autograd.Function):
         return to_logical(cur).to(ctx.x_dtype), None, None
 
 
+class _StageFn(torch.autograd.Function):
+    """One residual stage = ONE C call forward and ONE backward (`c3d_stage_fwd` / `c3d_stage_bwd`,
+    csrc/stage_driver.hip): the launch sequence of `_block_forward` / `_block_backward` above runs in C++ over a
+    single workspace; weight gradients go to the driver's side stream."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, stage):
+        ops.require_gpu(x, "stage input")
+        B, C, T, H, W = x.shape
+        act = stage.act_dtype
+        xin = to_ndhwc(x.detach()).to(act)
+        if xin.shape[-1] != cpad(C):
+            raise NotImplementedError("stage input channels must be a multiple of 8")
+        bind = stage.binding()
+        keep = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
+        bn0 = stage.res_blocks[0].branch2.norm_a
+        bind.refresh(B, T, H, W, ops.dt_code(act), stage.training, float(bn0.momentum), float(bn0.eps), with_grads=False)
+        ws_bytes, _, y_bytes, _ = bind.sizes()
+        last = stage.res_blocks[-1]
+        s0 = stage.res_blocks[0].stride
+        Ho, Wo = (H - 1) // s0 + 1, (W - 1) // s0 + 1
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        y = torch.empty((B, T, Ho, Wo, cpad(last.cout)), dtype=act, device=x.device)
+        assert y.numel() * y.element_size() == y_bytes
+        ops.stage_fwd(bind, xin, ws, y)
+        if keep:
+            ctx.stage, ctx.saved_ws, ctx.xin, ctx.y, ctx.x_dtype, ctx.dims = stage, ws, xin, y, x.dtype, (B, T, H, W)
+        return to_logical(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        stage, ws, xin, y = ctx.stage, ctx.saved_ws, ctx.xin, ctx.y
+        B, T, H, W = ctx.dims
+        act = stage.act_dtype
+        dyc = to_ndhwc(dy).to(act)
+        bind = stage.binding()
+        bn0 = stage.res_blocks[0].branch2.norm_a
+        bind.refresh(B, T, H, W, ops.dt_code(act), True, float(bn0.momentum), float(bn0.eps), with_grads=True)
+        _, wb_bytes, _, dx_bytes = bind.sizes()
+        wb = torch.empty(wb_bytes, dtype=torch.uint8, device=dy.device)
+        dx = torch.empty(xin.shape, dtype=act, device=dy.device)
+        assert dx.numel() * dx.element_size() == dx_bytes
+        ops.stage_bwd(bind, xin, y, dyc, ws, wb, dx)
+        # the driver's side stream may still read these: they are released at the next full side_join()
+        # (queued here as the autograd end-of-pass callback, or right now outside a backward pass)
+        ops.keep_until_join(ws, wb, xin, y, dyc)
+        ctx.saved_ws = ctx.xin = ctx.y = None
+        if stage.post_backward is not None:  # data-parallel hook: this stage's grads must be final
+            ops.side_join()
+            stage.post_backward()
+        return to_logical(dx).to(ctx.x_dtype), None, None
+
+
+PY_STAGE = os.environ.get("C3D_PY_STAGE", "0") == "1"
+
+
 class X3DResStage(nn.Module):
     """`blocks[1..4]` (reference model/x3d.py:331-412)."""
 
@@ -382,9 +441,17 @@ class X3DResStage(nn.Module):
                         use_se=bool((i + 1) % 2) and se_ratio > 0, se_ratio=se_ratio) for i in range(depth)])
         self.act_dtype = act_dtype
         self.post_backward = None
+        self._binding = None
+
+    def binding(self):
+        if self._binding is None:
+            self._binding = ops.StageBinding(self)
+        return self._binding
 
     def forward(self, x):
-        return _StageFn.apply(x, self.res_blocks[0].branch2.conv_a.weight, self)
+        per_kernel = PY_STAGE or ops.PROFILE is not None or ops.TRACE is not None
+        fn = _StageFnPy if per_kernel else _StageFn
+        return fn.apply(x, self.res_blocks[0].branch2.conv_a.weight, self)
 
 
 class X3DHead(nn.Module):
@@ -558,9 +625,22 @@ def stage_saved_activations(y):
     [2][Cp]) and the real channel counts `C_a` ... -- tests recompute the statistics in f64 from these
     (tests/test_bf16_fullsize_gpu.py)."""
     fn = y.grad_fn
-    if fn is None or not hasattr(fn, "stage") or not hasattr(fn, "saved"):
+    if fn is None or not hasattr(fn, "stage"):
         raise ValueError("not the output of a residual stage evaluated with grad enabled")
     out = []
+    if hasattr(fn, "saved_ws"):   # C++ stage driver: views into the forward workspace
+        bind, ws, act = fn.stage.binding(), fn.saved_ws, fn.stage.act_dtype
+        for i, blk in enumerate(fn.stage.res_blocks):
+            rec = dict(C_a=blk.cinner, C_b=blk.cinner, C_c=blk.cout, C_sc=blk.cout)
+            for name, cp in (("a", cpad(blk.cinner)), ("b", cpad(blk.cinner)), ("c", cpad(blk.cout)), ("sc", cpad(blk.cout))):
+                if name == "sc" and blk.branch1_norm is None:
+                    continue
+                off, n = bind.saved(i, name)
+                rec[name] = ws[off:off + n].view(act).view(-1, cp)
+                off, n = bind.saved(i, "mr_" + name)
+                rec["mr_" + name] = ws[off:off + n].view(torch.float32)
+            out.append(rec)
+        return out
     for blk, sv in zip(fn.stage.res_blocks, fn.saved):
         rec = dict(a=sv["a"], b=sv["b"], c=sv["c"], mr_a=sv["mr_a"], mr_b=sv["mr_b"], mr_c=sv["mr_c"],
                    C_a=blk.cinner, C_b=blk.cinner, C_c=blk.cout)

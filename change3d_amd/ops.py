@@ -136,13 +136,31 @@ def side_mark():
 
 
 def side_join(upto=None):
-    """Make the current stream wait for the side work issued up to mark `upto` (default: all of it)
-    and release the tensors it was reading."""
+    """Make the current stream wait for the side work issued up to mark `upto` (default: all of it --
+    including the C++ stage driver's own side stream) and release the tensors it was reading."""
     last = None
     while _side_pending and (upto is None or _side_pending[0][0] <= upto):
         last = _side_pending.pop(0)
     if last is not None:
         torch.cuda.current_stream().wait_event(last[1])
+    if upto is None and _driver_keep:
+        rc = L.lib().c3d_side_join(_stream())
+        if rc != 0:
+            raise L.Change3DHipError(f"c3d_side_join failed with code {rc}")
+        _driver_keep.clear()
+
+
+_driver_keep = []   # workspaces the stage driver's side stream may still be reading (freed at the next full join)
+
+
+def keep_until_join(*tensors):
+    """Keep `tensors` alive until the next full `side_join()`; inside an autograd backward pass that join is
+    queued as an end-of-pass callback, so after backward() returns p.grad is safe to read."""
+    _driver_keep.extend(t for t in tensors if t is not None)
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(side_join)
+    except RuntimeError:   # not inside backward(): join now
+        side_join()
 
 
 def _detail(name, a):
@@ -420,3 +438,91 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, n, hp_dev, lr, bc1, bc2_sqrt, be
 
 def confusion2(prob, target, cm4):
     _launch("c3d_confusion2", prob.numel() * 8, L.lib().c3d_confusion2, _p(prob), _p(target), prob.numel(), _p(cm4), _stream())
+
+
+# ------------------------------------------------------------------------------ stage driver
+class StageBinding:
+    """ctypes descriptor (include/change3d_hip.h: c3d_stage_desc) of one residual stage, bound to the tensors of
+    the reference-shaped module tree (`X3DResStage.res_blocks[j].branch2.conv_a.weight`, ...).  Pointers are
+    re-read on every call (parameters move when a ParamArena is built or the module is moved; gradients move
+    when they are reset): ~600 attribute reads per step, no struct write unless something changed."""
+
+    def __init__(self, stage):
+        blocks = list(stage.res_blocks)
+        self.n = len(blocks)
+        self.blocks = (L.BlockDesc * self.n)()
+        self.desc = L.StageDesc()
+        self.desc.n_blocks = self.n
+        self.desc.blocks = C.cast(self.blocks, C.POINTER(L.BlockDesc))
+        self.params, self.buffers = [], []      # (struct, field, grad_struct, grad_field, parameter) / (struct, field, tensor-getter)
+        for bd, blk in zip(self.blocks, blocks):
+            b2 = blk.branch2
+            se = b2.norm_b[1] if blk.use_se else None
+            bd.cin, bd.cinner, bd.cout, bd.stride = blk.cin, blk.cinner, blk.cout, blk.stride
+            bd.se_width = se.block[0].weight.shape[0] if se is not None else 0
+            bd.has_sc_conv = 1 if blk.branch1_conv is not None else 0
+            bd.has_sc_bn = 1 if blk.branch1_norm is not None else 0
+            self.params += [(bd, "w_a", bd, "dw_a", b2.conv_a), (bd, "w_b", bd, "dw_b", b2.conv_b),
+                            (bd, "w_c", bd, "dw_c", b2.conv_c)]
+            if blk.branch1_conv is not None:
+                self.params.append((bd, "w_sc", bd, "dw_sc", blk.branch1_conv))
+            bns = [(bd.bn_a, b2.norm_a), (bd.bn_b, b2.norm_b[0]), (bd.bn_c, b2.norm_c)]
+            if blk.branch1_norm is not None:
+                bns.append((bd.bn_sc, blk.branch1_norm))
+            for st, bn in bns:
+                self.params += [(st, "gamma", st, "dgamma", (bn, "weight")), (st, "beta", st, "dbeta", (bn, "bias"))]
+                self.buffers += [(st, "running_mean", bn, "running_mean"), (st, "running_var", bn, "running_var"),
+                                 (st, "num_batches_tracked", bn, "num_batches_tracked")]
+            if se is not None:
+                self.params += [(bd, "se_w1", bd, "dse_w1", (se.block[0], "weight")), (bd, "se_b1", bd, "dse_b1", (se.block[0], "bias")),
+                                (bd, "se_w2", bd, "dse_w2", (se.block[2], "weight")), (bd, "se_b2", bd, "dse_b2", (se.block[2], "bias"))]
+        # normalise: (struct, field, gstruct, gfield, module, attribute)
+        self.params = [(s, f, gs, gf) + (m if isinstance(m, tuple) else (m, "weight")) for s, f, gs, gf, m in self.params]
+        self._ptr_cache = {}
+
+    def _set(self, st, field, ptr):
+        key = (id(st), field)
+        if self._ptr_cache.get(key) != ptr:
+            setattr(st, field, ptr)
+            self._ptr_cache[key] = ptr
+
+    def refresh(self, B, T, H, W, dtype, training, momentum, eps, with_grads):
+        d = self.desc
+        d.B, d.T, d.H, d.W, d.dtype, d.training = B, T, H, W, dtype, 1 if training else 0
+        d.momentum, d.eps = momentum, eps
+        for st, f, gs, gf, mod, attr in self.params:
+            p = getattr(mod, attr)
+            self._set(st, f, p.data_ptr())
+            if with_grads:
+                g = p.grad
+                if g is None:
+                    g = grad_of(p)
+                self._set(gs, gf, g.data_ptr())
+        for st, f, mod, attr in self.buffers:
+            self._set(st, f, getattr(mod, attr).data_ptr())
+        return d
+
+    def sizes(self):
+        out = [C.c_int64() for _ in range(4)]
+        rc = L.lib().c3d_stage_ws_bytes(C.byref(self.desc), *[C.byref(v) for v in out])
+        if rc != 0:
+            raise L.Change3DHipError(f"c3d_stage_ws_bytes failed with code {rc}")
+        return tuple(int(v.value) for v in out)   # ws_fwd, ws_bwd, y, dx bytes
+
+    def saved(self, blk, name):
+        off, n = C.c_int64(), C.c_int64()
+        rc = L.lib().c3d_stage_saved(C.byref(self.desc), blk, name.encode(), C.byref(off), C.byref(n))
+        return None if rc != 0 else (int(off.value), int(n.value))
+
+
+def stage_fwd(binding, x, ws, y):
+    rc = L.lib().c3d_stage_fwd(C.byref(binding.desc), x.data_ptr(), ws.data_ptr(), y.data_ptr(), _stream())
+    if rc != 0:
+        raise L.Change3DHipError(f"c3d_stage_fwd failed with code {rc}")
+
+
+def stage_bwd(binding, x, y, dy, ws, wb, dx):
+    rc = L.lib().c3d_stage_bwd(C.byref(binding.desc), x.data_ptr(), y.data_ptr(), dy.data_ptr(), ws.data_ptr(),
+                               wb.data_ptr(), dx.data_ptr(), _stream())
+    if rc != 0:
+        raise L.Change3DHipError(f"c3d_stage_bwd failed with code {rc}")

@@ -22,13 +22,17 @@ def make_args(num_perception_frame=1, size=256, dataset="LEVIR-CD", num_class=1)
                            in_height=size, in_width=size, dataset=dataset, num_class=num_class)
 
 
-def synth_state_dict(model, seed=16, mask_margin=1.0):
+def synth_state_dict(model, seed=16, mask_margin=1.0, branch_gain=1.0):
     """Fill every tensor of `model.state_dict()` from a key-ordered PCG64 stream.
 
     conv / linear weights: N(0, sqrt(2/fan_in)); BN weight U(0.5,1.5), bias N(0,0.1),
     running_mean N(0,0.1), running_var U(0.5,1.5); conv biases N(0,0.1);
     perception_frames N(0,1).  `mask_margin` scales `*.up_c1.0.weight` so sigmoid
-    outputs move away from 0.5 (SURVEY.md §7 'mask parity is fragile')."""
+    outputs move away from 0.5 (SURVEY.md §7 'mask parity is fragile').  `branch_gain` scales every
+    `norm_c.weight` (the last BatchNorm of each residual branch): 1.0 is the default, chaotic network (each of the
+    55 blocks adds a branch as large as its shortcut; a 2^-24 input perturbation moves gradients by ~1e-2), small
+    values give a trained-network-like, well-conditioned residual stack for tests that need rounding errors to
+    stay in the linear regime (bf16 storage).  The random stream is identical for every value."""
     rng = np.random.default_rng(seed)
     out = {}
     for key, ref in model.state_dict().items():
@@ -44,6 +48,8 @@ def synth_state_dict(model, seed=16, mask_margin=1.0):
         elif len(shape) == 1:
             is_norm_w = key.endswith("weight")
             val = rng.uniform(0.5, 1.5, shape) if is_norm_w else rng.normal(0.0, 0.1, shape)
+            if key.endswith("norm_c.weight"):
+                val = val * branch_gain
         else:
             fan_in = int(np.prod(shape[1:]))
             val = rng.normal(0.0, np.sqrt(2.0 / fan_in), shape)

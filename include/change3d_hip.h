@@ -271,6 +271,63 @@ int c3d_cossim_bwd(const float* x1, const float* x2, const int64_t* label_change
                    int32_t NC, int64_t HW, int64_t bstride1, int64_t cstride1, int64_t bstride2, int64_t cstride2,
                    float* dx1, float* dx2, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Residual-stage step driver: ONE call enqueues every kernel of `blocks[i](x)` for a whole X3D residual
+ * stage (reference model/x3d.py:331-412 = ResStage of ResBlocks, driven by `self.x3d.blocks[i](x)` at
+ * reference model/trainer.py:126-139), forward or backward, from C++ -- the ~25 launches per block are no
+ * longer issued one by one through Python/ctypes (19-22 ms of host time per B=32 step in round 1).
+ *
+ * All pointers are device pointers; parameter / gradient / BN-buffer pointers are the tensors of the
+ * reference's own module tree (state-dict keys in the comments).  Gradients are ACCUMULATED (+=).
+ * The forward workspace `ws_fwd` (c3d_stage_ws_bytes) holds every activation the backward pass re-reads
+ * (a, b, c, shortcut, block outputs), the BatchNorm scale/shift and mean/rstd vectors, SE gates and the
+ * f64 statistics accumulators; the caller keeps it alive until c3d_stage_bwd has run.  `ws_bwd` holds the
+ * backward temporaries.  Weight gradients run on an internal side stream that forks from / joins `stream`
+ * with events (C3D_WGRAD_SIDE=0 disables it); c3d_side_join makes `stream` wait for everything issued
+ * there so far (call it before reading parameter gradients and before freeing ws_fwd / ws_bwd).
+ * ------------------------------------------------------------------------------------ */
+typedef struct c3d_bn_ptrs {
+  const float* gamma; const float* beta;       /* .weight / .bias                                       */
+  float* running_mean; float* running_var;     /* .running_mean / .running_var (updated in training)    */
+  int64_t* num_batches_tracked;                /* .num_batches_tracked (incremented in training)        */
+  float* dgamma; float* dbeta;                 /* gradients (may be NULL in c3d_stage_fwd)              */
+} c3d_bn_ptrs;
+
+typedef struct c3d_block_desc {
+  int32_t cin, cinner, cout, stride;           /* dim_in, dim_inner, dim_out, spatial stride (1|2)      */
+  int32_t se_width;                            /* 0 = no SqueezeExcitation in this block                */
+  int32_t has_sc_conv, has_sc_bn;              /* branch1_conv / branch1_norm present                   */
+  int32_t reserved;
+  const float* w_a; const float* w_b; const float* w_c; const float* w_sc;   /* branch2.conv_{a,b,c}.weight, branch1_conv.weight */
+  float* dw_a; float* dw_b; float* dw_c; float* dw_sc;
+  c3d_bn_ptrs bn_a, bn_b, bn_c, bn_sc;         /* branch2.norm_a, norm_b.0, norm_c, branch1_norm        */
+  const float* se_w1; const float* se_b1; const float* se_w2; const float* se_b2;   /* norm_b.1.block.{0,2}.{weight,bias} */
+  float* dse_w1; float* dse_b1; float* dse_w2; float* dse_b2;
+} c3d_block_desc;
+
+typedef struct c3d_stage_desc {
+  int32_t n_blocks;
+  int32_t B, T, H, W;                          /* stage INPUT extent; block 0 applies the stride        */
+  int32_t dtype;                               /* activation storage type                               */
+  int32_t training;                            /* 1: batch statistics (+ running-stat update), 0: eval  */
+  int32_t reserved;
+  float momentum, eps;                         /* BatchNorm3d momentum / eps (0.1 / 1e-5)               */
+  const c3d_block_desc* blocks;                /* HOST array of n_blocks descriptors                    */
+} c3d_stage_desc;
+
+/* bytes of the two workspaces and of the stage output y [B][T][Ho][Wo][cpad(cout)] / input gradient dx */
+int c3d_stage_ws_bytes(const c3d_stage_desc* d, int64_t* ws_fwd_bytes, int64_t* ws_bwd_bytes, int64_t* y_bytes,
+                       int64_t* dx_bytes);
+/* x: [B][T][H][W][cpad(cin)] channels-last, storage dtype.  y: stage output (also re-read by backward).      */
+int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws_fwd, void* y, void* stream);
+/* dy: gradient of y (same layout); dx: gradient of x (written).  x / y / ws_fwd as given to c3d_stage_fwd.   */
+int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void* y, const void* dy, void* ws_fwd, void* ws_bwd,
+                  void* dx, void* stream);
+int c3d_side_join(void* stream);
+/* byte offsets (into ws_fwd) and sizes of what block `blk` stored: name is one of "a","b","c","sc","mr_a","mr_b",
+ * "mr_c","mr_sc","ss_a","ss_b","ss_c","ss_sc","gate" -- test / debug access (returns C3D_E_BADARG if absent). */
+int c3d_stage_saved(const c3d_stage_desc* d, int32_t blk, const char* name, int64_t* offset, int64_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif
