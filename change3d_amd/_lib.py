@@ -101,10 +101,14 @@ SIGNATURES = {
     "c3d_cossim_bwd": (i32, [vp, vp, vp, vp, i64, i32, i64, i64, i64, i64, i64, vp, vp, vp]),
     "c3d_adam_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
     "c3d_confusion2": (i32, [vp, vp, i64, vp, vp]),
+    "c3d_bcd_preprocess": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "c3d_stage_ws_bytes": (i32, [C.POINTER(StageDesc), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "c3d_stage_fwd": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp]),
     "c3d_stage_bwd": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp, vp, vp, vp]),
     "c3d_side_join": (i32, [vp]),
+    "c3d_stage_fold_bytes": (i32, [C.POINTER(StageDesc), C.POINTER(i64), C.POINTER(i64)]),
+    "c3d_stage_fold_bn": (i32, [C.POINTER(StageDesc), vp, vp]),
+    "c3d_stage_fwd_folded": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp, vp]),
     "c3d_stage_saved": (i32, [C.POINTER(StageDesc), i32, C.c_char_p, C.POINTER(i64), C.POINTER(i64)]),
 }
 

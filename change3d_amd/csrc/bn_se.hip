@@ -89,6 +89,15 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
     const bool own = c >= c_lo && c < c_hi;
     if (c >= C) { if (q == 0 && own) { ss[c] = 0.f; ss[Cp + c] = 0.f; if (mr) { mr[c] = 0.f; mr[Cp + c] = 0.f; } } continue; }
     double mean, var;
+    if (training == 2) {   // folded BatchNorm (eval): scale / shift are given, only the SE gate is computed
+      const float sc2 = ss[c], sh2 = ss[Cp + c];
+      if (w1) {
+#pragma unroll 4
+        for (int n = q; n < B; n += 4)
+          z[(size_t)n * C + c] = fmaf(sc2, (float)(nc[((size_t)n * Cp + c) * 2] / cnt_per_sample), sh2);
+      }
+      continue;
+    }
     if (training) {
       double s1 = 0, s2 = 0;
 #pragma unroll 4
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
       mean = s1 / count;
       var = s2 / count - mean * mean;
       if (var < 0) var = 0;
-      if (running_mean && q == 0 && own) {
+      if (running_mean && q == 0 && own && training == 1) {
         const double unb = count > 1 ? var * count / (count - 1) : var;
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);

@@ -1,0 +1,87 @@
+// On-device input pipeline of the BCD train step: what the reference does per sample on the
+// host with numpy / cv2 before the tensors ever reach the GPU (reference data/transforms.py:100-154:
+// random_flip -> random_exchange -> normalize -> to_tensor, composed at scripts/train_BCD.py:262-270) runs here
+// as ONE pass over the raw uint8 batch already resident in HBM:
+//
+//   image u8 [B][H][W][6] (pre RGB | post RGB, the reference's 6-channel HWC array), label u8 [B][H][W]
+//   flags u8 [B][3] = (flip around the x axis = cv2.flip(.,0), flip around the y axis = cv2.flip(.,1), exchange)
+//   -> pre f32 [B][3][H][W], post f32 [B][3][H][W] = ((u8 / 255) - mean) / std   (f32, IEEE division: bit-identical
+//      to numpy's `image.astype(float32) / 255.0`, `(image - mean) / std`),  label f32 [B][1][H][W] = ceil(u8/255).
+//
+// HBM-bound byte shuffling: 7 B read, 28 B written per pixel; each thread owns 4 consecutive output pixels of one
+// row so that the f32 stores are 16-byte vectors (the u8 reads of a wave cover a contiguous 6 KB span).
+#include "common.h"
+#include "../../include/change3d_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void bcd_preprocess_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ lab,
+                                                             const uint8_t* __restrict__ flags, const float* __restrict__ mean,
+                                                             const float* __restrict__ stdv, float* __restrict__ pre,
+                                                             float* __restrict__ post, float* __restrict__ label, int B, int H,
+                                                             int W) {
+  const int wq = (W + 3) >> 2;                                    // 4-pixel groups per row
+  const int64_t total = (int64_t)B * H * wq;
+  float m[6], s[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { m[c] = mean[c]; s[c] = stdv[c]; }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % wq);
+    const int64_t r = i / wq;
+    const int y = (int)(r % H), b = (int)(r / H);
+    const bool fy = flags && flags[b * 3 + 0], fx = flags && flags[b * 3 + 1], ex = flags && flags[b * 3 + 2];
+    const int ys = fy ? H - 1 - y : y;                            // source row
+    float o[6][4];
+    float l[4];
+    const int x0 = q * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int x = x0 + k;
+      const int xs = x < W ? (fx ? W - 1 - x : x) : 0;
+      const uint8_t* p = img + (((int64_t)b * H + ys) * W + xs) * 6;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        // channel c of the OUTPUT 6-channel image: after an exchange the first three come from post
+        const int cs = ex ? (c < 3 ? c + 3 : c - 3) : c;
+        const float v = (float)p[cs] / 255.0f;
+        o[c][k] = (v - m[c]) / s[c];
+      }
+      l[k] = lab ? (lab[((int64_t)b * H + ys) * W + xs] ? 1.0f : 0.0f) : 0.0f;
+    }
+    const int64_t plane = (int64_t)H * W;
+    const int64_t base = (int64_t)y * W + x0;
+    if (x0 + 3 < W && (W & 3) == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        *reinterpret_cast<float4*>(pre + ((int64_t)b * 3 + c) * plane + base) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+        *reinterpret_cast<float4*>(post + ((int64_t)b * 3 + c) * plane + base) = make_float4(o[c + 3][0], o[c + 3][1], o[c + 3][2], o[c + 3][3]);
+      }
+      if (label) *reinterpret_cast<float4*>(label + (int64_t)b * plane + base) = make_float4(l[0], l[1], l[2], l[3]);
+    } else {
+      for (int k = 0; k < 4 && x0 + k < W; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          pre[((int64_t)b * 3 + c) * plane + base + k] = o[c][k];
+          post[((int64_t)b * 3 + c) * plane + base + k] = o[c + 3][k];
+        }
+        if (label) label[(int64_t)b * plane + base + k] = l[k];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int c3d_bcd_preprocess(const uint8_t* image6, const uint8_t* label, const uint8_t* flags, const float* mean6,
+                                  const float* std6, float* pre, float* post, float* label_out, int32_t B, int32_t H,
+                                  int32_t W, void* stream) {
+  if (!image6 || !mean6 || !std6 || !pre || !post || B <= 0 || H <= 0 || W <= 0) return C3D_E_BADARG;
+  if ((label == nullptr) != (label_out == nullptr)) return C3D_E_BADARG;
+  const int64_t total = (int64_t)B * H * ((W + 3) / 4);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  bcd_preprocess_kernel<<<dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+      image6, label, flags, mean6, std6, pre, post, label_out, B, H, W);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

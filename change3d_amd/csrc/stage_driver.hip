@@ -272,6 +272,74 @@ struct WgCall {
 inline char* at(void* base, size_t off) { return off == SIZE_MAX ? nullptr : reinterpret_cast<char*>(base) + off; }
 template <typename T> inline T* atT(void* base, size_t off) { return reinterpret_cast<T*>(at(base, off)); }
 
+
+// ------------------------------------------------------------------------------------------ eval: folded BatchNorm
+// Eval-mode BatchNorm is the per-channel affine map y = x*scale + shift with scale = gamma / sqrt(running_var + eps),
+// shift = beta - running_mean*scale (reference scripts/train_BCD.py:92-154 runs the model under model.eval()).
+// The scale is folded into the rows of the producing convolution's weight matrix ONCE (c3d_stage_fold_bn); what is
+// left of every BatchNorm is a bias that the consumer adds on operand load.  The eval forward then needs no
+// statistics, no finalize launches (4-5 kernels per block instead of 7) and no saved activations (ring workspace).
+__global__ void fold_bn_kernel(const float* __restrict__ w, float* __restrict__ wf, int N, int K, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var,
+                               float eps, float* __restrict__ ss, int Cp) {
+  const int n = blockIdx.x;
+  if (n >= Cp) return;
+  float sc = 0.f, sh = 0.f;
+  if (n < N) {
+    // same arithmetic as bn_finalize_kernel's eval branch: rstd in f64, rounded once
+    const float rstd = (float)(1.0 / sqrt((double)var[n] + (double)eps));
+    sc = gamma[n] * rstd;
+    sh = beta[n] - mean[n] * sc;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) wf[(size_t)n * K + k] = w[(size_t)n * K + k] * sc;
+  }
+  if (threadIdx.x == 0) { ss[n] = n < N ? 1.f : 0.f; ss[Cp + n] = sh; }
+}
+
+struct BlkFold { size_t w_a, w_b, w_c, w_sc, ss_a, ss_b, ss_c, ss_1; };
+struct BlkEval { size_t a, b, c, sc, y, gate, hid, nc_b; };
+struct FoldPlan {
+  std::vector<BlkFold> f;
+  std::vector<BlkEval> e;
+  size_t fold_total = 0, ws_total = 0, acc_off = 0, acc_bytes = 0;
+};
+
+int make_fold_plan(const c3d_stage_desc* d, const Plan& P, FoldPlan& Q) {
+  const int n = d->n_blocks;
+  const size_t e = es(d->dtype);
+  Q.f.resize(n); Q.e.resize(n);
+  Carver cf;
+  for (int i = 0; i < n; ++i) {
+    const BlkGeom& G = P.g[i];
+    BlkFold& F = Q.f[i];
+    F.w_a = cf.take((size_t)G.Ci * G.Cin * 4); F.w_b = cf.take((size_t)G.Ci * 27 * 4);
+    F.w_c = cf.take((size_t)G.Co * G.Ci * 4);
+    F.w_sc = G.sc_conv ? cf.take((size_t)G.Co * G.Cin * 4) : SIZE_MAX;
+    F.ss_a = cf.take(2 * G.Cip * 4); F.ss_b = cf.take(2 * G.Cip * 4); F.ss_c = cf.take(2 * G.Cop * 4);
+    F.ss_1 = G.sc_bn ? cf.take(2 * G.Cop * 4) : SIZE_MAX;
+  }
+  Q.fold_total = cf.off;
+  size_t mx_a = 0, mx_b = 0, mx_c = 0, mx_y = 0, mx_gate = 0, mx_hid = 0, mx_nc = 0;
+  for (int i = 0; i < n; ++i) {
+    const BlkGeom& G = P.g[i];
+    mx_a = std::max(mx_a, (size_t)G.M * G.Cip * e); mx_b = std::max(mx_b, (size_t)G.Mo * G.Cip * e);
+    mx_c = std::max(mx_c, (size_t)G.Mo * G.Cop * e); mx_y = std::max(mx_y, (size_t)G.Mo * G.Cop * e);
+    mx_gate = std::max(mx_gate, (size_t)d->B * G.Cip * 4); mx_hid = std::max(mx_hid, (size_t)d->B * std::max(G.Cr, 1) * 4);
+    mx_nc = std::max(mx_nc, (size_t)d->B * G.Cip * 2 * 8);
+  }
+  Carver cw;
+  const size_t a = cw.take(mx_a), b = cw.take(mx_b), c = cw.take(mx_c), sc = cw.take(mx_c);
+  const size_t y0 = cw.take(mx_y), y1 = cw.take(mx_y), gate = cw.take(mx_gate), hid = cw.take(mx_hid);
+  Q.acc_off = cw.off;
+  for (int i = 0; i < n; ++i) {
+    BlkEval& E = Q.e[i];
+    E.a = a; E.b = b; E.c = c; E.sc = sc; E.y = (i & 1) ? y1 : y0; E.gate = gate; E.hid = hid;
+    E.nc_b = P.g[i].se ? cw.take((size_t)d->B * P.g[i].Cip * 2 * 8) : SIZE_MAX;   // only SE blocks need the per-sample means
+  }
+  Q.acc_bytes = cw.off - Q.acc_off;
+  Q.ws_total = cw.off;
+  return 0;
+}
+
 }  // namespace
 
 // =================================================================================================== C ABI
@@ -482,6 +550,98 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     prev_mark = side_mark();
     have_prev = true;
     cur_dy = dx;
+  }
+  return 0;
+}
+
+extern "C" int c3d_stage_fold_bytes(const c3d_stage_desc* d, int64_t* fold_bytes, int64_t* ws_eval_bytes) {
+  Plan P;
+  RC(make_plan(d, P));
+  FoldPlan Q;
+  RC(make_fold_plan(d, P, Q));
+  if (fold_bytes) *fold_bytes = (int64_t)Q.fold_total;
+  if (ws_eval_bytes) *ws_eval_bytes = (int64_t)Q.ws_total;
+  return 0;
+}
+
+extern "C" int c3d_stage_fold_bn(const c3d_stage_desc* d, void* fold, void* stream) {
+  Plan P;
+  RC(make_plan(d, P));
+  FoldPlan Q;
+  RC(make_fold_plan(d, P, Q));
+  if (!fold) return C3D_E_BADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int i = 0; i < d->n_blocks; ++i) {
+    const c3d_block_desc& k = d->blocks[i];
+    const BlkGeom& G = P.g[i];
+    const BlkFold& F = Q.f[i];
+    struct Job { const float* w; size_t wf; int N, K; const c3d_bn_ptrs* bn; size_t ss; int Cp; bool on; };
+    const Job jobs[4] = {{k.w_a, F.w_a, G.Ci, G.Cin, &k.bn_a, F.ss_a, G.Cip, true},
+                         {k.w_b, F.w_b, G.Ci, 27, &k.bn_b, F.ss_b, G.Cip, true},
+                         {k.w_c, F.w_c, G.Co, G.Ci, &k.bn_c, F.ss_c, G.Cop, true},
+                         {k.w_sc, F.w_sc, G.Co, G.Cin, &k.bn_sc, F.ss_1, G.Cop, G.sc_bn}};
+    for (const Job& j : jobs) {
+      if (!j.on) continue;
+      if (!j.w || !j.bn->gamma || !j.bn->beta || !j.bn->running_mean || !j.bn->running_var) return C3D_E_BADARG;
+      fold_bn_kernel<<<dim3(j.Cp), dim3(64), 0, st>>>(j.w, atT<float>(fold, j.wf), j.N, j.K, j.bn->gamma, j.bn->beta,
+                                                     j.bn->running_mean, j.bn->running_var, d->eps, atT<float>(fold, j.ss), j.Cp);
+    }
+    if (G.sc_conv && !G.sc_bn)   // shortcut convolution without BatchNorm (stage 1 block 0): plain copy of the weights
+      HIPRC(hipMemcpyAsync(at(fold, F.w_sc), k.w_sc, (size_t)G.Co * G.Cin * 4, hipMemcpyDeviceToDevice, st));
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int c3d_stage_fwd_folded(const c3d_stage_desc* d, const void* fold_c, const void* x, void* ws, void* y_out,
+                                    void* stream) {
+  Plan P;
+  RC(make_plan(d, P));
+  FoldPlan Q;
+  RC(make_fold_plan(d, P, Q));
+  if (!fold_c || !x || !ws || !y_out) return C3D_E_BADARG;
+  void* fold = const_cast<void*>(fold_c);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int dt = d->dtype, B = d->B, T = d->T;
+  if (Q.acc_bytes) HIPRC(hipMemsetAsync(at(ws, Q.acc_off), 0, Q.acc_bytes, st));
+  const void* cur = x;
+  for (int i = 0; i < d->n_blocks; ++i) {
+    const c3d_block_desc& k = d->blocks[i];
+    const BlkGeom& G = P.g[i];
+    const BlkFold& F = Q.f[i];
+    const BlkEval& E = Q.e[i];
+    void* a = at(ws, E.a); void* b = at(ws, E.b); void* c = at(ws, E.c); void* sc = at(ws, E.sc);
+    void* y = i + 1 == d->n_blocks ? y_out : at(ws, E.y);
+    float* ss_a = atT<float>(fold, F.ss_a); float* ss_b = atT<float>(fold, F.ss_b); float* ss_c = atT<float>(fold, F.ss_c);
+    float* ss_1 = atT<float>(fold, F.ss_1);
+    float* gate = G.se ? atT<float>(ws, E.gate) : nullptr;
+    double* nc_b = atT<double>(ws, E.nc_b);
+    const int64_t rps = (int64_t)T * G.Ho * G.Wo;
+    {
+      PwCall p(cur, atT<float>(fold, F.w_a), a, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
+      RC(c3d_pw_gemm(&p.a, st));
+    }
+    RC(c3d_dw333_fwd(a, ss_a, atT<float>(fold, F.w_b), b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+    if (G.se)   // SE gate from the per-sample means of the (already scaled) conv_b output: training = 2 -> ss is given
+      RC(c3d_bn_se_finalize(nc_b, B, (double)rps, k.bn_b.gamma, k.bn_b.beta, k.bn_b.running_mean, k.bn_b.running_var, nullptr,
+                            d->momentum, d->eps, G.Ci, G.Cip, 2, k.se_w1, k.se_b1, k.se_w2, k.se_b2, G.Cr, ss_b, nullptr,
+                            gate, atT<float>(ws, E.hid), st));
+    {
+      PwCall p(b, atT<float>(fold, F.w_c), c, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
+      p.a.pro_mode = C3D_PRO_BN_SE_SWISH; p.a.pro_p = ss_b; p.a.pro_gate = gate; p.a.rows_per_sample = rps;
+      RC(c3d_pw_gemm(&p.a, st));
+    }
+    int mode = SC_IDENTITY;
+    const void* scp = cur;
+    if (G.sc_conv) {
+      PwCall p(cur, atT<float>(fold, F.w_sc), sc, G.Mo, G.Cin, G.Co, G.Cin, 1, dt);
+      p.a.row_mode = G.s == 2 ? C3D_ROWS_STRIDE2 : C3D_ROWS_DENSE; p.a.H = G.H; p.a.W = G.W;
+      RC(c3d_pw_gemm(&p.a, st));
+      mode = G.sc_bn ? SC_BN : SC_RAW;
+      scp = sc;
+    }
+    RC(c3d_block_out_fwd(c, ss_c, scp, ss_1, mode, y, G.Mo, G.Cop, dt, st));
+    cur = y;
   }
   return 0;
 }

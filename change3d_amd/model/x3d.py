@@ -345,7 +345,7 @@ class _StageFnPy(torch.autograd.Function):
         ops.require_gpu(x, "stage input")
         B, C, T, H, W = x.shape
         cur = to_ndhwc(x.detach()).to(stage.act_dtype)
-        keep = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
+        keep = any(ctx.needs_input_grad)  # (also True under no_grad: this per-kernel path is for profiling only)
         saved = []
         pool = _AccPool(sum(_n_acc_fwd(blk, B) for blk in stage.res_blocks), cur.device)
         for blk in stage.res_blocks:
@@ -381,7 +381,7 @@ class _StageFn(torch.autograd.Function):
     single workspace; weight gradients go to the driver's side stream."""
 
     @staticmethod
-    def forward(ctx, x, anchor, stage):
+    def forward(ctx, x, anchor, stage, grad_mode):
         ops.require_gpu(x, "stage input")
         B, C, T, H, W = x.shape
         act = stage.act_dtype
@@ -389,16 +389,29 @@ class _StageFn(torch.autograd.Function):
         if xin.shape[-1] != cpad(C):
             raise NotImplementedError("stage input channels must be a multiple of 8")
         bind = stage.binding()
-        keep = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
+        # needs_input_grad reports requires_grad of the inputs even under torch.no_grad(); the caller's grad mode
+        # (grad mode is always off inside Function.forward) is passed in explicitly
+        keep = grad_mode and any(ctx.needs_input_grad)
         bn0 = stage.res_blocks[0].branch2.norm_a
         bind.refresh(B, T, H, W, ops.dt_code(act), stage.training, float(bn0.momentum), float(bn0.eps), with_grads=False)
         ws_bytes, _, y_bytes, _ = bind.sizes()
         last = stage.res_blocks[-1]
         s0 = stage.res_blocks[0].stride
         Ho, Wo = (H - 1) // s0 + 1, (W - 1) // s0 + 1
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         y = torch.empty((B, T, Ho, Wo, cpad(last.cout)), dtype=act, device=x.device)
         assert y.numel() * y.element_size() == y_bytes
+        if not stage.training and not keep and stage.fold_bn_eval:
+            # inference: BatchNorm folded into the conv weights (reference scripts/train_BCD.py:92-154 val())
+            fold_bytes, ws_eval = ops.stage_fold_sizes(bind)
+            if stage._fold is None or stage._fold.numel() != fold_bytes or stage._fold.device != x.device:
+                stage._fold, stage._fold_valid = torch.empty(fold_bytes, dtype=torch.uint8, device=x.device), False
+            if not stage._fold_valid:
+                ops.stage_fold_bn(bind, stage._fold)
+                stage._fold_valid = True
+            ws = torch.empty(ws_eval, dtype=torch.uint8, device=x.device)
+            ops.stage_fwd_folded(bind, stage._fold, xin, ws, y)
+            return to_logical(y)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         ops.stage_fwd(bind, xin, ws, y)
         if keep:
             ctx.stage, ctx.saved_ws, ctx.xin, ctx.y, ctx.x_dtype, ctx.dims = stage, ws, xin, y, x.dtype, (B, T, H, W)
@@ -425,7 +438,7 @@ class _StageFn(torch.autograd.Function):
         if stage.post_backward is not None:  # data-parallel hook: this stage's grads must be final
             ops.side_join()
             stage.post_backward()
-        return to_logical(dx).to(ctx.x_dtype), None, None
+        return to_logical(dx).to(ctx.x_dtype), None, None, None
 
 
 PY_STAGE = os.environ.get("C3D_PY_STAGE", "0") == "1"
@@ -442,6 +455,26 @@ class X3DResStage(nn.Module):
         self.act_dtype = act_dtype
         self.post_backward = None
         self._binding = None
+        # eval / no-grad forward with BatchNorm folded into the conv weights.  The folded copy is rebuilt lazily
+        # after every train()/eval() switch and load_state_dict(); code that edits parameters or running statistics
+        # by hand while the module stays in eval mode must call invalidate_folded_bn().
+        self.fold_bn_eval = os.environ.get("C3D_FOLD_BN", "1") != "0"
+        self._fold, self._fold_valid = None, False
+
+    def invalidate_folded_bn(self):
+        self._fold_valid = False
+
+    def train(self, mode=True):
+        self._fold_valid = False
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._fold_valid = False
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._fold_valid = False
+        return super()._apply(fn, *args, **kwargs)
 
     def binding(self):
         if self._binding is None:
@@ -450,8 +483,9 @@ class X3DResStage(nn.Module):
 
     def forward(self, x):
         per_kernel = PY_STAGE or ops.PROFILE is not None or ops.TRACE is not None
-        fn = _StageFnPy if per_kernel else _StageFn
-        return fn.apply(x, self.res_blocks[0].branch2.conv_a.weight, self)
+        if per_kernel:
+            return _StageFnPy.apply(x, self.res_blocks[0].branch2.conv_a.weight, self)
+        return _StageFn.apply(x, self.res_blocks[0].branch2.conv_a.weight, self, torch.is_grad_enabled())
 
 
 class X3DHead(nn.Module):

@@ -515,6 +515,27 @@ class StageBinding:
         return None if rc != 0 else (int(off.value), int(n.value))
 
 
+def stage_fold_sizes(binding):
+    a, b = C.c_int64(), C.c_int64()
+    rc = L.lib().c3d_stage_fold_bytes(C.byref(binding.desc), C.byref(a), C.byref(b))
+    if rc != 0:
+        raise L.Change3DHipError(f"c3d_stage_fold_bytes failed with code {rc}")
+    return int(a.value), int(b.value)
+
+
+def stage_fold_bn(binding, fold):
+    rc = L.lib().c3d_stage_fold_bn(C.byref(binding.desc), fold.data_ptr(), _stream())
+    if rc != 0:
+        raise L.Change3DHipError(f"c3d_stage_fold_bn failed with code {rc}")
+
+
+def stage_fwd_folded(binding, fold, x, ws, y):
+    rc = L.lib().c3d_stage_fwd_folded(C.byref(binding.desc), fold.data_ptr(), x.data_ptr(), ws.data_ptr(), y.data_ptr(),
+                                      _stream())
+    if rc != 0:
+        raise L.Change3DHipError(f"c3d_stage_fwd_folded failed with code {rc}")
+
+
 def stage_fwd(binding, x, ws, y):
     rc = L.lib().c3d_stage_fwd(C.byref(binding.desc), x.data_ptr(), ws.data_ptr(), y.data_ptr(), _stream())
     if rc != 0:
@@ -526,3 +547,9 @@ def stage_bwd(binding, x, y, dy, ws, wb, dx):
                                wb.data_ptr(), dx.data_ptr(), _stream())
     if rc != 0:
         raise L.Change3DHipError(f"c3d_stage_bwd failed with code {rc}")
+
+
+# ------------------------------------------------------------------------------ input pipeline
+def bcd_preprocess(image6, label, flags, mean6, std6, pre, post, label_out, B, H, W):
+    _launch("c3d_bcd_preprocess", B * H * W * (7 + 28), L.lib().c3d_bcd_preprocess, _p(image6), _p(label), _p(flags),
+            _p(mean6), _p(std6), _p(pre), _p(post), _p(label_out), B, H, W, _stream())

@@ -118,7 +118,8 @@ int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream);
  * Train-mode BatchNorm3d split (reference model/x3d.py:97,179,207,220,298): statistics are
  * accumulated by producer epilogues, finalised here, applied by consumer prologues.
  *   sums : f64 [stripes][2][C] (sum, sumsq), summed over the stripes;   ss : f32 scale[Cp], shift[Cp];   mr : f32 mean[Cp], rstd[Cp]
- * training=0 builds scale/shift from the running statistics (eval mode).
+ * training=0 builds scale/shift from the running statistics (eval mode); c3d_bn_se_finalize also accepts
+ * training=2: scale/shift are GIVEN in ss (BatchNorm already folded into the weights), only the SE gate is computed.
  * ------------------------------------------------------------------------------------ */
 int c3d_bn_finalize(const double* sums, int32_t stripes, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
@@ -272,6 +273,18 @@ int c3d_cossim_bwd(const float* x1, const float* x2, const int64_t* label_change
                    float* dx1, float* dx2, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * On-device input pipeline of the BCD step (reference data/transforms.py:100-154: random_flip,
+ * random_exchange, normalize, to_tensor as composed at scripts/train_BCD.py:262-270) over a raw uint8 batch
+ * resident in HBM.  image6: u8 [B][H][W][6] (pre RGB | post RGB); label: u8 [B][H][W] or NULL;
+ * flags: u8 [B][3] = (cv2.flip(.,0), cv2.flip(.,1), exchange pre/post) per sample, or NULL (no augmentation =
+ * the validation transform); mean6 / std6: f32 [6] DEVICE vectors.  Outputs: pre, post f32 [B][3][H][W]
+ * = ((u8/255) - mean)/std, bit-identical to the numpy arithmetic; label_out f32 [B][1][H][W] = ceil(u8/255).
+ * ------------------------------------------------------------------------------------ */
+int c3d_bcd_preprocess(const uint8_t* image6, const uint8_t* label, const uint8_t* flags, const float* mean6,
+                       const float* std6, float* pre, float* post, float* label_out, int32_t B, int32_t H,
+                       int32_t W, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Residual-stage step driver: ONE call enqueues every kernel of `blocks[i](x)` for a whole X3D residual
  * stage (reference model/x3d.py:331-412 = ResStage of ResBlocks, driven by `self.x3d.blocks[i](x)` at
  * reference model/trainer.py:126-139), forward or backward, from C++ -- the ~25 launches per block are no
@@ -324,6 +337,14 @@ int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws_fwd, void* y,
 int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void* y, const void* dy, void* ws_fwd, void* ws_bwd,
                   void* dx, void* stream);
 int c3d_side_join(void* stream);
+/* Eval / inference (reference scripts/train_BCD.py:92-154 `val()` under model.eval() + torch.no_grad()): BatchNorm
+ * folded into the convolution weights.  c3d_stage_fold_bn writes, once per set of weights, W' = W * gamma/sqrt(var+eps)
+ * (rows of conv_a / conv_b / conv_c / branch1_conv) and the remaining per-channel biases into `fold`
+ * (c3d_stage_fold_bytes); c3d_stage_fwd_folded then runs the stage with 4-5 launches per block (no statistics, no
+ * finalize kernels, no saved activations: `ws` is a small ring of c3d_stage_fold_bytes' ws_eval_bytes).          */
+int c3d_stage_fold_bytes(const c3d_stage_desc* d, int64_t* fold_bytes, int64_t* ws_eval_bytes);
+int c3d_stage_fold_bn(const c3d_stage_desc* d, void* fold, void* stream);
+int c3d_stage_fwd_folded(const c3d_stage_desc* d, const void* fold, const void* x, void* ws, void* y, void* stream);
 /* byte offsets (into ws_fwd) and sizes of what block `blk` stored: name is one of "a","b","c","sc","mr_a","mr_b",
  * "mr_c","mr_sc","ss_a","ss_b","ss_c","ss_sc","gate" -- test / debug access (returns C3D_E_BADARG if absent). */
 int c3d_stage_saved(const c3d_stage_desc* d, int32_t blk, const char* name, int64_t* offset, int64_t* bytes);

@@ -22,8 +22,10 @@ DEV = "cuda:0"
 # bf16 has 8 mantissa bits (2^-9 = 2e-3 relative rounding error per stored tensor); the error random-walks through
 # 4 / 19 / 49 / 124 stored tensors behind the four taps and is amplified by train-mode BN (SURVEY BASELINE.md 5:
 # CPU bf16-vs-fp32, train BN: max |dp| 0.31; tools/grad_error_report.py: this synthetic-weight network amplifies a
-# 2^-24 perturbation 1e5-fold).  Measured on MI355X (round 2, B=32): 3.1e-3 / 1.3e-2 / 6.8e-2 / see log.
-BF16_STAGE_BOUND = (1.0e-2, 4.0e-2, 1.5e-1, 4.0e-1)
+# 2^-24 perturbation 1e5-fold).  Measured on MI355X (round 2, B=32): 3.1e-3 / 1.3e-2 / 6.8e-2 / 4.0e-1 with the
+# default (chaotic) synthetic weights -- bounds leave ~2x.  With every residual branch scaled by 0.1 (a
+# well-conditioned, trained-network-like stack; `branch_gain`) the same taps must agree ~10x tighter.
+BF16_STAGE_BOUND = {1.0: (1.0e-2, 4.0e-2, 1.5e-1, 8.0e-1), 0.1: (1.0e-2, 2.0e-2, 3.0e-2, 5.0e-2)}
 
 
 def _need_gpu():
@@ -56,13 +58,14 @@ def _step(net, arena, pre, post, tgt, taps=None):
     return prob.detach(), loss.detach()
 
 
-def test_bf16_b32_256_step_finite_reproducible_and_tracks_f32():
+@pytest.mark.parametrize("branch_gain", [1.0, 0.1])
+def test_bf16_b32_256_step_finite_reproducible_and_tracks_f32(branch_gain):
     _need_gpu()
     from change3d_amd import synthetic as synth
     from change3d_amd.model.utils import ParamArena, hot_path_named_params
     B, S = 32, 256
     pre, post, tgt = (t.to(DEV) for t in synth.synth_batch(B, S, seed=0))
-    net, sd = _build(S, torch.bfloat16)
+    net, sd = _build(S, torch.bfloat16, branch_gain=branch_gain)
     arena = ParamArena(hot_path_named_params(net), torch.device(DEV))
     bufs0 = {k: v.clone() for k, v in net.state_dict().items()}
     runs = []
@@ -86,7 +89,7 @@ def test_bf16_b32_256_step_finite_reproducible_and_tracks_f32():
     assert worst < 5e-5, worst
     # ---- the same step through the f32 HIP path (the parity-tested path) on the same weights / inputs
     del runs, p1, g1
-    net32, _ = _build(S, torch.float32)
+    net32, _ = _build(S, torch.float32, branch_gain=branch_gain)
     arena32 = ParamArena(hot_path_named_params(net32), torch.device(DEV))
     taps32 = []
     p32, l32 = _step(net32, arena32, pre, post, tgt, taps32)
@@ -97,16 +100,16 @@ def test_bf16_b32_256_step_finite_reproducible_and_tracks_f32():
     assert zero_bf16 == zero_f32 and all(".norm_b.1.block." in n for n in zero_bf16), (zero_bf16 ^ zero_f32)
     for i, (a, b) in enumerate(zip(t0, taps32)):
         r = ((a - b).norm() / (b.norm() + 1e-30)).item()
-        print(f"stage tap c{i + 1}: bf16 vs f32 HIP rel-L2 {r:.3e} (bound {BF16_STAGE_BOUND[i]:.1e}), "
+        print(f"stage tap c{i + 1} (branch_gain {branch_gain}): bf16 vs f32 HIP rel-L2 {r:.3e} (bound {BF16_STAGE_BOUND[branch_gain][i]:.1e}), "
               f"mean {float(a.mean()):+.4f} vs {float(b.mean()):+.4f}, std {float(a.std()):.4f} vs {float(b.std()):.4f}")
-        assert r < BF16_STAGE_BOUND[i], (i, r)
+        assert r < BF16_STAGE_BOUND[branch_gain][i], (i, r)
         assert abs(float(a.std()) - float(b.std())) < 0.05 * float(b.std()) + 1e-3
     inter = ((p0 > 0.5) & (p32 > 0.5)).sum().item()
     union = ((p0 > 0.5) | (p32 > 0.5)).sum().item()
     print(f"bf16 vs f32 HIP at B=32: loss {l0:.5f} vs {float(l32):.5f}, mask IoU {inter / max(union, 1):.4f}, "
           f"max|dp| {(p0 - p32).abs().max().item():.3e}")
     assert abs(l0 - float(l32)) < 0.05 * abs(float(l32))
-    assert inter / max(union, 1) > 0.8
+    assert inter / max(union, 1) > (0.8 if branch_gain == 1.0 else 0.95)
     # gradient direction agrees with the f32 path (whole-buffer cosine; per-parameter bounds are test (b))
     cos = torch.nn.functional.cosine_similarity(g0.double(), arena32.flat_grad.double(), dim=0).item()
     print(f"flat gradient cosine(bf16, f32 HIP) = {cos:.5f}")

@@ -161,3 +161,71 @@ def test_e2e_bda_forward_backward_vs_oracle_size64():
     g64 = {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
     assert set(names) == set(g32.keys())
     _grad_check(names, g_hip, g32, g64)
+
+
+@pytest.mark.parametrize("shape", [(5, 33, 40), (4, 64, 64), (3, 17, 23)])
+@pytest.mark.parametrize("imagenet", [False, True])
+def test_device_input_pipeline_bit_exact_vs_numpy_oracle(shape, imagenet):
+    """flip / exchange / normalize / to_tensor on the GPU (c3d_bcd_preprocess) against the numpy
+    restatement of reference data/transforms.py:100-154 -- bit-exact (byte shuffling + two IEEE f32 divisions)."""
+    _need_gpu()
+    from oracle import transforms as ot
+    from change3d_amd.data.transforms import BCDTransforms, DeviceBatchTransform, draw_augmentation_flags
+    B, H, W = shape
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, size=(B, H, W, 6), dtype=np.uint8)
+    lab = (rng.integers(0, 3, size=(B, H, W)) * 127 + (rng.random((B, H, W)) < 0.3)).astype(np.uint8)  # 0,1,127,128,254,255
+    flags = draw_augmentation_flags(B, rng)
+    flags[0] = (1, 1, 1)
+    if B > 1:
+        flags[1] = (0, 0, 0)
+    mean, std = (BCDTransforms.IMAGENET_MEAN, BCDTransforms.IMAGENET_STD) if imagenet else (BCDTransforms.DEFAULT_MEAN, BCDTransforms.DEFAULT_STD)
+    want_pre, want_post, want_lab = ot.bcd_transform_batch(img, lab, flags, mean, std)
+    tf = DeviceBatchTransform(DEV, mean, std)
+    pre, post, lb = tf(img, lab, flags)
+    torch.cuda.synchronize()
+    assert np.array_equal(pre.cpu().numpy(), want_pre) and np.array_equal(post.cpu().numpy(), want_post)
+    assert np.array_equal(lb.cpu().numpy(), want_lab)
+    pre2, post2, none = tf(img)                    # validation transform: no flags, no label
+    w2 = ot.bcd_transform_batch(img, lab, np.zeros((B, 3), np.uint8), mean, std)
+    assert none is None and np.array_equal(pre2.cpu().numpy(), w2[0]) and np.array_equal(post2.cpu().numpy(), w2[1])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-1)])
+def test_eval_folded_bn_matches_unfolded_eval(dtype, tol):
+    """SURVEY.md 8(f).4 (reference scripts/train_BCD.py:92-154 `val()`): the inference path with BatchNorm folded
+    into the conv weights (c3d_stage_fold_bn / c3d_stage_fwd_folded) against the same eval forward with the
+    BatchNorms applied from their running statistics; the folded copy must follow weight updates."""
+    _need_gpu()
+    from change3d_amd import synthetic as synth
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.x3d import X3DResStage
+    S, B = 64, 3
+    args = synth.make_args(size=S)
+    args.act_dtype = dtype
+    net = Trainer(args)
+    net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25, branch_gain=0.3))
+    net = net.to(DEV).eval()
+    stages = [m for m in net.modules() if isinstance(m, X3DResStage)]
+    assert all(s.fold_bn_eval for s in stages)
+    pre, post, _ = (t.to(DEV) for t in synth.synth_batch(B, S, seed=2))
+
+    def run(fold):
+        for s in stages:
+            s.fold_bn_eval = fold
+        with torch.no_grad():
+            return net.update_bcd(pre, post).clone()
+
+    p_fold, p_plain = run(True), run(False)
+    assert all(s._fold is not None and s._fold_valid for s in stages[:3])
+    err = (p_fold - p_plain).abs().max().item()
+    print(f"folded vs unfolded eval ({dtype}): max|dp| {err:.3e}")
+    assert err < tol and 0.05 < float(p_plain.std())
+    # weights change (load_state_dict): the folded copy must be rebuilt
+    net.load_state_dict(synth.synth_state_dict(net, seed=17, mask_margin=0.25, branch_gain=0.3))
+    p2_fold, p2_plain = run(True), run(False)
+    assert (p2_plain - p_plain).abs().max().item() > 10 * tol
+    assert (p2_fold - p2_plain).abs().max().item() < tol
+    # train() / eval() round trip invalidates too
+    net.train(); net.eval()
+    assert not any(s._fold_valid for s in stages)
