@@ -19,13 +19,19 @@ STAT_STRIPES = 16
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
 
+class BnFin(C.Structure):
+    _fields_ = [("ticket", vp), ("gamma", vp), ("beta", vp), ("running_mean", vp), ("running_var", vp), ("nbt", vp),
+                ("ss", vp), ("mr", vp), ("count", f64), ("momentum", f32), ("eps", f32), ("training", i32),
+                ("reserved", i32)]
+
+
 class PwArgs(C.Structure):
     _fields_ = [("x", vp), ("x2", vp), ("y", vp), ("e1", vp), ("w", vp), ("pro_p", vp), ("pro_gate", vp),
                 ("epi_p", vp), ("epi_gate", vp), ("epi_q", vp), ("stats", vp),
                 ("M", i64), ("gstride", i64), ("rows_per_sample", i64),
                 ("K", i32), ("Kp", i32), ("N", i32), ("Np", i32), ("w_sn", i32), ("w_sk", i32),
                 ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32),
-                ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32)]
+                ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32), ("fin", BnFin)]
 
 
 class PwWgradArgs(C.Structure):
@@ -75,11 +81,15 @@ SIGNATURES = {
     "c3d_dw333_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_dw333_bwd_data": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
                                  i32, vp]),
+    "c3d_dw333_bwd_data_fin": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
+                                     i32, C.POINTER(BnFin), vp]),
     "c3d_dw333_wgrad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_dw333_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
                             i32, vp]),
     "c3d_block_out_fwd": (i32, [vp, vp, vp, vp, i32, vp, i64, i32, i32, vp]),
     "c3d_block_out_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "c3d_block_out_bwd_fin": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, C.POINTER(BnFin),
+                                    C.POINTER(BnFin), vp]),
     "c3d_frame_absdiff": (i32, [vp, vp, i32, i32, i64, i32, i32, i32, i32, vp]),
     "c3d_enhance_apply": (i32, [vp, vp, vp, i32, i32, i64, i32, i32, i32, vp]),
     "c3d_enhance_bwd_mask": (i32, [vp, vp, vp, i32, i32, i64, i32, i32, i32, vp]),

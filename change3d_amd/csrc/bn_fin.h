@@ -1,0 +1,110 @@
+// In-kernel BatchNorm finalisation by the LAST workgroup of the producing kernel ("last-workgroup-done" ticket).
+//
+// Round 1 ran one tiny kernel after every statistics producer (c3d_bn_finalize / c3d_bn_bwd_coef: 166 launches of
+// 5-7 us per B=32 step, every one on the critical path between two latency-bound kernels, plus two kernel
+// boundaries each).  Here the producer's workgroups take a ticket after their statistics atomics; the workgroup
+// that draws the last ticket reads the completed f64 sums and writes scale/shift (+ running statistics) or the
+// BatchNorm-backward coefficients itself.
+//
+// Protocol (MI355X: 8 XCDs with private L2s; HIP promises no dispatch order):
+//   every workgroup : f64 atomicAdd (agent scope, performed at the memory side, not in an XCD's L2)
+//                     -> s_waitcnt vmcnt(0) in every wave that issued them  (the atomics have been performed)
+//                     -> __syncthreads() -> ONE returning agent-scope atomic increment of the ticket word
+//   last workgroup  : ticket == gridDim - 1 -> ONE agent-scope acquire fence -> __syncthreads()
+//                     -> reads the sums with relaxed agent-scope atomic loads (L1 bypassed; the lines were only
+//                        ever touched by memory-side atomics in this launch) -> writes the outputs with plain
+//                        stores: their readers are LATER kernels.
+// No release fence is needed: the payload is atomics, not plain stores.  The ticket word lives in the stage's
+// accumulator region, zeroed by the same memset as the sums.
+#pragma once
+#include "common.h"
+#include "../../include/change3d_hip.h"
+
+namespace c3dfin {
+
+__device__ __forceinline__ double ld_sum(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// All threads of the workgroup call this after issuing their statistics atomics.  `flag` is one int of LDS scratch.
+// Returns true (workgroup-uniform) in the workgroup that took the last of `nblocks` tickets.
+__device__ __forceinline__ bool last_workgroup(uint32_t* ticket, uint32_t nblocks, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (t == nblocks - 1u) ? 1 : 0;
+    if (t == nblocks - 1u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
+// Forward: sums f64 [stripes][2][C] (sum, sum of squares) -> ss = (scale | shift), mr = (mean | rstd), running
+// statistics (same arithmetic as bn_finalize_kernel).  Called by every thread of the last workgroup; `nthreads` is a
+// multiple of 16 (16 adjacent lanes share a channel: one stripe each, fixed-order butterfly).
+__device__ __forceinline__ void bn_forward(const c3d_bn_fin& f, const double* sums, int stripes, int C, int Cp,
+                                           int tid, int nthreads) {
+  if (tid == 0 && f.training && f.nbt) *f.nbt += 1;
+  if (tid >= nthreads) return;   // (whole 16-lane groups only)
+  const int kq = tid & 15;
+  for (int c0 = 0; c0 < Cp; c0 += nthreads >> 4) {
+    const int c = c0 + (tid >> 4);
+    double s1 = 0, s2 = 0;
+    if (c < C) {
+      for (int k = kq; k < stripes; k += 16) { s1 += ld_sum(sums + (size_t)k * 2 * C + c); s2 += ld_sum(sums + (size_t)k * 2 * C + C + c); }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (kq != 0 || c >= Cp) continue;
+    if (c >= C) { f.ss[c] = 0.f; f.ss[Cp + c] = 0.f; if (f.mr) { f.mr[c] = 0.f; f.mr[Cp + c] = 0.f; } continue; }
+    const double mean = s1 / f.count;
+    double var = s2 / f.count - mean * mean;
+    if (var < 0) var = 0;
+    if (f.running_mean) {
+      const double unb = f.count > 1 ? var * f.count / (f.count - 1) : var;
+      f.running_mean[c] = (float)((1.0 - f.momentum) * f.running_mean[c] + f.momentum * mean);
+      f.running_var[c] = (float)((1.0 - f.momentum) * f.running_var[c] + f.momentum * unb);
+    }
+    const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float meanf = (float)mean;
+    const float sc = f.gamma[c] * rstd;
+    f.ss[c] = sc;
+    f.ss[Cp + c] = f.beta[c] - meanf * sc;
+    if (f.mr) { f.mr[c] = meanf; f.mr[Cp + c] = rstd; }
+  }
+}
+
+// Backward: dsums f64 [stripes][2][C] = (sum g, sum g*xhat) -> coef = (A | B | C) with dx = A*g + B + C*x, and the
+// BatchNorm parameter gradients (+=) (same arithmetic as bn_bwd_coef_kernel).  f.ss is the coefficient vector [3][Cp],
+// f.mr the saved (mean | rstd), f.running_mean / f.running_var carry dgamma / dbeta.
+__device__ __forceinline__ void bn_backward(const c3d_bn_fin& f, const double* dsums, int stripes, int C, int Cp,
+                                            int tid, int nthreads) {
+  if (tid >= nthreads) return;   // (whole 16-lane groups only)
+  const int kq = tid & 15;
+  float* coef = f.ss;
+  float* dgamma = f.running_mean;
+  float* dbeta = f.running_var;
+  for (int c0 = 0; c0 < Cp; c0 += nthreads >> 4) {
+    const int c = c0 + (tid >> 4);
+    double s1 = 0, s2 = 0;
+    if (c < C) {
+      for (int k = kq; k < stripes; k += 16) { s1 += ld_sum(dsums + (size_t)k * 2 * C + c); s2 += ld_sum(dsums + (size_t)k * 2 * C + C + c); }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (kq != 0 || c >= Cp) continue;
+    if (c >= C) { coef[c] = 0.f; coef[Cp + c] = 0.f; coef[2 * Cp + c] = 0.f; continue; }
+    const double mean = f.mr[c], rstd = f.mr[Cp + c];
+    const double A = (double)f.gamma[c] * rstd;
+    const double Cc = -A * rstd * s2 / f.count;
+    const double Bc = -A * s1 / f.count - Cc * mean;
+    coef[c] = (float)A;
+    coef[Cp + c] = (float)Bc;
+    coef[2 * Cp + c] = (float)Cc;
+    if (dgamma) dgamma[c] += (float)s2;
+    if (dbeta) dbeta[c] += (float)s1;
+  }
+}
+
+}  // namespace c3dfin

@@ -13,6 +13,7 @@
 // All T frames of a spatial tile are resident in LDS (T = 3 for BCD, 5 for SCD).  A thread
 // owns one output pixel and one 8-channel vector for all T frames.
 #include "pw_common.h"  // common.h + device_cus()
+#include "bn_fin.h"
 #include "../../include/change3d_hip.h"
 #include <cstdlib>
 
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
     const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
     const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
     const T* __restrict__ a, const float* __restrict__ ss_a, const float* __restrict__ mr_a, T* __restrict__ t2,
-    double* __restrict__ dsums, const DwGeom g, const int tiles_per_wg) {
+    double* __restrict__ dsums, const DwGeom g, const int tiles_per_wg, const c3d_bn_fin fin) {
   typedef RawD<T> RW;
   constexpr int DH = (S == 1) ? TH + 2 : TH / 2 + 2;
   constexpr int DW_ = (S == 1) ? TW + 2 : TW / 2 + 2;
@@ -494,6 +495,12 @@ __global__ __launch_bounds__(TH * TW * DW_CV) void dw_bwd_data_kernel(
     for (int wv = 0; wv < NTHR / 64; ++wv) sacc += red64[(wv * DW_CV + v) * 16 + k];
     const int c = c0 + v * 8 + (k & 7);
     if (c < g.C) atomicAdd(dsums + (size_t)(k >> 3) * g.C + c, sacc);
+  }
+  if (fin.ticket) {   // last workgroup: BatchNorm_a backward coefficients (no separate c3d_bn_bwd_coef launch)
+    // workgroups padded onto the grid by chunk_order_grid() returned at the top without a ticket
+    const uint32_t active = (uint32_t)((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8)) * (uint32_t)(gx * g.B);
+    if (c3dfin::last_workgroup(fin.ticket, active, reinterpret_cast<int*>(wl)))
+      c3dfin::bn_backward(fin, dsums, 1, g.C, g.Cp, tid, NTHR);
   }
   DCLK(8)
   DCLK_FLUSH
@@ -1915,6 +1922,8 @@ int launch_fwd(const void* x, const float* ss, const float* w, void* y, double* 
   return launch_fwd_t<T, S, 5>(x, ss, w, y, nc, g, stream);
 }
 
+thread_local c3d_bn_fin g_bwd_data_fin = {};   // set by c3d_dw333_bwd_data_fin for the launch it wraps
+
 template <typename T, int S, int TT>
 int launch_bwd_data_t(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC,
                       const float* w, const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums,
@@ -1943,7 +1952,7 @@ int launch_bwd_data_t(const void* t1, const void* bb, const float* cA, const flo
   dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
   dw_bwd_data_kernel<T, S, TH, TW, TT><<<grid, dim3(NTHR), lds, stream>>>(
       reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, w, reinterpret_cast<const T*>(a),
-      ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, g, tpw);
+      ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, g, tpw, g_bwd_data_fin);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -2111,6 +2120,17 @@ extern "C" int c3d_dw333_bwd_data(const void* t1, const void* b, const float* co
     return stride == 1 ? launch_bwd_data<bf16_t, 1>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, g, s)
                        : launch_bwd_data<bf16_t, 2>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, g, s);
   return C3D_E_BADARG;
+}
+
+extern "C" int c3d_dw333_bwd_data_fin(const void* t1, const void* b, const float* coefA, const float* coefB,
+                                      const float* coefC, const float* w, const void* a, const float* ss_a,
+                                      const float* mr_a, void* t2, double* dsums, int32_t B, int32_t T, int32_t H, int32_t W,
+                                      int32_t C, int32_t Cp, int32_t stride, int32_t dtype, const c3d_bn_fin* fin, void* stream) {
+  if (fin && fin->ticket && (!fin->gamma || !fin->ss || !fin->mr || !(fin->count > 0))) return C3D_E_BADARG;
+  g_bwd_data_fin = fin ? *fin : c3d_bn_fin{};
+  const int rc = c3d_dw333_bwd_data(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, B, T, H, W, C, Cp, stride, dtype, stream);
+  g_bwd_data_fin = c3d_bn_fin{};
+  return rc;
 }
 
 extern "C" int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const float* coefB,

@@ -5,6 +5,7 @@
 // Threads keep a FIXED channel vector (blockDim is a multiple of Cp/8 and so is the grid stride),
 // so per-channel parameters and partial sums stay in registers.
 #include "common.h"
+#include "bn_fin.h"
 #include <cstdlib>
 #include "../../include/change3d_hip.h"
 
@@ -49,7 +50,8 @@ template <typename T>
 __global__ void block_out_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ c,
                                      const T* __restrict__ s, T* __restrict__ g, const float* __restrict__ mr_c,
                                      const float* __restrict__ mr_1, double* __restrict__ dsums_c,
-                                     double* __restrict__ dsums_1, int64_t nvec, int G, int C) {
+                                     double* __restrict__ dsums_1, int64_t nvec, int G, int C, const c3d_bn_fin fin_c,
+                                     const c3d_bn_fin fin_1) {
   extern __shared__ float red[];  // [blockDim][24]
   const int v = threadIdx.x % G;
   const int Cp = G * 8;
@@ -93,6 +95,12 @@ __global__ void block_out_bwd_kernel(const T* __restrict__ dy, const T* __restri
       if (which == 0) { atomicAdd(dsums_c + ch, acc); if (dsums_1) atomicAdd(dsums_1 + ch, acc); }
       else if (which == 1) atomicAdd(dsums_c + C + ch, acc);
       else if (dsums_1) atomicAdd(dsums_1 + C + ch, acc);
+    }
+  }
+  if (fin_c.ticket) {   // last workgroup: BatchNorm_c (and shortcut BatchNorm) backward coefficients
+    if (c3dfin::last_workgroup(fin_c.ticket, gridDim.x, reinterpret_cast<int*>(red))) {
+      c3dfin::bn_backward(fin_c, dsums_c, 1, C, Cp, threadIdx.x, blockDim.x & ~15);
+      if (dsums_1 && fin_1.ss) c3dfin::bn_backward(fin_1, dsums_1, 1, C, Cp, threadIdx.x, blockDim.x & ~15);
     }
   }
 }
@@ -236,8 +244,19 @@ extern "C" int c3d_block_out_fwd(const void* c, const float* ss_c, const void* s
 extern "C" int c3d_block_out_bwd(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
                                  const float* mr_c, const float* mr_1, double* dsums_c, double* dsums_1, int64_t M,
                                  int32_t C, int32_t Cp, int32_t dtype, void* stream) {
+  return c3d_block_out_bwd_fin(dy, y, c, s_bn, g, mr_c, mr_1, dsums_c, dsums_1, M, C, Cp, dtype, nullptr, nullptr, stream);
+}
+
+extern "C" int c3d_block_out_bwd_fin(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
+                                     const float* mr_c, const float* mr_1, double* dsums_c, double* dsums_1, int64_t M,
+                                     int32_t C, int32_t Cp, int32_t dtype, const c3d_bn_fin* fc, const c3d_bn_fin* f1,
+                                     void* stream) {
   if (!dy || !y || !c || !g || !mr_c || !dsums_c || M <= 0 || (Cp & 7) || Cp > 256) return C3D_E_BADARG;
   if ((s_bn == nullptr) != (dsums_1 == nullptr) || (s_bn && !mr_1)) return C3D_E_BADARG;
+  if (fc && fc->ticket && (!fc->gamma || !fc->ss || !fc->mr || !(fc->count > 0))) return C3D_E_BADARG;
+  if (fc && fc->ticket && s_bn && (!f1 || !f1->gamma || !f1->ss || !f1->mr || !(f1->count > 0))) return C3D_E_BADARG;
+  const c3d_bn_fin fin_c = fc ? *fc : c3d_bn_fin{};
+  const c3d_bn_fin fin_1 = (f1 && s_bn) ? *f1 : c3d_bn_fin{};
   const int G = Cp / 8, blk = ew_block(G);
   const int64_t nvec = M * G;
   int grid = ew_grid(nvec, blk);
@@ -251,11 +270,11 @@ extern "C" int c3d_block_out_bwd(const void* dy, const void* y, const void* c, c
   EW_DISPATCH(dtype,
               (block_out_bwd_kernel<float><<<grid, blk, lds, st>>>((const float*)dy, (const float*)y,
                                                                     (const float*)c, (const float*)s_bn, (float*)g,
-                                                                    mr_c, mr_1, dsums_c, dsums_1, nvec, G, C)),
+                                                                    mr_c, mr_1, dsums_c, dsums_1, nvec, G, C, fin_c, fin_1)),
               (block_out_bwd_kernel<bf16_t><<<grid, blk, lds, st>>>((const bf16_t*)dy, (const bf16_t*)y,
                                                                      (const bf16_t*)c, (const bf16_t*)s_bn,
                                                                      (bf16_t*)g, mr_c, mr_1, dsums_c, dsums_1, nvec,
-                                                                     G, C)));
+                                                                     G, C, fin_c, fin_1)));
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "../../include/change3d_hip.h"
 #include "pw_common.h"
+#include "bn_fin.h"
 #include <cstdlib>
 
 #ifdef C3D_PW_CLOCK
@@ -779,6 +780,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         float acc = 0.f;
         for (int wv = 0; wv < WAVES; ++wv) acc += wave_value(wv, which, c);
         atomicAdd(dst + which * a.N + c, (double)acc);
+      }
+      if (a.fin.ticket) {   // last workgroup: BatchNorm scale/shift + running statistics (no separate finalize launch)
+        int* flag = reinterpret_cast<int*>(smem + L.p_off);   // prologue-parameter region: dead after the tile loop
+        if (c3dfin::last_workgroup(a.fin.ticket, gridDim.x, flag))
+          c3dfin::bn_forward(a.fin, a.stats, C3D_STAT_STRIPES, a.N, a.Np, tid, WAVES * 64);
       }
     } else {
       // Per-(sample, channel) sums.  The waves of a workgroup almost always end inside the same sample:

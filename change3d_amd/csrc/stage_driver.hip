@@ -47,12 +47,14 @@ struct BlkFwd {   // byte offsets into ws_fwd
   size_t a, b, c, sc, y;                                        // activations (y: SIZE_MAX for the last block)
   size_t ss_a, mr_a, ss_b, mr_b, gate, hid, ss_c, mr_c, ss_1, mr_1;   // f32 vectors
   size_t sums_a, nc_b, sums_c, sums_1;                          // f64 accumulators
+  size_t tick;                                                  // u32 [4] last-workgroup tickets (a, c, shortcut)
 };
 
 struct BlkBwd {   // byte offsets into ws_bwd (ring slot for the big tensors)
   size_t g, t1, t2, dxs, dx;
   size_t coef_c, coef_1, coef_a, cA, cC, cB;                   // f32 vectors
   size_t dsums_c, dsums_1, nc3, dsums_a;                        // f64 accumulators
+  size_t tick;                                                  // u32 [4] last-workgroup tickets (c (+shortcut), a)
 };
 
 struct Plan {
@@ -121,6 +123,7 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
     F.nc_b = cf.take((size_t)d->B * G.Cip * 2 * 8);
     F.sums_c = cf.take((size_t)S * 2 * G.Co * 8);
     F.sums_1 = G.sc_bn ? cf.take((size_t)S * 2 * G.Co * 8) : SIZE_MAX;
+    F.tick = cf.take(16);
   }
   P.fwd_acc_bytes = cf.off - P.fwd_acc_off;
   P.fwd_total = cf.off;
@@ -166,6 +169,7 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
     Bk.dsums_1 = G.sc_bn ? cb.take(2 * G.Co * 8) : SIZE_MAX;
     Bk.nc3 = cb.take((size_t)d->B * G.Cip * 3 * 8);
     Bk.dsums_a = cb.take(2 * G.Ci * 8);
+    Bk.tick = cb.take(16);
   }
   P.bwd_acc_bytes = cb.off - P.bwd_acc_off;
   P.bwd_total = cb.off;
@@ -268,6 +272,35 @@ struct WgCall {
     a.dw_sn = dw_sn; a.dw_sk = dw_sk; a.dtype = dtype; a.q_mode = C3D_PRO_NONE; a.row_mode = C3D_ROWS_DENSE;
   }
 };
+
+// C3D_FOLD_FIN=1: BatchNorm finalisation by the LAST WORKGROUP of the statistics producers (csrc/bn_fin.h) instead of
+// separate c3d_bn_finalize / c3d_bn_bwd_coef launches.  Default OFF -- measured on MI355X (B=32, bf16, round 2,
+// profiles/r02_fold_finalize_ab.json): 166 launches of 6.5 us disappear (-1.07 ms) but the producers grow by
+// 8-13 us per launch (+1.70 ms: pw_gemm +0.86, dw333_bwd_data +0.53, block_out_bwd +0.32): the hand-off is a chain of
+// memory-side round trips (statistics atomics -> vmcnt(0) -> ticket atomic -> acquire -> sc1 loads of the sums), each
+// ~2 us on this chip, serialised at the tail of the last workgroup -- MORE than a kernel boundary plus a 6 us kernel.
+bool fold_fin() {
+  static const bool on = getenv("C3D_FOLD_FIN") && atoi(getenv("C3D_FOLD_FIN")) == 1;
+  return on;
+}
+
+inline c3d_bn_fin fin_fwd(uint32_t* ticket, const c3d_bn_ptrs& bn, int training, double count, float momentum, float eps,
+                          float* ss, float* mr) {
+  c3d_bn_fin f;
+  std::memset(&f, 0, sizeof(f));
+  f.ticket = ticket; f.gamma = bn.gamma; f.beta = bn.beta; f.running_mean = bn.running_mean; f.running_var = bn.running_var;
+  f.nbt = training ? bn.num_batches_tracked : nullptr; f.ss = ss; f.mr = mr; f.count = count; f.momentum = momentum;
+  f.eps = eps; f.training = training;
+  return f;
+}
+
+inline c3d_bn_fin fin_bwd(uint32_t* ticket, const c3d_bn_ptrs& bn, double count, float* coef, const float* mr) {
+  c3d_bn_fin f;
+  std::memset(&f, 0, sizeof(f));
+  f.ticket = ticket; f.gamma = bn.gamma; f.running_mean = bn.dgamma; f.running_var = bn.dbeta; f.ss = coef;
+  f.mr = const_cast<float*>(mr); f.count = count;
+  return f;
+}
 
 inline char* at(void* base, size_t off) { return off == SIZE_MAX ? nullptr : reinterpret_cast<char*>(base) + off; }
 template <typename T> inline T* atT(void* base, size_t off) { return reinterpret_cast<T*>(at(base, off)); }
@@ -405,14 +438,18 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
     double* sums_a = atT<double>(ws, F.sums_a); double* nc_b = atT<double>(ws, F.nc_b);
     double* sums_c = atT<double>(ws, F.sums_c); double* sums_1 = atT<double>(ws, F.sums_1);
     const int64_t rps = (int64_t)T * G.Ho * G.Wo;
+    uint32_t* tick = atT<uint32_t>(ws, F.tick);
+    const bool fold = tr && fold_fin();   // (eval mode has no statistics: the finalize launches build scale/shift)
     // conv_a (1x1x1) + BN_a statistics
     {
       PwCall p(cur, k.w_a, a, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
       p.a.epi_mode = epi; p.a.stats = sums_a;
+      if (fold) p.a.fin = fin_fwd(tick + 0, k.bn_a, tr, (double)G.M, d->momentum, d->eps, ss_a, mr_a);
       RC(c3d_pw_gemm(&p.a, st));
     }
-    RC(c3d_bn_finalize(sums_a, S, (double)G.M, k.bn_a.gamma, k.bn_a.beta, k.bn_a.running_mean, k.bn_a.running_var,
-                       tr ? k.bn_a.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr, ss_a, mr_a, st));
+    if (!fold)
+      RC(c3d_bn_finalize(sums_a, S, (double)G.M, k.bn_a.gamma, k.bn_a.beta, k.bn_a.running_mean, k.bn_a.running_var,
+                         tr ? k.bn_a.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr, ss_a, mr_a, st));
     // conv_b (depthwise 3x3x3, BN_a + ReLU on load) + per-sample statistics; BN_b + SE
     RC(c3d_dw333_fwd(a, ss_a, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
     RC(c3d_bn_se_finalize(nc_b, B, (double)rps, k.bn_b.gamma, k.bn_b.beta, k.bn_b.running_mean, k.bn_b.running_var,
@@ -423,10 +460,12 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       PwCall p(b, k.w_c, c, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
       p.a.pro_mode = C3D_PRO_BN_SE_SWISH; p.a.pro_p = ss_b; p.a.pro_gate = gate; p.a.rows_per_sample = rps;
       p.a.epi_mode = epi; p.a.stats = sums_c;
+      if (fold) p.a.fin = fin_fwd(tick + 1, k.bn_c, tr, (double)G.Mo, d->momentum, d->eps, ss_c, mr_c);
       RC(c3d_pw_gemm(&p.a, st));
     }
-    RC(c3d_bn_finalize(sums_c, S, (double)G.Mo, k.bn_c.gamma, k.bn_c.beta, k.bn_c.running_mean, k.bn_c.running_var,
-                       tr ? k.bn_c.num_batches_tracked : nullptr, d->momentum, d->eps, G.Co, G.Cop, tr, ss_c, mr_c, st));
+    if (!fold)
+      RC(c3d_bn_finalize(sums_c, S, (double)G.Mo, k.bn_c.gamma, k.bn_c.beta, k.bn_c.running_mean, k.bn_c.running_var,
+                         tr ? k.bn_c.num_batches_tracked : nullptr, d->momentum, d->eps, G.Co, G.Cop, tr, ss_c, mr_c, st));
     // shortcut
     int mode = SC_IDENTITY;
     const void* scp = cur;
@@ -434,11 +473,13 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       PwCall p(cur, k.w_sc, sc, G.Mo, G.Cin, G.Co, G.Cin, 1, dt);
       p.a.row_mode = G.s == 2 ? C3D_ROWS_STRIDE2 : C3D_ROWS_DENSE; p.a.H = G.H; p.a.W = G.W;
       p.a.epi_mode = G.sc_bn ? epi : C3D_EPI_STORE; p.a.stats = sums_1;
+      if (fold && G.sc_bn) p.a.fin = fin_fwd(tick + 2, k.bn_sc, tr, (double)G.Mo, d->momentum, d->eps, ss_1, mr_1);
       RC(c3d_pw_gemm(&p.a, st));
       if (G.sc_bn) {
-        RC(c3d_bn_finalize(sums_1, S, (double)G.Mo, k.bn_sc.gamma, k.bn_sc.beta, k.bn_sc.running_mean,
-                           k.bn_sc.running_var, tr ? k.bn_sc.num_batches_tracked : nullptr, d->momentum, d->eps,
-                           G.Co, G.Cop, tr, ss_1, mr_1, st));
+        if (!fold)
+          RC(c3d_bn_finalize(sums_1, S, (double)G.Mo, k.bn_sc.gamma, k.bn_sc.beta, k.bn_sc.running_mean,
+                             k.bn_sc.running_var, tr ? k.bn_sc.num_batches_tracked : nullptr, d->momentum, d->eps,
+                             G.Co, G.Cop, tr, ss_1, mr_1, st));
         mode = SC_BN;
       } else {
         mode = SC_RAW;
@@ -486,9 +527,18 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     const int64_t rps = (int64_t)T * G.Ho * G.Wo;
     const bool scbn = G.sc_bn;
     // ---- y = relu(bn_c(c) + shortcut)
-    RC(c3d_block_out_bwd(cur_dy, y, c, scbn ? sc : nullptr, g, mr_c, scbn ? mr_1 : nullptr, dsums_c,
-                         scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, st));
-    RC(c3d_bn_bwd_coef(dsums_c, 1, (double)G.Mo, k.bn_c.gamma, mr_c, G.Co, G.Cop, coef_c, k.bn_c.dgamma, k.bn_c.dbeta, st));
+    uint32_t* tick = atT<uint32_t>(wb, Bk.tick);
+    const bool fold = fold_fin();
+    if (fold) {
+      const c3d_bn_fin fc = fin_bwd(tick + 0, k.bn_c, (double)G.Mo, coef_c, mr_c);
+      const c3d_bn_fin f1 = scbn ? fin_bwd(tick + 0, k.bn_sc, (double)G.Mo, coef_1, mr_1) : c3d_bn_fin{};
+      RC(c3d_block_out_bwd_fin(cur_dy, y, c, scbn ? sc : nullptr, g, mr_c, scbn ? mr_1 : nullptr, dsums_c,
+                               scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, &fc, scbn ? &f1 : nullptr, st));
+    } else {
+      RC(c3d_block_out_bwd(cur_dy, y, c, scbn ? sc : nullptr, g, mr_c, scbn ? mr_1 : nullptr, dsums_c,
+                           scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, st));
+      RC(c3d_bn_bwd_coef(dsums_c, 1, (double)G.Mo, k.bn_c.gamma, mr_c, G.Co, G.Cop, coef_c, k.bn_c.dgamma, k.bn_c.dbeta, st));
+    }
     // ---- conv_c data gradient, Swish / SE backward in the epilogue; weight gradient on the side stream
     {
       PwCall p(g, k.w_c, t1, G.Mo, G.Co, G.Ci, 1, G.Ci, dt);
@@ -507,11 +557,17 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
                           k.se_w2, gate, hid, G.Cr, cA, cC, cB, k.bn_b.dgamma, k.bn_b.dbeta, k.dse_w1, k.dse_b1,
                           k.dse_w2, k.dse_b2, st));
     // ---- depthwise conv_b
-    RC(c3d_dw333_bwd_data(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+    if (fold) {
+      const c3d_bn_fin fa = fin_bwd(tick + 1, k.bn_a, (double)G.M, coef_a, mr_a);
+      RC(c3d_dw333_bwd_data_fin(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, &fa, st));
+    } else {
+      RC(c3d_dw333_bwd_data(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+    }
     RC(side_run(st, [&](hipStream_t s2) {
       return c3d_dw333_wgrad(t1, b, cA, cB, cC, a, ss_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, s2);
     }));
-    RC(c3d_bn_bwd_coef(dsums_a, 1, (double)G.M, k.bn_a.gamma, mr_a, G.Ci, G.Cip, coef_a, k.bn_a.dgamma, k.bn_a.dbeta, st));
+    if (!fold)
+      RC(c3d_bn_bwd_coef(dsums_a, 1, (double)G.M, k.bn_a.gamma, mr_a, G.Ci, G.Cip, coef_a, k.bn_a.dgamma, k.bn_a.dbeta, st));
     // ---- shortcut branch
     const void* res = g;
     int res_mode = 0;
@@ -519,8 +575,9 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       const int rm = G.s == 2 ? C3D_ROWS_STRIDE2 : C3D_ROWS_DENSE;
       PwCall p(g, k.w_sc, dxs, G.Mo, G.Co, G.Cin, 1, G.Cin, dt);
       if (scbn) {
-        RC(c3d_bn_bwd_coef(dsums_1, 1, (double)G.Mo, k.bn_sc.gamma, mr_1, G.Co, G.Cop, coef_1, k.bn_sc.dgamma,
-                           k.bn_sc.dbeta, st));
+        if (!fold)
+          RC(c3d_bn_bwd_coef(dsums_1, 1, (double)G.Mo, k.bn_sc.gamma, mr_1, G.Co, G.Cop, coef_1, k.bn_sc.dgamma,
+                             k.bn_sc.dbeta, st));
         p.a.x2 = sc; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_1;
       }
       RC(c3d_pw_gemm(&p.a, st));

@@ -187,12 +187,12 @@ class _AccPool:
 def _n_acc_fwd(blk, B):
     S = ops.STAT_STRIPES
     return (S * 2 * blk.cinner + B * cpad(blk.cinner) * 2 + S * 2 * blk.cout
-            + (S * 2 * blk.cout if blk.branch1_norm is not None else 0))
+            + (S * 2 * blk.cout if blk.branch1_norm is not None else 0) + 2)
 
 
 def _n_acc_bwd(blk, B):
     S = ops.STAT_STRIPES
-    return 4 * blk.cout + B * cpad(blk.cinner) * 3 + S * 2 * blk.cinner   # upper bound (shortcut BN or not)
+    return 4 * blk.cout + B * cpad(blk.cinner) * 3 + S * 2 * blk.cinner + 2   # upper bound (shortcut BN or not)
 
 
 def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None):
@@ -207,18 +207,22 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None):
     has_bn1 = blk.branch1_norm is not None
     # f64 accumulators in one zeroed buffer
     S = ops.STAT_STRIPES  # pointwise-GEMM statistics are accumulated in S striped sets
-    n_acc = S * 2 * Ci + B * Cip * 2 + S * 2 * Co + (S * 2 * Co if has_bn1 else 0)
+    n_acc = S * 2 * Ci + B * Cip * 2 + S * 2 * Co + (S * 2 * Co if has_bn1 else 0) + 2
     acc = pool.take(n_acc) if pool is not None else torch.zeros(n_acc, dtype=torch.float64, device=dev)
     sums_a, o = acc[:S * 2 * Ci], S * 2 * Ci
     nc_b, o = acc[o:o + B * Cip * 2], o + B * Cip * 2
     sums_c, o = acc[o:o + S * 2 * Co], o + S * 2 * Co
     sums_1 = acc[o:o + S * 2 * Co] if has_bn1 else None
+    tick = acc[n_acc - 2:].view(torch.int32)   # last-workgroup tickets (zeroed with the accumulators)
+    fold = training and ops.FOLD_FIN           # BatchNorm finalised by the producer's last workgroup
     epi = ops.EPI_STATS if training else ops.EPI_STORE
 
     a = torch.empty((M, Cip), dtype=act_dtype, device=dev)
-    ops.pw_gemm(x, b2.conv_a.weight, a, M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt, epi_mode=epi, stats=sums_a)
     ss_a, mr_a = _f32(2 * Cip, dev), _f32(2 * Cip, dev)
-    ops.bn_finalize(sums_a, M, b2.norm_a, Ci, ss_a, mr_a, training, stripes=S)
+    ops.pw_gemm(x, b2.conv_a.weight, a, M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt, epi_mode=epi, stats=sums_a,
+                fin=ops.fin_fwd(tick, 0, b2.norm_a, training, M, ss_a, mr_a) if fold else None)
+    if not fold:
+        ops.bn_finalize(sums_a, M, b2.norm_a, Ci, ss_a, mr_a, training, stripes=S)
 
     b = torch.empty((Mo, Cip), dtype=act_dtype, device=dev)
     ops.dw_fwd(a, ss_a, b2.conv_b.weight, b, nc_b, B, T, H, W, Ci, s, dt)
@@ -228,20 +232,25 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None):
     ops.bn_se_finalize(nc_b, B, T * Ho * Wo, b2.norm_b[0], se, Ci, ss_b, mr_b, gate, hid, training)
 
     c = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
-    ops.pw_gemm(b, b2.conv_c.weight, c, M=Mo, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH,
-                pro_p=ss_b, pro_gate=gate, rows_per_sample=T * Ho * Wo, epi_mode=epi, stats=sums_c)
     ss_c, mr_c = _f32(2 * Cop, dev), _f32(2 * Cop, dev)
-    ops.bn_finalize(sums_c, Mo, b2.norm_c, Co, ss_c, mr_c, training, stripes=S)
+    ops.pw_gemm(b, b2.conv_c.weight, c, M=Mo, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH,
+                pro_p=ss_b, pro_gate=gate, rows_per_sample=T * Ho * Wo, epi_mode=epi, stats=sums_c,
+                fin=ops.fin_fwd(tick, 1, b2.norm_c, training, Mo, ss_c, mr_c) if fold else None)
+    if not fold:
+        ops.bn_finalize(sums_c, Mo, b2.norm_c, Co, ss_c, mr_c, training, stripes=S)
 
     ss_1 = mr_1 = None
     if blk.branch1_conv is not None:
         sc = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
-        ops.pw_gemm(x, blk.branch1_conv.weight, sc, M=Mo, K=Cin, N=Co, w_sn=Cin, w_sk=1, dtype=dt,
-                    row_mode=ops.ROWS_STRIDE2 if s == 2 else ops.ROWS_DENSE, H=H, W=W,
-                    epi_mode=epi if has_bn1 else ops.EPI_STORE, stats=sums_1)
         if has_bn1:
             ss_1, mr_1 = _f32(2 * Cop, dev), _f32(2 * Cop, dev)
-            ops.bn_finalize(sums_1, Mo, blk.branch1_norm, Co, ss_1, mr_1, training, stripes=S)
+        ops.pw_gemm(x, blk.branch1_conv.weight, sc, M=Mo, K=Cin, N=Co, w_sn=Cin, w_sk=1, dtype=dt,
+                    row_mode=ops.ROWS_STRIDE2 if s == 2 else ops.ROWS_DENSE, H=H, W=W,
+                    epi_mode=epi if has_bn1 else ops.EPI_STORE, stats=sums_1,
+                    fin=ops.fin_fwd(tick, 2, blk.branch1_norm, training, Mo, ss_1, mr_1) if (fold and has_bn1) else None)
+        if has_bn1:
+            if not fold:
+                ops.bn_finalize(sums_1, Mo, blk.branch1_norm, Co, ss_1, mr_1, training, stripes=S)
             mode = ops.SC_BN
         else:
             mode = ops.SC_RAW
@@ -267,8 +276,10 @@ def _block_backward(blk, dy, sv, act_dtype, pool=None):
     mode = sv["mode"]
     x, a, b, c, sc, y = sv["x"], sv["a"], sv["b"], sv["c"], sv["sc"], sv["y"]
     S = ops.STAT_STRIPES
-    n_acc = 2 * Co + (2 * Co if mode == ops.SC_BN else 0) + B * Cip * 3 + S * 2 * Ci
+    n_acc = 2 * Co + (2 * Co if mode == ops.SC_BN else 0) + B * Cip * 3 + S * 2 * Ci + 2
     acc = pool.take(n_acc) if pool is not None else torch.zeros(n_acc, dtype=torch.float64, device=dev)
+    tick = acc[n_acc - 2:].view(torch.int32)
+    fold = ops.FOLD_FIN
     dsums_c, o = acc[:2 * Co], 2 * Co
     dsums_1 = None
     if mode == ops.SC_BN:
@@ -278,10 +289,17 @@ def _block_backward(blk, dy, sv, act_dtype, pool=None):
 
     # ---- y = relu(bn_c(c) + shortcut)
     g = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
-    ops.block_out_bwd(dy, y, c, sc if mode == ops.SC_BN else None, g, sv["mr_c"],
-                      sv["mr_1"] if mode == ops.SC_BN else None, dsums_c, dsums_1, Mo, Co, dt)
     coef_c = _f32(3 * Cop, dev)
-    ops.bn_bwd_coef(dsums_c, Mo, b2.norm_c, sv["mr_c"], Co, coef_c)
+    coef_1 = _f32(3 * Cop, dev) if mode == ops.SC_BN else None
+    if fold:
+        ops.block_out_bwd_fin(dy, y, c, sc if mode == ops.SC_BN else None, g, sv["mr_c"],
+                              sv["mr_1"] if mode == ops.SC_BN else None, dsums_c, dsums_1, Mo, Co, dt,
+                              ops.fin_bwd(tick, 0, b2.norm_c, Mo, coef_c, sv["mr_c"]),
+                              ops.fin_bwd(tick, 0, blk.branch1_norm, Mo, coef_1, sv["mr_1"]) if mode == ops.SC_BN else None)
+    else:
+        ops.block_out_bwd(dy, y, c, sc if mode == ops.SC_BN else None, g, sv["mr_c"],
+                          sv["mr_1"] if mode == ops.SC_BN else None, dsums_c, dsums_1, Mo, Co, dt)
+        ops.bn_bwd_coef(dsums_c, Mo, b2.norm_c, sv["mr_c"], Co, coef_c)
     # ---- conv_c (data + weight), Swish / SE backward in the epilogue
     t1 = torch.empty((Mo, Cip), dtype=act_dtype, device=dev)
     ops.pw_gemm(g, b2.conv_c.weight, t1, M=Mo, K=Co, N=Ci, w_sn=1, w_sk=Ci, dtype=dt, x2=c, pro_mode=ops.PRO_AFFINE2,
@@ -299,21 +317,25 @@ def _block_backward(blk, dy, sv, act_dtype, pool=None):
     t2 = torch.empty((M, Cip), dtype=act_dtype, device=dev)
     # (c3d_dw333_bwd, the single-pass fused variant, is exported and tested but currently slower than
     # the split pair on MI355X — LDS-read bound; see DESIGN.md "what comes next")
-    ops.dw_bwd_data(t1, b, cA, cB, cC, b2.conv_b.weight, a, sv["ss_a"], sv["mr_a"], t2, dsums_a, B, T, H, W, Ci, s, dt)
+    coef_a = _f32(3 * Cip, dev)
+    if fold:
+        ops.dw_bwd_data_fin(t1, b, cA, cB, cC, b2.conv_b.weight, a, sv["ss_a"], sv["mr_a"], t2, dsums_a, B, T, H, W, Ci, s, dt,
+                            ops.fin_bwd(tick, 1, b2.norm_a, M, coef_a, sv["mr_a"]))
+    else:
+        ops.dw_bwd_data(t1, b, cA, cB, cC, b2.conv_b.weight, a, sv["ss_a"], sv["mr_a"], t2, dsums_a, B, T, H, W, Ci, s, dt)
     gw_b = ops.grad_of(b2.conv_b.weight)
     ops.side_run(lambda: ops.dw_wgrad(t1, b, cA, cB, cC, a, sv["ss_a"], gw_b, B, T, H, W, Ci, s, dt),
              t1, b, cA, cB, cC, a, sv["ss_a"])
-    stripes_a = 1
-    coef_a = _f32(3 * Cip, dev)
-    ops.bn_bwd_coef(dsums_a, M, b2.norm_a, sv["mr_a"], Ci, coef_a, stripes=stripes_a)
+    if not fold:
+        ops.bn_bwd_coef(dsums_a, M, b2.norm_a, sv["mr_a"], Ci, coef_a, stripes=1)
     # ---- shortcut branch
     dx = torch.empty((B, T, H, W, Cinp), dtype=act_dtype, device=dev)
     if blk.branch1_conv is not None:
         rm = ops.ROWS_STRIDE2 if s == 2 else ops.ROWS_DENSE
         dxs = torch.empty((Mo, Cinp), dtype=act_dtype, device=dev)
         if mode == ops.SC_BN:
-            coef_1 = _f32(3 * Cop, dev)
-            ops.bn_bwd_coef(dsums_1, Mo, blk.branch1_norm, sv["mr_1"], Co, coef_1)
+            if not fold:
+                ops.bn_bwd_coef(dsums_1, Mo, blk.branch1_norm, sv["mr_1"], Co, coef_1)
             ops.pw_gemm(g, blk.branch1_conv.weight, dxs, M=Mo, K=Co, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=sc,
                         pro_mode=ops.PRO_AFFINE2, pro_p=coef_1)
             gw_1 = ops.grad_of(blk.branch1_conv.weight)

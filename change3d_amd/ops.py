@@ -201,11 +201,37 @@ def grad_of(p):
 
 
 # ----------------------------------------------------------------------------- pointwise GEMM
+FOLD_FIN = os.environ.get("C3D_FOLD_FIN", "0") == "1"   # BatchNorm finalisation by the producers' last workgroup (measured slower: off)
+
+
+def fin_fwd(tick, idx, bn, training, count, ss, mr):
+    """c3d_bn_fin for a forward statistics producer (include/change3d_hip.h); tick: zeroed int32 tensor."""
+    f = L.BnFin()
+    f.ticket = tick.data_ptr() + 4 * idx
+    f.gamma, f.beta = _p(bn.weight), _p(bn.bias)
+    f.running_mean, f.running_var = _p(bn.running_mean), _p(bn.running_var)
+    f.nbt = _p(bn.num_batches_tracked) if training else None
+    f.ss, f.mr, f.count = _p(ss), _p(mr), float(count)
+    f.momentum, f.eps, f.training = float(bn.momentum), float(bn.eps), 1 if training else 0
+    return f
+
+
+def fin_bwd(tick, idx, bn, count, coef, mr):
+    f = L.BnFin()
+    f.ticket = tick.data_ptr() + 4 * idx
+    f.gamma = _p(bn.weight)
+    f.running_mean, f.running_var = _p(grad_of(bn.weight)), _p(grad_of(bn.bias))   # carry dgamma / dbeta
+    f.ss, f.mr, f.count = _p(coef), _p(mr), float(count)
+    return f
+
+
 def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, pro_p=None,
             pro_gate=None, epi_mode=EPI_STORE, e1=None, epi_p=None, epi_gate=None, epi_q=None, stats=None,
             rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, res_mode=0,
-            x_ptr=None, e1_ptr=None):
+            x_ptr=None, e1_ptr=None, fin=None):
     a = L.PwArgs()
+    if fin is not None:
+        a.fin = fin
     a.x = x_ptr if x_ptr is not None else _p(x)
     a.x2 = _p(x2)
     a.y = _p(y)
@@ -303,6 +329,11 @@ def dw_bwd_data(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, B, T, H, W, C_, 
                                        _p(dsums), B, T, H, W, C_, cpad(C_), stride, dtype, _stream())
 
 
+def dw_bwd_data_fin(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, B, T, H, W, C_, stride, dtype, fin):
+    _launch("c3d_dw333_bwd_data", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_data_fin, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2),
+            _p(dsums), B, T, H, W, C_, cpad(C_), stride, dtype, C.byref(fin), _stream())
+
+
 def dw_wgrad(t1, b, cA, cB, cC, a, ss_a, dw, B, T, H, W, C_, stride, dtype):
     _launch("c3d_dw333_wgrad", (t1.numel() + b.numel() + a.numel()) * _es(dtype), L.lib().c3d_dw333_wgrad, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(a), _p(ss_a), _p(dw), B, T, H, W,
                                     C_, cpad(C_), stride, dtype, _stream())
@@ -324,6 +355,11 @@ def block_out_fwd(c, ss_c, shortcut, ss_1, mode, y, M, Cp, dtype):
 def block_out_bwd(dy, y, c, s_bn, g, mr_c, mr_1, dsums_c, dsums_1, M, C_, dtype):
     _launch("c3d_block_out_bwd", M * cpad(C_) * (5 if s_bn is not None else 4) * _es(dtype), L.lib().c3d_block_out_bwd, _p(dy), _p(y), _p(c), _p(s_bn), _p(g), _p(mr_c), _p(mr_1), _p(dsums_c), _p(dsums_1), M, C_,
                                       cpad(C_), dtype, _stream())
+
+
+def block_out_bwd_fin(dy, y, c, s_bn, g, mr_c, mr_1, dsums_c, dsums_1, M, C_, dtype, fin_c, fin_1):
+    _launch("c3d_block_out_bwd", M * cpad(C_) * (5 if s_bn is not None else 4) * _es(dtype), L.lib().c3d_block_out_bwd_fin, _p(dy), _p(y), _p(c), _p(s_bn), _p(g), _p(mr_c), _p(mr_1), _p(dsums_c), _p(dsums_1), M, C_,
+            cpad(C_), dtype, C.byref(fin_c), C.byref(fin_1) if fin_1 is not None else None, _stream())
 
 
 def frame_absdiff(y, d, B, T, HW, Cp, t_pre, t_post, dtype):

@@ -59,6 +59,24 @@ int c3d_device_cus(void);
 #define C3D_ROWS_STRIDE2 2 /* row m=(bt,ho,wo) gathers input pixel (bt,2ho,2wo) of [BT][H][W] */
 #define C3D_ROWS_S2SHIFT 3 /* (wgrad only) as STRIDE2 but pixel (2ho+dy, 2wo+dx), zero outside */
 
+/* In-kernel BatchNorm finalisation by the last workgroup of a statistics producer (csrc/bn_fin.h): when `ticket`
+ * is non-NULL the producing kernel itself turns the completed sums into scale/shift (+ running statistics), or into
+ * the BatchNorm-backward coefficients, instead of a separate c3d_bn_finalize / c3d_bn_bwd_coef launch.
+ *   forward  (c3d_pw_gemm C3D_EPI_STATS)          : ss = scale|shift [2][Cp], mr = mean|rstd [2][Cp] (may be NULL)
+ *   backward (c3d_block_out_bwd, c3d_dw333_bwd_data): ss = coefficients A|B|C [3][Cp], mr = saved mean|rstd (input),
+ *              running_mean / running_var carry dgamma / dbeta (accumulated), beta / nbt unused
+ * `ticket` is a zeroed uint32 (re-zeroed by the caller before every launch that uses it).                        */
+typedef struct c3d_bn_fin {
+  uint32_t* ticket;
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var;
+  int64_t* nbt;
+  float* ss; float* mr;
+  double count;
+  float momentum, eps;
+  int32_t training, reserved;
+} c3d_bn_fin;
+
 typedef struct c3d_pw_args {
   const void* x;         /* A-side tensor, storage dtype, rows of Kp elements                */
   const void* x2;        /* second A-side tensor for C3D_PRO_AFFINE2 (same addressing)       */
@@ -81,6 +99,7 @@ typedef struct c3d_pw_args {
   int32_t pro_mode, epi_mode;
   int32_t res_mode;      /* EPI_ADD: 0 dense [M][Np]; 1 e1 is [BT][H/2][W/2][Np], added where h,w even */
   int32_t dtype;
+  c3d_bn_fin fin;        /* C3D_EPI_STATS: fin.ticket != NULL -> the last workgroup finalises the BatchNorm    */
 } c3d_pw_args;
 
 int c3d_pw_gemm(const c3d_pw_args* args, void* stream);
@@ -162,6 +181,11 @@ int c3d_dw333_bwd_data(const void* t1, const void* b, const float* coefA, const 
                        const float* coefC, const float* w, const void* a, const float* ss_a,
                        const float* mr_a, void* t2, double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
                        int32_t stride, int32_t dtype, void* stream);
+/* as c3d_dw333_bwd_data; with fin->ticket != NULL the last workgroup also writes BatchNorm_a's backward coefficients */
+int c3d_dw333_bwd_data_fin(const void* t1, const void* b, const float* coefA, const float* coefB,
+                           const float* coefC, const float* w, const void* a, const float* ss_a,
+                           const float* mr_a, void* t2, double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
+                           int32_t stride, int32_t dtype, const c3d_bn_fin* fin, void* stream);
 int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const float* coefB,
                     const float* coefC, const void* a, const float* ss_a, float* dw, int32_t B, int32_t T,
                     int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
@@ -183,6 +207,12 @@ int c3d_block_out_fwd(const void* c, const float* ss_c, const void* shortcut, co
 int c3d_block_out_bwd(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
                       const float* mr_c, const float* mr_1, double* dsums_c, double* dsums_1, int64_t M,
                       int32_t C, int32_t Cp, int32_t dtype, void* stream);
+/* as c3d_block_out_bwd; with fin_c->ticket != NULL the last workgroup also writes the backward coefficients of
+ * BatchNorm_c (fin_c) and, when s_bn is given, of the shortcut BatchNorm (fin_1; shares fin_c's ticket). */
+int c3d_block_out_bwd_fin(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
+                          const float* mr_c, const float* mr_1, double* dsums_c, double* dsums_1, int64_t M,
+                          int32_t C, int32_t Cp, int32_t dtype, const c3d_bn_fin* fin_c, const c3d_bn_fin* fin_1,
+                          void* stream);
 
 /* Encoder.enhance pieces (reference model/trainer.py:71-108); HW = H*W pixels per frame.    */
 int c3d_frame_absdiff(const void* y, void* d, int32_t B, int32_t T, int64_t HW, int32_t Cp, int32_t t_pre,

@@ -224,8 +224,8 @@ def test_eval_folded_bn_matches_unfolded_eval(dtype, tol):
     # weights change (load_state_dict): the folded copy must be rebuilt
     net.load_state_dict(synth.synth_state_dict(net, seed=17, mask_margin=0.25, branch_gain=0.3))
     p2_fold, p2_plain = run(True), run(False)
-    assert (p2_plain - p_plain).abs().max().item() > 10 * tol
-    assert (p2_fold - p2_plain).abs().max().item() < tol
+    assert (p2_plain - p_plain).abs().max().item() > 0.2      # the new weights give a different answer ...
+    assert (p2_fold - p2_plain).abs().max().item() < tol      # ... and the folded path follows them
     # train() / eval() round trip invalidates too
     net.train(); net.eval()
     assert not any(s._fold_valid for s in stages)
