@@ -16,10 +16,34 @@ import numpy as np
 import torch
 
 
-def make_args(num_perception_frame=1, size=256, dataset="LEVIR-CD", num_class=1):
-    """The argparse fields `Trainer(args)` reads (reference model/trainer.py:28-56,175-220)."""
+def make_args(num_perception_frame=1, size=256, dataset="LEVIR-CD", num_class=1, **extra):
+    """The argparse fields `Trainer(args)` reads (reference model/trainer.py:28-56,175-220); `extra` carries the
+    caption-decoder fields of the CC task (vocab_size, embed_dim, n_head, n_layer, dropout: reference
+    scripts/train_CC.py:423,553-579)."""
     return SimpleNamespace(pretrained="/nonexistent", num_perception_frame=num_perception_frame,
-                           in_height=size, in_width=size, dataset=dataset, num_class=num_class)
+                           in_height=size, in_width=size, dataset=dataset, num_class=num_class, **extra)
+
+
+def make_cc_args(size=256, vocab_size=501, dropout=0.1):
+    """Change-captioning configuration (BASELINE.json configs[4]; reference scripts/train_CC.py:553-579 defaults:
+    embed_dim 192 = res5 width, 8 heads, 3 layers, dropout 0.1; vocabulary = len(WORDMAP), synthetic 501)."""
+    return make_args(size=size, dataset="LEVIR-CC", vocab_size=vocab_size, embed_dim=192, n_head=8, n_layer=3,
+                     dropout=dropout)
+
+
+def synth_captions(batch, seed=0, vocab_size=501, max_len=52):
+    """(caps int64 [B, 52], caplens int64 [B, 1]) shaped like the LEVIR-CC loader's output (reference
+    scripts/train_CC.py:105-116): <start>=vocab-2, words in 1..vocab-3, <end>=vocab-1, then <pad>=0."""
+    rng = np.random.default_rng(3000 + seed)
+    caps = np.zeros((batch, max_len), dtype=np.int64)
+    lens = np.zeros((batch, 1), dtype=np.int64)
+    for b in range(batch):
+        n = int(rng.integers(5, max_len - 2))
+        caps[b, 0] = vocab_size - 2
+        caps[b, 1:1 + n] = rng.integers(1, vocab_size - 2, size=n)
+        caps[b, 1 + n] = vocab_size - 1
+        lens[b, 0] = n + 2
+    return torch.from_numpy(caps), torch.from_numpy(lens)
 
 
 def synth_state_dict(model, seed=16, mask_margin=1.0, branch_gain=1.0):

@@ -8,6 +8,8 @@ weights/inputs from `oracle/synth.py`, first asserting that the repo's restateme
 
     tests/golden/bcd_s{S}_b{B}.npz      (BCD: update_bcd, BCE+Dice, 3 Adam steps, eval mode)
     tests/golden/scd_s64_b{B}.npz       (SCD, SURVEY.md 8(f).1: update_scd + the train_SCD.py loss)
+    tests/golden/cc_s{S}_b{B}.npz       (CC, SURVEY.md 8(f).2: encoder blocks 0-4 + CaptionDecoder + packed CE,
+                                         two Adam steps with gradient clipping as scripts/train_CC.py:118-147)
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden [--sizes 64 256]
 The fixtures are DATA (inputs are regenerated from seeds; expected outputs are stored).
@@ -242,18 +244,135 @@ def run_scd(size, batch):
           f"loss {loss.item():.6f} (fp64 {loss64.item():.6f})")
 
 
+CC_STEPS, CC_LR, CC_CLIP = 2, 1e-4, 5.0
+
+
+def ref_cc_forward(net, pre, post, caps, caplens):
+    """The reference CC forward (scripts/train_CC.py:111-132) through the REAL reference modules.  Two lines of the
+    reference cannot run on torch 2.10 / CPU: `nn.TransformerDecoder.forward` passes
+    `tgt_is_causal=` to the custom layer (TypeError) and `mask.cuda()`; the layers are therefore applied in a loop
+    (there is no final norm: model/caption_decoder.py:555) with the mask built by the reference's own formula."""
+    feat = net.update_cc(pre, post)
+    B, C, H, W = feat.shape
+    memory = feat.permute(2, 3, 0, 1).reshape(H * W, B, C)          # einops 'b c h w -> (h w) b c'
+    dec = net.decoder
+    tgt = caps.permute(1, 0)
+    n = tgt.size(0)
+    mask = (torch.triu(torch.ones(n, n)) == 1).transpose(0, 1)
+    mask = mask.float().masked_fill(mask == 0, float("-inf")).masked_fill(mask == 1, float(0.0))
+    x = dec.position_encoding(dec.vocab_embedding(tgt))
+    for layer in dec.transformer.layers:
+        x = layer(x, memory, tgt_mask=mask)
+    pred = dec.wdc(dec.dropout_layer(x)).permute(1, 0, 2)
+    lens, sort_ind = caplens.squeeze(1).sort(dim=0, descending=True)
+    caps_sorted, pred = caps[sort_ind], pred[sort_ind]
+    decode_lengths = (lens - 1).tolist()
+    from torch.nn.utils.rnn import pack_padded_sequence
+    scores = pack_padded_sequence(pred, decode_lengths, batch_first=True).data
+    targets = pack_padded_sequence(caps_sorted[:, 1:], decode_lengths, batch_first=True).data
+    crit = torch.nn.CrossEntropyLoss(ignore_index=0)
+    return crit(scores, targets), scores, targets, feat
+
+
+def run_cc(size, batch):
+    """SURVEY.md 8(f).2 fixture: reference encoder (`update_cc`, blocks 0-4) + reference `CaptionDecoder` modules,
+    packed cross-entropy, gradient clipping and the two Adam optimisers of scripts/train_CC.py:436-458 (dropout 0 so
+    that the result is deterministic); the restatement (oracle/caption.py) must reproduce all of it bit-for-bit."""
+    import contextlib
+    import io
+    from . import caption as oc
+    tr, mu, _ = ref_import.import_reference()
+    args = synth.make_cc_args(size=size, dropout=0.0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = tr.Trainer(args)
+    ora = om.Trainer(args)
+    assert list(ref.state_dict().keys()) == list(ora.state_dict().keys())
+    sd = synth.synth_state_dict(ref, seed=WEIGHT_SEED)
+    sd["decoder.position_encoding.pe"] = ref.state_dict()["decoder.position_encoding.pe"].clone()   # constant table
+    ref.load_state_dict(sd, strict=True)
+    ora.load_state_dict(sd, strict=True)
+    pre, post, _ = synth.synth_batch(batch, size, seed=DATA_SEED)
+    caps, caplens = synth.synth_captions(batch, seed=DATA_SEED, vocab_size=args.vocab_size)
+    ref.train(); ora.train()
+    # reference quirk (model/caption_decoder.py:557): `PositionalEncoding(args.embed_dim)` keeps its DEFAULT dropout
+    # 0.1 whatever --dropout says; it is switched off on the instances so that the fixture is deterministic
+    ref.decoder.position_encoding.dropout.p = 0.0
+    ora.decoder.position_encoding.dropout.p = 0.0
+    enc_r, dec_r = oc.make_cc_optimizers(ref, CC_LR, CC_LR)
+    enc_o, dec_o = oc.make_cc_optimizers(ora, CC_LR, CC_LR)
+    out = {"meta": np.array([size, batch, WEIGHT_SEED, DATA_SEED, CC_STEPS, args.vocab_size], dtype=np.int64),
+           "lr": np.array(CC_LR), "grad_clip": np.array(CC_CLIP)}
+    losses = []
+    for it in range(CC_STEPS):
+        loss, scores, targets, feat = ref_cc_forward(ref, pre, post, caps, caplens)
+        lo, so, to, fo = oc.cc_forward_loss(ora, pre, post, caps, caplens)
+        assert torch.equal(feat, fo) and torch.equal(scores, so) and torch.equal(targets, to) and loss.item() == lo.item()
+        for o in (dec_r, enc_r, dec_o, enc_o):
+            o.zero_grad()
+        loss.backward(); lo.backward()
+        named, on = dict(ref.named_parameters()), dict(ora.named_parameters())
+        names = [n for n, p in ref.named_parameters() if p.grad is not None]
+        assert names == [n for n, p in ora.named_parameters() if p.grad is not None]
+        assert all(torch.equal(on[n].grad, named[n].grad) for n in names)
+        if it == 0:
+            stride = max(feat.shape[-1] // 8, 1)
+            out["feat_lattice"] = feat.detach()[:, :, ::stride, ::stride].numpy()
+            out["feat_summary"] = summarize(feat)
+            out["scores_summary"] = summarize(scores)
+            out["scores_rows"] = scores.detach()[::max(scores.shape[0] // 16, 1)].numpy()
+            out["targets"] = targets.numpy()
+            out["grad_names"] = np.array(names)
+            out["grad_norms"] = np.array([named[n].grad.norm().item() for n in names])
+            out["unused_param_count"] = np.array(sum(p.numel() for p in ref.parameters() if p.grad is None))
+            top1 = (scores.argmax(1) == targets).float().mean().item()
+            out["top1"] = np.array(top1)
+        for net, (eo, do) in ((ref, (enc_r, dec_r)), (ora, (enc_o, dec_o))):
+            mu.clip_gradient(do, CC_CLIP)
+            mu.clip_gradient(eo, CC_CLIP)
+            eo.step(); do.step()
+        losses.append(loss.item())
+    out["loss_curve"] = np.array(losses)
+    fin, fo = ref.state_dict(), ora.state_dict()
+    assert all(torch.equal(fin[k], fo[k]) for k in fin)
+    out["final_param_l2"] = np.array([fin[str(n)].double().norm().item() for n in out["grad_names"]])
+    # fp64 yardstick (same reference modules)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref64 = tr.Trainer(args)
+    ref64.load_state_dict(sd, strict=True)
+    ref64 = ref64.double().train()
+    ref64.decoder.position_encoding.dropout.p = 0.0
+    l64, s64, _, f64 = ref_cc_forward(ref64, pre.double(), post.double(), caps, caplens)
+    l64.backward()
+    n64 = dict(ref64.named_parameters())
+    stride = max(f64.shape[-1] // 8, 1)
+    out["loss_f64"] = np.array(l64.item())
+    out["feat_lattice_f64"] = f64.detach()[:, :, ::stride, ::stride].numpy()
+    out["scores_rows_f64"] = s64.detach()[::max(s64.shape[0] // 16, 1)].numpy()
+    out["grad_norms_f64"] = np.array([n64[str(n)].grad.norm().item() for n in out["grad_names"]])
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(GOLDEN_DIR, f"cc_s{size}_b{batch}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[gen_golden] CC restatement == reference (encoder feature, logits, loss, every gradient, {CC_STEPS} clipped "
+          f"Adam steps); wrote {path} ({os.path.getsize(path) / 1024:.1f} kB); loss curve {losses} (fp64 first {l64.item():.6f})")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", type=int, nargs="+", default=[64, 256])
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--scd-only", action="store_true", help="only regenerate the SCD fixture")
+    ap.add_argument("--cc-only", action="store_true", help="only regenerate the CC fixtures")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    if not a.scd_only:
+    if not a.scd_only and not a.cc_only:
         for s in a.sizes:
             run(s, a.batch)
-    run_scd(64, a.batch)
+    if not a.cc_only:
+        run_scd(64, a.batch)
+    if not a.scd_only:
+        for s in (64, 256):
+            run_cc(s, a.batch)
 
 
 if __name__ == "__main__":

@@ -254,8 +254,11 @@ class Trainer(nn.Module):
             self.decoder_loc = ChangeDecoder(args, in_dim=self.embed_dims, has_sigmoid=True)
             weight_init(self.decoder_cls)
             weight_init(self.decoder_loc)
+        elif k == 1 and "CC" in args.dataset:   # change captioning (reference model/trainer.py:217-218)
+            from .caption import CaptionDecoder
+            self.decoder = CaptionDecoder(args)
         else:
-            raise AssertionError("CC head not part of this oracle yet")
+            assert False
 
     def update_bcd(self, x, y):
         feats = self.encoder(x, y)
@@ -266,6 +269,10 @@ class Trainer(nn.Module):
         return (self.decoder_pre([f[0] for f in feats]),
                 self.decoder_post([f[2] for f in feats]),
                 self.decoder_change([f[1] for f in feats]))
+
+    def update_cc(self, x, y):
+        """reference model/trainer.py:292-306: blocks 0..4 without enhancement, perception frame of res5."""
+        return self.encoder(x, y, output_final=True)
 
     def update_bda(self, x, y):
         feats = self.encoder(x, y)

@@ -340,3 +340,84 @@ def test_shrink_lr_prints_like_the_reference(capsys):
     assert "DECAYING learning rate" in capsys.readouterr().out
     adjust_learning_rate(None, opt, shrink_factor=0.5, verbose=False)
     assert capsys.readouterr().out == ""
+
+
+# ------------------------------------------------------------------ change captioning: oracle side
+def _cc_oracle(size, batch, vocab):
+    from oracle import caption as oc, model as om, synth
+    args = synth.make_cc_args(size=size, vocab_size=vocab, dropout=0.0)
+    net = om.Trainer(args)
+    sd = synth.synth_state_dict(net, seed=16)
+    sd["decoder.position_encoding.pe"] = net.state_dict()["decoder.position_encoding.pe"].clone()   # constant table
+    net.load_state_dict(sd)
+    net.train()
+    net.decoder.position_encoding.dropout.p = 0.0   # reference quirk: fixed 0.1 regardless of --dropout (see gen_golden)
+    pre, post, _ = synth.synth_batch(batch, size, seed=0)
+    caps, caplens = synth.synth_captions(batch, seed=0, vocab_size=vocab)
+    return net, oc, (pre, post, caps, caplens)
+
+
+def test_oracle_cc_matches_reference_golden_s64(golden_dir):
+    """The CC restatement (oracle/caption.py + Trainer.update_cc) against the fixture the REAL reference modules
+    produced: encoder feature (B,192,4,4), packed logits, loss, gradient norms, two clipped Adam steps."""
+    G = np.load(os.path.join(golden_dir, "cc_s64_b2.npz"))
+    size, batch, vocab = int(G["meta"][0]), int(G["meta"][1]), int(G["meta"][5])
+    net, oc, (pre, post, caps, caplens) = _cc_oracle(size, batch, vocab)
+    enc_o, dec_o = oc.make_cc_optimizers(net, float(G["lr"]), float(G["lr"]))
+    losses = []
+    for it in range(int(G["meta"][4])):
+        loss, scores, targets, feat = oc.cc_forward_loss(net, pre, post, caps, caplens)
+        enc_o.zero_grad(); dec_o.zero_grad()
+        loss.backward()
+        if it == 0:
+            stride = max(feat.shape[-1] // 8, 1)
+            assert np.abs(feat.detach()[:, :, ::stride, ::stride].numpy() - G["feat_lattice"]).max() < 2e-5
+            rows = scores.detach()[::max(scores.shape[0] // 16, 1)].numpy()
+            assert np.abs(rows - G["scores_rows"]).max() < 2e-4
+            assert np.array_equal(targets.numpy(), G["targets"])
+            named = dict(net.named_parameters())
+            names = [str(n) for n in G["grad_names"]]
+            assert names == [n for n, p in net.named_parameters() if p.grad is not None]
+            gn = np.array([named[n].grad.norm().item() for n in names])
+            assert np.allclose(gn, G["grad_norms"], rtol=5e-3, atol=1e-9)
+            assert sum(p.numel() for p in net.parameters() if p.grad is None) == int(G["unused_param_count"])
+        oc.clip_gradient(net.decoder.parameters(), float(G["grad_clip"]))
+        oc.clip_gradient(net.encoder.parameters(), float(G["grad_clip"]))
+        enc_o.step(); dec_o.step()
+        losses.append(loss.item())
+    assert np.abs(np.array(losses) - G["loss_curve"]).max() < 2e-4, (losses, G["loss_curve"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model"), reason="reference tree only exists in the build container")
+def test_cc_oracle_equals_imported_reference():
+    """State-dict keys of the CC Trainer and bit-identical logits / loss / gradients against the REAL reference
+    modules (model/caption_decoder.py) driven through the per-layer loop of SURVEY.md 8(c)."""
+    import contextlib
+    import io
+    from oracle import caption as oc, model as om, ref_import, synth
+    from oracle.gen_golden import ref_cc_forward
+    tr, _, _ = ref_import.import_reference()
+    args = synth.make_cc_args(size=32, vocab_size=97, dropout=0.0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = tr.Trainer(args)
+    ora = om.Trainer(args)
+    assert list(ref.state_dict().keys()) == list(ora.state_dict().keys())
+    assert all(a.shape == b.shape for a, b in zip(ref.state_dict().values(), ora.state_dict().values()))
+    sd = synth.synth_state_dict(ref, seed=5)
+    sd["decoder.position_encoding.pe"] = ref.state_dict()["decoder.position_encoding.pe"].clone()
+    assert torch.equal(sd["decoder.position_encoding.pe"], ora.state_dict()["decoder.position_encoding.pe"])
+    ref.load_state_dict(sd); ora.load_state_dict(sd)
+    ref.train(); ora.train()
+    ref.decoder.position_encoding.dropout.p = ora.decoder.position_encoding.dropout.p = 0.0
+    pre, post, _ = synth.synth_batch(3, 32, seed=1)
+    caps, caplens = synth.synth_captions(3, seed=1, vocab_size=97)
+    la, sa, ta, fa = ref_cc_forward(ref, pre, post, caps, caplens)
+    lb, sb, tb, fb = oc.cc_forward_loss(ora, pre, post, caps, caplens)
+    assert torch.equal(fa, fb) and torch.equal(sa, sb) and torch.equal(ta, tb) and la.item() == lb.item()
+    la.backward(); lb.backward()
+    for (n, p), (_, q) in zip(ref.named_parameters(), ora.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), n
+    unused = {n.split(".")[4] for n, p in ref.named_parameters() if p.grad is None and n.startswith("decoder.transformer.layers.0.")}
+    assert unused == {"self_attn2", "multihead_attn", "multihead_attn3", "linear1", "linear2", "norm3", "fc_alpha1", "fc_alpha2", "fc_alpha3"}
