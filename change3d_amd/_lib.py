@@ -100,6 +100,8 @@ SIGNATURES = {
     "c3d_stem_bwd_wx": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_convT4s2_fwd": (i32, [vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, vp]),
     "c3d_convT4s2_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "c3d_convT4s2_wgrad_ws_floats": (i64, [i32, i32, i32, i32]),
+    "c3d_convT4s2_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "c3d_col_sum": (i32, [vp, vp, i64, i32, i32, i32, vp]),
     "c3d_head3x3_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_head3x3_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -1,0 +1,403 @@
+// ConvTranspose2d k=4 s=2 p=1 of the ChangeDecoder (reference model/change_decoder.py:30-45: `up_c4/up_c3/up_c2[1]`,
+// C -> C channels, C = 48 / 24 / 24) on MFMA for the bf16 (throughput) path: forward, data gradient and weight
+// gradient.  The round-1 kernels were scalar-FMA stencils (decoder.hip; kept for the f32 parity path): at the top
+// decoder level (24 channels, 128x128 -> 256x256, B=32) they ran at 0.24 / 0.28 ms (forward / data gradient) and the
+// weight gradient -- 16 shifted passes of the generic pointwise weight-gradient kernel -- at 0.75 ms, against ~50 us of
+// HBM time each.  A transposed convolution is 2304 MAC per output pixel at C=24: matrix-core work.
+//
+//   forward   out[b, 2qy+py, 2qx+px, co] = bias[co] + skip[...] + sum_{jy,jx,ci} in[b, qy+dy, qx+dx, ci] W[ci][co][ky][kx]
+//             -> per output parity class (py,px) a GEMM  [16 pixels] x [K = 4 taps x C] x [C]:  the data operand of a
+//             lane is 8 consecutive channels of ONE neighbour pixel = one 16-byte global load (no LDS staging: the 3x3
+//             neighbourhood re-reads hit L1/L2), the weight operand is a ready-made fragment image in LDS.
+//   bwd data  din[b, iy, ix, ci] = sum_{ky,kx,co} dout[b, 2iy-1+ky, 2ix-1+kx, co] W[ci][co][ky][kx]
+//             -> one GEMM [16 pixels] x [K = 16 taps x C] x [C], same operand scheme.
+//   wgrad     dW[ci][co][ky][kx] = sum_{b,i,j} t[b,i,j,ci] dcur[b, 2i-1+ky, 2j-1+kx, co]: the contraction runs over
+//             PIXELS, so both operands are read "transposed" (one channel, 8 consecutive pixels) from an LDS copy of a
+//             4x32-pixel tile of t and its (10 x 66)-pixel patch of dcur, staged ONCE for all 16 taps (the generic
+//             kernel re-read dcur 16 times); wave w owns the 4 taps with ky = w; per-workgroup partial sums go to a
+//             workspace and a small reducer adds them into dW (fixed order: deterministic).
+#include "common.h"
+#include "../../include/change3d_hip.h"
+#include "pw_common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4_t mfma_bf16(const u32x4 a, const u32x4 b, const f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// output parity (0|1), tap index j (0|1) -> kernel index k and input offset d (out = 2*in - 1 + k)
+__device__ __forceinline__ void par_tap(const int par, const int j, int& k, int& d) {
+  if (par == 0) { k = j ? 3 : 1; d = j ? -1 : 0; }
+  else { k = j ? 2 : 0; d = j ? 0 : 1; }
+}
+
+__device__ __forceinline__ u32x4 ld16(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int C>
+__global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const bf16_t* __restrict__ skip,
+                                                             const int64_t skip_bstride, bf16_t* __restrict__ out, const int B,
+                                                             const int h, const int wd) {
+  constexpr int NT = (C + 15) / 16, KS = 4 * C / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* Wl = reinterpret_cast<u32x4*>(smem);   // [4 parities][NT][KS][64 lanes] weight fragments
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- weight fragment image: element (f, l, e): co = nt*16 + (l&15), k = ks*32 + (l>>4)*8 + e = tap*C + ci
+  for (int i = tid; i < 4 * NT * KS * 64; i += 256) {
+    const int l = i & 63, f = i >> 6;
+    const int ks = f % KS, nt = (f / KS) % NT, par = f / (KS * NT);
+    const int co = nt * 16 + (l & 15);
+    uint32_t pk[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      float v[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int k = ks * 32 + (l >> 4) * 8 + e2 * 2 + hh;
+        const int tap = k / C, ci = k - tap * C;
+        int ky, kx, dd;
+        par_tap(par >> 1, tap >> 1, ky, dd);
+        par_tap(par & 1, tap & 1, kx, dd);
+        v[hh] = co < C ? w[(((size_t)ci * C + co) * 4 + ky) * 4 + kx] : 0.f;
+      }
+      pk[e2] = pack_bf16x2(v[0], v[1]);
+    }
+    Wl[i] = u32x4{pk[0], pk[1], pk[2], pk[3]};
+  }
+  __syncthreads();
+  const int p = lane & 15, g = lane >> 4;
+  const int tiles_x = (wd + 15) >> 4;
+  const int64_t ntile = (int64_t)B * h * tiles_x;
+  const int H = 2 * h, W = 2 * wd;
+  int tapv[KS], civ[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) { const int k0 = ks * 32 + g * 8; tapv[ks] = k0 / C; civ[ks] = k0 - tapv[ks] * C; }
+  float bv[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int co = nt * 16 + g * 4 + r; bv[nt][r] = co < C ? bias[co] : 0.f; }
+  for (int64_t t = ((int64_t)blockIdx.x * 4 + wave); t < ntile; t += (int64_t)gridDim.x * 4) {
+    const int tx = (int)(t % tiles_x);
+    const int64_t r_ = t / tiles_x;
+    const int qy = (int)(r_ % h), b = (int)(r_ / h);
+    const int qx = tx * 16 + p;
+    const bf16_t* inb = in + (size_t)b * h * wd * C;
+#pragma unroll
+    for (int par = 0; par < 4; ++par) {
+      const int py = par >> 1, px = par & 1;
+      u32x4 xf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        int ky, kx, dy, dx;
+        par_tap(py, tapv[ks] >> 1, ky, dy);
+        par_tap(px, tapv[ks] & 1, kx, dx);
+        const int yy = qy + dy, xx = qx + dx;
+        const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < wd;
+        xf[ks] = ok ? ld16(inb + ((size_t)yy * wd + xx) * C + civ[ks]) : u32x4{0u, 0u, 0u, 0u};
+      }
+      f32x4_t acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{bv[nt][0], bv[nt][1], bv[nt][2], bv[nt][3]};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(Wl[((par * NT + nt) * KS + ks) * 64 + lane], xf[ks], acc[nt]);
+      if (qx < wd) {
+        const int oy = 2 * qy + py, ox = 2 * qx + px;
+        const size_t o = ((size_t)oy * W + ox) * C;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = nt * 16 + g * 4;
+          if (co < C) {
+            float v0 = acc[nt][0], v1 = acc[nt][1], v2 = acc[nt][2], v3 = acc[nt][3];
+            if (skip) {
+              const uint2 s = *reinterpret_cast<const uint2*>(skip + (size_t)b * skip_bstride + o + co);
+              v0 += __uint_as_float(s.x << 16); v1 += __uint_as_float(s.x & 0xffff0000u);
+              v2 += __uint_as_float(s.y << 16); v3 += __uint_as_float(s.y & 0xffff0000u);
+            }
+            *reinterpret_cast<uint2*>(out + (size_t)b * H * W * C + o + co) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ data gradient
+template <int C>
+__global__ __launch_bounds__(256) void convt_bwd_data_mfma_kernel(const bf16_t* __restrict__ dout, const float* __restrict__ w,
+                                                                  bf16_t* __restrict__ din, const int B, const int h,
+                                                                  const int wd) {
+  constexpr int NT = (C + 15) / 16, KS = 16 * C / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* Wl = reinterpret_cast<u32x4*>(smem);   // [NT][KS][64]: A[i = ci][k = tap16*C + co] = W[ci][co][ky][kx]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < NT * KS * 64; i += 256) {
+    const int l = i & 63, f = i >> 6;
+    const int ks = f % KS, nt = f / KS;
+    const int ci = nt * 16 + (l & 15);
+    uint32_t pk[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      float v[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int k = ks * 32 + (l >> 4) * 8 + e2 * 2 + hh;
+        const int tap = k / C, co = k - tap * C;
+        v[hh] = ci < C ? w[((size_t)ci * C + co) * 16 + tap] : 0.f;
+      }
+      pk[e2] = pack_bf16x2(v[0], v[1]);
+    }
+    Wl[i] = u32x4{pk[0], pk[1], pk[2], pk[3]};
+  }
+  __syncthreads();
+  const int p = lane & 15, g = lane >> 4;
+  const int tiles_x = (wd + 15) >> 4;
+  const int64_t ntile = (int64_t)B * h * tiles_x;
+  const int H = 2 * h, W = 2 * wd;
+  for (int64_t t = ((int64_t)blockIdx.x * 4 + wave); t < ntile; t += (int64_t)gridDim.x * 4) {
+    const int tx = (int)(t % tiles_x);
+    const int64_t r_ = t / tiles_x;
+    const int iy = (int)(r_ % h), b = (int)(r_ / h);
+    const int ix = tx * 16 + p;
+    const bf16_t* db = dout + (size_t)b * H * W * C;
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k0 = ks * 32 + g * 8;
+      const int tap = k0 / C, co0 = k0 - tap * C;
+      const int oy = 2 * iy - 1 + (tap >> 2), ox = 2 * ix - 1 + (tap & 3);
+      const bool ok = oy >= 0 && oy < H && ox >= 0 && ox < W && ix < wd;
+      const u32x4 xf = ok ? ld16(db + ((size_t)oy * W + ox) * C + co0) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(Wl[(nt * KS + ks) * 64 + lane], xf, acc[nt]);
+    }
+    if (ix < wd) {
+      bf16_t* o = din + (((size_t)b * h + iy) * wd + ix) * C;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ci = nt * 16 + g * 4;
+        if (ci < C)
+          *reinterpret_cast<uint2*>(o + ci) = make_uint2(pack_bf16x2(acc[nt][0], acc[nt][1]), pack_bf16x2(acc[nt][2], acc[nt][3]));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+constexpr int WG_TH = 4, WG_TW = 32;                       // tile of input-resolution pixels (one k-step = one row)
+constexpr int WG_PH = 2 * WG_TH + 2, WG_PW = 2 * WG_TW + 2;  // its dcur patch
+
+template <int C>
+__global__ __launch_bounds__(256) void convt_wgrad_mfma_kernel(const bf16_t* __restrict__ tin, const bf16_t* __restrict__ dcur,
+                                                               float* __restrict__ ws, const int B, const int h, const int wd) {
+  constexpr int NT = (C + 15) / 16;
+  constexpr int CP = C + 2;            // LDS pixel stride in bf16 (odd dword count: spreads the 8-pixel column reads over banks)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Tl = reinterpret_cast<bf16_t*>(smem);                       // [WG_TH][WG_TW][CP]
+  bf16_t* Dl = Tl + WG_TH * WG_TW * CP;                               // [WG_PH][WG_PW][CP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // wave = ky
+  const int i15 = lane & 15, g = lane >> 4;
+  const int tiles_x = (wd + WG_TW - 1) / WG_TW, tiles_y = (h + WG_TH - 1) / WG_TH;
+  const int64_t ntile = (int64_t)B * tiles_y * tiles_x;
+  const int H = 2 * h, W = 2 * wd;
+  f32x4_t acc[4][NT][NT];   // [kx][ci tile][co tile]
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int c = 0; c < NT; ++c) acc[kx][a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  constexpr int VPP = C / 8;   // 16-byte vectors per pixel
+  for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int tx = (int)(t % tiles_x);
+    const int64_t r_ = t / tiles_x;
+    const int ty = (int)(r_ % tiles_y), b = (int)(r_ / tiles_y);
+    const int iy0 = ty * WG_TH, ix0 = tx * WG_TW;
+    __syncthreads();   // previous tile's reads are done
+    // ---- stage t tile and dcur patch (zero outside the image); 8 bf16 per 16-byte load, written as 4 dwords (CP is even)
+    for (int i = tid; i < WG_TH * WG_TW * VPP; i += 256) {
+      const int v = i % VPP, px = (i / VPP) % WG_TW, py = i / (VPP * WG_TW);
+      const int iy = iy0 + py, ix = ix0 + px;
+      u32x4 x = u32x4{0u, 0u, 0u, 0u};
+      if (iy < h && ix < wd) x = ld16(tin + (((size_t)b * h + iy) * wd + ix) * C + v * 8);
+      uint32_t* d = reinterpret_cast<uint32_t*>(Tl + (py * WG_TW + px) * CP + v * 8);
+      d[0] = x[0]; d[1] = x[1]; d[2] = x[2]; d[3] = x[3];
+    }
+    for (int i = tid; i < WG_PH * WG_PW * VPP; i += 256) {
+      const int v = i % VPP, px = (i / VPP) % WG_PW, py = i / (VPP * WG_PW);
+      const int oy = 2 * iy0 - 1 + py, ox = 2 * ix0 - 1 + px;
+      u32x4 x = u32x4{0u, 0u, 0u, 0u};
+      if (oy >= 0 && oy < H && ox >= 0 && ox < W) x = ld16(dcur + (((size_t)b * H + oy) * W + ox) * C + v * 8);
+      uint32_t* d = reinterpret_cast<uint32_t*>(Dl + (py * WG_PW + px) * CP + v * 8);
+      d[0] = x[0]; d[1] = x[1]; d[2] = x[2]; d[3] = x[3];
+    }
+    __syncthreads();
+    // ---- one k-step per tile row: K = 32 pixels (j = g*8 + e)
+#pragma unroll 1
+    for (int r = 0; r < WG_TH; ++r) {
+      u32x4 af[NT];   // A[i = ci][k = pixel] = t[r][j][ci]
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int ci = a * 16 + i15;
+        uint32_t pk[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const bf16_t* s = Tl + (r * WG_TW + g * 8 + e2 * 2) * CP + ci;
+          const uint32_t lo = ci < C ? s[0] : 0, hi = ci < C ? s[CP] : 0;
+          pk[e2] = lo | (hi << 16);
+        }
+        af[a] = u32x4{pk[0], pk[1], pk[2], pk[3]};
+      }
+      const int prow = 2 * r + wave;        // patch row of tap ky = wave: oy - (2*iy0 - 1) = 2r + ky
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+          const int co = c * 16 + i15;
+          uint32_t pk[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const bf16_t* s = Dl + (prow * WG_PW + 2 * (g * 8 + e2 * 2) + kx) * CP + co;   // B[k = pixel][j = co]
+            const uint32_t lo = co < C ? s[0] : 0, hi = co < C ? s[2 * CP] : 0;
+            pk[e2] = lo | (hi << 16);
+          }
+          const u32x4 bfrag = u32x4{pk[0], pk[1], pk[2], pk[3]};
+#pragma unroll
+          for (int a = 0; a < NT; ++a) acc[kx][a][c] = mfma_bf16(af[a], bfrag, acc[kx][a][c]);
+        }
+      }
+    }
+  }
+  // ---- per-workgroup partial: ws[wg][tap = ky*4+kx][ci][co] (C x C each); D[i = ci = g*4 + r][j = co = i15]
+  float* dst = ws + (size_t)blockIdx.x * 16 * C * C;
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const int co = c * 16 + i15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = a * 16 + g * 4 + r;
+          if (ci < C && co < C) dst[((size_t)(wave * 4 + kx) * C + ci) * C + co] = acc[kx][a][c][r];
+        }
+      }
+}
+
+// dw[ci][co][ky][kx] += sum over workgroups of ws[wg][tap][ci][co]
+__global__ void convt_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, const int nwg, const int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = 16 * C * C;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int g = 0; g < nwg; ++g) s += ws[(size_t)g * n + i];
+  const int co = i % C, ci = (i / C) % C, tap = i / (C * C);
+  dw[((size_t)ci * C + co) * 16 + tap] += s;
+}
+
+int persistent_grid(const int64_t work_items, const int per_cu) {
+  int64_t gmax = (int64_t)device_cus() * per_cu;
+  if (gmax > work_items) gmax = work_items;
+  return (int)(gmax < 1 ? 1 : gmax);
+}
+
+template <int C>
+int launch_fwd(const void* in, const float* w, const float* bias, const void* skip, int64_t skip_bstride, void* out, int B,
+               int h, int wd, hipStream_t st) {
+  constexpr int NT = (C + 15) / 16, KS = 4 * C / 32;
+  const size_t lds = (size_t)4 * NT * KS * 64 * 16;
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_fwd_mfma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return C3D_E_UNSUPPORTED;
+    attr = true;
+  }
+  const int64_t wave_tiles = (int64_t)B * h * ((wd + 15) / 16);
+  const int grid = persistent_grid((wave_tiles + 3) / 4, C <= 24 ? 6 : 2);
+  convt_fwd_mfma_kernel<C><<<grid, 256, lds, st>>>((const bf16_t*)in, w, bias, (const bf16_t*)skip, skip_bstride, (bf16_t*)out, B, h, wd);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int C>
+int launch_bwd_data(const void* dout, const float* w, void* din, int B, int h, int wd, hipStream_t st) {
+  constexpr int NT = (C + 15) / 16, KS = 16 * C / 32;
+  const size_t lds = (size_t)NT * KS * 64 * 16;
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_bwd_data_mfma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return C3D_E_UNSUPPORTED;
+    attr = true;
+  }
+  const int64_t wave_tiles = (int64_t)B * h * ((wd + 15) / 16);
+  const int grid = persistent_grid((wave_tiles + 3) / 4, C <= 24 ? 6 : 2);
+  convt_bwd_data_mfma_kernel<C><<<grid, 256, lds, st>>>((const bf16_t*)dout, w, (bf16_t*)din, B, h, wd);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int C>
+int wgrad_grid(int B, int h, int wd) {
+  const int64_t tiles = (int64_t)B * ((h + WG_TH - 1) / WG_TH) * ((wd + WG_TW - 1) / WG_TW);
+  return persistent_grid(tiles, 2);
+}
+
+template <int C>
+int launch_wgrad(const void* t, const void* dcur, float* dw, float* ws, int B, int h, int wd, hipStream_t st) {
+  constexpr int CP = C + 2;
+  const size_t lds = (size_t)(WG_TH * WG_TW + WG_PH * WG_PW) * CP * 2;
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_wgrad_mfma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return C3D_E_UNSUPPORTED;
+    attr = true;
+  }
+  const int grid = wgrad_grid<C>(B, h, wd);
+  convt_wgrad_mfma_kernel<C><<<grid, 256, lds, st>>>((const bf16_t*)t, (const bf16_t*)dcur, ws, B, h, wd);
+  C3D_CHECK_LAUNCH();
+  const int n = 16 * C * C;
+  convt_wgrad_reduce_kernel<<<(n + 255) / 256, 256, 0, st>>>(ws, dw, grid, C);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+// bf16 dispatch used by c3d_convT4s2_fwd / c3d_convT4s2_bwd_data (decoder.hip); returns C3D_E_UNSUPPORTED for shapes
+// the MFMA kernels do not cover (the caller then falls back to the scalar kernels).
+int c3d_detail_convt_fwd_bf16(const void* in, const float* w, const float* bias, const void* skip, int64_t skip_bstride, void* out,
+                              int B, int h, int wd, int C, hipStream_t st) {
+  if ((skip_bstride & 3) != 0) return C3D_E_UNSUPPORTED;
+  if (C == 24) return launch_fwd<24>(in, w, bias, skip, skip_bstride, out, B, h, wd, st);
+  if (C == 48) return launch_fwd<48>(in, w, bias, skip, skip_bstride, out, B, h, wd, st);
+  return C3D_E_UNSUPPORTED;
+}
+
+int c3d_detail_convt_bwd_data_bf16(const void* dout, const float* w, void* din, int B, int h, int wd, int C, hipStream_t st) {
+  if (C == 24) return launch_bwd_data<24>(dout, w, din, B, h, wd, st);
+  if (C == 48) return launch_bwd_data<48>(dout, w, din, B, h, wd, st);
+  return C3D_E_UNSUPPORTED;
+}
+
+extern "C" int64_t c3d_convT4s2_wgrad_ws_floats(int32_t B, int32_t h, int32_t wd, int32_t C) {
+  if (C == 24) return (int64_t)wgrad_grid<24>(B, h, wd) * 16 * C * C;
+  if (C == 48) return (int64_t)wgrad_grid<48>(B, h, wd) * 16 * C * C;
+  return -1;
+}
+
+extern "C" int c3d_convT4s2_wgrad(const void* t, const void* dcur, float* dw, float* ws, int32_t B, int32_t h, int32_t wd,
+                                  int32_t C, int32_t dtype, void* stream) {
+  if (!t || !dcur || !dw || !ws || B <= 0 || h <= 0 || wd <= 0) return C3D_E_BADARG;
+  if (dtype != C3D_DT_BF16) return C3D_E_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (C == 24) return launch_wgrad<24>(t, dcur, dw, ws, B, h, wd, st);
+  if (C == 48) return launch_wgrad<48>(t, dcur, dw, ws, B, h, wd, st);
+  return C3D_E_UNSUPPORTED;
+}

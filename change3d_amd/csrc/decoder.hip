@@ -372,10 +372,23 @@ __global__ __launch_bounds__(HD_TH * HD_TW) void head_bwd_kernel(
 
 }  // namespace
 
+// bf16 (throughput) path: MFMA kernels in convt_mfma.hip (C3D_CONVT_MFMA=0 keeps the scalar kernels for A/B runs)
+int c3d_detail_convt_fwd_bf16(const void* in, const float* w, const float* bias, const void* skip, int64_t skip_bstride, void* out,
+                              int B, int h, int wd, int C, hipStream_t st);
+int c3d_detail_convt_bwd_data_bf16(const void* dout, const float* w, void* din, int B, int h, int wd, int C, hipStream_t st);
+static bool convt_mfma_on() {
+  static const bool on = !(getenv("C3D_CONVT_MFMA") && atoi(getenv("C3D_CONVT_MFMA")) == 0);
+  return on;
+}
+
 extern "C" int c3d_convT4s2_fwd(const void* in, const float* w, const float* bias, const void* skip,
                                 int64_t skip_bstride, void* out, int32_t B, int32_t h, int32_t wd, int32_t C,
                                 int32_t dtype, void* stream) {
   if (!in || !w || !bias || !out || B <= 0 || h <= 0 || wd <= 0 || (C & 7) || C > 96) return C3D_E_BADARG;
+  if (dtype == C3D_DT_BF16 && convt_mfma_on()) {
+    const int rc = c3d_detail_convt_fwd_bf16(in, w, bias, skip, skip_bstride, out, B, h, wd, C, reinterpret_cast<hipStream_t>(stream));
+    if (rc != C3D_E_UNSUPPORTED) return rc;
+  }
   const int G = C / 8;
   const size_t lds = (size_t)4 * C * C * sizeof(float);
   const int nthr = (CT_QH * CT_QW / 2) * G;
@@ -403,6 +416,10 @@ extern "C" int c3d_convT4s2_fwd(const void* in, const float* w, const float* bia
 extern "C" int c3d_convT4s2_bwd_data(const void* dout, const float* w, void* din, int32_t B, int32_t h, int32_t wd,
                                      int32_t C, int32_t dtype, void* stream) {
   if (!dout || !w || !din || B <= 0 || h <= 0 || wd <= 0 || (C & 7) || C > 96) return C3D_E_BADARG;
+  if (dtype == C3D_DT_BF16 && convt_mfma_on()) {
+    const int rc = c3d_detail_convt_bwd_data_bf16(dout, w, din, B, h, wd, C, reinterpret_cast<hipStream_t>(stream));
+    if (rc != C3D_E_UNSUPPORTED) return rc;
+  }
   const int G = C / 8;
   const size_t lds = (size_t)4 * C * C * sizeof(float);
   const int nthr = CT_QH * CT_QW * G;

@@ -95,8 +95,11 @@ class _DecoderFn(torch.autograd.Function):
                 ops.col_sum(dcur, gb, B * 4 * h * w, Cout, dt)
                 # the 4x4 taps (ky, kx) in ONE launch: tap t reads dcur at (2i + ky - 1, 2j + kx - 1) and
                 # accumulates at gw[ci][co][ky][kx] (16 launches of ~20-50 us each before)
-                ops.pw_wgrad(t, dcur, gw, M=M, K=Cout, N=Cout, dw_sn=Cout * 16, dw_sk=16, dtype=dt,
-                             row_mode=ops.ROWS_S2SHIFT, H=2 * h, W=2 * w, taps=16, dw_tap_stride=1)
+                if dt == ops.DT_BF16 and ops.CONVT_MFMA and Cout in (24, 48):
+                    ops.convT_wgrad(t, dcur, gw, B, h, w, Cout, dt)   # one MFMA pass over t and dcur for all 16 taps
+                else:
+                    ops.pw_wgrad(t, dcur, gw, M=M, K=Cout, N=Cout, dw_sn=Cout * 16, dw_sk=16, dtype=dt,
+                                 row_mode=ops.ROWS_S2SHIFT, H=2 * h, W=2 * w, taps=16, dw_tap_stride=1)
 
             ops.side_run(convt_param_grads, dcur, t)   # leaves of the backward graph: side stream
             dx = torch.empty((B, h, w, cpad(Cin)), dtype=act, device=dev)

@@ -410,6 +410,16 @@ def convT_bwd_data(dout, w, din, B, h, wd, C_, dtype):
     _launch("c3d_convT4s2_bwd_data", (dout.numel() + din.numel()) * _es(dtype), L.lib().c3d_convT4s2_bwd_data, _p(dout), _p(w), _p(din), B, h, wd, C_, dtype, _stream())
 
 
+CONVT_MFMA = os.environ.get("C3D_CONVT_MFMA", "1") != "0"
+
+
+def convT_wgrad(t, dout, dw, B, h, wd, C_, dtype):
+    """ConvTranspose2d k4s2p1 weight gradient on MFMA (bf16 storage only)."""
+    ws = _ws(t.device, L.lib().c3d_convT4s2_wgrad_ws_floats(B, h, wd, C_))
+    _launch("c3d_convT4s2_wgrad", (t.numel() + dout.numel()) * _es(dtype), L.lib().c3d_convT4s2_wgrad, _p(t), _p(dout), _p(dw),
+            ws.data_ptr(), B, h, wd, C_, dtype, _stream())
+
+
 def col_sum(x, out, M, C_, dtype):
     _launch("c3d_col_sum", M * cpad(C_) * _es(dtype), L.lib().c3d_col_sum, _p(x), _p(out), M, C_, cpad(C_), dtype, _stream())
 

@@ -256,6 +256,13 @@ int c3d_convT4s2_fwd(const void* in, const float* w, const float* bias, const vo
                      int32_t dtype, void* stream);
 int c3d_convT4s2_bwd_data(const void* dout, const float* w, void* din, int32_t B, int32_t h, int32_t wd,
                           int32_t C, int32_t dtype, void* stream);
+/* weight gradient of the transposed convolution on MFMA (bf16 storage, C = 24 | 48): dw[ci][co][ky][kx] +=
+ * sum t[b,i,j,ci] * dout[b,2i-1+ky,2j-1+kx,co]; t is the layer input [B][h][wd][C], dout its output gradient
+ * [B][2h][2wd][C]; ws: f32 scratch of c3d_convT4s2_wgrad_ws_floats elements.  (f32 storage uses c3d_pw_wgrad with
+ * C3D_ROWS_S2SHIFT / taps = 16; this entry returns C3D_E_UNSUPPORTED for it.)                               */
+int64_t c3d_convT4s2_wgrad_ws_floats(int32_t B, int32_t h, int32_t wd, int32_t C);
+int c3d_convT4s2_wgrad(const void* t, const void* dout, float* dw, float* ws, int32_t B, int32_t h, int32_t wd,
+                       int32_t C, int32_t dtype, void* stream);
 int c3d_col_sum(const void* x, float* out, int64_t M, int32_t C, int32_t Cp, int32_t dtype, void* stream);
 int c3d_head3x3_fwd(const void* x, const float* w, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
                     int32_t NC, int32_t has_sigmoid, int32_t dtype, void* stream);
