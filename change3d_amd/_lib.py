@@ -113,6 +113,7 @@ SIGNATURES = {
     "c3d_cossim_bwd": (i32, [vp, vp, vp, vp, i64, i32, i64, i64, i64, i64, i64, vp, vp, vp]),
     "c3d_adam_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
     "c3d_confusion2": (i32, [vp, vp, i64, vp, vp]),
+    "c3d_build_clip": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "c3d_bcd_preprocess": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "c3d_stage_ws_bytes": (i32, [C.POINTER(StageDesc), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "c3d_stage_fwd": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp]),

@@ -70,7 +70,46 @@ __global__ __launch_bounds__(256) void bcd_preprocess_kernel(const uint8_t* __re
   }
 }
 
+// clip[b][c][t][y][x] (f32 NCDHW, what the stem reads): t = 0 <- pre, t = 1..K <- perception frames (shared by the
+// batch), t = K+1 <- post.  One 16-byte vector per thread per step; replaces expand + torch.cat
+// (reference model/trainer.py:155-162).
+__global__ __launch_bounds__(256) void build_clip_kernel(const float* __restrict__ pre, const float* __restrict__ post,
+                                                         const float* __restrict__ P, float* __restrict__ clip, int B, int K,
+                                                         int64_t hw4) {
+  const int T = K + 2;
+  const int64_t total = (int64_t)B * 3 * T * hw4;
+  const float4* p4 = reinterpret_cast<const float4*>(pre);
+  const float4* q4 = reinterpret_cast<const float4*>(post);
+  const float4* f4 = reinterpret_cast<const float4*>(P);
+  float4* o4 = reinterpret_cast<float4*>(clip);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i % hw4;
+    int64_t q = i / hw4;
+    const int t = (int)(q % T); q /= T;
+    const int c = (int)(q % 3);
+    const int b = (int)(q / 3);
+    float4 v;
+    if (t == 0) v = p4[((int64_t)b * 3 + c) * hw4 + r];
+    else if (t == T - 1) v = q4[((int64_t)b * 3 + c) * hw4 + r];
+    else v = f4[((int64_t)c * K + (t - 1)) * hw4 + r];
+    o4[i] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int c3d_build_clip(const float* pre, const float* post, const float* frames, float* clip, int32_t B, int32_t K,
+                              int32_t H, int32_t W, void* stream) {
+  if (!pre || !post || !frames || !clip || B <= 0 || K <= 0 || H <= 0 || W <= 0) return C3D_E_BADARG;
+  if (((int64_t)H * W) & 3) return C3D_E_UNSUPPORTED;
+  const int64_t hw4 = (int64_t)H * W / 4, total = (int64_t)B * 3 * (K + 2) * hw4;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  build_clip_kernel<<<dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(pre, post, frames, clip, B,
+                                                                                                  K, hw4);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int c3d_bcd_preprocess(const uint8_t* image6, const uint8_t* label, const uint8_t* flags, const float* mean6,
                                   const float* std6, float* pre, float* post, float* label_out, int32_t B, int32_t H,

@@ -14,7 +14,7 @@ from .. import ops
 from ..ops import cpad
 from .change_decoder import ChangeDecoder
 from .utils import weight_init
-from .x3d import create_x3d, to_logical, to_ndhwc
+from .x3d import _ClipStemFn, create_x3d, to_logical, to_ndhwc
 
 
 class _EnhanceFn(torch.autograd.Function):
@@ -141,20 +141,28 @@ class Encoder(nn.Module):
     def enhance(self, x: torch.Tensor, fc: nn.Module) -> torch.Tensor:
         return _EnhanceFn.apply(x, fc[0].weight, self.args.num_perception_frame + 1)
 
-    def base_forward(self, x: torch.Tensor, output_final: bool = False):
+    def base_forward(self, x: torch.Tensor, output_final: bool = False, _stem_out=None):
+        """`_stem_out`: blocks[0] already applied (the fused clip + stem path of `forward`)."""
         if output_final:
             for i in range(5):
-                x = self.x3d.blocks[i](x)
+                x = _stem_out if (i == 0 and _stem_out is not None) else self.x3d.blocks[i](x)
             return x[:, :, self.args.num_perception_frame]
         out = []
         for i in range(4):
-            x = self.x3d.blocks[i](x)
+            x = _stem_out if (i == 0 and _stem_out is not None) else self.x3d.blocks[i](x)
             x = self.enhance(x, self.fc[i])
             x, frames = tap_frames(x, 1, self.args.num_perception_frame)
             out.append(frames)
         return out
 
     def forward(self, x: torch.Tensor, y: torch.Tensor, output_final: bool = False):
+        stem = self.x3d.blocks[0]
+        if (x.is_cuda and not x.requires_grad and not y.requires_grad and x.dim() == 4 and x.shape[1] == 3
+                and (x.shape[2] * x.shape[3]) % 4 == 0 and tuple(x.shape[2:]) == tuple(self.perception_frames.shape[3:])):
+            # torch.cat([x, perception_frames.expand(B), y], dim=2) + blocks[0] as one function: HIP clip assembly,
+            # batch-summed perception-frame gradient written by the stem's own backward kernel
+            s0 = _ClipStemFn.apply(x, y, self.perception_frames, stem.norm.weight, stem)
+            return self.base_forward(None, output_final, _stem_out=s0)
         expand = self.perception_frames.expand(x.shape[0], -1, -1, -1, -1)
         frames = torch.cat([x.unsqueeze(2), expand, y.unsqueeze(2)], dim=2)
         return self.base_forward(frames, output_final)

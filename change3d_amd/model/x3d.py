@@ -66,54 +66,95 @@ def _f32(n, dev):
 
 
 # ---------------------------------------------------------------------------------- stem
+def _stem_forward(ctx, xin, stem):
+    B, Ci, T, H, W = xin.shape
+    dev, dt = xin.device, ops.dt_code(stem.act_dtype)
+    training = stem.training
+    conv_s, conv_t = stem.conv.conv_t, stem.conv.conv_xy  # names swapped upstream (x3d.py:87-92)
+    C = conv_s.weight.shape[0]
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=dev) if training else None
+    u = torch.empty((B, T, H, W, C), dtype=stem.act_dtype, device=dev)
+    ops.stem_fwd(xin, conv_s.weight, conv_t.weight, u, sums, B, T, H, W, dt)
+    ss, mr = _f32(2 * cpad(C), dev), _f32(2 * cpad(C), dev)
+    ops.bn_finalize(sums, B * T * H * W, stem.norm, C, ss, mr, training)
+    y = torch.empty_like(u)
+    ops.block_out_fwd(u, ss, None, None, ops.SC_NONE, y, B * T * H * W, cpad(C), dt)
+    ctx.stem, ctx.saved = stem, (xin, u, y, mr)
+    return to_logical(y)
+
+
+def _stem_backward(ctx, dy, frames_grad=None):
+    """Returns the per-sample input gradient (or None); with `frames_grad` = (tensor [3][K][H][W], t_first, K) the
+    batch-summed gradient of those frames is accumulated into it instead."""
+    stem = ctx.stem
+    xin, u, y, mr = ctx.saved
+    B, _, T, H, W = xin.shape
+    dev, dt = xin.device, ops.dt_code(stem.act_dtype)
+    conv_s, conv_t = stem.conv.conv_t, stem.conv.conv_xy
+    C = conv_s.weight.shape[0]
+    M = B * T * H * W
+    dyc = to_ndhwc(dy).to(stem.act_dtype)
+    g = torch.empty_like(u)
+    dsums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    ops.block_out_bwd(dyc, y, u, None, g, mr, None, dsums, None, M, C, dt)
+    coef = _f32(3 * cpad(C), dev)
+    ops.bn_bwd_coef(dsums, M, stem.norm, mr, C, coef)
+    dv = torch.empty_like(u)
+    ops.stem_bwd_dv(xin, conv_s.weight, conv_t.weight, g, u, coef, dv, ops.grad_of(conv_t.weight), B, T, H, W, dt)
+    dx = None
+    if frames_grad is not None:
+        gp, t0, nf = frames_grad
+        ops.stem_bwd_wx(xin, conv_s.weight, dv, ops.grad_of(conv_s.weight), gp, B, T, H, W, t0, nf, False, dt)
+    elif ctx.x_needs_grad:
+        t0, nf = stem.grad_frames if stem.grad_frames is not None else (0, T)
+        dx = torch.zeros_like(xin)
+        ops.stem_bwd_wx(xin, conv_s.weight, dv, ops.grad_of(conv_s.weight), dx, B, T, H, W, t0, nf, True, dt)
+    else:
+        ops.stem_bwd_wx(xin, conv_s.weight, dv, ops.grad_of(conv_s.weight), None, B, T, H, W, 0, 0, False, dt)
+    return dx
+
+
 class _StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, stem):
         ops.require_gpu(x, "stem input")
-        B, Ci, T, H, W = x.shape
-        if Ci != 3:
+        if x.shape[1] != 3:
             raise NotImplementedError("stem kernel is specialised for 3 input channels")
-        dev, dt = x.device, ops.dt_code(stem.act_dtype)
-        xin = x.detach().contiguous().float()
-        training = stem.training
-        conv_s, conv_t = stem.conv.conv_t, stem.conv.conv_xy  # names swapped upstream (x3d.py:87-92)
-        C = conv_s.weight.shape[0]
-        sums = torch.zeros(2 * C, dtype=torch.float64, device=dev) if training else None
-        u = torch.empty((B, T, H, W, C), dtype=stem.act_dtype, device=dev)
-        ops.stem_fwd(xin, conv_s.weight, conv_t.weight, u, sums, B, T, H, W, dt)
-        ss, mr = _f32(2 * cpad(C), dev), _f32(2 * cpad(C), dev)
-        ops.bn_finalize(sums, B * T * H * W, stem.norm, C, ss, mr, training)
-        y = torch.empty_like(u)
-        ops.block_out_fwd(u, ss, None, None, ops.SC_NONE, y, B * T * H * W, cpad(C), dt)
-        ctx.stem, ctx.saved = stem, (xin, u, y, mr)
         ctx.x_needs_grad = x.requires_grad
-        return to_logical(y)
+        return _stem_forward(ctx, x.detach().contiguous().float(), stem)
 
     @staticmethod
     def backward(ctx, dy):
-        stem = ctx.stem
-        xin, u, y, mr = ctx.saved
-        B, _, T, H, W = xin.shape
-        dev, dt = xin.device, ops.dt_code(stem.act_dtype)
-        conv_s, conv_t = stem.conv.conv_t, stem.conv.conv_xy
-        C = conv_s.weight.shape[0]
-        M = B * T * H * W
-        dyc = to_ndhwc(dy).to(stem.act_dtype)
-        g = torch.empty_like(u)
-        dsums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
-        ops.block_out_bwd(dyc, y, u, None, g, mr, None, dsums, None, M, C, dt)
-        coef = _f32(3 * cpad(C), dev)
-        ops.bn_bwd_coef(dsums, M, stem.norm, mr, C, coef)
-        dv = torch.empty_like(u)
-        ops.stem_bwd_dv(xin, conv_s.weight, conv_t.weight, g, u, coef, dv, ops.grad_of(conv_t.weight), B, T, H, W, dt)
-        dx = None
-        if ctx.x_needs_grad:
-            t0, nf = stem.grad_frames if stem.grad_frames is not None else (0, T)
-            dx = torch.zeros_like(xin)
-            ops.stem_bwd_wx(xin, conv_s.weight, dv, ops.grad_of(conv_s.weight), dx, B, T, H, W, t0, nf, True, dt)
-        else:
-            ops.stem_bwd_wx(xin, conv_s.weight, dv, ops.grad_of(conv_s.weight), None, B, T, H, W, 0, 0, False, dt)
-        return dx, None, None
+        return _stem_backward(ctx, dy), None, None
+
+
+class _ClipStemFn(torch.autograd.Function):
+    """`stem(cat([pre, perception_frames.expand(B), post], dim=2))` (reference model/trainer.py:155-162 + :128-130 for
+    block 0) as ONE function: the clip is assembled by a HIP copy kernel, and in backward the stem's input-gradient
+    kernel writes the BATCH-SUMMED gradient of the perception frames straight into their `.grad` (no full-size
+    zero-filled dx, no expand-backward reduction)."""
+
+    @staticmethod
+    def forward(ctx, pre, post, frames, anchor, stem):
+        ops.require_gpu(pre, "encoder input")
+        B, Ci, H, W = pre.shape
+        K = frames.shape[2]
+        if Ci != 3 or tuple(frames.shape) != (1, 3, K, H, W) or tuple(post.shape) != tuple(pre.shape):
+            raise NotImplementedError("clip assembly expects (B,3,H,W) images and (1,3,K,H,W) perception frames")
+        clip = torch.empty((B, 3, K + 2, H, W), dtype=torch.float32, device=pre.device)
+        ops.build_clip(pre.detach().contiguous().float(), post.detach().contiguous().float(),
+                       frames.detach().contiguous().float(), clip, B, K, H, W)
+        ctx.frames, ctx.K, ctx.x_needs_grad = frames, K, False
+        ctx.need_frames = ctx.needs_input_grad[2]
+        return _stem_forward(ctx, clip, stem)
+
+    @staticmethod
+    def backward(ctx, dy):
+        gp = None
+        if ctx.need_frames:
+            gp = torch.zeros(ctx.frames.shape, dtype=torch.float32, device=dy.device)
+        _stem_backward(ctx, dy, (gp, 1, ctx.K) if gp is not None else None)
+        return None, None, gp, None, None
 
 
 class X3DStem(nn.Module):
@@ -496,6 +537,7 @@ class X3DResStage(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self._fold_valid = False
+        self._binding = None      # Module._apply replaces buffer tensors: re-resolve the bound objects
         return super()._apply(fn, *args, **kwargs)
 
     def binding(self):

@@ -500,7 +500,8 @@ class StageBinding:
         self.desc = L.StageDesc()
         self.desc.n_blocks = self.n
         self.desc.blocks = C.cast(self.blocks, C.POINTER(L.BlockDesc))
-        self.params, self.buffers = [], []      # (struct, field, grad_struct, grad_field, parameter) / (struct, field, tensor-getter)
+        self.params, self.buffers = [], []      # (struct, field, grad_struct, grad_field, parameter) / (struct, field, buffer)
+        self._grad_refs = None
         for bd, blk in zip(self.blocks, blocks):
             b2 = blk.branch2
             se = b2.norm_b[1] if blk.use_se else None
@@ -522,9 +523,13 @@ class StageBinding:
             if se is not None:
                 self.params += [(bd, "se_w1", bd, "dse_w1", (se.block[0], "weight")), (bd, "se_b1", bd, "dse_b1", (se.block[0], "bias")),
                                 (bd, "se_w2", bd, "dse_w2", (se.block[2], "weight")), (bd, "se_b2", bd, "dse_b2", (se.block[2], "bias"))]
-        # normalise: (struct, field, gstruct, gfield, module, attribute)
-        self.params = [(s, f, gs, gf) + (m if isinstance(m, tuple) else (m, "weight")) for s, f, gs, gf, m in self.params]
+        # resolve to the Parameter / buffer OBJECTS once (nn.Module.__getattr__ costs ~1 us per lookup, 600 lookups
+        # per stage pass): Parameters keep their identity across .to() / load_state_dict() / arena placement;
+        # buffers are REPLACED by Module._apply, which is why X3DResStage._apply drops this binding
+        self.params = [(s, f, gs, gf, getattr(*(m if isinstance(m, tuple) else (m, "weight")))) for s, f, gs, gf, m in self.params]
+        self.buffers = [(s, f, getattr(mod, attr)) for s, f, mod, attr in self.buffers]
         self._ptr_cache = {}
+        self._last = {False: None, True: None}   # pointer signatures of the forward / backward bindings
 
     def _set(self, st, field, ptr):
         key = (id(st), field)
@@ -536,16 +541,24 @@ class StageBinding:
         d = self.desc
         d.B, d.T, d.H, d.W, d.dtype, d.training = B, T, H, W, dtype, 1 if training else 0
         d.momentum, d.eps = momentum, eps
-        for st, f, gs, gf, mod, attr in self.params:
-            p = getattr(mod, attr)
-            self._set(st, f, p.data_ptr())
-            if with_grads:
-                g = p.grad
-                if g is None:
-                    g = grad_of(p)
-                self._set(gs, gf, g.data_ptr())
-        for st, f, mod, attr in self.buffers:
-            self._set(st, f, getattr(mod, attr).data_ptr())
+        # pointer signature of everything bound (data, gradients, buffers): ~0.1 us per tensor; the ctypes structs are
+        # rewritten only when it changed (first call, new arena, gradients re-created, module moved)
+        if with_grads:
+            grads = [p.grad if p.grad is not None else grad_of(p) for _, _, _, _, p in self.params]
+            sig = tuple([p.data_ptr() for _, _, _, _, p in self.params] + [g.data_ptr() for g in grads] +
+                        [b.data_ptr() for _, _, b in self.buffers])
+        else:
+            grads = None
+            sig = tuple([p.data_ptr() for _, _, _, _, p in self.params] + [b.data_ptr() for _, _, b in self.buffers])
+        if sig != self._last[with_grads]:
+            for i, (st, f, gs, gf, p) in enumerate(self.params):
+                self._set(st, f, p.data_ptr())
+                if grads is not None:
+                    self._set(gs, gf, grads[i].data_ptr())
+            for st, f, b in self.buffers:
+                self._set(st, f, b.data_ptr())
+            self._last[with_grads] = sig
+        self._grad_refs = grads   # keep the bound gradient tensors alive while kernels may write them
         return d
 
     def sizes(self):
@@ -599,3 +612,8 @@ def stage_bwd(binding, x, y, dy, ws, wb, dx):
 def bcd_preprocess(image6, label, flags, mean6, std6, pre, post, label_out, B, H, W):
     _launch("c3d_bcd_preprocess", B * H * W * (7 + 28), L.lib().c3d_bcd_preprocess, _p(image6), _p(label), _p(flags),
             _p(mean6), _p(std6), _p(pre), _p(post), _p(label_out), B, H, W, _stream())
+
+
+def build_clip(pre, post, frames, clip, B, K, H, W):
+    _launch("c3d_build_clip", clip.numel() * 8, L.lib().c3d_build_clip, _p(pre), _p(post), _p(frames), _p(clip), B, K, H, W,
+            _stream())

@@ -317,6 +317,11 @@ int c3d_cossim_bwd(const float* x1, const float* x2, const int64_t* label_change
  * the validation transform); mean6 / std6: f32 [6] DEVICE vectors.  Outputs: pre, post f32 [B][3][H][W]
  * = ((u8/255) - mean)/std, bit-identical to the numpy arithmetic; label_out f32 [B][1][H][W] = ceil(u8/255).
  * ------------------------------------------------------------------------------------ */
+/* The (B, 3, T = K+2, H, W) f32 clip the encoder feeds to the stem (reference model/trainer.py:155-162:
+ * `torch.cat([x.unsqueeze(2), perception_frames.expand(B, ...), y.unsqueeze(2)], dim=2)`): frame 0 = pre [B][3][H][W],
+ * frames 1..K = the learnable perception frames [3][K][H][W] shared by the batch, frame K+1 = post.  H*W % 4 == 0.  */
+int c3d_build_clip(const float* pre, const float* post, const float* frames, float* clip, int32_t B, int32_t K,
+                   int32_t H, int32_t W, void* stream);
 int c3d_bcd_preprocess(const uint8_t* image6, const uint8_t* label, const uint8_t* flags, const float* mean6,
                        const float* std6, float* pre, float* post, float* label_out, int32_t B, int32_t H,
                        int32_t W, void* stream);

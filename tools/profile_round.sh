@@ -24,9 +24,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   C3D_WGRAD_SIDE=0 timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- \
       python bench.py --no-cpu-baseline --no-graph --no-kernel-profile --steps 1 --warmup 1 > $d.log 2>&1
 done
-# MFMA utilisation of the pointwise kernels (own pass; summarised by hand into profiles/r01_pmc_mfma.json)
+# MFMA utilisation of the pointwise kernels (own pass)
 rm -rf gpurun_out/pmc_mfma
 C3D_WGRAD_SIDE=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
     -d gpurun_out/pmc_mfma -- python bench.py --no-cpu-baseline --no-graph --no-kernel-profile --steps 1 --warmup 1 > gpurun_out/pmc_mfma.log 2>&1
-python tools/summarize_rocprof.py gpurun_out r01
+python tools/summarize_rocprof.py gpurun_out ${C3D_ROUND_TAG:-r02}
+# host-side profile of the step loop (where the enqueue time goes)
+timeout 600 python -m cProfile -o gpurun_out/host.prof bench.py --no-cpu-baseline --no-kernel-profile --steps 30 --warmup 5 > /dev/null 2> gpurun_out/host_prof.err
+python -c "
+import pstats
+p = pstats.Stats('gpurun_out/host.prof'); p.sort_stats('cumulative').print_stats(45)" > gpurun_out/host_prof.txt 2>&1
 ls -la gpurun_out/*.json

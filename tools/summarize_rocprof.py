@@ -22,7 +22,9 @@ ENTRY = [  # kernel-name prefix -> C-ABI entry point (bench.py's kernel table ke
     ("block_out_fwd", "c3d_block_out_fwd"), ("block_out_bwd", "c3d_block_out_bwd"),
     ("se_bn_bwd_coef", "c3d_se_bn_bwd_coef"), ("bn_se_finalize", "c3d_bn_se_finalize"),
     ("bn_finalize", "c3d_bn_finalize"), ("bn_bwd_coef", "c3d_bn_bwd_coef"), ("stem_", "c3d_stem_*"),
-    ("convT", "c3d_convT4s2_*"), ("head3x3", "c3d_head3x3_*"), ("adam", "c3d_adam_step"),
+    ("convT", "c3d_convT4s2_*"), ("convt_", "c3d_convT4s2_*"), ("head3x3", "c3d_head3x3_*"), ("adam", "c3d_adam_step"),
+    ("enhance_", "c3d_enhance_*"), ("frame_", "c3d_frame_*"), ("bce_dice", "c3d_bce_dice_*"), ("confusion", "c3d_confusion2"),
+    ("col_sum", "c3d_col_sum"), ("fold_bn", "c3d_stage_fold_bn"), ("bcd_preprocess", "c3d_bcd_preprocess"),
 ]
 
 
@@ -81,6 +83,8 @@ def main():
         print("pmc", key, f)
     if traffic:
         ents = sorted(set(traffic.get("fetch", {})) | set(traffic.get("write", {})))
+        steps = max(1, (traffic.get("fetch") or traffic.get("write")).get("c3d_adam_step", {"dispatches": 1})["dispatches"])
+        total = sum(v["bytes_total"] for k in ("fetch", "write") for v in traffic.get(k, {}).values())
         out = {}
         for e in ents:
             fd, wd = traffic.get("fetch", {}).get(e), traffic.get("write", {}).get(e)
@@ -91,7 +95,10 @@ def main():
         json.dump({"source": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace (separate passes) -- python bench.py "
                              "--no-cpu-baseline --no-graph --no-kernel-profile --steps 1 --warmup 1",
                    "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); WRITE_SIZE x1",
-                   "note": "2 steps (1 warm-up + 1 timed) of B=32 bf16; per-launch averages over all dispatches of an entry",
+                   "note": f"{steps} steps of B=32 bf16 (one Adam launch per step); per-launch averages over all dispatches of an entry",
+                   "steps": steps, "hbm_bytes_per_step": round(total / steps),
+                   "hbm_bytes_per_sample": round(total / steps / 32),
+                   "by_entry_per_step": {e: round(sum(traffic.get(k, {}).get(e, {"bytes_total": 0})["bytes_total"] for k in ("fetch", "write")) / steps) for e in ents},
                    "by_entry": out}, open(os.path.join(root, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 
 
