@@ -31,7 +31,7 @@ class PwArgs(C.Structure):
                 ("M", i64), ("gstride", i64), ("rows_per_sample", i64),
                 ("K", i32), ("Kp", i32), ("N", i32), ("Np", i32), ("w_sn", i32), ("w_sk", i32),
                 ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32),
-                ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32), ("fin", BnFin)]
+                ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32), ("fin", BnFin), ("bias", vp)]
 
 
 class PwWgradArgs(C.Structure):
@@ -115,6 +115,17 @@ SIGNATURES = {
     "c3d_confusion2": (i32, [vp, vp, i64, vp, vp]),
     "c3d_build_clip": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "c3d_bcd_preprocess": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "c3d_cap_embed_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, i32, vp]),
+    "c3d_cap_embed_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, i32, vp]),
+    "c3d_cap_dropout": (i32, [vp, vp, i64, i32, f32, C.c_uint64, i32, vp]),
+    "c3d_cap_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
+    "c3d_cap_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "c3d_cap_attn_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, f32, C.c_uint64, i32, vp]),
+    "c3d_cap_attn_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32,
+                               C.c_uint64, i32, vp]),
+    "c3d_cap_ce_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i32, vp]),
+    "c3d_cap_ce_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i32, vp]),
+    "c3d_clamp_": (i32, [vp, i64, f32, vp]),
     "c3d_stage_ws_bytes": (i32, [C.POINTER(StageDesc), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "c3d_stage_fwd": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp]),
     "c3d_stage_bwd": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp, vp, vp, vp]),

@@ -203,9 +203,9 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
   float* zz = dz + (size_t)B * C;      // [B][C]  forward z (input of the SE FCs)
   // FC weights and the hidden activations are staged once, coalesced: the FC loops below used to read them from
   // global memory element by element (chains of dependent L2 round trips in a single-digit-workgroup kernel)
-  float* w1s = zz + (size_t)B * C;     // [Cr][C]
-  float* w2s = w1s + (size_t)Cr * C;   // [C][Cr]
-  float* hids = w2s + (size_t)C * Cr;  // [B][Cr]
+  float* wst = zz + (size_t)B * C;     // [Cr*C]  ONE staged FC weight matrix at a time: w2 for the hidden gradient, then
+                                       //          w1 for dz (both at once did not fit LDS for res5: C=432, Cr=32, B=16)
+  float* hids = wst + (size_t)C * Cr;  // [B][Cr]
   const int tid = threadIdx.x;
   const double count = cnt_per_sample * B;
   const bool se = w1 != nullptr;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
   const int c_lo = (int)blockIdx.x * cs, c_hi = c_lo + cs < Cp ? c_lo + cs : Cp;
   const int cw = c_hi - c_lo;
   if (se) {
-    for (int i = tid; i < Cr * C; i += blockDim.x) { w1s[i] = w1[i]; w2s[i] = w2[i]; }
+    for (int i = tid; i < Cr * C; i += blockDim.x) wst[i] = w2[i];   // [C][Cr]
     for (int i = tid; i < B * Cr; i += blockDim.x) hids[i] = hid[i];
 #pragma unroll 4
     for (int i = tid; i < B * C; i += blockDim.x) {
@@ -229,16 +229,18 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
       const int i = idx >> 3, q = idx & 7;
       const int n = i / Cr, r = i - n * Cr;
       float a = 0.f;
-      for (int c = q; c < C; c += 8) a = fmaf(w2s[(size_t)c * Cr + r], du[(size_t)n * C + c], a);
+      for (int c = q; c < C; c += 8) a = fmaf(wst[(size_t)c * Cr + r], du[(size_t)n * C + c], a);
       a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
       if (q == 0) dh[i] = hids[i] > 0.f ? a : 0.f;
     }
+    __syncthreads();
+    for (int i = tid; i < Cr * C; i += blockDim.x) wst[i] = w1[i];   // [Cr][C]
     __syncthreads();
     for (int i = tid; i < B * cw; i += blockDim.x) {
       const int n = i / cw, c = c_lo + (i - n * cw);
       if (c >= C) continue;
       float a = 0.f;
-      for (int r = 0; r < Cr; ++r) a = fmaf(w1s[(size_t)r * C + c], dh[(size_t)n * Cr + r], a);
+      for (int r = 0; r < Cr; ++r) a = fmaf(wst[(size_t)r * C + c], dh[(size_t)n * Cr + r], a);
       dz[(size_t)n * C + c] = a;
     }
     // parameter gradients of the two FCs
@@ -359,7 +361,7 @@ extern "C" int c3d_se_bn_bwd_coef(const double* nc3, const double* ncf, int32_t 
   if (!nc3 || !ncf || !gamma || !mr || !ss || !coefA || !coefC || !coefB || C <= 0 || Cp < C || B <= 0)
     return C3D_E_BADARG;
   if (w1 && (!w2 || !gate || !hid || !dw1 || !db1 || !dw2 || !db2 || Cr <= 0)) return C3D_E_BADARG;
-  const size_t lds = w1 ? ((size_t)3 * B * C + (size_t)2 * B * Cr + (size_t)2 * C * Cr) * sizeof(float) : 0;
+  const size_t lds = w1 ? ((size_t)3 * B * C + (size_t)2 * B * Cr + (size_t)C * Cr) * sizeof(float) : 0;
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
     static bool attr_set = false;

@@ -445,7 +445,7 @@ extern "C" int c3d_convT4s2_bwd_data(const void* dout, const float* w, void* din
 
 extern "C" int c3d_col_sum(const void* x, float* out, int64_t M, int32_t C, int32_t Cp, int32_t dtype,
                            void* stream) {
-  if (!x || !out || M <= 0 || (Cp & 7) || Cp > 256 || C > Cp) return C3D_E_BADARG;
+  if (!x || !out || M <= 0 || (Cp & 7) || Cp > 1024 || C > Cp) return C3D_E_BADARG;   // (<= 1024: vocabulary logits)
   const int G = Cp / 8, blk = G * (256 / G);
   const int64_t nvec = M * G;
   int64_t grid = (nvec + blk - 1) / blk;

@@ -472,18 +472,27 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
 
 extern "C" int64_t c3d_pw_wgrad_ws_floats(int32_t N, int32_t K) { return (int64_t)WGRAD_MAX_PARTS * N * K; }
 
+int c3d_detail_pw_wgrad_wide(const c3d_pw_wgrad_args* args, void* stream);   // pw_wide.hip
+
 extern "C" int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream) {
   if (!args || !args->p || !args->q || !args->dw || !args->ws) return C3D_E_BADARG;
   const c3d_pw_wgrad_args& a = *args;
-  if (a.M <= 0 || (a.Kp & 7) || (a.Np & 7) || a.K > a.Kp || a.N > a.Np || a.Kp > 224 || a.Np > 224)
-    return C3D_E_BADARG;
+  if (a.M <= 0 || (a.Kp & 7) || (a.Np & 7) || a.K > a.Kp || a.N > a.Np) return C3D_E_BADARG;
+  if (a.Kp > 224 || a.Np > 224) {   // wide layers (res5, caption-decoder linears): block-tiled kernel, f32 atomics
+    if (a.Kp > 1024 || a.Np > 1024) return C3D_E_UNSUPPORTED;
+    if (a.p_coef && !a.p2) return C3D_E_BADARG;
+    if (a.q_mode == C3D_PRO_BN_SE_SWISH && (!a.q_ss || (a.q_gate && a.rows_per_sample <= 0))) return C3D_E_BADARG;
+    return c3d_detail_pw_wgrad_wide(args, stream);
+  }
   if (a.p_coef && !a.p2) return C3D_E_BADARG;
   if (a.q_mode == C3D_PRO_BN_SE_SWISH && (!a.q_ss || (a.q_gate && a.rows_per_sample <= 0))) return C3D_E_BADARG;
   if (a.M >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (a.dtype == C3D_DT_F32) return launch_wgrad<float>(a, s);
-  if (a.dtype == C3D_DT_BF16) return launch_wgrad<bf16_t>(a, s);
-  return C3D_E_BADARG;
+  int rc = C3D_E_BADARG;
+  if (a.dtype == C3D_DT_F32) rc = launch_wgrad<float>(a, s);
+  else if (a.dtype == C3D_DT_BF16) rc = launch_wgrad<bf16_t>(a, s);
+  if (rc == C3D_E_UNSUPPORTED) rc = c3d_detail_pw_wgrad_wide(args, stream);   // shapes that do not fit its LDS plan
+  return rc;
 }
 
 #ifdef C3D_PW_CLOCK

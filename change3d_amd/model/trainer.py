@@ -192,8 +192,9 @@ class Trainer(nn.Module):
             self.decoder_loc = ChangeDecoder(args, in_dim=self.embed_dims, has_sigmoid=True)
             weight_init(self.decoder_cls)
             weight_init(self.decoder_loc)
-        elif k == 1 and "CC" in args.dataset:
-            raise NotImplementedError("change-captioning head is not built yet (SURVEY.md §8f item 2)")
+        elif k == 1 and "CC" in args.dataset:   # change captioning (reference model/trainer.py:217-218)
+            from .caption_decoder import CaptionDecoder
+            self.decoder = CaptionDecoder(args)
         else:
             assert False
 
@@ -211,6 +212,11 @@ class Trainer(nn.Module):
         post_mask = self.decoder_post([f[2] for f in features])
         change_mask = self.decoder_change([f[1] for f in features])
         return pre_mask, post_mask, change_mask
+
+    def update_cc(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """reference model/trainer.py:292-306: X3D blocks 0..4 without enhancement, the perception frame of res5
+        -> (B, 192, H/16, W/16)."""
+        return self.encoder(x, y, output_final=True)
 
     def update_bda(self, x: torch.Tensor, y: torch.Tensor):
         features = self.encoder(x, y)

@@ -333,3 +333,28 @@ def hot_path_named_params(trainer):
     never-executed `encoder.x3d.blocks.4` (res5) and `.blocks.5` (head)."""
     skip = ("encoder.x3d.blocks.4.", "encoder.x3d.blocks.5.")
     return [(n, p) for n, p in trainer.named_parameters() if not n.startswith(skip)]
+
+
+def cc_named_params(trainer):
+    """Parameters that receive gradients on the change-captioning path (reference scripts/train_CC.py:436-458 builds one
+    Adam over `trainer.encoder.parameters()` and one over `trainer.decoder.parameters()`; parameters whose `.grad` stays
+    None -- the X3D head, `encoder.fc.*`, and the decoder modules the layer never runs -- are skipped by Adam there and
+    are simply not placed in the arenas here).  Returns (encoder_named, decoder_named)."""
+    enc = [(n, p) for n, p in trainer.named_parameters()
+           if n.startswith("encoder.") and not n.startswith(("encoder.x3d.blocks.5.", "encoder.fc."))]
+    used = {id(p) for p in trainer.decoder.used_parameters()}
+    dec = [(n, p) for n, p in trainer.named_parameters() if n.startswith("decoder.") and id(p) in used]
+    return enc, dec
+
+
+def clip_gradient(optimizer, grad_clip):
+    """reference model/utils.py:481-491: clamp every gradient to [-grad_clip, grad_clip]; for a FusedAdam over a
+    ParamArena that is ONE HIP pass over the flat gradient buffer."""
+    arena = getattr(optimizer, "arena", None)
+    if arena is not None and arena.flat_grad.is_cuda:
+        ops.clamp_(arena.flat_grad, grad_clip)
+        return
+    for group in optimizer.param_groups:
+        for param in group["params"]:
+            if param.grad is not None:
+                param.grad.data.clamp_(-grad_clip, grad_clip)

@@ -228,10 +228,11 @@ def fin_bwd(tick, idx, bn, count, coef, mr):
 def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, pro_p=None,
             pro_gate=None, epi_mode=EPI_STORE, e1=None, epi_p=None, epi_gate=None, epi_q=None, stats=None,
             rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, res_mode=0,
-            x_ptr=None, e1_ptr=None, fin=None):
+            x_ptr=None, e1_ptr=None, fin=None, bias=None):
     a = L.PwArgs()
     if fin is not None:
         a.fin = fin
+    a.bias = _p(bias)
     a.x = x_ptr if x_ptr is not None else _p(x)
     a.x2 = _p(x2)
     a.y = _p(y)
@@ -617,3 +618,73 @@ def bcd_preprocess(image6, label, flags, mean6, std6, pre, post, label_out, B, H
 def build_clip(pre, post, frames, clip, B, K, H, W):
     _launch("c3d_build_clip", clip.numel() * 8, L.lib().c3d_build_clip, _p(pre), _p(post), _p(frames), _p(clip), B, K, H, W,
             _stream())
+
+
+# ------------------------------------------------------------------------------ caption decoder (change captioning)
+def cap_embed_fwd(tokens, emb, pe, out, B, Lq, D, V, p, seed, dtype):
+    _launch("c3d_cap_embed_fwd", out.numel() * _es(dtype), L.lib().c3d_cap_embed_fwd, _p(tokens), _p(emb), _p(pe), _p(out), B, Lq, D, V,
+            float(p), int(seed), dtype, _stream())
+
+
+def cap_embed_bwd(tokens, dout, demb, B, Lq, D, V, p, seed, dtype):
+    _launch("c3d_cap_embed_bwd", dout.numel() * _es(dtype), L.lib().c3d_cap_embed_bwd, _p(tokens), _p(dout), _p(demb), B, Lq, D, V,
+            float(p), int(seed), dtype, _stream())
+
+
+def cap_dropout(x, y, rows, D, p, seed, dtype):
+    _launch("c3d_cap_dropout", 2 * x.numel() * _es(dtype), L.lib().c3d_cap_dropout, _p(x), _p(y), rows, D, float(p), int(seed), dtype, _stream())
+
+
+def cap_layernorm_fwd(x, a, ln, y, mr, rows, D, dtype):
+    _launch("c3d_cap_layernorm_fwd", 3 * x.numel() * _es(dtype), L.lib().c3d_cap_layernorm_fwd, _p(x), _p(a), _p(ln.weight), _p(ln.bias), _p(y),
+            _p(mr), rows, D, float(ln.eps), dtype, _stream())
+
+
+def cap_layernorm_bwd(x, a, dy, ln, mr, dx, rows, D, dtype):
+    _launch("c3d_cap_layernorm_bwd", 4 * x.numel() * _es(dtype), L.lib().c3d_cap_layernorm_bwd, _p(x), _p(a), _p(dy), _p(ln.weight), _p(mr), _p(dx),
+            _p(grad_of(ln.weight)), _p(grad_of(ln.bias)), rows, D, dtype, _stream())
+
+
+def cap_attn_fwd(q, k, v, ldq, ldk, ldv, o, ldo, P, B, H, Lq, Lk, hd, scale, causal, p, seed, dtype, q_off=0, k_off=0, v_off=0):
+    es = _es(dtype)
+    _launch("c3d_cap_attn_fwd", (q.numel() + k.numel() + o.numel()) * es, L.lib().c3d_cap_attn_fwd, q.data_ptr() + q_off * es,
+            k.data_ptr() + k_off * es, v.data_ptr() + v_off * es, ldq, ldk, ldv, _p(o), ldo, _p(P), B, H, Lq, Lk, hd, float(scale),
+            1 if causal else 0, float(p), int(seed), dtype, _stream())
+
+
+def cap_attn_bwd(q, k, v, ldq, ldk, ldv, dout, ldo, P, dq, dk, dv, lddq, lddk, lddv, B, H, Lq, Lk, hd, scale, p, seed, dtype,
+                 q_off=0, k_off=0, v_off=0, dq_off=0, dk_off=0, dv_off=0):
+    es = _es(dtype)
+    _launch("c3d_cap_attn_bwd", (q.numel() + k.numel() + dout.numel()) * 2 * es, L.lib().c3d_cap_attn_bwd, q.data_ptr() + q_off * es,
+            k.data_ptr() + k_off * es, v.data_ptr() + v_off * es, ldq, ldk, ldv, _p(dout), ldo, _p(P), dq.data_ptr() + dq_off * es,
+            dk.data_ptr() + dk_off * es, dv.data_ptr() + dv_off * es, lddq, lddk, lddv, B, H, Lq, Lk, hd, float(scale), float(p),
+            int(seed), dtype, _stream())
+
+
+def cap_ce_fwd(logits, caps, declen, acc2, lse, loss, B, Lq, V, ignore_index, dtype):
+    _launch("c3d_cap_ce_fwd", logits.numel() * _es(dtype), L.lib().c3d_cap_ce_fwd, _p(logits), _p(caps), _p(declen), _p(acc2), _p(lse), _p(loss),
+            B, Lq, V, ignore_index, dtype, _stream())
+
+
+def cap_ce_bwd(logits, caps, declen, acc2, lse, dloss, dlogits, B, Lq, V, ignore_index, dtype):
+    _launch("c3d_cap_ce_bwd", 2 * logits.numel() * _es(dtype), L.lib().c3d_cap_ce_bwd, _p(logits), _p(caps), _p(declen), _p(acc2), _p(lse), _p(dloss),
+            _p(dlogits), B, Lq, V, ignore_index, dtype, _stream())
+
+
+def clamp_(g, limit):
+    _launch("c3d_clamp_", g.numel() * 8, L.lib().c3d_clamp_, _p(g), g.numel(), float(limit), _stream())
+
+
+def linear_fwd(x, weight, bias, y, M, K, N, dtype):
+    """y[M][Np] = x[M][Kp] @ weight[N][K]^T + bias (nn.Linear / in_proj slices)."""
+    pw_gemm(x, weight, y, M=M, K=K, N=N, w_sn=weight.stride(0), w_sk=1, dtype=dtype, bias=bias)
+
+
+def linear_bwd(x, weight, dy, dx, gw, gb, M, K, N, dtype, accumulate_dx=None):
+    """dx = dy @ weight (written, or added to `accumulate_dx`), gw += dy^T x, gb += colsum(dy)."""
+    if dx is not None:
+        pw_gemm(dy, weight, dx, M=M, K=N, N=K, w_sn=1, w_sk=weight.stride(0), dtype=dtype,
+                epi_mode=EPI_ADD if accumulate_dx is not None else EPI_STORE, e1=accumulate_dx, res_mode=0)
+    pw_wgrad(dy, x, gw, M=M, K=K, N=N, dw_sn=gw.stride(0), dw_sk=1, dtype=dtype)
+    if gb is not None:
+        col_sum(dy, gb, M, N, dtype)

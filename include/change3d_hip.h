@@ -100,8 +100,12 @@ typedef struct c3d_pw_args {
   int32_t res_mode;      /* EPI_ADD: 0 dense [M][Np]; 1 e1 is [BT][H/2][W/2][Np], added where h,w even */
   int32_t dtype;
   c3d_bn_fin fin;        /* C3D_EPI_STATS: fin.ticket != NULL -> the last workgroup finalises the BatchNorm    */
+  const float* bias;     /* optional bias[N] added before the epilogue (linear layers of the caption decoder)  */
 } c3d_pw_args;
 
+/* K, N <= 224 run the wave-private-tile kernel (pw_gemm_impl.h); wider layers (X3D res5: 432 inner channels; the
+ * caption decoder's 192 -> 576 / vocabulary projections) or a non-NULL bias run the block-tiled kernel of
+ * pw_wide.hip with the same prologues / epilogues (row modes DENSE and STRIDE2; no in-kernel finalisation). */
 int c3d_pw_gemm(const c3d_pw_args* args, void* stream);
 
 /* Weight gradient of the same family:
@@ -390,6 +394,48 @@ int c3d_stage_fwd_folded(const c3d_stage_desc* d, const void* fold, const void* 
 /* byte offsets (into ws_fwd) and sizes of what block `blk` stored: name is one of "a","b","c","sc","mr_a","mr_b",
  * "mr_c","mr_sc","ss_a","ss_b","ss_c","ss_sc","gate" -- test / debug access (returns C3D_E_BADARG if absent). */
 int c3d_stage_saved(const c3d_stage_desc* d, int32_t blk, const char* name, int64_t* offset, int64_t* bytes);
+
+/* ------------------------------------------------------------------------------------
+ * Caption decoder of the change-captioning path (reference model/caption_decoder.py:526-613 CaptionDecoder, :316-423
+ * Mesh_TransformerDecoderLayer, :272-314 PositionalEncoding; loss: scripts/train_CC.py:124-132).  Activations are
+ * sequence-first rows (row = l*B + b, nn.MultiheadAttention's default layout) of Dp = round_up(D, 8) elements in the
+ * storage dtype; the linear layers run on c3d_pw_gemm / c3d_pw_wgrad (bias through c3d_pw_args.bias, bias gradient
+ * through c3d_col_sum).  Dropout masks are counter-based: (seed, element index) -> keep/drop, regenerated in backward.
+ * ------------------------------------------------------------------------------------ */
+/* out[l*B+b] = dropout_p(emb[tokens[b][l]] + pe[l]); tokens int64 [B][L]; emb f32 [V][D]; pe f32 [>=L][D]        */
+int c3d_cap_embed_fwd(const int64_t* tokens, const float* emb, const float* pe, void* out, int32_t B, int32_t L,
+                      int32_t D, int32_t V, float p, uint64_t seed, int32_t dtype, void* stream);
+/* demb[tokens[b][l]] += dropout-mask * dout[l*B+b]   (f32 atomics)                                                */
+int c3d_cap_embed_bwd(const int64_t* tokens, const void* dout, float* demb, int32_t B, int32_t L, int32_t D, int32_t V,
+                      float p, uint64_t seed, int32_t dtype, void* stream);
+/* y = x * mask(seed) / (1-p): the same call is the forward and (on the gradient) the backward                     */
+int c3d_cap_dropout(const void* x, void* y, int64_t rows, int32_t D, float p, uint64_t seed, int32_t dtype, void* stream);
+/* y = LayerNorm(x + a) (a may be NULL), mr f32 [rows][2] = saved (mean, rstd); backward: dx (= gradient of x and of a),
+ * dgamma / dbeta accumulated (+=)                                                                                 */
+int c3d_cap_layernorm_fwd(const void* x, const void* a, const float* gamma, const float* beta, void* y, float* mr,
+                          int64_t rows, int32_t D, float eps, int32_t dtype, void* stream);
+int c3d_cap_layernorm_bwd(const void* x, const void* a, const void* dy, const float* gamma, const float* mr, void* dx,
+                          float* dgamma, float* dbeta, int64_t rows, int32_t D, int32_t dtype, void* stream);
+/* multi-head attention, one workgroup per (sample, head): q/k/v/o rows (l*B+b) with leading dimensions ld* (elements),
+ * head h at column h*hd; P f32 [H*B][Lq][Lk] = softmax(scale*q.k^T (+causal mask)) BEFORE dropout (saved for backward);
+ * o = dropout_p(P) v.                                                                                             */
+int c3d_cap_attn_fwd(const void* q, const void* k, const void* v, int32_t ldq, int32_t ldk, int32_t ldv, void* o, int32_t ldo,
+                     float* P, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale, int32_t causal,
+                     float p, uint64_t seed, int32_t dtype, void* stream);
+int c3d_cap_attn_bwd(const void* q, const void* k, const void* v, int32_t ldq, int32_t ldk, int32_t ldv, const void* dout,
+                     int32_t ldo, const float* P, void* dq, void* dk, void* dv, int32_t lddq, int32_t lddk, int32_t lddv,
+                     int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale, float p, uint64_t seed,
+                     int32_t dtype, void* stream);
+/* CrossEntropyLoss(ignore_index) over the decoded steps (pack_padded_sequence of scripts/train_CC.py:124-132 without the
+ * gather): logits rows (l*B+b) of round_up(V,8) columns; target = caps[b][l+1] (caps int64 [B][L], sorted by length);
+ * a step counts iff l < declen[b] (int64 [B]) and target != ignore_index; loss = mean; acc2 f64 [2], lse f32 [L*B]. */
+int c3d_cap_ce_fwd(const void* logits, const int64_t* caps, const int64_t* declen, double* acc2, float* lse, float* loss,
+                   int32_t B, int32_t L, int32_t V, int64_t ignore_index, int32_t dtype, void* stream);
+int c3d_cap_ce_bwd(const void* logits, const int64_t* caps, const int64_t* declen, const double* acc2, const float* lse,
+                   const float* dloss, void* dlogits, int32_t B, int32_t L, int32_t V, int64_t ignore_index, int32_t dtype,
+                   void* stream);
+/* clip_gradient (reference model/utils.py:481-491): g = clamp(g, -limit, limit) over a flat f32 gradient buffer     */
+int c3d_clamp_(float* g, int64_t n, float limit, void* stream);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,7 @@ def randomize(module, seed):
 
 
 @pytest.mark.parametrize("cfg", [dict(cin=24, cinner=54, cout=24), dict(cin=24, cinner=108, cout=48),
-                                 dict(cin=48, cinner=216, cout=96)])
+                                 dict(cin=48, cinner=216, cout=96), dict(cin=96, cinner=432, cout=192)])
 def test_res_stage_fwd_bwd(cfg):
     _need_gpu()
     from oracle import model as om, synth
