@@ -30,6 +30,7 @@ sys.dont_write_bytecode = True
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 A_BCD_ELEMS = 159_784_960        # materialised activation elements per sample
 A_SCD_ELEMS = 269_280_000        # same for the SCD path (K=3, T=5; SURVEY.md §8d: 269.28 M)
+A_CC_ELEMS = 170_270_000         # change-captioning encoder (blocks 0-4, K=1; SURVEY.md §8d: 170.27 M; decoder < 0.1 %)
 
 
 def parse():
@@ -38,8 +39,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 for BCD = BASELINE config, 16 for SCD)")
-    ap.add_argument("--task", choices=["bcd", "scd"], default="bcd",
-                    help="bcd = the north-star workload; scd = SURVEY.md 8(f).1 (K=3, T=5, three decoders, 7 classes)")
+    ap.add_argument("--task", choices=["bcd", "scd", "cc"], default="bcd",
+                    help="bcd = the north-star workload; scd = SURVEY.md 8(f).1 (K=3, T=5, three decoders, 7 classes); "
+                         "cc = SURVEY.md 8(f).2 (X3D blocks 0-4 + caption decoder, packed CE, two clipped Adam optimisers)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--graph", action="store_true",
@@ -195,22 +197,41 @@ def main():
     from change3d_amd.utils.metric_tool import ConfuseMatrixMeter
 
     act = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    scd = a.task == "scd"
+    scd, cc = a.task == "scd", a.task == "cc"
     if a.batch <= 0:
-        a.batch = 16 if scd else 32
-    margs = make_args(num_perception_frame=3, size=a.size, dataset="SECOND", num_class=7) if scd else make_args(size=a.size)
+        a.batch = 16 if (scd or cc) else 32
+    if cc:
+        margs = synth.make_cc_args(size=a.size, vocab_size=501, dropout=0.1)   # reference scripts/train_CC.py defaults
+    else:
+        margs = make_args(num_perception_frame=3, size=a.size, dataset="SECOND", num_class=7) if scd else make_args(size=a.size)
     margs.act_dtype = act
     margs.lr_mode, margs.lr, margs.max_epochs, margs.step_loss = "poly", 2e-4, 1, 100
     with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
         net = Trainer(margs)
-    net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25))
+    sd0 = synth.synth_state_dict(net, seed=16, mask_margin=0.25)
+    if cc:
+        sd0["decoder.position_encoding.pe"] = net.state_dict()["decoder.position_encoding.pe"].clone()   # constant table
+    net.load_state_dict(sd0)
     net = net.to(dev).train()
     broadcast_module_state(net)
-    arena, sync = setup_data_parallel(net, dev, overlap=True)
+    if cc:   # two optimisers (reference scripts/train_CC.py:436-458); gradients exchanged as two flat buffers
+        from change3d_amd.model.utils import ParamArena, cc_named_params, clip_gradient
+        from change3d_amd.model.caption_decoder import packed_cross_entropy
+        from change3d_amd.parallel import GradSync
+        enc_named, dec_named = cc_named_params(net)
+        arena, dec_arena = ParamArena(enc_named, dev), ParamArena(dec_named, dev)
+        sync, dec_sync = GradSync(arena, len(enc_named)), GradSync(dec_arena, len(dec_named))
+    else:
+        arena, sync = setup_data_parallel(net, dev, overlap=True)
     dist_world = dist.get_world_size() if world > 1 else 1
     if dist_world != a.gpus or sync.world != a.gpus:
         raise SystemExit(f"process group has {dist_world} ranks (GradSync {sync.world}) but --gpus {a.gpus}")
-    opt = FusedAdam(arena, lr=margs.lr, capturable=True)
+    if cc:
+        opt = FusedAdam(arena, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, capturable=True)
+        dec_opt = FusedAdam(dec_arena, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, capturable=True)
+        caps, caplens = (t.to(dev) for t in synth.synth_captions(a.batch, seed=rank, vocab_size=501))
+    else:
+        opt = FusedAdam(arena, lr=margs.lr, capturable=True)
     meter = ConfuseMatrixMeter(2)
     pre, post, tgt = (t.to(dev) for t in synth.synth_batch(a.batch, a.size, seed=rank))
     if scd:
@@ -223,6 +244,17 @@ def main():
 
     def fwd_bwd():
         opt.zero_grad()
+        if cc:    # reference scripts/train_CC.py:111-145
+            dec_opt.zero_grad()
+            feat = net.update_cc(pre, post)
+            Bc, Cc, Hc, Wc = feat.shape
+            logits = net.decoder.logits_seq_first(feat.permute(2, 3, 0, 1).reshape(Hc * Wc, Bc, Cc), caps)
+            loss, stats = packed_cross_entropy(logits, caps, caplens, 501, ignore_index=0, return_stats=True)
+            loss.backward()
+            dec_sync.finish()
+            clip_gradient(dec_opt, 5.0)
+            dec_opt.launch(*dec_hp)
+            return loss.detach(), stats
         if scd:   # reference scripts/train_SCD.py:216-233
             masks = net.update_scd(pre, post)
             loss = scd_loss(seg_loss, sim_loss, masks, labels)[0]
@@ -237,7 +269,12 @@ def main():
     graph = None
     use_graph = a.graph and not a.no_graph and world == 1  # N>1: the overlapped all-reduce is issued from inside backward
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-    adjust_learning_rate(margs, opt, 0, 0, MAX_ITER)
+    dec_hp = (0.0, 1.0, 1.0)
+    if cc:
+        use_graph = False
+        dec_hp = dec_opt.prepare_step()
+    else:
+        adjust_learning_rate(margs, opt, 0, 0, MAX_ITER)
     opt.prepare_step()
     if use_graph:
         # every pre-capture step runs on the capture stream (autograd's AccumulateGrad nodes remember
@@ -264,18 +301,26 @@ def main():
     else:
         state["loss"], state["prob"] = fwd_bwd()
         sync.finish()
+        if cc:
+            clip_gradient(opt, 5.0)
         opt.launch()
         torch.cuda.synchronize()
 
     def step():
+        nonlocal dec_hp
         h0 = time.perf_counter()
-        adjust_learning_rate(margs, opt, 0, state["it"], MAX_ITER)
+        if cc:
+            dec_hp = dec_opt.prepare_step()      # StepLR(900, gamma=1): constant learning rate
+        else:
+            adjust_learning_rate(margs, opt, 0, state["it"], MAX_ITER)
         opt.prepare_step()
         if graph is not None:
             graph.replay()
         else:
             state["loss"], state["prob"] = fwd_bwd()
             sync.finish()
+            if cc:
+                clip_gradient(opt, 5.0)
             opt.launch()
         state["host_s"] = state.get("host_s", 0.0) + time.perf_counter() - h0   # enqueue only (no read-back)
         state["it"] += 1
@@ -309,15 +354,16 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = a.batch * world * a.steps / elapsed
     es = 2 if a.dtype == "bf16" else 4
-    bytes_per_sample = 5 * (A_SCD_ELEMS if scd else A_BCD_ELEMS) * es * (a.size / 256.0) ** 2
+    bytes_per_sample = 5 * (A_SCD_ELEMS if scd else A_CC_ELEMS if cc else A_BCD_ELEMS) * es * (a.size / 256.0) ** 2
     out = {
         "metric": f"train images/sec (256x256 pairs, X3D-L {a.task.upper()})", "value": round(value, 2), "unit": "images/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"{a.task.upper()} X3D-L {a.dtype}, B={a.batch}/GPU, {a.size}x{a.size} synthetic "
-                               f"{'SECOND' if scd else 'LEVIR-CD'}-shaped "
-                               f"pairs, T={5 if scd else 3}, train step (fwd+{'0.5*CE+BCE/Dice+ChangeSimilarity' if scd else 'BCE/Dice'}"
-                               f"+bwd+Adam)",
+                               f"{'SECOND' if scd else 'LEVIR-CC' if cc else 'LEVIR-CD'}-shaped "
+                               f"pairs{' + 52-token captions (vocab 501, dropout 0.1)' if cc else ''}, T={5 if scd else 3}, train step "
+                               f"(fwd+{'0.5*CE+BCE/Dice+ChangeSimilarity' if scd else 'packed CE' if cc else 'BCE/Dice'}"
+                               f"+bwd+{'clip+2xAdam' if cc else 'Adam'})",
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "dist_world_size": dist_world,
                    "dist_backend": (dist.get_backend() if world > 1 else None),
                    "hip_graph": graph is not None, "final_loss": round(final_loss, 5),
@@ -330,6 +376,8 @@ def main():
     # ---- dominant kernel, timed live with HIP events on the launch stream (one extra eager step)
     if rank == 0 and not a.no_kernel_profile:
         net.encoder.x3d.blocks[3].post_backward = None
+        if cc:
+            dec_hp = dec_opt.prepare_step()
         # per-kernel durations are taken with the side stream OFF: launches then do not overlap, so an
         # event pair brackets exactly one kernel (profiles/*_rocprof_kernel_stats_serial.json is the
         # rocprofv3 trace of the same mode; the timed region above runs with the overlap ON)
@@ -349,7 +397,7 @@ def main():
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                            "share_of_kernel_time": round(d["ms_total"] / max(tot, 1e-9), 3),
                            "timing": "HIP events on the launch stream, one eager step with the side stream off"}
-        if not scd:   # the committed counter summary is a BCD run
+        if not scd and not cc:   # the committed counter summary is a BCD run
             out["roofline"].update(pmc_traffic(name))
         ops.SIDE_STREAM = side_was
         rows = [{"kernel": k, "launches": v["launches"], "ms_total": round(v["ms_total"], 3),
@@ -372,7 +420,7 @@ def main():
             print(f"[kernels] {r['kernel']:24s} x{r['launches']:4d} {r['ms_total']:9.3f} ms {r['GBps']:8.1f} GB/s",
                   file=sys.stderr)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.size) if not scd else None   # the CPU leg times the BCD oracle only
+        out["cpu_baseline"] = cpu_baseline(a.size) if not (scd or cc) else None   # the CPU leg times the BCD oracle only
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

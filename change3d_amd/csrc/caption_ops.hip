@@ -203,6 +203,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qb,
 }
 
 // backward: dPd = dO V^T ; dP = dPd * mask ; dS = P * (dP - sum_j dP*P) ; dQ = scale * dS K ; dK = scale * dS^T Q ; dV = Pd^T dO
+// Two passes over one [Lq][Lk] LDS matrix (first dS, then the dropped probabilities): every (key, channel) element of
+// dK / dV is owned by one thread that sums over the query rows -- no atomics (the first version accumulated dK / dV with
+// LDS atomics per query row: 0.59 ms per launch for 128 workgroups).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qb, const T* __restrict__ kb, const T* __restrict__ vb,
                                                        int ldq, int ldk, int ldv, const T* __restrict__ dob, int ldo,
@@ -214,17 +217,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qb,
   float* vs = ks + (size_t)Lk * hd;        // [Lk][hd]
   float* qs = vs + (size_t)Lk * hd;        // [Lq][hd]
   float* dos = qs + (size_t)Lq * hd;       // [Lq][hd]
-  float* dks = dos + (size_t)Lq * hd;      // [Lk][hd]
-  float* dvs = dks + (size_t)Lk * hd;      // [Lk][hd]
-  float* dsw = dvs + (size_t)Lk * hd;      // [4 waves][Lk]  dS row
-  float* pdw = dsw + (size_t)4 * Lk;       // [4 waves][Lk]  dropped P row
+  float* DS = dos + (size_t)Lq * hd;       // [Lq][Lk]: dS, then dropped P
   const int b = blockIdx.x % B, h = blockIdx.x / B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < Lk * hd; i += 256) {
     const int j = i / hd, d = i - j * hd;
     ks[i] = ld1<T>(kb + ((int64_t)j * B + b) * ldk + h * hd + d);
     vs[i] = ld1<T>(vb + ((int64_t)j * B + b) * ldv + h * hd + d);
-    dks[i] = 0.f; dvs[i] = 0.f;
   }
   for (int i = tid; i < Lq * hd; i += 256) {
     const int l = i / hd, d = i - l * hd;
@@ -233,18 +232,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qb,
   }
   __syncthreads();
   const float* Pin = P + (size_t)blockIdx.x * Lq * Lk;
-  float* ds = dsw + (size_t)wave * Lk;
-  float* pd = pdw + (size_t)wave * Lk;
   for (int i = wave; i < Lq; i += 4) {
+    float* ds = DS + (size_t)i * Lk;
     float dot = 0.f;
     for (int j = lane; j < Lk; j += 64) {
       const float pr = Pin[(size_t)i * Lk + j];
-      const float ksc = keep_scale(p, seed, ((uint64_t)blockIdx.x * Lq + i) * Lk + j);
       float dpd = 0.f;
       for (int d = 0; d < hd; ++d) dpd = fmaf(dos[i * hd + d], vs[j * hd + d], dpd);
-      const float dp = dpd * ksc;
-      pd[j] = pr * ksc;
-      ds[j] = dp;            // dP for now
+      const float dp = dpd * keep_scale(p, seed, ((uint64_t)blockIdx.x * Lq + i) * Lk + j);
+      ds[j] = dp;
       dot += dp * pr;
     }
     dot = wave_sum(dot);
@@ -255,24 +251,28 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qb,
       for (int j = 0; j < Lk; ++j) o = fmaf(ds[j], ks[j * hd + lane], o);
       st1<T>(dqb + ((int64_t)i * B + b) * lddq + h * hd + lane, o);
     }
-    // dK_j += dS[i][j] * Q_i ; dV_j += Pd[i][j] * dO_i   (LDS atomics: 4 waves share the accumulators)
-    for (int e = lane; e < Lk * hd; e += 64) {
-      const int j = e / hd, d = e - j * hd;
-      if (ds[j] != 0.f) atomicAdd(dks + e, ds[j] * qs[i * hd + d]);
-      if (pd[j] != 0.f) atomicAdd(dvs + e, pd[j] * dos[i * hd + d]);
-    }
-    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  for (int i = tid; i < Lk * hd; i += 256) {
-    const int j = i / hd, d = i - j * hd;
-    st1<T>(dkb + ((int64_t)j * B + b) * lddk + h * hd + d, dks[i]);
-    st1<T>(dvb + ((int64_t)j * B + b) * lddv + h * hd + d, dvs[i]);
+  for (int e = tid; e < Lk * hd; e += 256) {   // dK_j = sum_i dS[i][j] Q_i
+    const int j = e / hd, d = e - j * hd;
+    float o = 0.f;
+    for (int i = 0; i < Lq; ++i) o = fmaf(DS[(size_t)i * Lk + j], qs[i * hd + d], o);
+    st1<T>(dkb + ((int64_t)j * B + b) * lddk + h * hd + d, o);
+  }
+  __syncthreads();
+  for (int e = tid; e < Lq * Lk; e += 256)
+    DS[e] = Pin[e] * keep_scale(p, seed, (uint64_t)blockIdx.x * Lq * Lk + e);
+  __syncthreads();
+  for (int e = tid; e < Lk * hd; e += 256) {   // dV_j = sum_i Pd[i][j] dO_i
+    const int j = e / hd, d = e - j * hd;
+    float o = 0.f;
+    for (int i = 0; i < Lq; ++i) o = fmaf(DS[(size_t)i * Lk + j], dos[i * hd + d], o);
+    st1<T>(dvb + ((int64_t)j * B + b) * lddv + h * hd + d, o);
   }
 }
 
 // ---- cross-entropy over the decoded steps.  logits row (l, b) = l*B + b, Vp columns; target = caps[b][l+1];
-// valid iff l < declen[b] and target != ignore.  acc f64 [2] = (sum nll, count), zeroed by the caller.
+// valid iff l < declen[b] and target != ignore.  acc f64 [3] = (sum nll, count, top-1 hits), zeroed by the entry point.
 template <typename T>
 __global__ __launch_bounds__(256) void cap_ce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ caps,
                                                          const int64_t* __restrict__ declen, double* __restrict__ acc,
@@ -285,9 +285,14 @@ __global__ __launch_bounds__(256) void cap_ce_fwd_kernel(const T* __restrict__ l
   const bool valid = l < declen[b] && tgt != ignore && tgt >= 0 && tgt < V;
   if (!valid) { if (lane == 0) lse[row] = 0.f; return; }
   float mx = -INFINITY;
-  for (int j = lane; j < V; j += 64) mx = fmaxf(mx, ld1<T>(logits + row * Vp + j));
+  int am = 0;
+  for (int j = lane; j < V; j += 64) { const float x = ld1<T>(logits + row * Vp + j); if (x > mx) { mx = x; am = j; } }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  for (int o = 32; o > 0; o >>= 1) {   // arg max (first index on ties, as torch.topk(1))
+    const float mo = __shfl_xor(mx, o, 64);
+    const int ao = __shfl_xor(am, o, 64);
+    if (mo > mx || (mo == mx && ao < am)) { mx = mo; am = ao; }
+  }
   double s = 0.0;
   for (int j = lane; j < V; j += 64) s += (double)expf(ld1<T>(logits + row * Vp + j) - mx);
   s = wave_sum_d(s);
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(256) void cap_ce_fwd_kernel(const T* __restrict__ l
     lse[row] = l_s_e;
     atomicAdd(acc, (double)(l_s_e - ld1<T>(logits + row * Vp + tgt)));
     atomicAdd(acc + 1, 1.0);
+    if (am == tgt) atomicAdd(acc + 2, 1.0);
   }
 }
 
@@ -424,7 +430,7 @@ extern "C" int c3d_cap_attn_bwd(const void* q, const void* k, const void* v, int
                                 int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale, float p, uint64_t seed,
                                 int32_t dtype, void* stream) {
   if (!q || !k || !v || !dout || !P || !dq || !dk || !dv || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || hd <= 0 || hd > 64) return C3D_E_BADARG;
-  const size_t lds = ((size_t)4 * Lk * hd + (size_t)2 * Lq * hd + (size_t)8 * Lk) * sizeof(float);
+  const size_t lds = ((size_t)2 * Lk * hd + (size_t)2 * Lq * hd + (size_t)Lq * Lk) * sizeof(float);
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr = false;
@@ -444,7 +450,7 @@ extern "C" int c3d_cap_ce_fwd(const void* logits, const int64_t* caps, const int
   if (!logits || !caps || !declen || !acc2 || !lse || !loss || B <= 0 || L <= 0 || V <= 0) return C3D_E_BADARG;
   const int Vp = (V + 7) / 8 * 8;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(acc2, 0, 2 * sizeof(double), s);
+  hipError_t e = hipMemsetAsync(acc2, 0, 3 * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
   const int g = (int)(((int64_t)L * B + 3) / 4);
   CAP_DISPATCH(dtype, (cap_ce_fwd_kernel<float><<<g, 256, 0, s>>>((const float*)logits, caps, declen, acc2, lse, B, L, V, Vp, ignore_index)),

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
   lds_t* Ws = Xs + WB_M * KL;                                       // [112][KL]
   float* Os = reinterpret_cast<float*>(Ws + WB_N * KL);             // [64][OL]
   float* red = Os + WB_M * OL;                                      // STATS: [18][112][2]; SWISH_SE_BWD: [5][112][3]
+  float* Pp = red + WB_SLOTS * WB_N * 3;                            // prologue parameters [3][Kp] (scale|shift or A|B|C)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * WB_M;
   const int n0 = (int)blockIdx.y * WB_N;
@@ -50,6 +51,14 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
   f32x4_t acc[WB_NT];
 #pragma unroll
   for (int nt = 0; nt < WB_NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (PRO != C3D_PRO_NONE) {
+    const int np = (PRO == C3D_PRO_AFFINE2 ? 3 : 2) * Kp;
+    for (int i = tid; i < np; i += 256) Pp[i] = a.pro_p[i];
+  }
+  // weights: 4 consecutive elements along their contiguous dimension per load when the layout allows it
+  const bool kc_contig = a.w_sk == 1;
+  const bool w_vec4 = ((uintptr_t)a.w & 15) == 0 && (kc_contig ? ((a.w_sn & 3) == 0 && (a.K & 3) == 0)
+                                                               : (a.w_sn == 1 && (a.w_sk & 3) == 0 && (a.N & 3) == 0));
 
   for (int kc = 0; kc < Kp; kc += KC) {
     __syncthreads();
@@ -65,30 +74,44 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
         const int64_t off = wide_row_offset(a, m) + k0;
         Vec8<T>::load(X + off, f);
         if (PRO == C3D_PRO_BN_SE_SWISH) {
-          const int64_t n = m / rps;
+          float g[8];
+          if (a.pro_gate) Vec8<float>::load(a.pro_gate + (m / rps) * Kp + k0, g);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float g = a.pro_gate ? a.pro_gate[n * Kp + k0 + j] : 1.f;
-            const float q = g * fmaf(f[j], a.pro_p[k0 + j], a.pro_p[Kp + k0 + j]);
+            const float q = (a.pro_gate ? g[j] : 1.f) * fmaf(f[j], Pp[k0 + j], Pp[Kp + k0 + j]);
             f[j] = q * sigmoid_t<T>(q);
           }
         } else if (PRO == C3D_PRO_AFFINE2) {
           float f2[8];
           Vec8<T>::load(X2 + off, f2);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            f[j] = fmaf(a.pro_p[k0 + j], f[j], fmaf(a.pro_p[2 * Kp + k0 + j], f2[j], a.pro_p[Kp + k0 + j]));
+          for (int j = 0; j < 8; ++j) f[j] = fmaf(Pp[k0 + j], f[j], fmaf(Pp[2 * Kp + k0 + j], f2[j], Pp[Kp + k0 + j]));
         }
       }
       MM::store8(Xs + r * KL + kv * 8, f);
     }
     // ---- W chunk: Ws[n][k] = w[(n0+n)*w_sn + (kc+k)*w_sk]; threads run along the contiguous dimension of w
-    for (int i = tid; i < WB_N * KC; i += 256) {
-      int n, k;
-      if (a.w_sk == 1) { k = i % KC; n = i / KC; } else { n = i % WB_N; k = i / WB_N; }
-      const int gn = n0 + n, gk = kc + k;
-      const float v = (gn < a.N && gk < a.K) ? a.w[(size_t)gn * a.w_sn + (size_t)gk * a.w_sk] : 0.f;
-      Ws[n * KL + k] = MM::cvt(v);
+    if (w_vec4) {
+      for (int i = tid; i < WB_N * KC / 4; i += 256) {
+        int n, k;
+        if (kc_contig) { k = (i % (KC / 4)) * 4; n = i / (KC / 4); } else { n = (i % (WB_N / 4)) * 4; k = i / (WB_N / 4); }
+        const int gn = n0 + n, gk = kc + k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gn < a.N && gk < a.K) v = *reinterpret_cast<const float4*>(a.w + (size_t)gn * a.w_sn + (size_t)gk * a.w_sk);
+        if (kc_contig) {
+          Ws[n * KL + k] = MM::cvt(v.x); Ws[n * KL + k + 1] = MM::cvt(v.y); Ws[n * KL + k + 2] = MM::cvt(v.z); Ws[n * KL + k + 3] = MM::cvt(v.w);
+        } else {
+          Ws[n * KL + k] = MM::cvt(v.x); Ws[(n + 1) * KL + k] = MM::cvt(v.y); Ws[(n + 2) * KL + k] = MM::cvt(v.z); Ws[(n + 3) * KL + k] = MM::cvt(v.w);
+        }
+      }
+    } else {
+      for (int i = tid; i < WB_N * KC; i += 256) {
+        int n, k;
+        if (kc_contig) { k = i % KC; n = i / KC; } else { n = i % WB_N; k = i / WB_N; }
+        const int gn = n0 + n, gk = kc + k;
+        const float v = (gn < a.N && gk < a.K) ? a.w[(size_t)gn * a.w_sn + (size_t)gk * a.w_sk] : 0.f;
+        Ws[n * KL + k] = MM::cvt(v);
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -229,7 +252,7 @@ int launch_wide(const c3d_pw_args& a, hipStream_t st) {
   constexpr int KC = sizeof(T) == 2 ? 64 : 32;
   constexpr int KL = KC + MM::KPAD;
   const size_t lds = (size_t)(WB_M + WB_N) * KL * sizeof(typename MM::lds_t) + (size_t)WB_M * (WB_N + 4) * 4 +
-                     (size_t)WB_SLOTS * WB_N * 3 * 4;
+                     (size_t)WB_SLOTS * WB_N * 3 * 4 + (size_t)3 * a.Kp * 4;
   dim3 grid((unsigned)((a.M + WB_M - 1) / WB_M), (unsigned)((a.Np + WB_N - 1) / WB_N));
   pw_wide_kernel<T, PRO, EPI><<<grid, 256, lds, st>>>(a);
   C3D_CHECK_LAUNCH();

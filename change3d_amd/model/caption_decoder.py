@@ -269,15 +269,16 @@ class _PackedCEFn(torch.autograd.Function):
         B, L = caps.shape
         dt = ops.dt_code(logits_sf.dtype)
         lg = logits_sf.detach().contiguous()
-        acc = torch.empty(2, dtype=torch.float64, device=lg.device)
+        acc = torch.empty(3, dtype=torch.float64, device=lg.device)
         lse = torch.empty(L * B, dtype=torch.float32, device=lg.device)
         loss = torch.empty(1, dtype=torch.float32, device=lg.device)
         ops.cap_ce_fwd(lg, caps, declen, acc, lse, loss, B, L, V, ignore_index, dt)
         ctx.saved, ctx.meta = (lg, caps, declen, acc, lse), (B, L, V, ignore_index, dt)
-        return loss[0]
+        ctx.mark_non_differentiable(acc)
+        return loss[0], acc
 
     @staticmethod
-    def backward(ctx, dloss):
+    def backward(ctx, dloss, _dacc=None):
         lg, caps, declen, acc, lse = ctx.saved
         B, L, V, ignore_index, dt = ctx.meta
         d = torch.empty_like(lg)
@@ -285,10 +286,13 @@ class _PackedCEFn(torch.autograd.Function):
         return d, None, None, None, None
 
 
-def packed_cross_entropy(logits_seq_first, caps, caplens, vocab_size, ignore_index=0):
+def packed_cross_entropy(logits_seq_first, caps, caplens, vocab_size, ignore_index=0, return_stats=False):
     """`CrossEntropyLoss(ignore_index)(pack_padded_sequence(scores, decode_lengths).data, pack_padded_sequence(
     caps_sorted[:, 1:], decode_lengths).data)` of reference scripts/train_CC.py:124-132 as one fused pass: the mean
     over the decoded steps does not depend on the packing order, so neither the sort nor the gather is materialised.
-    logits_seq_first: `CaptionDecoder.logits_seq_first(...)`; caps int64 [B, L]; caplens int64 [B, 1]."""
+    logits_seq_first: `CaptionDecoder.logits_seq_first(...)`; caps int64 [B, L]; caplens int64 [B, 1].
+    `return_stats`: also return the device tensor f64 [3] = (sum nll, decoded steps, top-1 hits) -- the inputs of the
+    reference's `caption_accuracy(scores, targets, 1)` and `losses.update(loss, sum(decode_lengths))` without a sync."""
     declen = (caplens.reshape(-1) - 1).contiguous()
-    return _PackedCEFn.apply(logits_seq_first, caps.contiguous(), declen, ignore_index, vocab_size)
+    loss, acc = _PackedCEFn.apply(logits_seq_first, caps.contiguous(), declen, ignore_index, vocab_size)
+    return (loss, acc) if return_stats else loss

@@ -173,3 +173,44 @@ def test_caption_decoder_dropout_is_reproducible_and_unbiased():
     kept = (y != 0).float().mean().item()
     assert abs(kept - 0.9) < 5e-3 and abs(y.mean().item() - 1.0) < 5e-3
     assert torch.all((y == 0) | ((y - 1.0 / 0.9).abs() < 1e-6))
+
+
+def test_e2e_cc_vs_oracle_conditioned_weights():
+    """The default synthetic weights make the 70-block CC encoder chaotic (the fp32 reference's own gradient norms are
+    ~80-96 % away from its fp64 evaluation: see the fixture test above), which leaves only distribution-level checks.
+    With every residual branch scaled by 0.1 (`branch_gain`, a trained-network-like stack) rounding stays in the linear
+    regime and EVERY gradient of the whole path -- encoder blocks 0-4 through the caption decoder -- is compared
+    parameter by parameter with the fp32 oracle."""
+    _need_gpu()
+    from oracle import caption as oc, model as om
+    from change3d_amd import synthetic as synth
+    from change3d_amd.model.caption_decoder import packed_cross_entropy
+    from change3d_amd.model.utils import cc_named_params
+    size, batch, vocab = 64, 2, 157
+    args = synth.make_cc_args(size=size, vocab_size=vocab, dropout=0.0)
+    ora = om.Trainer(args)
+    sd = synth.synth_state_dict(ora, seed=21, branch_gain=0.1)
+    sd["decoder.position_encoding.pe"] = ora.state_dict()["decoder.position_encoding.pe"].clone()
+    ora.load_state_dict(sd)
+    ora.train()
+    ora.decoder.position_encoding.dropout.p = 0.0
+    net = _mirror(args, sd)
+    pre, post, _ = synth.synth_batch(batch, size, seed=3)
+    caps, caplens = synth.synth_captions(batch, seed=3, vocab_size=vocab)
+    lo, so, _, fo = oc.cc_forward_loss(ora, pre, post, caps, caplens)
+    lo.backward()
+    feat = net.update_cc(pre.to(DEV), post.to(DEV))
+    B, C, H, W = feat.shape
+    lg = net.decoder.logits_seq_first(feat.permute(2, 3, 0, 1).reshape(H * W, B, C), caps.to(DEV))
+    loss = packed_cross_entropy(lg, caps.to(DEV), caplens.to(DEV), vocab)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f"conditioned CC: feature rel-L2 {rel(feat, fo):.2e}, loss hip {loss.item():.6f} oracle {lo.item():.6f}")
+    assert rel(feat, fo) < 1e-4 and abs(loss.item() - lo.item()) < 1e-4
+    enc_named, dec_named = cc_named_params(net)
+    po = dict(ora.named_parameters())
+    errs = {n: rel(p.grad, po[n].grad) for n, p in enc_named + dec_named}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("conditioned CC: worst per-parameter gradient rel-L2:", [(n, f"{e:.1e}") for n, e in worst])
+    # measured on MI355X (round 2): worst of the 665 tensors 9.8e-6
+    assert np.median(list(errs.values())) < 2e-5 and worst[0][1] < 1e-4, worst
