@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from change3d_amd.data.transforms import DeviceBatchTransform, draw_augmentation_flags  # noqa: E402
 from change3d_amd.model.trainer import Trainer  # noqa: E402
 from change3d_amd.model.utils import BCEDiceLoss, FusedAdam, adjust_learning_rate  # noqa: E402
 from change3d_amd.parallel import broadcast_module_state, setup_data_parallel  # noqa: E402
@@ -32,13 +33,16 @@ from change3d_amd.utils.metric_tool import ConfuseMatrixMeter  # noqa: E402
 
 
 class SyntheticBCDLoader:
-    """Stand-in for the reference DataLoader (reference scripts/train_BCD.py:31-89): yields
-    (img[B,6,H,W] float32, target[B,1,H,W] int64) with the LEVIR normalisation
-    (u8/255-0.5)/0.5 (reference data/transforms.py:127-137)."""
+    """Stand-in for the reference DataLoader (reference scripts/train_BCD.py:31-89).  It yields what the reference's
+    dataset holds BEFORE its per-sample numpy transforms -- raw uint8 pairs (B, H, W, 6), uint8 labels {0, 255}
+    (B, H, W) and the random_flip / random_exchange draws -- and `DeviceBatchTransform` (change3d_amd/data/transforms.py,
+    kernel c3d_bcd_preprocess) turns a batch into the normalised float tensors on the GPU in one pass
+    (reference data/transforms.py:100-154 does the same per sample on the host)."""
 
-    def __init__(self, n_pairs, batch_size, size, seed, drop_last=False):
-        self.n, self.bs, self.size, self.seed = n_pairs, batch_size, size, seed
+    def __init__(self, n_pairs, batch_size, size, seed, drop_last=False, train=False):
+        self.n, self.bs, self.size, self.seed, self.train = n_pairs, batch_size, size, seed, train
         self.nb = n_pairs // batch_size if drop_last else -(-n_pairs // batch_size)
+        self.transform = None
 
     def __len__(self):
         return self.nb
@@ -47,19 +51,22 @@ class SyntheticBCDLoader:
         rng = np.random.default_rng(self.seed)
         for i in range(self.nb):
             b = min(self.bs, self.n - i * self.bs)
-            u8 = rng.integers(0, 256, size=(b, 6, self.size, self.size), dtype=np.uint8)
-            img = (u8.astype(np.float32) / 255.0 - 0.5) / 0.5
-            tgt = np.zeros((b, 1, self.size, self.size), dtype=np.int64)
+            u8 = rng.integers(0, 256, size=(b, self.size, self.size, 6), dtype=np.uint8)
+            lab = np.zeros((b, self.size, self.size), dtype=np.uint8)
             for k in range(b):
                 for _ in range(int(rng.integers(1, 4))):
                     h, w = (int(rng.integers(self.size // 16, self.size // 4)) for _ in range(2))
                     y0, x0 = int(rng.integers(0, self.size - h)), int(rng.integers(0, self.size - w))
-                    tgt[k, 0, y0:y0 + h, x0:x0 + w] = 1
-            yield torch.from_numpy(img), torch.from_numpy(tgt)
+                    lab[k, y0:y0 + h, x0:x0 + w] = 255
+            flags = draw_augmentation_flags(b, rng, train=self.train)
+            if self.transform is None:
+                self.transform = DeviceBatchTransform(torch.device("cuda", torch.cuda.current_device()))
+            pre, post, target = self.transform(u8, lab, flags)       # device tensors: (B,3,H,W) x2, (B,1,H,W)
+            yield torch.cat([pre, post], dim=1), target
 
 
 def create_data_loaders(args, rank=0):
-    train = SyntheticBCDLoader(args.synthetic_pairs, args.batch_size, args.in_height, seed=10 + rank, drop_last=True)
+    train = SyntheticBCDLoader(args.synthetic_pairs, args.batch_size, args.in_height, seed=10 + rank, drop_last=True, train=True)
     val = SyntheticBCDLoader(max(args.batch_size, args.synthetic_pairs // 8), args.batch_size, args.in_height, seed=5)
     test = SyntheticBCDLoader(max(args.batch_size, args.synthetic_pairs // 8), args.batch_size, args.in_height, seed=6)
     return train, val, test, len(train)
