@@ -40,6 +40,11 @@ class PositionalEncoding(nn.Module):
         self.register_buffer("pe", pe.unsqueeze(0).transpose(0, 1))
         self.embedding_1D = nn.Embedding(52, int(d_model))     # constructed, never used (reference :299)
 
+    def forward(self, x):
+        """(L, B, D) embeddings + positions (reference :301-314); used by the reference's evaluation loop, which calls
+        the sub-modules one by one (scripts/train_CC.py:260-261).  The training path fuses this into c3d_cap_embed_fwd."""
+        return self.dropout(x + self.pe[:x.size(0), :])
+
 
 class Mesh_TransformerDecoderLayer(nn.Module):
     """Parameter holder with the reference layer's attribute names (reference model/caption_decoder.py:316-383)."""
@@ -76,6 +81,73 @@ class _Layers(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(n)])
         self.norm = None
+        self.n_head, self.act_dtype = layer.self_attn.num_heads, torch.float32
+
+    def forward(self, tgt, memory, tgt_mask=None, **_unused):
+        """Inference-only `nn.TransformerDecoder.forward(tgt, memory, tgt_mask=causal)` on the HIP kernels: what the
+        reference's beam search calls at every step (scripts/train_CC.py:264).  tgt (L, B, D), memory (S, B, D) ->
+        (L, B, D).  Training goes through `CaptionDecoder.forward` (one fused autograd node)."""
+        if torch.is_grad_enabled() and (tgt.requires_grad or memory.requires_grad or self.training):
+            raise NotImplementedError("_Layers.forward is the no-grad evaluation path; train through CaptionDecoder.forward")
+        L, B, D = tgt.shape
+        if tgt_mask is not None:
+            ref = torch.triu(torch.ones(L, L, device=tgt_mask.device), diagonal=1) > 0
+            if tgt_mask.shape != (L, L) or not bool(((tgt_mask == float("-inf")) == ref).all()):
+                raise NotImplementedError("only the reference's causal mask is supported")
+        ops.require_gpu(tgt, "caption decoder input")
+        act = self.act_dtype
+        x = tgt.detach().to(act).contiguous().view(L * B, D)
+        kv = project_memory(self, memory)
+        h = _infer_layers(self, x, kv, memory.shape[0], B, L, causal=tgt_mask is not None)
+        return h.view(L, B, -1)[:, :, :D].to(tgt.dtype)
+
+
+def project_memory(stack, memory):
+    """Per layer, the key/value projection of the encoder memory (S, B, D) -> [S*B][2D] rows: constant over the steps
+    of a beam search, so it is computed once per image pair."""
+    S, B, D = memory.shape
+    act = stack.act_dtype
+    dt = ops.dt_code(act)
+    mem = memory.detach().to(act).contiguous().view(S * B, D)
+    out = []
+    for layer in stack.layers:
+        ca = layer.multihead_attn2
+        kv2 = torch.empty((S * B, 2 * D), dtype=act, device=mem.device)
+        ops.linear_fwd(mem, ca.in_proj_weight[D:], ca.in_proj_bias[D:], kv2, S * B, D, 2 * D, dt)
+        out.append(kv2)
+    return out
+
+
+def _infer_layers(stack, x, kv, S, B, L, causal=True):
+    """Evaluation-mode layer stack (no dropout, nothing saved): x rows [L*B][D] sequence-first -> rows [L*B][D]."""
+    D = x.shape[1]
+    H = stack.n_head
+    hd = D // H
+    act, dev = x.dtype, x.device
+    dt = ops.dt_code(act)
+    if cpad(D) != D:
+        raise NotImplementedError("embed_dim must be a multiple of 8")
+    R, scale = L * B, 1.0 / math.sqrt(hd)
+    new = lambda *s: torch.empty(s, dtype=act, device=dev)  # noqa: E731
+    P1 = torch.empty((H * B, L, L), dtype=torch.float32, device=dev)
+    P2 = torch.empty((H * B, L, S), dtype=torch.float32, device=dev)
+    mr = torch.empty((R, 2), dtype=torch.float32, device=dev)
+    qkv, o, a, q2 = new(R, 3 * D), new(R, D), new(R, D), new(R, D)
+    for layer, kv2 in zip(stack.layers, kv):
+        sa, ca = layer.self_attn, layer.multihead_attn2
+        ops.linear_fwd(x, sa.in_proj_weight, sa.in_proj_bias, qkv, R, D, 3 * D, dt)
+        ops.cap_attn_fwd(qkv, qkv, qkv, 3 * D, 3 * D, 3 * D, o, D, P1, B, H, L, L, hd, scale, causal, 0.0, 0, dt,
+                         q_off=0, k_off=D, v_off=2 * D)
+        ops.linear_fwd(o, sa.out_proj.weight, sa.out_proj.bias, a, R, D, D, dt)
+        x1 = new(R, D)
+        ops.cap_layernorm_fwd(x, a, layer.norm1, x1, mr, R, D, dt)
+        ops.linear_fwd(x1, ca.in_proj_weight[:D], ca.in_proj_bias[:D], q2, R, D, D, dt)
+        ops.cap_attn_fwd(q2, kv2, kv2, D, 2 * D, 2 * D, o, D, P2, B, H, L, S, hd, scale, False, 0.0, 0, dt, k_off=0, v_off=D)
+        ops.linear_fwd(o, ca.out_proj.weight, ca.out_proj.bias, a, R, D, D, dt)
+        x2 = new(R, D)
+        ops.cap_layernorm_fwd(x1, a, layer.norm2, x2, mr, R, D, dt)
+        x = x2
+    return x
 
 
 def _mha_used_params(m):
@@ -227,6 +299,7 @@ class CaptionDecoder(nn.Module):
         layer = Mesh_TransformerDecoderLayer(args.embed_dim, args.n_head, dim_feedforward=args.embed_dim * 4,
                                              dropout=args.dropout)
         self.transformer = _Layers(layer, args.n_layer)
+        self.transformer.act_dtype = self.act_dtype
         self.position_encoding = PositionalEncoding(args.embed_dim)
         self.wdc = nn.Linear(args.embed_dim, args.vocab_size)
         self.dropout_layer = nn.Dropout(p=args.dropout)
@@ -260,6 +333,88 @@ class CaptionDecoder(nn.Module):
         pred = pred[sort_ind]
         decode_lengths = (caption_lengths - 1).tolist()
         return pred, encoded_captions, decode_lengths, sort_ind
+
+
+    @torch.no_grad()
+    def beam_search(self, encoder_out, start_id, end_id, beam_size, max_len=52):
+        """Caption one image pair: the beam search of the reference's `evaluate()` (scripts/train_CC.py:214-330).
+        encoder_out (S, 1, D) = rearrange(encoder(..., output_final=True), 'b c h w -> (h w) b c').
+        Returns (best_seq or None, complete_seqs, complete_seqs_scores) -- None when no beam ever emits <end>, in
+        which case the reference records no caption for the pair (:326-328).
+
+        Same hypotheses as the reference, less work per step: the causal mask makes position step-1 independent of the
+        (all-<pad>) positions after it, so only the first `step` tokens are decoded instead of the 52-token window
+        (26x fewer rows on average); the vocabulary projection runs on the `s` rows of position step-1 only; the
+        memory key/value projections are computed once per pair (all beams attend to the same memory, so shrinking the
+        beam only drops columns).  Embedding, attention, LayerNorm and the projections are the HIP kernels of the
+        training path; log-softmax / top-k over [s, vocab] are torch device ops (bookkeeping)."""
+        was_training = self.training
+        self.eval()
+        try:
+            return self._beam_search(encoder_out, start_id, end_id, beam_size, max_len)
+        finally:
+            self.train(was_training)
+
+    def _beam_search(self, encoder_out, start_id, end_id, beam_size, max_len):
+        ops.require_gpu(encoder_out, "caption decoder memory")
+        S, one, D = encoder_out.shape
+        if one != 1:
+            raise ValueError("beam_search captions one image pair: encoder_out must be (S, 1, D)")
+        k, V, dev, act = beam_size, self.vocab_size, encoder_out.device, self.act_dtype
+        dt = ops.dt_code(act)
+        kv1 = project_memory(self.transformer, encoder_out)                   # per layer [S][2D]
+        kv_of = {}
+
+        def kv_for(s):                                                        # [S*s][2D], rows (position, beam)
+            if s not in kv_of:
+                kv_of[s] = [t.view(S, 1, 2 * D).expand(S, s, 2 * D).contiguous().view(S * s, 2 * D) for t in kv1]
+            return kv_of[s]
+
+        pe = self.position_encoding.pe.view(-1, D)
+        words = torch.zeros((k, max_len), dtype=torch.int64, device=dev)
+        words[:, 0] = start_id
+        seqs = torch.full((k, 1), start_id, dtype=torch.int64, device=dev)
+        top_k_scores = torch.zeros((k, 1), dtype=torch.float32, device=dev)
+        complete_seqs, complete_scores = [], []
+        Vp = cpad(V)
+        step = 1
+        while True:
+            s, L = words.shape[0], step
+            tok = words[:, :L].contiguous()
+            x = torch.empty((L * s, D), dtype=act, device=dev)
+            ops.cap_embed_fwd(tok, self.vocab_embedding.weight, pe, x, s, L, D, V, 0.0, 0, dt)
+            h = _infer_layers(self.transformer, x, kv_for(s), S, s, L, causal=True)
+            logits = torch.empty((s, Vp), dtype=act, device=dev)
+            ops.linear_fwd(h[(L - 1) * s:], self.wdc.weight, self.wdc.bias, logits, s, D, V, dt)
+            scores = torch.log_softmax(logits[:, :V].float(), dim=1)
+            scores = top_k_scores.expand_as(scores) + scores
+            if step == 1:
+                top_k_scores, top_k_words = scores[0].topk(k, 0, True, True)
+            else:
+                top_k_scores, top_k_words = scores.reshape(-1).topk(k, 0, True, True)
+            prev_word_inds = top_k_words // V
+            next_word_inds = top_k_words % V
+            seqs = torch.cat([seqs[prev_word_inds], next_word_inds.unsqueeze(1)], dim=1)
+            done = (next_word_inds == end_id)
+            done_host = done.tolist()                                         # the one host sync per step
+            if any(done_host):
+                complete_seqs.extend(seqs[done].tolist())
+                complete_scores.extend(top_k_scores[done].tolist())
+            k -= sum(done_host)
+            if k == 0:
+                break
+            keep = ~done
+            seqs = seqs[keep]
+            top_k_scores = top_k_scores[keep].unsqueeze(1)
+            words = words[:k].clone()
+            words[:, :step + 1] = seqs
+            if step > 50:
+                break
+            step += 1
+        if not complete_scores:
+            return None, complete_seqs, complete_scores
+        best = complete_scores.index(max(complete_scores))
+        return complete_seqs[best], complete_seqs, complete_scores
 
 
 class _PackedCEFn(torch.autograd.Function):

@@ -3,7 +3,8 @@
 scripts/train_CC.py:75-168 `train`, :420-520 `main`): same step (encoder(output_final=True) -> 'b c h w -> (h w) b c'
 -> CaptionDecoder -> packed cross-entropy -> zero_grad x2 -> backward -> clip_gradient -> encoder / decoder Adam steps
 with StepLR(900, gamma=1)), same hyper-parameters (Adam lr 1e-4, weight_decay 1e-5, grad_clip 5, dropout 0.1, 8 heads,
-3 layers, embed_dim 192).  File datasets, the word map and the caption metrics (BLEU / CIDEr, beam search) are outside
+3 layers, embed_dim 192), and the beam-search captioning of `evaluate()` (:170-330; `--eval_pairs N`).  File datasets,
+the word map and the caption metrics (BLEU / METEOR / ROUGE / CIDEr: host-side text scoring, `eval_func/`) are outside
 SURVEY.md section 8: `--dataset SYNTH-CC` draws LEVIR-CC-shaped synthetic pairs + token sequences.
 
     python -m change3d_amd.scripts.train_CC --batch_size 16 --max_steps 20 --act_dtype bf16
@@ -53,6 +54,23 @@ def train_step(args, model, enc_opt, dec_opt, imgs_a, imgs_b, caps, caplens):
     return loss.detach(), stats
 
 
+@torch.no_grad()
+def evaluate(args, model, pairs, start_id, end_id, pad_id=0):
+    """reference scripts/train_CC.py:170-399 without the file I/O and the text metrics: eval mode (BatchNorm folded
+    into the encoder weights), one pair at a time as the reference's batch_size=1 loader does, beam search of width
+    `args.beam_size`; returns the hypotheses (special tokens stripped, :345) -- `None` entries are pairs for which no
+    beam emitted <end> (the reference records no caption for them, :326-328)."""
+    model.eval()
+    hyps = []
+    for pre, post in pairs:
+        feat = model.update_cc(pre, post)                                       # (1, 192, H/16, W/16)
+        B, C, H, W = feat.shape
+        memory = feat.permute(2, 3, 0, 1).reshape(H * W, B, C)
+        best, _, _ = model.decoder.beam_search(memory, start_id, end_id, args.beam_size)
+        hyps.append(None if best is None else [w for w in best if w not in (start_id, end_id, pad_id)])
+    return hyps
+
+
 def main():
     p = ArgumentParser()
     p.add_argument("--dataset", default="SYNTH-CC")
@@ -71,6 +89,8 @@ def main():
     p.add_argument("--pretrained", default="model/X3D_L.pyth")
     p.add_argument("--vocab_size", type=int, default=501, help="len(WORDMAP) of the reference; synthetic here")
     p.add_argument("--max_steps", type=int, default=100)
+    p.add_argument("--beam_size", type=int, default=1, help="reference default (scripts/train_CC.py:600)")
+    p.add_argument("--eval_pairs", type=int, default=0, help="caption this many synthetic pairs after training")
     p.add_argument("--act_dtype", choices=["bf16", "f32"], default="bf16")
     args = p.parse_args()
     if "CC" not in args.dataset:
@@ -89,6 +109,17 @@ def main():
             s = stats.cpu()
             print(f"step: {i}/{args.max_steps} Loss: {loss.item():.4f} Top-1 Accuracy: {100.0 * s[2].item() / max(s[1].item(), 1):.4f} "
                   f"Batch_time: {(time.time() - start) / (i + 1):.4f}s")
+    if args.eval_pairs:
+        n = args.eval_pairs
+        ep, eq, _ = (t.to(device) for t in synth.synth_batch(n, args.in_height, seed=1))
+        start_id, end_id = args.vocab_size - 2, args.vocab_size - 1            # synthetic word map: <start>, <end> last
+        torch.cuda.synchronize()
+        t0 = time.time()
+        hyps = evaluate(args, model, [(ep[i:i + 1], eq[i:i + 1]) for i in range(n)], start_id, end_id)
+        torch.cuda.synchronize()
+        done = [h for h in hyps if h is not None]
+        print(f"evaluate: {n} pairs, beam {args.beam_size}, {len(done)} captions, mean length "
+              f"{sum(map(len, done)) / max(len(done), 1):.1f}, {(time.time() - t0) / n * 1e3:.1f} ms/pair")
 
 
 if __name__ == "__main__":

@@ -160,3 +160,105 @@ def make_cc_optimizers(trainer, encoder_lr=1e-4, decoder_lr=1e-4):
     enc = torch.optim.Adam([p for p in trainer.encoder.parameters() if p.requires_grad], lr=encoder_lr, weight_decay=1e-5)
     dec = torch.optim.Adam([p for p in trainer.decoder.parameters() if p.requires_grad], lr=decoder_lr, weight_decay=1e-5)
     return enc, dec
+
+
+def decoder_step_scores(decoder, k_prev_words, memory_bf):
+    """One decoding pass of the reference's evaluation loop (scripts/train_CC.py:258-267) through `decoder`'s own
+    sub-modules: k_prev_words int64 [s, 52], memory_bf [s, S, D] (beam first) -> scores [s, 52, vocab].  `decoder` may
+    be this file's `CaptionDecoder` or the REAL reference module (the layers are looped for the torch-2.10 reason in
+    the header); that is how `beam_search` below is pinned: identical captions through both."""
+    tgt = k_prev_words.permute(1, 0)
+    mask = causal_mask(tgt.size(0), tgt.device)
+    x = decoder.position_encoding(decoder.vocab_embedding(tgt))
+    enc = memory_bf.permute(1, 0, 2)
+    for layer in decoder.transformer.layers:
+        x = layer(x, enc, tgt_mask=mask)
+    return decoder.wdc(x).permute(1, 0, 2)
+
+
+def beam_search(decoder, encoder_out, start_id, end_id, beam_size, vocab_size, max_len=52, step_scores=None):
+    """Restatement of the beam search inside `evaluate()` (reference scripts/train_CC.py:214-330) for ONE image pair.
+    encoder_out: (S, 1, D) = rearrange(encoder(..., output_final=True), 'b c h w -> (h w) b c').
+    Returns (best_seq or None, complete_seqs, complete_seqs_scores).
+
+    Kept exactly: the whole 52-token window is re-decoded at every step (no key/value cache) and the scores are read
+    at position step-1; at step 1 only beam 0 is expanded; hypotheses leave the beam when they emit <end>; the loop
+    stops when the beam is empty or after step 51; the winner is the FIRST maximum of the completed scores; a pair
+    whose beams never emit <end> yields no caption (`complete_inds` of the last step is empty, :326-328).
+    `evaluate()` itself cannot be imported here (torchvision, cv2, h5py, skimage and the java-backed METEOR scorer
+    are absent), so this loop's bookkeeping is pinned only through the decoder arithmetic (see decoder_step_scores):
+    PARITY UNPINNED for the bookkeeping lines, stated in DESIGN.md."""
+    import torch.nn.functional as F
+    step_scores = step_scores or decoder_step_scores
+    k = beam_size
+    dev = encoder_out.device
+    k_prev_words = torch.zeros(k, max_len, dtype=torch.int64, device=dev)
+    k_prev_words[:, 0] = start_id
+    seqs = torch.full((k, 1), start_id, dtype=torch.int64, device=dev)
+    top_k_scores = torch.zeros(k, 1, device=dev)
+    complete_seqs, complete_seqs_scores = [], []
+    S, D = encoder_out.size(0), encoder_out.size(-1)
+    enc = encoder_out.expand(S, k, D).permute(1, 0, 2)            # [k, S, D]
+    step = 1
+    with torch.no_grad():
+        while True:
+            scores = step_scores(decoder, k_prev_words, enc)       # [s, 52, V]
+            scores = F.log_softmax(scores[:, step - 1, :], dim=1)
+            scores = top_k_scores.expand_as(scores) + scores
+            if step == 1:
+                top_k_scores, top_k_words = scores[0].topk(k, 0, True, True)
+            else:
+                top_k_scores, top_k_words = scores.view(-1).topk(k, 0, True, True)
+            prev_word_inds = top_k_words // vocab_size
+            next_word_inds = top_k_words % vocab_size
+            seqs = torch.cat([seqs[prev_word_inds], next_word_inds.unsqueeze(1)], dim=1)
+            incomplete_inds = [i for i, w in enumerate(next_word_inds.tolist()) if w != end_id]
+            complete_inds = sorted(set(range(len(next_word_inds))) - set(incomplete_inds))
+            if complete_inds:
+                complete_seqs.extend(seqs[complete_inds].tolist())
+                complete_seqs_scores.extend(top_k_scores[complete_inds].tolist())
+            k -= len(complete_inds)
+            if k == 0:
+                break
+            seqs = seqs[incomplete_inds]
+            enc = enc[prev_word_inds[incomplete_inds]]
+            top_k_scores = top_k_scores[incomplete_inds].unsqueeze(1)
+            k_prev_words = k_prev_words[incomplete_inds]
+            k_prev_words[:, :step + 1] = seqs
+            if step > 50:
+                break
+            step += 1
+    if not complete_seqs_scores:
+        return None, complete_seqs, complete_seqs_scores
+    best = complete_seqs_scores.index(max(complete_seqs_scores))
+    return complete_seqs[best], complete_seqs, complete_seqs_scores
+
+
+def strip_special(seq, start_id, end_id, pad_id=0):
+    """Hypothesis words as `evaluate()` stores them (reference scripts/train_CC.py:345)."""
+    return [w for w in seq if w not in {start_id, end_id, pad_id}]
+
+
+# (weight seed, beam size, embedding scale, <end> id) of tests/golden/cc_beam.npz.  Random decoder weights give nearly
+# context-free logits; scaling the token embedding makes the hypotheses depend on their history, and <end> is a
+# token those weights emit mid-sequence (found by decoding once without an <end>), so beams complete at different
+# steps, shrink, and keep going.  The last case never emits its <end>: no caption (reference :326-328).
+BEAM_CASES = ((6, 4, 10.0, 63), (4, 5, 30.0, 13), (6, 4, 10.0, 84), (6, 1, 10.0, 84), (3, 3, 30.0, 9), (4, 3, 30.0, 1))
+
+
+def beam_case(seed, embed_scale=30.0, vocab=97, size=32):
+    """Set-up shared by the beam-search tests and the fixture generator: CC Trainer (this oracle) with seeded synthetic
+    weights; <start> = vocab-2, <pad> = 0.  Returns (args, trainer, state_dict, memory (S, 1, D))."""
+    from . import model as om, synth
+    args = synth.make_cc_args(size=size, vocab_size=vocab, dropout=0.0)
+    ora = om.Trainer(args)
+    sd = synth.synth_state_dict(ora, seed=seed)
+    sd["decoder.position_encoding.pe"] = ora.state_dict()["decoder.position_encoding.pe"].clone()
+    sd["decoder.vocab_embedding.weight"] = sd["decoder.vocab_embedding.weight"] * embed_scale
+    ora.load_state_dict(sd)
+    ora.eval()
+    pre, post, _ = synth.synth_batch(1, size, seed=seed + 1)
+    with torch.no_grad():
+        feat = ora.update_cc(pre, post)
+    B, C, H, W = feat.shape
+    return args, ora, sd, feat.permute(2, 3, 0, 1).reshape(H * W, B, C)

@@ -356,15 +356,50 @@ def run_cc(size, batch):
           f"Adam steps); wrote {path} ({os.path.getsize(path) / 1024:.1f} kB); loss curve {losses} (fp64 first {l64.item():.6f})")
 
 
+def run_cc_beam():
+    """tests/golden/cc_beam.npz: the beam search of reference scripts/train_CC.py:214-330 (restated in
+    oracle/caption.py::beam_search -- `evaluate()` itself is not importable here) with every decoding step running
+    through the REAL reference `CaptionDecoder` sub-modules, on the seeded cases of oracle/caption.py::BEAM_CASES."""
+    import contextlib
+    import io
+    import numpy as np
+    from . import caption as oc
+    tr, _, _ = ref_import.import_reference()
+    best = np.zeros((len(oc.BEAM_CASES), 53), dtype=np.int64)
+    best_len = np.zeros(len(oc.BEAM_CASES), dtype=np.int64)
+    scores = np.full((len(oc.BEAM_CASES), 8), np.nan, dtype=np.float64)
+    for i, (seed, beam, es, end_id) in enumerate(oc.BEAM_CASES):
+        args, ora, sd, memory = oc.beam_case(seed, es)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = tr.Trainer(args)
+        ref.load_state_dict(sd)
+        ref.eval()
+        V = args.vocab_size
+        b, seqs, sc = oc.beam_search(ref.decoder, memory, V - 2, end_id, beam, V)
+        b2, seqs2, sc2 = oc.beam_search(ora.decoder, memory, V - 2, end_id, beam, V)
+        assert b == b2 and seqs == seqs2 and sc == sc2
+        best_len[i] = len(b or [])
+        best[i, :best_len[i]] = b or []
+        scores[i, :len(sc)] = sc
+        print(f"[gen_golden] beam case seed={seed} k={beam}: complete lens {[len(s) for s in seqs]}, best len {best_len[i]}, "
+              f"scores {[round(s, 3) for s in sc]}")
+    path = os.path.join(GOLDEN_DIR, "cc_beam.npz")
+    np.savez_compressed(path, cases=np.array(oc.BEAM_CASES, dtype=np.float64), best=best, best_len=best_len, scores=scores)
+    print(f"[gen_golden] wrote {path}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", type=int, nargs="+", default=[64, 256])
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--scd-only", action="store_true", help="only regenerate the SCD fixture")
     ap.add_argument("--cc-only", action="store_true", help="only regenerate the CC fixtures")
+    ap.add_argument("--cc-beam", action="store_true", help="only regenerate the CC beam-search fixture")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     torch.set_num_threads(min(8, os.cpu_count() or 1))
+    if a.cc_beam:
+        return run_cc_beam()
     if not a.scd_only and not a.cc_only:
         for s in a.sizes:
             run(s, a.batch)

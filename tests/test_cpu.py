@@ -421,3 +421,44 @@ def test_cc_oracle_equals_imported_reference():
             assert torch.equal(p.grad, q.grad), n
     unused = {n.split(".")[4] for n, p in ref.named_parameters() if p.grad is None and n.startswith("decoder.transformer.layers.0.")}
     assert unused == {"self_attn2", "multihead_attn", "multihead_attn3", "linear1", "linear2", "norm3", "fc_alpha1", "fc_alpha2", "fc_alpha3"}
+
+
+def test_cc_beam_search_oracle_through_reference_modules():
+    """The beam search restatement (oracle/caption.py::beam_search, reference scripts/train_CC.py:214-330) decodes
+    the same captions with the same scores whether each step runs through the oracle's decoder or through the REAL
+    reference `CaptionDecoder` sub-modules."""
+    import contextlib
+    import io
+    from oracle import caption as oc, ref_import
+    tr, _, _ = ref_import.import_reference()
+    lens = []
+    for seed, beam, es, end_id in oc.BEAM_CASES[:3] + oc.BEAM_CASES[-1:]:
+        args, ora, sd, memory = oc.beam_case(seed, es)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = tr.Trainer(args)
+        ref.load_state_dict(sd)
+        ref.eval()
+        V = args.vocab_size
+        a = oc.beam_search(ora.decoder, memory, V - 2, end_id, beam, V)
+        b = oc.beam_search(ref.decoder, memory, V - 2, end_id, beam, V)
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+        assert a[0] is None or (a[0][0] == V - 2 and a[0][-1] == end_id and len(a[0]) <= 53)
+        lens += [len(s) for s in a[1]]
+    assert len(set(lens)) >= 3 and max(lens) > 5          # the cases exercise shrinking beams, not one-step captions
+
+
+def test_cc_beam_search_golden_fixture():
+    """tests/golden/cc_beam.npz (oracle/gen_golden.py --cc-beam: every step through the REAL reference modules):
+    the oracle reproduces its captions and scores; tests/test_cc_gpu.py decodes the same cases on the GPU."""
+    import numpy as np
+    from oracle import caption as oc
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cc_beam.npz"))
+    assert g["cases"].tolist() == [list(map(float, c)) for c in oc.BEAM_CASES]
+    for i, (seed, beam, es, end_id) in enumerate(oc.BEAM_CASES):
+        args, ora, _, memory = oc.beam_case(seed, es)
+        V = args.vocab_size
+        best, seqs, scores = oc.beam_search(ora.decoder, memory, V - 2, end_id, beam, V)
+        n = int(g["best_len"][i])
+        assert (best or []) == g["best"][i, :n].tolist()
+        assert np.allclose(scores, g["scores"][i, :len(scores)], rtol=0, atol=1e-5)
+        assert np.isnan(g["scores"][i, len(scores):]).all()

@@ -235,7 +235,7 @@ def test_eval_folded_bn_matches_unfolded_eval(dtype, tol):
     ("change3d_amd.scripts.train_BCD", ["--max_steps", "8", "--batch_size", "2", "--in_height", "64", "--in_width", "64",
                                         "--synthetic_pairs", "8", "--act_dtype", "bf16"]),
     ("change3d_amd.scripts.train_CC", ["--max_steps", "4", "--batch_size", "2", "--in_height", "64", "--in_width", "64",
-                                       "--print_freq", "1", "--act_dtype", "f32"]),
+                                       "--print_freq", "1", "--act_dtype", "f32", "--eval_pairs", "2", "--beam_size", "3"]),
 ])
 def test_training_script_mirrors_run_end_to_end(script, extra, tmp_path):
     """The `scripts/train_*.py`-shaped drivers (reference scripts/train_BCD.py:179-360, scripts/train_CC.py:75-168) run
@@ -255,4 +255,4 @@ def test_training_script_mirrors_run_end_to_end(script, extra, tmp_path):
         saved = [f for _, _, fs in os.walk(tmp_path) for f in fs]
         assert "checkpoint.pth.tar" in saved and "best_model.pth" in saved, saved
     else:
-        assert "Loss:" in text
+        assert "Loss:" in text and "evaluate: 2 pairs, beam 3" in text
