@@ -284,6 +284,20 @@ bool fold_fin() {
   return on;
 }
 
+// C3D_WHATIF=<bits>: TIMING EXPERIMENTS ONLY (results are wrong on purpose; tools/whatif.sh).  After the first 8 calls
+// of each driver entry (so that every buffer holds finite values from a regular pass): bit 0 skips the plain
+// BatchNorm finalize / backward-coefficient launches, bit 1 the SE finalize / coefficient launches, bit 2 the
+// residual add + ReLU launches (forward) -- upper bounds for what folding those launches into neighbours could win.
+int whatif_bits() {
+  static const int bits = getenv("C3D_WHATIF") ? atoi(getenv("C3D_WHATIF")) : 0;
+  return bits;
+}
+struct WhatIf {
+  int bits;
+  explicit WhatIf(int* calls) : bits(0) { if (whatif_bits() && ++*calls > 9) bits = whatif_bits(); }
+  bool skip(int bit) const { return (bits >> bit) & 1; }
+};
+
 inline c3d_bn_fin fin_fwd(uint32_t* ticket, const c3d_bn_ptrs& bn, int training, double count, float momentum, float eps,
                           float* ss, float* mr) {
   c3d_bn_fin f;
@@ -421,6 +435,8 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
   if (!x || !ws || !y_out) return C3D_E_BADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int dt = d->dtype, tr = d->training ? 1 : 0, B = d->B, T = d->T;
+  static int whatif_calls = 0;
+  const WhatIf wi(&whatif_calls);
   HIPRC(hipMemsetAsync(at(ws, P.fwd_acc_off), 0, P.fwd_acc_bytes, st));
   const int epi = tr ? C3D_EPI_STATS : C3D_EPI_STORE;
   const void* cur = x;
@@ -447,11 +463,12 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       if (fold) p.a.fin = fin_fwd(tick + 0, k.bn_a, tr, (double)G.M, d->momentum, d->eps, ss_a, mr_a);
       RC(c3d_pw_gemm(&p.a, st));
     }
-    if (!fold)
+    if (!fold && !wi.skip(0))
       RC(c3d_bn_finalize(sums_a, S, (double)G.M, k.bn_a.gamma, k.bn_a.beta, k.bn_a.running_mean, k.bn_a.running_var,
                          tr ? k.bn_a.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr, ss_a, mr_a, st));
     // conv_b (depthwise 3x3x3, BN_a + ReLU on load) + per-sample statistics; BN_b + SE
     RC(c3d_dw333_fwd(a, ss_a, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+    if (!wi.skip(1))
     RC(c3d_bn_se_finalize(nc_b, B, (double)rps, k.bn_b.gamma, k.bn_b.beta, k.bn_b.running_mean, k.bn_b.running_var,
                           tr ? k.bn_b.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr,
                           G.se ? k.se_w1 : nullptr, k.se_b1, k.se_w2, k.se_b2, G.Cr, ss_b, mr_b, gate, hid, st));
@@ -463,7 +480,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       if (fold) p.a.fin = fin_fwd(tick + 1, k.bn_c, tr, (double)G.Mo, d->momentum, d->eps, ss_c, mr_c);
       RC(c3d_pw_gemm(&p.a, st));
     }
-    if (!fold)
+    if (!fold && !wi.skip(0))
       RC(c3d_bn_finalize(sums_c, S, (double)G.Mo, k.bn_c.gamma, k.bn_c.beta, k.bn_c.running_mean, k.bn_c.running_var,
                          tr ? k.bn_c.num_batches_tracked : nullptr, d->momentum, d->eps, G.Co, G.Cop, tr, ss_c, mr_c, st));
     // shortcut
@@ -476,7 +493,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       if (fold && G.sc_bn) p.a.fin = fin_fwd(tick + 2, k.bn_sc, tr, (double)G.Mo, d->momentum, d->eps, ss_1, mr_1);
       RC(c3d_pw_gemm(&p.a, st));
       if (G.sc_bn) {
-        if (!fold)
+        if (!fold && !wi.skip(0))
           RC(c3d_bn_finalize(sums_1, S, (double)G.Mo, k.bn_sc.gamma, k.bn_sc.beta, k.bn_sc.running_mean,
                              k.bn_sc.running_var, tr ? k.bn_sc.num_batches_tracked : nullptr, d->momentum, d->eps,
                              G.Co, G.Cop, tr, ss_1, mr_1, st));
@@ -486,8 +503,8 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       }
       scp = sc;
     }
-    RC(c3d_block_out_fwd(c, ss_c, scp, ss_1, mode, y, G.Mo, G.Cop, dt, st));
-    cur = y;
+    if (!wi.skip(2)) RC(c3d_block_out_fwd(c, ss_c, scp, ss_1, mode, y, G.Mo, G.Cop, dt, st));
+    cur = wi.skip(2) ? c : y;
   }
   return 0;
 }
@@ -499,6 +516,8 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   if (!x || !y_out || !dy || !ws || !wb || !dx_out) return C3D_E_BADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int dt = d->dtype, B = d->B, T = d->T;
+  static int whatif_calls = 0;
+  const WhatIf wi(&whatif_calls);
   HIPRC(hipMemsetAsync(at(wb, P.bwd_acc_off), 0, P.bwd_acc_bytes, st));
   float* wgws = atT<float>(wb, P.wgrad_ws);
   const void* cur_dy = dy;
@@ -537,6 +556,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     } else {
       RC(c3d_block_out_bwd(cur_dy, y, c, scbn ? sc : nullptr, g, mr_c, scbn ? mr_1 : nullptr, dsums_c,
                            scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, st));
+      if (!wi.skip(0))
       RC(c3d_bn_bwd_coef(dsums_c, 1, (double)G.Mo, k.bn_c.gamma, mr_c, G.Co, G.Cop, coef_c, k.bn_c.dgamma, k.bn_c.dbeta, st));
     }
     // ---- conv_c data gradient, Swish / SE backward in the epilogue; weight gradient on the side stream
@@ -553,6 +573,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       w.a.rows_per_sample = rps;
       return c3d_pw_wgrad(&w.a, s2);
     }));
+    if (!wi.skip(1))
     RC(c3d_se_bn_bwd_coef(nc3, nc_b, B, (double)rps, k.bn_b.gamma, mr_b, ss_b, G.Ci, G.Cip, G.se ? k.se_w1 : nullptr,
                           k.se_w2, gate, hid, G.Cr, cA, cC, cB, k.bn_b.dgamma, k.bn_b.dbeta, k.dse_w1, k.dse_b1,
                           k.dse_w2, k.dse_b2, st));
@@ -566,7 +587,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     RC(side_run(st, [&](hipStream_t s2) {
       return c3d_dw333_wgrad(t1, b, cA, cB, cC, a, ss_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, s2);
     }));
-    if (!fold)
+    if (!fold && !wi.skip(0))
       RC(c3d_bn_bwd_coef(dsums_a, 1, (double)G.M, k.bn_a.gamma, mr_a, G.Ci, G.Cip, coef_a, k.bn_a.dgamma, k.bn_a.dbeta, st));
     // ---- shortcut branch
     const void* res = g;
@@ -575,7 +596,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       const int rm = G.s == 2 ? C3D_ROWS_STRIDE2 : C3D_ROWS_DENSE;
       PwCall p(g, k.w_sc, dxs, G.Mo, G.Co, G.Cin, 1, G.Cin, dt);
       if (scbn) {
-        if (!fold)
+        if (!fold && !wi.skip(0))
           RC(c3d_bn_bwd_coef(dsums_1, 1, (double)G.Mo, k.bn_sc.gamma, mr_1, G.Co, G.Cop, coef_1, k.bn_sc.dgamma,
                              k.bn_sc.dbeta, st));
         p.a.x2 = sc; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_1;

@@ -112,6 +112,7 @@ def run(size, batch, check_restatement=True):
                 norms.append(p.grad.double().norm().item())
                 g = p.grad.detach().double().view(-1)
                 probes.append(g[probe_idx(g.numel(), 4, seed=11)].numpy())
+            ref_grads = {n: p.grad.detach().clone() for n, p in ref.named_parameters() if p.grad is not None}
             out["grad_names"] = np.array(names)
             out["grad_norms"] = np.array(norms)
             out["grad_probes"] = np.stack(probes)
@@ -175,7 +176,12 @@ def run(size, batch, check_restatement=True):
         assert np.array_equal(np.packbits(om.binarize(o).numpy().astype(np.uint8).reshape(-1)),
                               out["train_mask_bits"])
         assert abs(om.poly_lr(BASE_LR, 1, MAX_ITER, 0) - lrs[1]) < 1e-18
-        print(f"[gen_golden] restatement == reference at size {size} (loss {losses[0]:.6f})")
+        lo.backward()
+        ora_grads = {n: p.grad for n, p in ora.named_parameters() if p.grad is not None}
+        assert set(ora_grads) == set(ref_grads)
+        for n, g in ref_grads.items():
+            assert torch.equal(g, ora_grads[n]), n
+        print(f"[gen_golden] restatement == reference at size {size} (loss {losses[0]:.6f}, mask, all {len(ref_grads)} gradients bit-identical)")
 
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, f"bcd_s{size}_b{batch}.npz")
