@@ -14,8 +14,22 @@
 // owns one output pixel and one 8-channel vector for all T frames.
 #include "pw_common.h"  // common.h + device_cus()
 #include "bn_fin.h"
+#include "launch_hints.h"
 #include "../../include/change3d_hip.h"
 #include <cstdlib>
+
+thread_local int c3d_side_launch = 0;
+
+// Workgroups of the (single-round) depthwise weight-gradient kernels: every CU when the kernel has the GPU to itself,
+// half of them when the stage driver runs it beside the data-gradient chain (launch_hints.h).
+static long dw_wgrad_target_wgs() {
+  static const int env_wgs = getenv("C3D_DWWG_WGS") ? atoi(getenv("C3D_DWWG_WGS")) : 0;
+  static const int env_side = getenv("C3D_DWWG_SIDE_WGS") ? atoi(getenv("C3D_DWWG_SIDE_WGS")) : 0;
+  if (env_wgs > 0) return env_wgs;
+  if (c3d_side_launch) return env_side > 0 ? env_side : device_cus() / 2;
+  return device_cus();
+}
+
 
 #ifdef C3D_PW_CLOCK
 // Debug build only (tools/pw_phase_clock.py --dw): per-phase shader-clock sums of the data-gradient kernel.
@@ -1987,8 +2001,7 @@ int launch_wgrad(const void* t1, const void* bb, const float* cA, const float* c
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
   const long items = (long)g.B * ntiles;
   // one workgroup is resident per CU: size the walk so that the whole grid is ONE round of workgroups
-  static const int env_wgs = getenv("C3D_DWWG_WGS") ? atoi(getenv("C3D_DWWG_WGS")) : 0;
-  const long target = env_wgs > 0 ? env_wgs : device_cus();
+  const long target = dw_wgrad_target_wgs();
   long gx = target / chunks;
   if (gx >= N_XCD) gx = gx / N_XCD * N_XCD;  // whole XCD rows: the chunk-sibling order deals groups 8 at a time
   if (gx < 1) gx = 1;
@@ -2012,8 +2025,7 @@ int launch_wgrad_dma_t(const void* t1, const void* bb, const float* cA, const fl
   const int ntiles = ((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH);
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
   const long items = (long)g.B * ntiles;
-  static const int env_wgs = getenv("C3D_DWWG_WGS") ? atoi(getenv("C3D_DWWG_WGS")) : 0;
-  const long target = env_wgs > 0 ? env_wgs : device_cus();
+  const long target = dw_wgrad_target_wgs();
   long gx = target / chunks;
   if (gx >= N_XCD) gx = gx / N_XCD * N_XCD;  // whole XCD rows: the chunk-sibling order deals groups 8 at a time
   if (gx < 1) gx = 1;
@@ -2050,8 +2062,7 @@ int launch_wgrad_dot2(const void* t1, const void* bb, const float* cA, const flo
   const int ntiles = ((g.Wo + D2_TW - 1) / D2_TW) * ((g.Ho + D2_TH - 1) / D2_TH);
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
   const long items = (long)g.B * ntiles;
-  static const int env_wgs = getenv("C3D_DWWG_WGS") ? atoi(getenv("C3D_DWWG_WGS")) : 0;
-  const long target = env_wgs > 0 ? env_wgs : device_cus();
+  const long target = dw_wgrad_target_wgs();
   long gx = target / chunks;
   if (gx >= N_XCD) gx = gx / N_XCD * N_XCD;
   if (gx < 1) gx = 1;

@@ -1,0 +1,9 @@
+// Launch hints passed between translation units of the library (not part of the C ABI).
+#pragma once
+
+// Set by the stage driver around launches it places on its side stream.  Single-round kernels (one long-running
+// workgroup per CU for the whole launch) read it to leave CUs free: a side kernel that occupies every CU keeps EVERY
+// kernel of the data-gradient chain that becomes ready meanwhile -- including its 1-8 workgroup coefficient kernels --
+// waiting for its whole duration (measured on MI355X, B=32 bf16: depthwise weight gradient on 128 instead of 256
+// workgroups: step 35.6 -> 34.1 ms, and the 40 us stall around c3d_se_bn_bwd_coef disappears).
+extern thread_local int c3d_side_launch;

@@ -11,6 +11,7 @@
 #include "../../include/change3d_hip.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include "launch_hints.h"
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -49,6 +50,18 @@ struct BlkFwd {   // byte offsets into ws_fwd
   size_t sums_a, nc_b, sums_c, sums_1;                          // f64 accumulators
   size_t tick;                                                  // u32 [4] last-workgroup tickets (a, c, shortcut)
 };
+
+// Ring depth of the backward temporaries: block i shares its slot with block i+R, so the side stream (weight gradients)
+// may run up to R-1 blocks behind the data-gradient chain before the main stream has to wait for it.
+constexpr int BWD_RING_MAX = 4;
+int bwd_ring() {
+  static const int r = [] {
+    const char* s = getenv("C3D_BWD_RING");
+    const int v = s ? atoi(s) : 2;   // measured on MI355X (B=32 bf16): 2, 3, 4 slots -> 34.04 / 34.10 / 34.32 ms per step
+    return v < 2 ? 2 : (v > BWD_RING_MAX ? BWD_RING_MAX : v);
+  }();
+  return r;
+}
 
 struct BlkBwd {   // byte offsets into ws_bwd (ring slot for the big tensors)
   size_t g, t1, t2, dxs, dx;
@@ -127,8 +140,8 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
   }
   P.fwd_acc_bytes = cf.off - P.fwd_acc_off;
   P.fwd_total = cf.off;
-  // ---- backward workspace: two ring slots of big temporaries (the side stream lags the data-gradient chain by at
-  //      most one block), per-block f32 coefficient vectors, one f64 accumulator region, the split-K scratch of
+  // ---- backward workspace: bwd_ring() ring slots of big temporaries (the side stream may lag the data-gradient chain
+  //      by ring-1 blocks), per-block f32 coefficient vectors, one f64 accumulator region, the split-K scratch of
   //      the pointwise weight gradient
   size_t mx_g = 0, mx_t1 = 0, mx_t2 = 0, mx_dxs = 0, mx_dx = 0;
   int64_t wsf = 0;
@@ -144,8 +157,9 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
     wsf = std::max(wsf, c3d_pw_wgrad_ws_floats(G.Co, G.Cin));
   }
   Carver cb;
-  size_t ring[2][5];
-  for (int r = 0; r < 2; ++r) {
+  const int R = bwd_ring();
+  size_t ring[BWD_RING_MAX][5];
+  for (int r = 0; r < R; ++r) {
     ring[r][0] = cb.take(mx_g); ring[r][1] = cb.take(mx_t1); ring[r][2] = cb.take(mx_t2);
     ring[r][3] = mx_dxs ? cb.take(mx_dxs) : SIZE_MAX; ring[r][4] = mx_dx ? cb.take(mx_dx) : SIZE_MAX;
   }
@@ -153,7 +167,7 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
   for (int i = 0; i < n; ++i) {
     const BlkGeom& G = P.g[i];
     BlkBwd& Bk = P.b[i];
-    const int r = i & 1;
+    const int r = i % R;
     Bk.g = ring[r][0]; Bk.t1 = ring[r][1]; Bk.t2 = ring[r][2]; Bk.dxs = ring[r][3];
     Bk.dx = i > 0 ? ring[r][4] : SIZE_MAX;
     Bk.coef_c = cb.take(3 * G.Cop * 4);
@@ -209,7 +223,16 @@ SideCtx* side_ctx() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   SideCtx& c = g_side[dev];
-  if (!c.side && hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (!c.side) {
+    // C3D_SIDE_PRIO=1: lowest stream priority for the weight-gradient stream (A/B knob)
+    static const bool low = getenv("C3D_SIDE_PRIO") && atoi(getenv("C3D_SIDE_PRIO")) == 1;
+    int lo = 0, hi = 0;
+    if (low && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) {
+      if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+    } else if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) {
+      return nullptr;
+    }
+  }
   return &c;
 }
 
@@ -224,7 +247,10 @@ int side_run(hipStream_t main, F&& fn) {
   if (!fork) return fn(main);
   HIPRC(hipEventRecord(fork, main));
   HIPRC(hipStreamWaitEvent(c->side, fork, 0));
-  RC(fn(c->side));
+  c3d_side_launch = 1;           // launch hint (launch_hints.h): this kernel runs beside the data-gradient chain
+  const int rc_fn = fn(c->side);
+  c3d_side_launch = 0;
+  RC(rc_fn);
   hipEvent_t done = c->ev();
   if (!done) return (int)hipErrorOutOfMemory;
   HIPRC(hipEventRecord(done, c->side));
@@ -286,7 +312,7 @@ bool fold_fin() {
 
 // C3D_WHATIF=<bits>: TIMING EXPERIMENTS ONLY (results are wrong on purpose; tools/whatif.sh).  After the first 8 calls
 // of each driver entry (so that every buffer holds finite values from a regular pass): bit 0 skips the plain
-// BatchNorm finalize / backward-coefficient launches, bit 1 the SE finalize / coefficient launches, bit 2 the
+// BatchNorm finalize / backward-coefficient launches, bit 1 the SE finalize launches (forward), bit 3 the SE coefficient launches (backward), bit 2 the
 // residual add + ReLU launches (forward) -- upper bounds for what folding those launches into neighbours could win.
 int whatif_bits() {
   static const int bits = getenv("C3D_WHATIF") ? atoi(getenv("C3D_WHATIF")) : 0;
@@ -521,8 +547,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   HIPRC(hipMemsetAsync(at(wb, P.bwd_acc_off), 0, P.bwd_acc_bytes, st));
   float* wgws = atT<float>(wb, P.wgrad_ws);
   const void* cur_dy = dy;
-  uint64_t prev_mark = 0;
-  bool have_prev = false;
+  std::deque<uint64_t> lag;   // side-stream marks of the blocks whose ring slots are still in flight
   for (int i = d->n_blocks - 1; i >= 0; --i) {
     const c3d_block_desc& k = d->blocks[i];
     const BlkGeom& G = P.g[i];
@@ -559,7 +584,16 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       if (!wi.skip(0))
       RC(c3d_bn_bwd_coef(dsums_c, 1, (double)G.Mo, k.bn_c.gamma, mr_c, G.Co, G.Cop, coef_c, k.bn_c.dgamma, k.bn_c.dbeta, st));
     }
-    // ---- conv_c data gradient, Swish / SE backward in the epilogue; weight gradient on the side stream
+    // ---- conv_c data gradient, Swish / SE backward in the epilogue; weight gradient on the side stream (it needs
+    //      coef_c, not the data gradient: it is forked BEFORE the data-gradient launch; C3D_WGC_EARLY=0 forks it after)
+    auto wgrad_c = [&](hipStream_t s2) {
+      WgCall w(g, b, k.dw_c, wgws, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
+      w.a.p2 = c; w.a.p_coef = coef_c; w.a.q_mode = C3D_PRO_BN_SE_SWISH; w.a.q_ss = ss_b; w.a.q_gate = gate;
+      w.a.rows_per_sample = rps;
+      return c3d_pw_wgrad(&w.a, s2);
+    };
+    static const bool wgc_early = !(getenv("C3D_WGC_EARLY") && atoi(getenv("C3D_WGC_EARLY")) == 0);
+    if (wgc_early) RC(side_run(st, wgrad_c));
     {
       PwCall p(g, k.w_c, t1, G.Mo, G.Co, G.Ci, 1, G.Ci, dt);
       p.a.x2 = c; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_c;
@@ -567,13 +601,8 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       p.a.stats = nc3; p.a.rows_per_sample = rps;
       RC(c3d_pw_gemm(&p.a, st));
     }
-    RC(side_run(st, [&](hipStream_t s2) {
-      WgCall w(g, b, k.dw_c, wgws, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
-      w.a.p2 = c; w.a.p_coef = coef_c; w.a.q_mode = C3D_PRO_BN_SE_SWISH; w.a.q_ss = ss_b; w.a.q_gate = gate;
-      w.a.rows_per_sample = rps;
-      return c3d_pw_wgrad(&w.a, s2);
-    }));
-    if (!wi.skip(1))
+    if (!wgc_early) RC(side_run(st, wgrad_c));
+    if (!wi.skip(3))
     RC(c3d_se_bn_bwd_coef(nc3, nc_b, B, (double)rps, k.bn_b.gamma, mr_b, ss_b, G.Ci, G.Cip, G.se ? k.se_w1 : nullptr,
                           k.se_w2, gate, hid, G.Cr, cA, cC, cB, k.bn_b.dgamma, k.bn_b.dbeta, k.dse_w1, k.dse_b1,
                           k.dse_w2, k.dse_b2, st));
@@ -623,10 +652,9 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       w.a.p2 = a; w.a.p_coef = coef_a;
       return c3d_pw_wgrad(&w.a, s2);
     }));
-    // the side stream may lag by ONE block: block i-1 reuses the ring slot of block i+1
-    if (have_prev) RC(side_join(st, prev_mark));
-    prev_mark = side_mark();
-    have_prev = true;
+    // the side stream may lag by ring-1 blocks: block i-1 reuses the ring slot of block i-1+ring
+    lag.push_back(side_mark());
+    if ((int)lag.size() >= bwd_ring()) { RC(side_join(st, lag.front())); lag.pop_front(); }
     cur_dy = dx;
   }
   return 0;
