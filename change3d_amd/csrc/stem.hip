@@ -10,6 +10,7 @@
 //                          the batch (the only input frames that are parameters,
 //                          reference model/trainer.py:51-54,155).
 #include "common.h"
+#include "stem_mfma.h"
 #include <cstdlib>
 #include "../../include/change3d_hip.h"
 
@@ -443,6 +444,10 @@ __global__ __launch_bounds__(SW_THREADS) void stem_bwd_wx_kernel(
 extern "C" int c3d_stem_fwd(const float* x, const float* w_t, const float* w_xy, void* u, double* sums, int32_t B,
                             int32_t T, int32_t H, int32_t W, int32_t dtype, void* stream) {
   if (!x || !w_t || !w_xy || !u || B <= 0 || T <= 0 || T > ST_MAXT || H <= 0 || W <= 0) return C3D_E_BADARG;
+  if (c3d_stem_mfma_enabled()) {
+    const int rc = c3d_stem_fwd_mfma(x, w_t, w_xy, u, sums, B, T, H, W, dtype, reinterpret_cast<hipStream_t>(stream));
+    if (rc != C3D_E_UNSUPPORTED) { if (rc == 0) C3D_CHECK_LAUNCH(); return rc; }
+  }
   StemGeom g{B, T, H, W};
   const size_t lds = (27 * ST_C + 5 * ST_C + 6 * 3 * 16 + (size_t)ST_CI * T * ST_IH * ST_IW) * sizeof(float);
   const int ntiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
@@ -466,6 +471,10 @@ extern "C" int c3d_stem_bwd_dv(const float* x, const float* w_t, const float* w_
                                int32_t W, int32_t dtype, void* stream) {
   if (!x || !w_t || !w_xy || !g0 || !u || !coef || !dv || !dw_xy || B <= 0 || T <= 0 || T > ST_MAXT)
     return C3D_E_BADARG;
+  if (c3d_stem_mfma_enabled()) {
+    const int rc = c3d_stem_bwd_dv_mfma(x, w_t, w_xy, g0, u, coef, dv, dw_xy, B, T, H, W, dtype, reinterpret_cast<hipStream_t>(stream));
+    if (rc != C3D_E_UNSUPPORTED) { if (rc == 0) C3D_CHECK_LAUNCH(); return rc; }
+  }
   StemGeom g{B, T, H, W};
   const size_t lds = (27 * ST_C + 5 * ST_C + 5 * ST_C + (size_t)ST_CI * T * ST_IH * ST_IW) * sizeof(float);
   const int ntiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
@@ -494,6 +503,11 @@ extern "C" int c3d_stem_bwd_wx(const float* x, const float* w_t, const void* dv,
                                int32_t dtype, void* stream) {
   if (!x || !w_t || !dv || !dw_t || B <= 0 || T <= 0 || T > ST_MAXT) return C3D_E_BADARG;
   if (dP && (t_first < 0 || n_frames <= 0 || t_first + n_frames > T)) return C3D_E_BADARG;
+  if (c3d_stem_mfma_enabled()) {
+    const int rc = c3d_stem_bwd_wx_mfma(x, w_t, dv, dw_t, dP, B, T, H, W, t_first, n_frames, per_sample, dtype,
+                                        reinterpret_cast<hipStream_t>(stream));
+    if (rc != C3D_E_UNSUPPORTED) { if (rc == 0) C3D_CHECK_LAUNCH(); return rc; }
+  }
   StemGeom g{B, T, H, W};
   const size_t lds = (27 * ST_C + (size_t)ST_CI * T * ST_IH * ST_IW + (size_t)T * ST_IH * ST_IW * ST_C) * sizeof(float);
   const int ntiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
