@@ -75,6 +75,53 @@ __device__ __forceinline__ void bn_forward(const c3d_bn_fin& f, const double* su
   }
 }
 
+// Consumer side: the sums were completed by an EARLIER launch (plain loads).  Every thread of the workgroup calls this;
+// scale/shift of the channels [c_lo, c_lo + n) land in lds_sc / lds_sh (zero for padding channels); the `owner`
+// workgroup of those channels also writes ss / mr / running statistics.  Four adjacent lanes share a channel and add
+// the 16 stripes in the SAME tree as bn_finalize_kernel's 16-lane butterfly (lane q: ((s[4q]+s[4q+1]) + (s[4q+2]+
+// s[4q+3])), then xor 1, xor 2), so the result is bit-identical to the separate launch.  Ends with __syncthreads().
+__device__ __forceinline__ void bn_consume(const c3d_bn_fin& f, int C, int Cp, int c_lo, int n, bool owner, float* lds_sc,
+                                           float* lds_sh, int tid, int nthreads) {
+  const int q = tid & 3;
+  for (int l0 = 0; l0 < n; l0 += nthreads >> 2) {
+    const bool grp = (tid >> 2) < (nthreads >> 2);      // (a trailing partial group of four idles)
+    const int lc = l0 + (tid >> 2), c = c_lo + lc;
+    const bool live = grp && lc < n && c < C;
+    double s1 = 0, s2 = 0;
+    if (live) {
+      const double* p = f.sums + (size_t)(4 * q) * 2 * C + c;
+      const double a0 = p[0], a1 = p[(size_t)2 * C], a2 = p[(size_t)4 * C], a3 = p[(size_t)6 * C];
+      const double b0 = p[C], b1 = p[(size_t)3 * C], b2 = p[(size_t)5 * C], b3 = p[(size_t)7 * C];
+      s1 = (a0 + a1) + (a2 + a3);
+      s2 = (b0 + b1) + (b2 + b3);
+    }
+    s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+    s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+    if (q != 0 || !grp || lc >= n) continue;
+    float sc = 0.f, sh = 0.f, meanf = 0.f, rstd = 0.f;
+    if (c < C) {
+      const double mean = s1 / f.count;
+      double var = s2 / f.count - mean * mean;
+      if (var < 0) var = 0;
+      if (owner && f.running_mean) {
+        const double unb = f.count > 1 ? var * f.count / (f.count - 1) : var;
+        f.running_mean[c] = (float)((1.0 - f.momentum) * f.running_mean[c] + f.momentum * mean);
+        f.running_var[c] = (float)((1.0 - f.momentum) * f.running_var[c] + f.momentum * unb);
+      }
+      rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+      meanf = (float)mean;
+      sc = f.gamma[c] * rstd;
+      sh = f.beta[c] - meanf * sc;
+    }
+    lds_sc[lc] = sc; lds_sh[lc] = sh;
+    if (owner && c < Cp) {
+      f.ss[c] = sc; f.ss[Cp + c] = sh;
+      if (f.mr) { f.mr[c] = meanf; f.mr[Cp + c] = rstd; }
+    }
+  }
+  __syncthreads();
+}
+
 // Backward: dsums f64 [stripes][2][C] = (sum g, sum g*xhat) -> coef = (A | B | C) with dx = A*g + B + C*x, and the
 // BatchNorm parameter gradients (+=) (same arithmetic as bn_bwd_coef_kernel).  f.ss is the coefficient vector [3][Cp],
 // f.mr the saved (mean | rstd), f.running_mean / f.running_var carry dgamma / dbeta.

@@ -17,6 +17,7 @@
 #include "launch_hints.h"
 #include "../../include/change3d_hip.h"
 #include <cstdlib>
+#include <cstring>
 
 thread_local int c3d_side_launch = 0;
 
@@ -1712,13 +1713,14 @@ template <typename T, int TT>
 __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x, const float* __restrict__ ss,
                                                         const float* __restrict__ w, T* __restrict__ y,
                                                         double* __restrict__ nc, const DwGeom g,
-                                                        const int tiles_per_wg) {
+                                                        const int tiles_per_wg, const c3d_bn_fin fin) {
   typedef RawD<T> RW;
   typedef V2Geo<TT> G;
   constexpr int NI = G::NI, SL = G::SL, PLANE = G::PLANE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wl = reinterpret_cast<float*>(smem);                  // [27][32]
-  float4* tile = reinterpret_cast<float4*>(wl + 27 * 32);      // [4 cv][2 halves][PLANE]
+  float* fss = wl + 27 * 32;                                   // [2][32] scale | shift of this chunk (fin.sums mode)
+  float4* tile = reinterpret_cast<float4*>(fss + 64);          // [4 cv][2 halves][PLANE]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wcv = __builtin_amdgcn_readfirstlane(tid >> 6);    // this wave's channel vector
@@ -1741,9 +1743,6 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
     const int tap = i / 32, c = c0 + (i & 31);
     wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
   }
-  float sc[8], sh[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { sc[j] = s_ok ? ss[sbase + j] : 0.f; sh[j] = s_ok ? ss[g.Cp + sbase + j] : 0.f; }
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -1771,6 +1770,18 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
   int tl1 = tl0 + tiles_per_wg;
   if (tl1 > ntiles) tl1 = ntiles;
   if (tl0 < tl1) V2_ISSUE(tl0)
+  // BatchNorm scale / shift of this chunk: given, or rebuilt from the producer's completed sums while the first
+  // tile's loads are in flight (csrc/bn_fin.h; the workgroup of (sample 0, walk 0) owns the chunk's global outputs)
+  float sc[8], sh[8];
+  if (fin.sums) {
+    if (tid == 0 && co.chunk == 0 && co.group == 0 && fin.training && fin.nbt) *fin.nbt += 1;
+    c3dfin::bn_consume(fin, g.C, g.Cp, c0, 32, co.group == 0, fss, fss + 32, tid, 256);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = s_ok ? fss[scv * 8 + j] : 0.f; sh[j] = s_ok ? fss[32 + scv * 8 + j] : 0.f; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = s_ok ? ss[sbase + j] : 0.f; sh[j] = s_ok ? ss[g.Cp + sbase + j] : 0.f; }
+  }
   for (int tl = tl0; tl < tl1; ++tl) {
     const int tx = tl % tiles_x, ty = tl / tiles_x;
     __syncthreads();
@@ -1869,8 +1880,8 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
 
 template <typename T, int TT>
 int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, double* nc, const DwGeom& g,
-                  hipStream_t stream) {
-  const size_t lds = 27 * 32 * sizeof(float) + (size_t)DW_CV * 2 * V2Geo<TT>::PLANE * sizeof(float4);
+                  hipStream_t stream, const c3d_bn_fin* fin = nullptr) {
+  const size_t lds = (27 * 32 + 64) * sizeof(float) + (size_t)DW_CV * 2 * V2Geo<TT>::PLANE * sizeof(float4);
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1890,8 +1901,10 @@ int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, doubl
   if (const char* e = getenv("C3D_DW_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;  // tuning knob
   if (tpw > ntiles) tpw = ntiles;
   dim3 grid(chunk_order_grid((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), (long)((ntiles + tpw - 1) / tpw) * g.B));
+  c3d_bn_fin f0;
+  std::memset(&f0, 0, sizeof(f0));
   dw_fwd_v2_kernel<T, TT><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
-                                                            reinterpret_cast<T*>(y), nc, g, tpw);
+                                                            reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -2113,6 +2126,29 @@ extern "C" int c3d_dw333_fwd(const void* x, const float* ss, const float* w, voi
   if (dtype == C3D_DT_BF16) return stride == 1 ? launch_fwd<bf16_t, 1>(x, ss, w, y, nc_sums, g, s)
                                                : launch_fwd<bf16_t, 2>(x, ss, w, y, nc_sums, g, s);
   return C3D_E_BADARG;
+}
+
+extern "C" int c3d_dw333_fwd_fin(const void* x, const c3d_bn_fin* fin, const float* w, void* y, double* nc_sums,
+                                 int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride,
+                                 int32_t dtype, void* stream) {
+  if (!fin || !fin->sums || !fin->ss || !fin->gamma || !fin->beta || !fin->training) return C3D_E_BADARG;
+  DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
+  if (!x || !w || !y || !geom_ok(g)) return C3D_E_BADARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stride == 1 && (dtype == C3D_DT_F32 || dtype == C3D_DT_BF16)) {
+    int rc;
+    if (dtype == C3D_DT_F32) rc = T <= 3 ? launch_fwd_v2<float, 3>(x, fin->ss, w, y, nc_sums, g, s, fin)
+                                         : launch_fwd_v2<float, 5>(x, fin->ss, w, y, nc_sums, g, s, fin);
+    else rc = T <= 3 ? launch_fwd_v2<bf16_t, 3>(x, fin->ss, w, y, nc_sums, g, s, fin)
+                     : launch_fwd_v2<bf16_t, 5>(x, fin->ss, w, y, nc_sums, g, s, fin);
+    if (rc != C3D_E_UNSUPPORTED) return rc;
+  }
+  // no folded kernel for this shape: the separate launch, then the plain kernel
+  const int rc = c3d_bn_finalize(fin->sums, C3D_STAT_STRIPES, fin->count, fin->gamma, fin->beta, fin->running_mean,
+                                 fin->running_var, fin->nbt, fin->momentum, fin->eps, C, Cp, fin->training, fin->ss,
+                                 fin->mr, stream);
+  if (rc) return rc;
+  return c3d_dw333_fwd(x, fin->ss, w, y, nc_sums, B, T, H, W, C, Cp, stride, dtype, stream);
 }
 
 extern "C" int c3d_dw333_bwd_data(const void* t1, const void* b, const float* coefA, const float* coefB,

@@ -6,6 +6,8 @@
 // so per-channel parameters and partial sums stay in registers.
 #include "common.h"
 #include "bn_fin.h"
+#include <cstring>
+#include <cstdlib>
 #include <cstdlib>
 #include "../../include/change3d_hip.h"
 
@@ -19,15 +21,35 @@ enum { SC_NONE = 0, SC_IDENTITY = 1, SC_BN = 2, SC_RAW = 3 };
 template <typename T>
 __global__ void block_out_fwd_kernel(const T* __restrict__ c, const float* __restrict__ ss_c,
                                      const T* __restrict__ sc, const float* __restrict__ ss_1, int sc_mode,
-                                     T* __restrict__ y, int64_t nvec, int G) {
+                                     T* __restrict__ y, int64_t nvec, int G, int C, const c3d_bn_fin fin_c,
+                                     const c3d_bn_fin fin_1) {
+  __shared__ float lss[4][256];   // scale_c | shift_c | scale_1 | shift_1 (consumer-side BatchNorm finalisation)
   const int v = threadIdx.x % G;
   const int Cp = G * 8;
   float a[8], b[8], a1[8], b1[8];
+  if (fin_c.sums) {
+    // every workgroup rebuilds the vectors from the producers' completed sums (csrc/bn_fin.h); workgroup 0 owns the
+    // global outputs (scale/shift, mean/rstd for backward, running statistics)
+    const bool owner = blockIdx.x == 0;
+    if (owner && threadIdx.x == 0 && fin_c.nbt) *fin_c.nbt += 1;
+    c3dfin::bn_consume(fin_c, C, Cp, 0, Cp, owner, lss[0], lss[1], threadIdx.x, blockDim.x);
+    if (sc_mode == SC_BN) {
+      if (owner && threadIdx.x == 0 && fin_1.nbt) *fin_1.nbt += 1;
+      c3dfin::bn_consume(fin_1, C, Cp, 0, Cp, owner, lss[2], lss[3], threadIdx.x, blockDim.x);
+    }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    a[j] = ss_c[v * 8 + j]; b[j] = ss_c[Cp + v * 8 + j];
-    a1[j] = (sc_mode == SC_BN) ? ss_1[v * 8 + j] : 1.f;
-    b1[j] = (sc_mode == SC_BN) ? ss_1[Cp + v * 8 + j] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      a[j] = lss[0][v * 8 + j]; b[j] = lss[1][v * 8 + j];
+      a1[j] = (sc_mode == SC_BN) ? lss[2][v * 8 + j] : 1.f;
+      b1[j] = (sc_mode == SC_BN) ? lss[3][v * 8 + j] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] = ss_c[v * 8 + j]; b[j] = ss_c[Cp + v * 8 + j];
+      a1[j] = (sc_mode == SC_BN) ? ss_1[v * 8 + j] : 1.f;
+      b1[j] = (sc_mode == SC_BN) ? ss_1[Cp + v * 8 + j] : 0.f;
+    }
   }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -223,22 +245,48 @@ inline int ew_grid(int64_t nvec, int block) {
   else if ((dtype) == C3D_DT_BF16) { CALL_BF16; } \
   else return C3D_E_BADARG;
 
+namespace {
+int block_out_fwd_launch(const void* c, const float* ss_c, const void* shortcut, const float* ss_1, int32_t sc_mode,
+                         void* y, int64_t M, int32_t C, int32_t Cp, int32_t dtype, void* stream, const c3d_bn_fin* fin_c,
+                         const c3d_bn_fin* fin_1) {
+  const int G = Cp / 8, blk = ew_block(G);
+  const int64_t nvec = M * G;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  c3d_bn_fin f0;
+  std::memset(&f0, 0, sizeof(f0));
+  const c3d_bn_fin fc = fin_c ? *fin_c : f0, f1 = fin_1 ? *fin_1 : f0;
+  // grid stride must stay a multiple of G: blk is, so any grid works.  With the finalisation folded in every
+  // workgroup starts with a ~1.5 us dependent prologue: ONE round of workgroups (4 per CU), each walking the rows.
+  int grid = ew_grid(nvec, blk);
+  static const int env_grid = getenv("C3D_BOF_GRID") ? atoi(getenv("C3D_BOF_GRID")) : 0;   // tuning knob
+  if (fin_c && grid > (env_grid > 0 ? env_grid : 1024)) grid = env_grid > 0 ? env_grid : 1024;
+  EW_DISPATCH(dtype,
+              (block_out_fwd_kernel<float><<<grid, blk, 0, s>>>(
+                  (const float*)c, ss_c, (const float*)shortcut, ss_1, sc_mode, (float*)y, nvec, G, C, fc, f1)),
+              (block_out_fwd_kernel<bf16_t><<<grid, blk, 0, s>>>(
+                  (const bf16_t*)c, ss_c, (const bf16_t*)shortcut, ss_1, sc_mode, (bf16_t*)y, nvec, G, C, fc, f1)));
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace
+
 extern "C" int c3d_block_out_fwd(const void* c, const float* ss_c, const void* shortcut, const float* ss_1,
                                  int32_t sc_mode, void* y, int64_t M, int32_t Cp, int32_t dtype, void* stream) {
   if (!c || !ss_c || !y || M <= 0 || (Cp & 7) || Cp > 256) return C3D_E_BADARG;
   if (sc_mode != SC_NONE && !shortcut) return C3D_E_BADARG;
   if (sc_mode == SC_BN && !ss_1) return C3D_E_BADARG;
-  const int G = Cp / 8, blk = ew_block(G);
-  const int64_t nvec = M * G;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // grid stride must stay a multiple of G: blk is, so any grid works
-  EW_DISPATCH(dtype,
-              (block_out_fwd_kernel<float><<<ew_grid(nvec, blk), blk, 0, s>>>(
-                  (const float*)c, ss_c, (const float*)shortcut, ss_1, sc_mode, (float*)y, nvec, G)),
-              (block_out_fwd_kernel<bf16_t><<<ew_grid(nvec, blk), blk, 0, s>>>(
-                  (const bf16_t*)c, ss_c, (const bf16_t*)shortcut, ss_1, sc_mode, (bf16_t*)y, nvec, G)));
-  C3D_CHECK_LAUNCH();
-  return 0;
+  return block_out_fwd_launch(c, ss_c, shortcut, ss_1, sc_mode, y, M, Cp, Cp, dtype, stream, nullptr, nullptr);
+}
+
+extern "C" int c3d_block_out_fwd_fin(const void* c, const c3d_bn_fin* fin_c, const void* shortcut,
+                                     const c3d_bn_fin* fin_1, int32_t sc_mode, void* y, int64_t M, int32_t C,
+                                     int32_t Cp, int32_t dtype, void* stream) {
+  if (!c || !fin_c || !fin_c->sums || !fin_c->ss || !fin_c->training || !y || M <= 0 || (Cp & 7) || Cp > 256 || C > Cp)
+    return C3D_E_BADARG;
+  if (sc_mode != SC_NONE && !shortcut) return C3D_E_BADARG;
+  if (sc_mode == SC_BN && (!fin_1 || !fin_1->sums || !fin_1->ss)) return C3D_E_BADARG;
+  return block_out_fwd_launch(c, fin_c->ss, shortcut, fin_1 ? fin_1->ss : nullptr, sc_mode, y, M, C, Cp, dtype, stream,
+                              fin_c, sc_mode == SC_BN ? fin_1 : nullptr);
 }
 
 extern "C" int c3d_block_out_bwd(const void* dy, const void* y, const void* c, const void* s_bn, void* g,

@@ -334,6 +334,20 @@ inline c3d_bn_fin fin_fwd(uint32_t* ticket, const c3d_bn_ptrs& bn, int training,
   return f;
 }
 
+// C3D_FIN_CONSUMER=0: separate c3d_bn_finalize launches in front of the depthwise forward and the residual add (the
+// default folds them into those kernels' prologues: csrc/bn_fin.h bn_consume)
+bool fin_consumer() {
+  static const bool on = !(getenv("C3D_FIN_CONSUMER") && atoi(getenv("C3D_FIN_CONSUMER")) == 0);
+  return on;
+}
+
+inline c3d_bn_fin fin_consume(const double* sums, const c3d_bn_ptrs& bn, double count, float momentum, float eps,
+                              float* ss, float* mr) {
+  c3d_bn_fin f = fin_fwd(nullptr, bn, 1, count, momentum, eps, ss, mr);
+  f.sums = sums;
+  return f;
+}
+
 inline c3d_bn_fin fin_bwd(uint32_t* ticket, const c3d_bn_ptrs& bn, double count, float* coef, const float* mr) {
   c3d_bn_fin f;
   std::memset(&f, 0, sizeof(f));
@@ -489,11 +503,18 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       if (fold) p.a.fin = fin_fwd(tick + 0, k.bn_a, tr, (double)G.M, d->momentum, d->eps, ss_a, mr_a);
       RC(c3d_pw_gemm(&p.a, st));
     }
-    if (!fold && !wi.skip(0))
-      RC(c3d_bn_finalize(sums_a, S, (double)G.M, k.bn_a.gamma, k.bn_a.beta, k.bn_a.running_mean, k.bn_a.running_var,
-                         tr ? k.bn_a.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr, ss_a, mr_a, st));
-    // conv_b (depthwise 3x3x3, BN_a + ReLU on load) + per-sample statistics; BN_b + SE
-    RC(c3d_dw333_fwd(a, ss_a, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+    // conv_b (depthwise 3x3x3, BN_a + ReLU on load) + per-sample statistics; BN_b + SE.  BN_a is finalised by the
+    // depthwise kernel's own prologue (or by a separate launch: eval mode, last-workgroup mode, C3D_FIN_CONSUMER=0)
+    const bool cons = tr && !fold && fin_consumer() && !whatif_bits();
+    if (cons) {
+      const c3d_bn_fin fa = fin_consume(sums_a, k.bn_a, (double)G.M, d->momentum, d->eps, ss_a, mr_a);
+      RC(c3d_dw333_fwd_fin(a, &fa, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+    } else {
+      if (!fold && !wi.skip(0))
+        RC(c3d_bn_finalize(sums_a, S, (double)G.M, k.bn_a.gamma, k.bn_a.beta, k.bn_a.running_mean, k.bn_a.running_var,
+                           tr ? k.bn_a.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr, ss_a, mr_a, st));
+      RC(c3d_dw333_fwd(a, ss_a, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+    }
     if (!wi.skip(1))
     RC(c3d_bn_se_finalize(nc_b, B, (double)rps, k.bn_b.gamma, k.bn_b.beta, k.bn_b.running_mean, k.bn_b.running_var,
                           tr ? k.bn_b.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr,
@@ -506,7 +527,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       if (fold) p.a.fin = fin_fwd(tick + 1, k.bn_c, tr, (double)G.Mo, d->momentum, d->eps, ss_c, mr_c);
       RC(c3d_pw_gemm(&p.a, st));
     }
-    if (!fold && !wi.skip(0))
+    if (!cons && !fold && !wi.skip(0))
       RC(c3d_bn_finalize(sums_c, S, (double)G.Mo, k.bn_c.gamma, k.bn_c.beta, k.bn_c.running_mean, k.bn_c.running_var,
                          tr ? k.bn_c.num_batches_tracked : nullptr, d->momentum, d->eps, G.Co, G.Cop, tr, ss_c, mr_c, st));
     // shortcut
@@ -519,7 +540,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       if (fold && G.sc_bn) p.a.fin = fin_fwd(tick + 2, k.bn_sc, tr, (double)G.Mo, d->momentum, d->eps, ss_1, mr_1);
       RC(c3d_pw_gemm(&p.a, st));
       if (G.sc_bn) {
-        if (!fold && !wi.skip(0))
+        if (!cons && !fold && !wi.skip(0))
           RC(c3d_bn_finalize(sums_1, S, (double)G.Mo, k.bn_sc.gamma, k.bn_sc.beta, k.bn_sc.running_mean,
                              k.bn_sc.running_var, tr ? k.bn_sc.num_batches_tracked : nullptr, d->momentum, d->eps,
                              G.Co, G.Cop, tr, ss_1, mr_1, st));
@@ -529,7 +550,14 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       }
       scp = sc;
     }
-    if (!wi.skip(2)) RC(c3d_block_out_fwd(c, ss_c, scp, ss_1, mode, y, G.Mo, G.Cop, dt, st));
+    if (cons) {
+      const c3d_bn_fin fc = fin_consume(sums_c, k.bn_c, (double)G.Mo, d->momentum, d->eps, ss_c, mr_c);
+      c3d_bn_fin f1;
+      if (mode == SC_BN) f1 = fin_consume(sums_1, k.bn_sc, (double)G.Mo, d->momentum, d->eps, ss_1, mr_1);
+      RC(c3d_block_out_fwd_fin(c, &fc, scp, mode == SC_BN ? &f1 : nullptr, mode, y, G.Mo, G.Co, G.Cop, dt, st));
+    } else if (!wi.skip(2)) {
+      RC(c3d_block_out_fwd(c, ss_c, scp, ss_1, mode, y, G.Mo, G.Cop, dt, st));
+    }
     cur = wi.skip(2) ? c : y;
   }
   return 0;

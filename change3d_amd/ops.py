@@ -216,6 +216,18 @@ def fin_fwd(tick, idx, bn, training, count, ss, mr):
     return f
 
 
+def fin_consume(sums, bn, count, ss, mr):
+    """c3d_bn_fin for the consumer-side finalisation (c3d_dw333_fwd_fin / c3d_block_out_fwd_fin): `sums` are the
+    completed f64 [16][2][C] statistics of an earlier launch."""
+    f = L.BnFin()
+    f.sums = _p(sums)
+    f.gamma, f.beta = _p(bn.weight), _p(bn.bias)
+    f.running_mean, f.running_var, f.nbt = _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked)
+    f.ss, f.mr, f.count = _p(ss), _p(mr), float(count)
+    f.momentum, f.eps, f.training = float(bn.momentum), float(bn.eps), 1
+    return f
+
+
 def fin_bwd(tick, idx, bn, count, coef, mr):
     f = L.BnFin()
     f.ticket = tick.data_ptr() + 4 * idx
@@ -325,6 +337,11 @@ def dw_fwd(x, ss, w, y, nc, B, T, H, W, C_, stride, dtype):
                                   _stream())
 
 
+def dw_fwd_fin(x, fin, w, y, nc, B, T, H, W, C_, stride, dtype):
+    _launch("c3d_dw333_fwd", (x.numel() + y.numel()) * _es(dtype), L.lib().c3d_dw333_fwd_fin, _p(x), C.byref(fin), _p(w), _p(y), _p(nc), B, T, H, W, C_, cpad(C_), stride,
+                                  dtype, _stream())
+
+
 def dw_bwd_data(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, B, T, H, W, C_, stride, dtype):
     _launch("c3d_dw333_bwd_data", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_data, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2),
                                        _p(dsums), B, T, H, W, C_, cpad(C_), stride, dtype, _stream())
@@ -351,6 +368,11 @@ def dw_bwd(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, dw, B, T, H, W, C_, s
 def block_out_fwd(c, ss_c, shortcut, ss_1, mode, y, M, Cp, dtype):
     _launch("c3d_block_out_fwd", M * Cp * (3 if shortcut is not None else 2) * _es(dtype), L.lib().c3d_block_out_fwd, _p(c), _p(ss_c), _p(shortcut), _p(ss_1), mode, _p(y), M, Cp, dtype,
                                       _stream())
+
+
+def block_out_fwd_fin(c, fin_c, shortcut, fin_1, mode, y, M, C_, dtype):
+    _launch("c3d_block_out_fwd", M * cpad(C_) * (3 if shortcut is not None else 2) * _es(dtype), L.lib().c3d_block_out_fwd_fin, _p(c), C.byref(fin_c), _p(shortcut),
+                                      C.byref(fin_1) if fin_1 is not None else None, mode, _p(y), M, C_, cpad(C_), dtype, _stream())
 
 
 def block_out_bwd(dy, y, c, s_bn, g, mr_c, mr_1, dsums_c, dsums_1, M, C_, dtype):

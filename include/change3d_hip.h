@@ -75,6 +75,10 @@ typedef struct c3d_bn_fin {
   double count;
   float momentum, eps;
   int32_t training, reserved;
+  /* consumer side (c3d_dw333_fwd_fin, c3d_block_out_fwd_fin): the completed f64 sums [C3D_STAT_STRIPES][2][C] of an
+   * EARLIER launch; every workgroup of the consuming kernel rebuilds scale/shift of the channels it reads, one
+   * workgroup also writes ss / mr / the running statistics.  `ticket` is unused (NULL) in this mode.                */
+  const double* sums;
 } c3d_bn_fin;
 
 typedef struct c3d_pw_args {
@@ -181,6 +185,12 @@ int c3d_se_bn_bwd_coef(const double* nc3, const double* ncf, int32_t B, double c
 int c3d_dw333_fwd(const void* x, const float* ss, const float* w, void* y, double* nc_sums, int32_t B,
                   int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
                   void* stream);
+/* Same, with the BatchNorm finalisation of the INPUT statistics folded in (no c3d_bn_finalize launch between the
+ * producer of `fin->sums` and this kernel): bit-identical scale/shift, running statistics and saved vectors.  Shapes
+ * without a folded kernel (stride 2) run c3d_bn_finalize + c3d_dw333_fwd internally.                              */
+int c3d_dw333_fwd_fin(const void* x, const c3d_bn_fin* fin, const float* w, void* y, double* nc_sums, int32_t B,
+                      int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
+                      void* stream);
 int c3d_dw333_bwd_data(const void* t1, const void* b, const float* coefA, const float* coefB,
                        const float* coefC, const float* w, const void* a, const float* ss_a,
                        const float* mr_a, void* t2, double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
@@ -208,6 +218,10 @@ int c3d_dw333_bwd(const void* t1, const void* b, const float* coefA, const float
  * ------------------------------------------------------------------------------------ */
 int c3d_block_out_fwd(const void* c, const float* ss_c, const void* shortcut, const float* ss_1,
                       int32_t sc_mode, void* y, int64_t M, int32_t Cp, int32_t dtype, void* stream);
+/* Same with BN_c (and, for sc_mode BN, the shortcut BatchNorm) finalised from their sums by the kernel itself;
+ * C = real channel count.  fin_1 is NULL unless sc_mode is BN.                                                     */
+int c3d_block_out_fwd_fin(const void* c, const c3d_bn_fin* fin_c, const void* shortcut, const c3d_bn_fin* fin_1,
+                          int32_t sc_mode, void* y, int64_t M, int32_t C, int32_t Cp, int32_t dtype, void* stream);
 int c3d_block_out_bwd(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
                       const float* mr_c, const float* mr_1, double* dsums_c, double* dsums_1, int64_t M,
                       int32_t C, int32_t Cp, int32_t dtype, void* stream);

@@ -570,3 +570,100 @@ def test_scd_losses_vs_torch():
     # every pixel ignored -> NaN, as torch
     z = torch.zeros_like(lab)
     assert torch.isnan(CrossEntropyLoss2d(ignore_index=0)(pd.detach(), z.to(DEV))).item()
+
+
+# --------------------------------------------------------------- consumer-side BatchNorm finalisation
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,T,stride,shape", [(54, 3, 1, (2, 16, 24)), (216, 3, 1, (3, 16, 16)), (108, 5, 1, (2, 16, 24)),
+                                              (54, 3, 2, (2, 16, 24))])
+def test_dw_fwd_with_folded_bn_finalize_is_bit_identical(dtype, C, T, stride, shape):
+    """c3d_dw333_fwd_fin (scale/shift rebuilt from the producer's sums in the kernel's prologue, csrc/bn_fin.h) against
+    c3d_bn_finalize + c3d_dw333_fwd: output, per-sample statistics, saved scale/shift and mean/rstd, running
+    statistics and num_batches_tracked are bit-identical (stride 2 runs the two launches internally)."""
+    _need_gpu()
+    from change3d_amd import ops
+    B, H, W = shape
+    Cp = ops.cpad(C)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    count = float(B * T * H * W)
+    a = padc(q(rnd((B, T, H, W, C), 60), dtype), Cp).to(DEV, dtype).contiguous()
+    w = rnd((C, 1, 3, 3, 3), 61, 0.3).to(DEV).contiguous()
+    g = torch.Generator().manual_seed(62)
+    sums = torch.zeros(16, 2, C, dtype=torch.float64)
+    sums[:, 0] = torch.randn(16, C, generator=g, dtype=torch.float64) * count / 64
+    sums[:, 1] = (torch.rand(16, C, generator=g, dtype=torch.float64) + 0.5) * count / 8
+    sums = sums.to(DEV)
+
+    def bn():
+        m = torch.nn.BatchNorm3d(C)
+        with torch.no_grad():
+            m.weight.copy_(rnd((C,), 63).abs() + 0.5); m.bias.copy_(rnd((C,), 64, 0.3))
+            m.running_mean.copy_(rnd((C,), 65, 0.2)); m.running_var.copy_(rnd((C,), 66).abs() + 0.3)
+        return m.to(DEV)
+
+    outs = []
+    for folded in (False, True):
+        m = bn()
+        ss = torch.full((2 * Cp,), float("nan"), device=DEV)
+        mr = torch.full((2 * Cp,), float("nan"), device=DEV)
+        b = torch.full((B, T, Ho, Wo, Cp), float("nan"), dtype=dtype, device=DEV)
+        nc = torch.zeros(B * Cp * 2, dtype=torch.float64, device=DEV)
+        if folded:
+            ops.dw_fwd_fin(a, ops.fin_consume(sums, m, count, ss, mr), w, b, nc, B, T, H, W, C, stride, ops.dt_code(dtype))
+        else:
+            ops.bn_finalize(sums, count, m, C, ss, mr, True, stripes=16)
+            ops.dw_fwd(a, ss, w, b, nc, B, T, H, W, C, stride, ops.dt_code(dtype))
+        torch.cuda.synchronize()
+        outs.append((b, nc, ss, mr, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()))
+    for i, (x0, x1) in enumerate(zip(*outs)):
+        assert torch.equal(x0, x1), i
+    assert int(outs[1][6]) == 1 and torch.isfinite(outs[1][0].float()).all() and outs[1][0].float().abs().max() > 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,mode,M", [(96, 1, 3000), (48, 2, 777), (24, 3, 5000), (192, 1, 640)])
+def test_block_out_fwd_with_folded_bn_finalize_is_bit_identical(dtype, C, mode, M):
+    """c3d_block_out_fwd_fin against c3d_bn_finalize (x1 or x2) + c3d_block_out_fwd: identical y, vectors and buffers
+    (modes: 1 identity shortcut, 2 shortcut conv + BatchNorm, 3 shortcut conv without BatchNorm)."""
+    _need_gpu()
+    from change3d_amd import ops
+    Cp = ops.cpad(C)
+    c = padc(q(rnd((M, C), 70), dtype), Cp).to(DEV, dtype).contiguous()
+    s = padc(q(rnd((M, C), 71), dtype), Cp).to(DEV, dtype).contiguous()
+    g = torch.Generator().manual_seed(72)
+
+    def mk_sums():
+        t = torch.zeros(16, 2, C, dtype=torch.float64)
+        t[:, 0] = torch.randn(16, C, generator=g, dtype=torch.float64) * M / 64
+        t[:, 1] = (torch.rand(16, C, generator=g, dtype=torch.float64) + 0.5) * M / 8
+        return t.to(DEV)
+
+    sums_c, sums_1 = mk_sums(), mk_sums()
+
+    def bn(seed):
+        m = torch.nn.BatchNorm3d(C)
+        with torch.no_grad():
+            m.weight.copy_(rnd((C,), seed).abs() + 0.5); m.bias.copy_(rnd((C,), seed + 1, 0.3))
+        return m.to(DEV)
+
+    outs = []
+    for folded in (False, True):
+        mc, m1 = bn(73), bn(75)
+        v = [torch.full((2 * Cp,), float("nan"), device=DEV) for _ in range(4)]   # ss_c, mr_c, ss_1, mr_1
+        y = torch.full((M, Cp), float("nan"), dtype=dtype, device=DEV)
+        if folded:
+            f1 = ops.fin_consume(sums_1, m1, float(M), v[2], v[3]) if mode == 2 else None
+            ops.block_out_fwd_fin(c, ops.fin_consume(sums_c, mc, float(M), v[0], v[1]), s, f1, mode, y, M, C, ops.dt_code(dtype))
+        else:
+            ops.bn_finalize(sums_c, float(M), mc, C, v[0], v[1], True, stripes=16)
+            if mode == 2:
+                ops.bn_finalize(sums_1, float(M), m1, C, v[2], v[3], True, stripes=16)
+            ops.block_out_fwd(c, v[0], s, v[2] if mode == 2 else None, mode, y, M, Cp, ops.dt_code(dtype))
+        torch.cuda.synchronize()
+        keep = [y, v[0], v[1], mc.running_mean.clone(), mc.running_var.clone(), mc.num_batches_tracked.clone()]
+        if mode == 2:
+            keep += [v[2], v[3], m1.running_mean.clone(), m1.num_batches_tracked.clone()]
+        outs.append(keep)
+    for i, (x0, x1) in enumerate(zip(*outs)):
+        assert torch.equal(x0, x1), i
+    assert torch.isfinite(outs[1][0].float()).all() and outs[1][0].float().abs().max() > 0
