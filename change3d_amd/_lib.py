@@ -40,7 +40,7 @@ class PwWgradArgs(C.Structure):
                 ("M", i64), ("gstride", i64), ("rows_per_sample", i64),
                 ("K", i32), ("Kp", i32), ("N", i32), ("Np", i32), ("dw_sn", i32), ("dw_sk", i32),
                 ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32), ("dy", i32), ("dx", i32),
-                ("q_mode", i32), ("dtype", i32), ("taps", i32), ("dw_tap_stride", i32)]
+                ("q_mode", i32), ("dtype", i32), ("taps", i32), ("dw_tap_stride", i32), ("p_fin", BnFin)]
 
 
 class BnPtrs(C.Structure):

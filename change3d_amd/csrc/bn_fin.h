@@ -154,4 +154,25 @@ __device__ __forceinline__ void bn_backward(const c3d_bn_fin& f, const double* d
   }
 }
 
+// Consumer side of the backward coefficients: one channel, from the completed single-stripe sums of an EARLIER launch
+// (plain loads).  Same arithmetic as bn_bwd_coef_kernel; `acc` = this caller also accumulates dgamma / dbeta
+// (f.running_mean / f.running_var) and writes the coefficient vector f.ss when it is non-NULL.
+__device__ __forceinline__ void bn_bwd_coef_consume(const c3d_bn_fin& f, int C, int Cp, int c, bool acc, float& cA,
+                                                    float& cB, float& cC) {
+  cA = 0.f; cB = 0.f; cC = 0.f;
+  if (c < C) {
+    const double s1 = f.sums[c], s2 = f.sums[C + c];
+    const double mean = f.mr[c], rstd = f.mr[Cp + c];
+    const double A = (double)f.gamma[c] * rstd;
+    const double Cc = -A * rstd * s2 / f.count;
+    const double Bc = -A * s1 / f.count - Cc * mean;
+    cA = (float)A; cB = (float)Bc; cC = (float)Cc;
+    if (acc) {
+      if (f.running_mean) f.running_mean[c] += (float)s2;
+      if (f.running_var) f.running_var[c] += (float)s1;
+    }
+  }
+  if (acc && f.ss && c < Cp) { f.ss[c] = cA; f.ss[Cp + c] = cB; f.ss[2 * Cp + c] = cC; }
+}
+
 }  // namespace c3dfin

@@ -27,9 +27,10 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   const c3d_pw_args& a = *args;
   if (a.M <= 0 || (a.Kp & 7) || (a.Np & 7) || a.K > a.Kp || a.N > a.Np) return C3D_E_BADARG;
   const bool wide = a.Kp > 224 || a.Np > 224 || a.bias != nullptr;
-  if (wide && (a.Kp > 1024 || a.Np > 1024 || a.fin.ticket)) return C3D_E_UNSUPPORTED;
+  if (wide && (a.Kp > 1024 || a.Np > 1024 || a.fin.ticket || a.fin.sums)) return C3D_E_UNSUPPORTED;
   if (a.pro_mode == C3D_PRO_AFFINE2 && !a.x2) return C3D_E_BADARG;
-  if (a.pro_mode != C3D_PRO_NONE && !a.pro_p) return C3D_E_BADARG;
+  if (a.pro_mode != C3D_PRO_NONE && !a.pro_p && !(a.pro_mode == C3D_PRO_AFFINE2 && a.fin.sums)) return C3D_E_BADARG;
+  if (a.fin.sums && a.pro_mode == C3D_PRO_AFFINE2 && (!a.fin.gamma || !a.fin.mr)) return C3D_E_BADARG;
   if (a.epi_mode == C3D_EPI_STATS && !a.stats) return C3D_E_BADARG;
   if (a.epi_mode == C3D_EPI_SWISH_SE_BWD &&
       (!a.stats || !a.e1 || !a.epi_p || !a.epi_q || a.rows_per_sample <= 0 || (!wide && (a.rows_per_sample & 15))))
@@ -44,7 +45,7 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   if (a.dtype == C3D_DT_F32) rc = c3d_detail_pw_gemm_f32(args, stream);
   else if (a.dtype == C3D_DT_BF16) rc = dispatch_mode<bf16_t>(a, s);
   // shapes the wave-private-tile kernel cannot hold in LDS (f32 storage with K*N near 224 x 224): block-tiled kernel
-  if (rc == C3D_E_UNSUPPORTED && !a.fin.ticket) rc = c3d_detail_pw_gemm_wide(args, stream);
+  if (rc == C3D_E_UNSUPPORTED && !a.fin.ticket && !a.fin.sums) rc = c3d_detail_pw_gemm_wide(args, stream);
   return rc;
 }
 

@@ -440,7 +440,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       MM::store8(Ws + i, z);
     }
-    if (PRO != C3D_PRO_NONE) {
+    if (PRO == C3D_PRO_AFFINE2 && a.fin.sums) {
+      // BatchNorm-backward coefficients rebuilt from the producer's completed sums (no c3d_bn_bwd_coef launch in
+      // front of this kernel); workgroup 0 also accumulates dgamma / dbeta and writes the vector for other readers
+      for (int c = tid; c < Kp; c += WAVES * 64) {
+        float cA, cB, cC;
+        c3dfin::bn_bwd_coef_consume(a.fin, a.K, Kp, c, blockIdx.x == 0, cA, cB, cC);
+        Pp[c] = cA; Pp[Kp + c] = cB; Pp[2 * Kp + c] = cC;
+      }
+    } else if (PRO != C3D_PRO_NONE) {
       const int np = (PRO == C3D_PRO_AFFINE2 ? 3 : 2) * Kp;
       for (int i = tid; i < np; i += WAVES * 64) Pp[i] = a.pro_p[i];
     }

@@ -2,6 +2,7 @@
 #include "common.h"
 #include "../../include/change3d_hip.h"
 #include "pw_common.h"
+#include "bn_fin.h"
 #include <cstdlib>
 
 #ifdef C3D_PW_CLOCK
@@ -172,9 +173,14 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
 #pragma unroll
   for (int j = 0; j < 8; ++j) { cA[j] = 1.f; cB[j] = 0.f; cC[j] = 0.f; }
   if (HASP2 && p_act) {
+    if (a.p_fin.sums) {   // coefficients rebuilt from the producer's sums (csrc/bn_fin.h); nothing is accumulated here
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      cA[j] = a.p_coef[vv * 8 + j]; cB[j] = a.p_coef[Np + vv * 8 + j]; cC[j] = a.p_coef[2 * Np + vv * 8 + j];
+      for (int j = 0; j < 8; ++j) c3dfin::bn_bwd_coef_consume(a.p_fin, a.N, Np, vv * 8 + j, false, cA[j], cB[j], cC[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        cA[j] = a.p_coef[vv * 8 + j]; cB[j] = a.p_coef[Np + vv * 8 + j]; cC[j] = a.p_coef[2 * Np + vv * 8 + j];
+      }
     }
   }
   if (q_act && a.q_mode == C3D_PRO_BN_SE_SWISH) {  // Q side reuses cA/cB as scale/shift
@@ -453,7 +459,7 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   blocks = (tiles + tpw - 1) / tpw;
   const bool qd = a.row_mode == C3D_ROWS_DENSE && taps == 1;
   const dim3 grid((unsigned)blocks, taps), blk(WG_THREADS);
-  if (a.p_coef) {
+  if (a.p_coef || a.p_fin.sums) {
     if (qd) pw_wgrad_kernel<T, true, true><<<grid, blk, lds, stream>>>(a, tpw, WN, WK, MT);
     else pw_wgrad_kernel<T, true, false><<<grid, blk, lds, stream>>>(a, tpw, WN, WK, MT);
   } else {
@@ -479,19 +485,19 @@ extern "C" int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream) {
   const c3d_pw_wgrad_args& a = *args;
   if (a.M <= 0 || (a.Kp & 7) || (a.Np & 7) || a.K > a.Kp || a.N > a.Np) return C3D_E_BADARG;
   if (a.Kp > 224 || a.Np > 224) {   // wide layers (res5, caption-decoder linears): block-tiled kernel, f32 atomics
-    if (a.Kp > 1024 || a.Np > 1024) return C3D_E_UNSUPPORTED;
-    if (a.p_coef && !a.p2) return C3D_E_BADARG;
+    if (a.Kp > 1024 || a.Np > 1024 || a.p_fin.sums) return C3D_E_UNSUPPORTED;
+    if ((a.p_coef || a.p_fin.sums) && !a.p2) return C3D_E_BADARG;
     if (a.q_mode == C3D_PRO_BN_SE_SWISH && (!a.q_ss || (a.q_gate && a.rows_per_sample <= 0))) return C3D_E_BADARG;
     return c3d_detail_pw_wgrad_wide(args, stream);
   }
-  if (a.p_coef && !a.p2) return C3D_E_BADARG;
+  if ((a.p_coef || a.p_fin.sums) && !a.p2) return C3D_E_BADARG;
   if (a.q_mode == C3D_PRO_BN_SE_SWISH && (!a.q_ss || (a.q_gate && a.rows_per_sample <= 0))) return C3D_E_BADARG;
   if (a.M >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = C3D_E_BADARG;
   if (a.dtype == C3D_DT_F32) rc = launch_wgrad<float>(a, s);
   else if (a.dtype == C3D_DT_BF16) rc = launch_wgrad<bf16_t>(a, s);
-  if (rc == C3D_E_UNSUPPORTED) rc = c3d_detail_pw_wgrad_wide(args, stream);   // shapes that do not fit its LDS plan
+  if (rc == C3D_E_UNSUPPORTED && !a.p_fin.sums) rc = c3d_detail_pw_wgrad_wide(args, stream);   // shapes that do not fit its LDS plan
   return rc;
 }
 

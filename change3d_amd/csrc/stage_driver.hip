@@ -348,6 +348,17 @@ inline c3d_bn_fin fin_consume(const double* sums, const c3d_bn_ptrs& bn, double 
   return f;
 }
 
+// backward consumer side: the AFFINE2 prologues of the data-gradient GEMM and of the weight-gradient kernel rebuild
+// A|B|C from the single-stripe sums; `accumulate` (the data-gradient GEMM only) adds dgamma / dbeta
+inline c3d_bn_fin fin_coef_consume(const double* dsums, const c3d_bn_ptrs& bn, double count, const float* mr,
+                                   bool accumulate) {
+  c3d_bn_fin f;
+  std::memset(&f, 0, sizeof(f));
+  f.sums = dsums; f.gamma = bn.gamma; f.mr = const_cast<float*>(mr); f.count = count;
+  if (accumulate) { f.running_mean = bn.dgamma; f.running_var = bn.dbeta; }
+  return f;
+}
+
 inline c3d_bn_fin fin_bwd(uint32_t* ticket, const c3d_bn_ptrs& bn, double count, float* coef, const float* mr) {
   c3d_bn_fin f;
   std::memset(&f, 0, sizeof(f));
@@ -601,6 +612,10 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     // ---- y = relu(bn_c(c) + shortcut)
     uint32_t* tick = atT<uint32_t>(wb, Bk.tick);
     const bool fold = fold_fin();
+    // BatchNorm-backward coefficients rebuilt by their consumers (narrow bf16 kernels; csrc/bn_fin.h) instead of
+    // c3d_bn_bwd_coef launches
+    const bool consb = !fold && fin_consumer() && !whatif_bits() && dt == C3D_DT_BF16 && G.Cip <= 224 && G.Cop <= 224 &&
+                       G.Cinp <= 224;
     if (fold) {
       const c3d_bn_fin fc = fin_bwd(tick + 0, k.bn_c, (double)G.Mo, coef_c, mr_c);
       const c3d_bn_fin f1 = scbn ? fin_bwd(tick + 0, k.bn_sc, (double)G.Mo, coef_1, mr_1) : c3d_bn_fin{};
@@ -609,7 +624,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     } else {
       RC(c3d_block_out_bwd(cur_dy, y, c, scbn ? sc : nullptr, g, mr_c, scbn ? mr_1 : nullptr, dsums_c,
                            scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, st));
-      if (!wi.skip(0))
+      if (!consb && !wi.skip(0))
       RC(c3d_bn_bwd_coef(dsums_c, 1, (double)G.Mo, k.bn_c.gamma, mr_c, G.Co, G.Cop, coef_c, k.bn_c.dgamma, k.bn_c.dbeta, st));
     }
     // ---- conv_c data gradient, Swish / SE backward in the epilogue; weight gradient on the side stream (it needs
@@ -618,6 +633,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       WgCall w(g, b, k.dw_c, wgws, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
       w.a.p2 = c; w.a.p_coef = coef_c; w.a.q_mode = C3D_PRO_BN_SE_SWISH; w.a.q_ss = ss_b; w.a.q_gate = gate;
       w.a.rows_per_sample = rps;
+      if (consb) w.a.p_fin = fin_coef_consume(dsums_c, k.bn_c, (double)G.Mo, mr_c, false);
       return c3d_pw_wgrad(&w.a, s2);
     };
     static const bool wgc_early = !(getenv("C3D_WGC_EARLY") && atoi(getenv("C3D_WGC_EARLY")) == 0);
@@ -625,6 +641,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     {
       PwCall p(g, k.w_c, t1, G.Mo, G.Co, G.Ci, 1, G.Ci, dt);
       p.a.x2 = c; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_c;
+      if (consb) p.a.fin = fin_coef_consume(dsums_c, k.bn_c, (double)G.Mo, mr_c, true);
       p.a.epi_mode = C3D_EPI_SWISH_SE_BWD; p.a.e1 = b; p.a.epi_p = ss_b; p.a.epi_gate = gate; p.a.epi_q = mr_b;
       p.a.stats = nc3; p.a.rows_per_sample = rps;
       RC(c3d_pw_gemm(&p.a, st));
@@ -644,7 +661,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     RC(side_run(st, [&](hipStream_t s2) {
       return c3d_dw333_wgrad(t1, b, cA, cB, cC, a, ss_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, s2);
     }));
-    if (!fold && !wi.skip(0))
+    if (!fold && !consb && !wi.skip(0))
       RC(c3d_bn_bwd_coef(dsums_a, 1, (double)G.M, k.bn_a.gamma, mr_a, G.Ci, G.Cip, coef_a, k.bn_a.dgamma, k.bn_a.dbeta, st));
     // ---- shortcut branch
     const void* res = g;
@@ -653,33 +670,42 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       const int rm = G.s == 2 ? C3D_ROWS_STRIDE2 : C3D_ROWS_DENSE;
       PwCall p(g, k.w_sc, dxs, G.Mo, G.Co, G.Cin, 1, G.Cin, dt);
       if (scbn) {
-        if (!fold && !wi.skip(0))
+        if (!fold && !consb && !wi.skip(0))
           RC(c3d_bn_bwd_coef(dsums_1, 1, (double)G.Mo, k.bn_sc.gamma, mr_1, G.Co, G.Cop, coef_1, k.bn_sc.dgamma,
                              k.bn_sc.dbeta, st));
         p.a.x2 = sc; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_1;
+        if (consb) p.a.fin = fin_coef_consume(dsums_1, k.bn_sc, (double)G.Mo, mr_1, true);
       }
       RC(c3d_pw_gemm(&p.a, st));
       RC(side_run(st, [&](hipStream_t s2) {
         WgCall w(g, xin, k.dw_sc, wgws, G.Mo, G.Cin, G.Co, G.Cin, 1, dt);
-        if (scbn) { w.a.p2 = sc; w.a.p_coef = coef_1; }
+        if (scbn) {
+          w.a.p2 = sc; w.a.p_coef = coef_1;
+          if (consb) w.a.p_fin = fin_coef_consume(dsums_1, k.bn_sc, (double)G.Mo, mr_1, false);
+        }
         w.a.row_mode = rm; w.a.H = G.H; w.a.W = G.W;
         return c3d_pw_wgrad(&w.a, s2);
       }));
       res = dxs;
       res_mode = G.s == 2 ? 1 : 0;
     }
-    // ---- conv_a data gradient (+ shortcut gradient in the epilogue) and weight gradient
+    // ---- conv_a data gradient (+ shortcut gradient in the epilogue) and weight gradient (forked first: it needs the
+    //      coefficients, not the data gradient)
+    auto wgrad_a = [&](hipStream_t s2) {
+      WgCall w(t2, xin, k.dw_a, wgws, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
+      w.a.p2 = a; w.a.p_coef = coef_a;
+      if (consb) w.a.p_fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, false);
+      return c3d_pw_wgrad(&w.a, s2);
+    };
+    if (wgc_early) RC(side_run(st, wgrad_a));
     {
       PwCall p(t2, k.w_a, dx, G.M, G.Ci, G.Cin, 1, G.Cin, dt);
       p.a.x2 = a; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_a;
+      if (consb) p.a.fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, true);
       p.a.epi_mode = C3D_EPI_ADD; p.a.e1 = res; p.a.res_mode = res_mode; p.a.H = G.H; p.a.W = G.W;
       RC(c3d_pw_gemm(&p.a, st));
     }
-    RC(side_run(st, [&](hipStream_t s2) {
-      WgCall w(t2, xin, k.dw_a, wgws, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
-      w.a.p2 = a; w.a.p_coef = coef_a;
-      return c3d_pw_wgrad(&w.a, s2);
-    }));
+    if (!wgc_early) RC(side_run(st, wgrad_a));
     // the side stream may lag by ring-1 blocks: block i-1 reuses the ring slot of block i-1+ring
     lag.push_back(side_mark());
     if ((int)lag.size() >= bwd_ring()) { RC(side_join(st, lag.front())); lag.pop_front(); }

@@ -103,7 +103,11 @@ typedef struct c3d_pw_args {
   int32_t pro_mode, epi_mode;
   int32_t res_mode;      /* EPI_ADD: 0 dense [M][Np]; 1 e1 is [BT][H/2][W/2][Np], added where h,w even */
   int32_t dtype;
-  c3d_bn_fin fin;        /* C3D_EPI_STATS: fin.ticket != NULL -> the last workgroup finalises the BatchNorm    */
+  c3d_bn_fin fin;        /* C3D_EPI_STATS: fin.ticket != NULL -> the last workgroup finalises the BatchNorm.      */
+                         /* C3D_PRO_AFFINE2: fin.sums != NULL -> A|B|C are rebuilt from the completed single-   */
+                         /* stripe sums f64 [2][K] (fin.gamma, fin.mr = mean|rstd, fin.count; workgroup 0 adds    */
+                         /* dgamma / dbeta into fin.running_mean / fin.running_var and writes fin.ss if non-NULL) */
+                         /* instead of read from pro_p (narrow kernel only: K, N <= 224, no bias).                */
   const float* bias;     /* optional bias[N] added before the epilogue (linear layers of the caption decoder)  */
 } c3d_pw_args;
 
@@ -136,6 +140,8 @@ typedef struct c3d_pw_wgrad_args {
   int32_t taps;                     /* C3D_ROWS_S2SHIFT: 16 = ONE launch covers the 4x4 taps of a ConvTranspose2d   */
   int32_t dw_tap_stride;            /* k4s2p1 weight gradient, (dy,dx) = (tap/4-1, tap%4-1), tap t accumulates at   */
                                     /* dw + t*dw_tap_stride (reference model/change_decoder.py:30-45); 0/1 = dy,dx */
+  c3d_bn_fin p_fin;                 /* p_fin.sums != NULL: the AFFINE2 coefficients are rebuilt from the completed   */
+                                    /* single-stripe sums (gamma, mr, count as in c3d_bn_bwd_coef) instead of p_coef  */
 } c3d_pw_wgrad_args;
 
 int64_t c3d_pw_wgrad_ws_floats(int32_t N, int32_t K);
