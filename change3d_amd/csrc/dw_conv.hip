@@ -1371,318 +1371,6 @@ __global__ __launch_bounds__(WgDot2<TT>::NCOMP + D2_LOADERS) void dw_wgrad_dot2_
 }
 
 // ----------------------------------------------------------------------------------------------
-// Fused backward: data gradient AND weight gradient from ONE staging of the (t1, b) and a tiles.
-//   * a workgroup walks `tiles_per_wg` 8x8 input-resolution tiles of one (sample, 32-channel chunk);
-//     the next tile's raw rows are prefetched into registers while the current one is processed;
-//   * phase 2 (256 threads = pixel x channel-vector): t2 = dconv(db) * (bn_a(a) > 0), BN_a-backward
-//     sums kept in registers for the whole walk;
-//   * phase 3 (216 threads = 27 taps x 4 channel-vectors x 2 pixel halves): weight-gradient partial
-//     sums kept in registers for the whole walk;
-//   * one flush per workgroup (statistics into C3D_STAT_STRIPES striped f64 sets, dW via f32 atomics).
-template <typename T, int S, int TT>
-__global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
-    const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
-    const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
-    const T* __restrict__ a, const float* __restrict__ ss_a, const float* __restrict__ mr_a, T* __restrict__ t2,
-    double* __restrict__ dsums, float* __restrict__ dw, const DwGeom g, const int tiles_per_wg) {
-  typedef typename LdsStore<T>::type L;
-  typedef RawD<T> RW;
-  constexpr int TH = 8, TW = 8, NTHR = 256;
-  constexpr int DH = (S == 1) ? TH + 2 : TH / 2 + 2, DWd = (S == 1) ? TW + 2 : TW / 2 + 2;
-  constexpr int AH = TH + 2, AW = TW + 2;
-  constexpr int OH = TH / S, OW = TW / S;          // output pixels owned by this tile (weight gradient)
-  constexpr int ND = TT * DH * DWd * DW_CV, NA = TT * AH * AW * DW_CV;
-  constexpr int DSL = (ND + NTHR - 1) / NTHR, ASL = (NA + NTHR - 1) / NTHR;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* wl = reinterpret_cast<float*>(smem);                 // [27][32]
-  float* red = wl + 27 * 32;                                  // [27][32] (dW) / [4 waves][4][16] (stats)
-  L* dtile = reinterpret_cast<L*>(red + 27 * 32);             // [T][DH][DWd][32]  db
-  L* atile = dtile + (size_t)TT * DH * DWd * 32;              // [T][AH][AW][32]   relu(bn_a(a))
-  L* araw = atile + (size_t)TT * AH * AW * 32;                // [T][TH][TW][32]   raw a (interior): the
-                                                              // epilogue must not load from global memory
-                                                              // behind the in-flight prefetch (vmcnt is in-order)
-  const int tid = threadIdx.x;
-  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
-  const int ntiles = tiles_x * tiles_y;
-  const int chunk = blockIdx.y, b = blockIdx.z;
-  const int c0 = chunk * DW_CV * 8;
-  const int cv = tid & (DW_CV - 1);
-  const int cbase = c0 + cv * 8;
-  const bool c_ok = cbase < g.Cp;
-
-  for (int i = tid; i < 27 * 32; i += NTHR) {
-    const int tap = i / 32, c = c0 + (i & 31);
-    wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
-    red[i] = 0.f;
-  }
-  float cA[8], cB[8], cC[8], sa[8], sb[8], ma[8], ra[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    cA[j] = c_ok ? coefA[cbase + j] : 0.f;
-    cB[j] = c_ok ? coefB[(size_t)b * g.Cp + cbase + j] : 0.f;
-    cC[j] = c_ok ? coefC[cbase + j] : 0.f;
-    sa[j] = c_ok ? ss_a[cbase + j] : 0.f; sb[j] = c_ok ? ss_a[g.Cp + cbase + j] : 0.f;
-    ma[j] = c_ok ? mr_a[cbase + j] : 0.f; ra[j] = c_ok ? mr_a[g.Cp + cbase + j] : 0.f;
-  }
-  float s1[8], s2[8], wacc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; wacc[j] = 0.f; }
-
-  // weight-gradient role
-  const bool w_act = tid < 27 * 8;
-  const int wtap = tid >> 3, wcv = tid & 3, whalf = (tid >> 2) & 1;
-  const int wkt = wtap / 9, wky = (wtap % 9) / 3, wkx = wtap % 3;
-  // data-gradient role
-  const int pix = tid >> 2;
-  const int px = pix % TW, py = pix / TW;
-
-  typename RW::type rd1[DSL], rd2[DSL], rav[ASL];
-  unsigned dmask = 0, amask = 0;
-
-#define DW_ISSUE(TL)                                                                              \
-  {                                                                                               \
-    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                         \
-    const int y0_ = ty_ * TH, x0_ = tx_ * TW;                                                     \
-    const int dy0_ = (S == 1) ? y0_ - 1 : (y0_ >> 1) - 1, dx0_ = (S == 1) ? x0_ - 1 : (x0_ >> 1) - 1; \
-    dmask = 0; amask = 0;                                                                         \
-    _Pragma("unroll") for (int sl = 0; sl < DSL; ++sl) {                                          \
-      const int i_ = tid + sl * NTHR;                                                             \
-      const int p_ = i_ >> 2;                                                                     \
-      const int ix_ = p_ % DWd, q_ = p_ / DWd;                                                    \
-      const int iy_ = q_ % DH, t_ = q_ / DH;                                                      \
-      const int gy_ = dy0_ + iy_, gx_ = dx0_ + ix_;                                               \
-      if (i_ < ND && c_ok && gy_ >= 0 && gy_ < g.Ho && gx_ >= 0 && gx_ < g.Wo) {                 \
-        const size_t off_ = ((((size_t)b * g.T + t_) * g.Ho + gy_) * g.Wo + gx_) * g.Cp + cbase;  \
-        rd1[sl] = RW::load(t1 + off_); rd2[sl] = RW::load(bb + off_); dmask |= 1u << sl;          \
-      }                                                                                           \
-    }                                                                                             \
-    _Pragma("unroll") for (int sl = 0; sl < ASL; ++sl) {                                          \
-      const int i_ = tid + sl * NTHR;                                                             \
-      const int p_ = i_ >> 2;                                                                     \
-      const int ix_ = p_ % AW, q_ = p_ / AW;                                                      \
-      const int iy_ = q_ % AH, t_ = q_ / AH;                                                      \
-      const int gy_ = y0_ - 1 + iy_, gx_ = x0_ - 1 + ix_;                                         \
-      if (i_ < NA && c_ok && gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W) {                   \
-        rav[sl] = RW::load(a + ((((size_t)b * g.T + t_) * g.H + gy_) * g.W + gx_) * g.Cp + cbase); \
-        amask |= 1u << sl;                                                                        \
-      }                                                                                           \
-    }                                                                                             \
-  }
-
-  const int tl0 = blockIdx.x * tiles_per_wg;
-  int tl1 = tl0 + tiles_per_wg;
-  if (tl1 > ntiles) tl1 = ntiles;
-  if (tl0 < tl1) DW_ISSUE(tl0)
-  for (int tl = tl0; tl < tl1; ++tl) {
-    const int tx = tl % tiles_x, ty = tl / tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW;
-    const int dy0 = (S == 1) ? y0 - 1 : (y0 >> 1) - 1, dx0 = (S == 1) ? x0 - 1 : (x0 >> 1) - 1;
-    __syncthreads();  // previous tile's readers are done (and the weight / red initialisation)
-    // ---- phase 1: raw registers -> LDS with the prologues -----------------------------------------
-#pragma unroll
-    for (int sl = 0; sl < DSL; ++sl) {
-      const int i = tid + sl * NTHR;
-      if (i < ND) {
-        float f[8];
-        if ((dmask >> sl) & 1u) {
-          float f2[8];
-          RW::cvt(rd1[sl], f);
-          RW::cvt(rd2[sl], f2);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j]));
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = 0.f;
-        }
-        Vec8<L>::store(dtile + (size_t)(i >> 2) * 32 + cv * 8, f);
-      }
-    }
-#pragma unroll
-    for (int sl = 0; sl < ASL; ++sl) {
-      const int i = tid + sl * NTHR;
-      if (i < NA) {
-        float f[8];
-        if ((amask >> sl) & 1u) {
-          RW::cvt(rav[sl], f);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = 0.f;
-        }
-        {
-          const int p_ = i >> 2;
-          const int ix_ = p_ % AW, q_ = p_ / AW;
-          const int iy_ = q_ % AH, t_ = q_ / AH;
-          if (ix_ >= 1 && ix_ <= TW && iy_ >= 1 && iy_ <= TH)
-            Vec8<L>::store(araw + ((size_t)(t_ * TH + iy_ - 1) * TW + ix_ - 1) * 32 + cv * 8, f);
-        }
-        if ((amask >> sl) & 1u) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sa[j], sb[j]), 0.f);
-        }
-        Vec8<L>::store(atile + (size_t)(i >> 2) * 32 + cv * 8, f);
-      }
-    }
-    if (tl + 1 < tl1) DW_ISSUE(tl + 1)  // prefetch: in flight during phases 2 and 3
-    __syncthreads();
-
-    // ---- phase 2: data gradient for this thread's input pixel --------------------------------------
-    {
-      const int iy = y0 + py, ix = x0 + px;
-      float acc[TT][8];
-#pragma unroll
-      for (int t = 0; t < TT; ++t)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int ny = iy + 1 - ky;
-        if (S == 2 && (ny & 1)) continue;
-        const int ly = ((S == 1) ? ny : (ny >> 1)) - dy0;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int nx = ix + 1 - kx;
-          if (S == 2 && (nx & 1)) continue;
-          const int lx = ((S == 1) ? nx : (nx >> 1)) - dx0;
-          float wk[3][8];
-#pragma unroll
-          for (int kt = 0; kt < 3; ++kt) {
-            const float4 w0 = *reinterpret_cast<const float4*>(wl + (kt * 9 + ky * 3 + kx) * 32 + cv * 8);
-            const float4 w1 = *reinterpret_cast<const float4*>(wl + (kt * 9 + ky * 3 + kx) * 32 + cv * 8 + 4);
-            wk[kt][0] = w0.x; wk[kt][1] = w0.y; wk[kt][2] = w0.z; wk[kt][3] = w0.w;
-            wk[kt][4] = w1.x; wk[kt][5] = w1.y; wk[kt][6] = w1.z; wk[kt][7] = w1.w;
-          }
-#pragma unroll
-          for (int to = 0; to < TT; ++to) {
-            if (to < g.T) {
-              float v[8];
-              Vec8<L>::load(dtile + ((size_t)(to * DH + ly) * DWd + lx) * 32 + cv * 8, v);
-#pragma unroll
-              for (int kt = 0; kt < 3; ++kt) {
-                const int ti = to + kt - 1;
-                if (ti >= 0 && ti < TT && ti < g.T) {
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) acc[ti][j] = fmaf(v[j], wk[kt][j], acc[ti][j]);
-                }
-              }
-            }
-          }
-        }
-      }
-      if (c_ok && iy < g.H && ix < g.W) {
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-          if (t < g.T) {
-            const size_t off = ((((size_t)b * g.T + t) * g.H + iy) * g.W + ix) * g.Cp + cbase;
-            float av[8], rv[8], o[8];
-            Vec8<L>::load(araw + ((size_t)(t * TH + py) * TW + px) * 32 + cv * 8, av);
-            Vec8<L>::load(atile + ((size_t)(t * AH + py + 1) * AW + px + 1) * 32 + cv * 8, rv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float d = round_as<T>(rv[j] > 0.f ? acc[t][j] : 0.f);
-              o[j] = d;
-              s1[j] += d; s2[j] += d * ((av[j] - ma[j]) * ra[j]);
-            }
-            Vec8<T>::store(t2 + off, o);
-          }
-        }
-      }
-    }
-    // ---- phase 3: weight gradient, thread = (tap, channel vector, half of the owned pixels) --------
-    if (w_act) {
-      for (int p = whalf * (OH * OW / 2); p < (whalf + 1) * (OH * OW / 2); ++p) {
-        const int oxl = p % OW, oyl = p / OW;
-#pragma unroll
-        for (int to = 0; to < TT; ++to) {
-          const int ti = to + wkt - 1;
-          if (to < g.T && ti >= 0 && ti < g.T) {
-            float d[8], r[8];
-            Vec8<L>::load(dtile + ((size_t)(to * DH + oyl + 1) * DWd + oxl + 1) * 32 + wcv * 8, d);
-            Vec8<L>::load(atile + ((size_t)(ti * AH + oyl * S + wky) * AW + oxl * S + wkx) * 32 + wcv * 8, r);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wacc[j] = fmaf(d[j], r[j], wacc[j]);
-          }
-        }
-      }
-    }
-  }
-#undef DW_ISSUE
-  // ---- flush: weight gradient --------------------------------------------------------------------------
-  __syncthreads();
-  if (w_act) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&red[wtap * 32 + wcv * 8 + j], wacc[j]);
-  }
-  __syncthreads();
-  for (int i = tid; i < 27 * 32; i += NTHR) {
-    const int tap = i / 32, c = c0 + (i & 31);
-    if (c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, red[i]);
-  }
-  __syncthreads();
-  // ---- flush: BN_a-backward sums (lanes -> wave -> workgroup -> striped f64 atomics) -----------------
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-#pragma unroll
-    for (int o = DW_CV; o < 64; o <<= 1) {
-      s1[j] += __shfl_xor(s1[j], o, 64);
-      s2[j] += __shfl_xor(s2[j], o, 64);
-    }
-  }
-  if (lane < DW_CV) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      red[(wave * DW_CV + lane) * 16 + j] = s1[j];
-      red[(wave * DW_CV + lane) * 16 + 8 + j] = s2[j];
-    }
-  }
-  __syncthreads();
-  if (tid < DW_CV * 16) {
-    const int v = tid / 16, k = tid & 15;
-    float sacc = 0.f;
-    for (int wv = 0; wv < NTHR / 64; ++wv) sacc += red[(wv * DW_CV + v) * 16 + k];
-    const int c = c0 + v * 8 + (k & 7);
-    double* dst = dsums + (size_t)((blockIdx.x + blockIdx.z) % C3D_STAT_STRIPES) * 2 * g.C;
-    if (c < g.C) atomicAdd(dst + (size_t)(k >> 3) * g.C + c, (double)sacc);
-  }
-}
-
-template <typename T, int S, int TT>
-int launch_bwd_fused(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC,
-                     const float* w, const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums,
-                     float* dw, const DwGeom& g, hipStream_t stream) {
-  typedef typename LdsStore<T>::type L;
-  constexpr int TH = 8, TW = 8;
-  constexpr int DH = (S == 1) ? TH + 2 : TH / 2 + 2, DWd = (S == 1) ? TW + 2 : TW / 2 + 2;
-  const size_t lds = 2 * 27 * 32 * sizeof(float) +
-                     (size_t)TT * (DH * DWd + (TH + 2) * (TW + 2) + TH * TW) * 32 * sizeof(L);
-  if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_fused_kernel<T, S, TT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const int ntiles = ((g.W + TW - 1) / TW) * ((g.H + TH - 1) / TH);
-  int tpw = 16;
-  if (tpw > ntiles) tpw = ntiles;
-  dim3 grid((ntiles + tpw - 1) / tpw, (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), g.B);
-  dw_bwd_fused_kernel<T, S, TT><<<grid, dim3(256), lds, stream>>>(
-      reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, w, reinterpret_cast<const T*>(a),
-      ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, dw, g, tpw);
-  C3D_CHECK_LAUNCH();
-  return 0;
-}
-
-template <typename T, int S>
-int launch_bwd_fused_t(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC,
-                       const float* w, const void* a, const float* ss_a, const float* mr_a, void* t2,
-                       double* dsums, float* dw, const DwGeom& g, hipStream_t stream) {
-  if (g.T <= 3) return launch_bwd_fused<T, S, 3>(t1, bb, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, dw, g, stream);
-  return launch_bwd_fused<T, S, 5>(t1, bb, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, dw, g, stream);
-}
-
-// ----------------------------------------------------------------------------------------------
 // Forward v2 (stride 1).  Mapping chosen from the round-1 profile (v1 was LDS-read bound at
 // 3.7 FMA per LDS read):
 //   * wave  = one 8-channel vector; the LDS tile is stored as per-vector planes [cv][t][y][x][8] so a
@@ -2205,25 +1893,6 @@ extern "C" int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA
     return stride == 1 ? launch_wgrad<bf16_t, 1>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s)
                        : launch_wgrad<bf16_t, 2>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
   }
-  return C3D_E_BADARG;
-}
-
-/* Fused data + weight gradient (one staging of the tiles); dsums is [C3D_STAT_STRIPES][2][C]. */
-extern "C" int c3d_dw333_bwd(const void* t1, const void* b, const float* coefA, const float* coefB,
-                             const float* coefC, const float* w, const void* a, const float* ss_a,
-                             const float* mr_a, void* t2, double* dsums, float* dw, int32_t B, int32_t T, int32_t H,
-                             int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype, void* stream) {
-  DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
-  if (!t1 || !b || !coefA || !coefB || !coefC || !w || !a || !ss_a || !mr_a || !t2 || !dsums || !dw || !geom_ok(g))
-    return C3D_E_BADARG;
-  if (stride == 2 && ((H | W) & 7)) return C3D_E_UNSUPPORTED;  // caller falls back to the split kernels
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == C3D_DT_F32)
-    return stride == 1 ? launch_bwd_fused_t<float, 1>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s)
-                       : launch_bwd_fused_t<float, 2>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s);
-  if (dtype == C3D_DT_BF16)
-    return stride == 1 ? launch_bwd_fused_t<bf16_t, 1>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s)
-                       : launch_bwd_fused_t<bf16_t, 2>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s);
   return C3D_E_BADARG;
 }
 

@@ -516,7 +516,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
     }
     // conv_b (depthwise 3x3x3, BN_a + ReLU on load) + per-sample statistics; BN_b + SE.  BN_a is finalised by the
     // depthwise kernel's own prologue (or by a separate launch: eval mode, last-workgroup mode, C3D_FIN_CONSUMER=0)
-    const bool cons = tr && !fold && fin_consumer() && !whatif_bits();
+    const bool cons = tr && !fold && fin_consumer() && !(whatif_bits() & 5);
     if (cons) {
       const c3d_bn_fin fa = fin_consume(sums_a, k.bn_a, (double)G.M, d->momentum, d->eps, ss_a, mr_a);
       RC(c3d_dw333_fwd_fin(a, &fa, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
@@ -614,7 +614,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     const bool fold = fold_fin();
     // BatchNorm-backward coefficients rebuilt by their consumers (narrow bf16 kernels; csrc/bn_fin.h) instead of
     // c3d_bn_bwd_coef launches
-    const bool consb = !fold && fin_consumer() && !whatif_bits() && dt == C3D_DT_BF16 && G.Cip <= 224 && G.Cop <= 224 &&
+    const bool consb = !fold && fin_consumer() && !(whatif_bits() & 1) && dt == C3D_DT_BF16 && G.Cip <= 224 && G.Cop <= 224 &&
                        G.Cinp <= 224;
     if (fold) {
       const c3d_bn_fin fc = fin_bwd(tick + 0, k.bn_c, (double)G.Mo, coef_c, mr_c);

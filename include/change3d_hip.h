@@ -210,12 +210,6 @@ int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const flo
                     const float* coefC, const void* a, const float* ss_a, float* dw, int32_t B, int32_t T,
                     int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
                     void* stream);
-/* bwd_data + wgrad fused (one staging of the tiles, prefetched, persistent workgroups);
- * dsums is f64 [C3D_STAT_STRIPES][2][C]. */
-int c3d_dw333_bwd(const void* t1, const void* b, const float* coefA, const float* coefB, const float* coefC,
-                  const float* w, const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums,
-                  float* dw, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride,
-                  int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Res-block output y = relu(bn_c(c) + shortcut) (reference model/x3d.py:326-327; also the

@@ -89,9 +89,6 @@ def dw_family():
         report(f"s{st} dw bwd-data", us, 4 * n)
         us = timeit(lambda: ops.dw_wgrad(t1, b_, cA, cB, cC, a_, ss, dw, B, T, H, H, Ci, 1, dt))
         report(f"s{st} dw wgrad", us, 3 * n)
-        ds16 = torch.zeros(16 * 2 * Ci, dtype=torch.float64, device=DEV)
-        us = timeit(lambda: ops.dw_bwd(t1, b_, cA, cB, cC, w, a_, ss, ss, t2, ds16, dw, B, T, H, H, Ci, 1, dt))
-        report(f"s{st} dw bwd FUSED (data+wgrad)", us, 4 * n)
 
 
 if __name__ == "__main__":
