@@ -15,6 +15,7 @@
 #include "pw_common.h"  // common.h + device_cus()
 #include "bn_fin.h"
 #include "launch_hints.h"
+#include "dw_toeplitz.h"
 #include "../../include/change3d_hip.h"
 #include <cstdlib>
 #include <cstring>
@@ -1800,6 +1801,10 @@ extern "C" int c3d_dw333_fwd(const void* x, const float* ss, const float* w, voi
   DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
   if (!x || !ss || !w || !y || !geom_ok(g)) return C3D_E_BADARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stride == 1 && dtype == C3D_DT_BF16 && T <= 3 && c3d_dw_toeplitz_enabled()) {   // matrix-core kernel (dw_toeplitz.hip)
+    const int rc = c3d_dw333_fwd_toeplitz(x, ss, w, y, nc_sums, B, T, H, W, C, Cp, s);
+    if (rc != C3D_E_UNSUPPORTED) { if (rc == 0) C3D_CHECK_LAUNCH(); return rc; }
+  }
   if (stride == 1) {  // v2 mapping (wave = channel vector, lane = x-strip)
     int rc = C3D_E_UNSUPPORTED;
     if (dtype == C3D_DT_F32) rc = T <= 3 ? launch_fwd_v2<float, 3>(x, ss, w, y, nc_sums, g, s)
@@ -1823,7 +1828,8 @@ extern "C" int c3d_dw333_fwd_fin(const void* x, const c3d_bn_fin* fin, const flo
   DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
   if (!x || !w || !y || !geom_ok(g)) return C3D_E_BADARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (stride == 1 && (dtype == C3D_DT_F32 || dtype == C3D_DT_BF16)) {
+  const bool tz = stride == 1 && dtype == C3D_DT_BF16 && T <= 3 && c3d_dw_toeplitz_enabled();
+  if (!tz && stride == 1 && (dtype == C3D_DT_F32 || dtype == C3D_DT_BF16)) {
     int rc;
     if (dtype == C3D_DT_F32) rc = T <= 3 ? launch_fwd_v2<float, 3>(x, fin->ss, w, y, nc_sums, g, s, fin)
                                          : launch_fwd_v2<float, 5>(x, fin->ss, w, y, nc_sums, g, s, fin);

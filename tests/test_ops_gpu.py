@@ -653,3 +653,32 @@ def test_block_out_fwd_with_folded_bn_finalize_is_bit_identical(dtype, C, mode, 
     for i, (x0, x1) in enumerate(zip(*outs)):
         assert torch.equal(x0, x1), i
     assert torch.isfinite(outs[1][0].float()).all() and outs[1][0].float().abs().max() > 0
+
+
+@pytest.mark.parametrize("C,shape", [(54, (2, 40, 72)), (216, (3, 32, 32)), (108, (1, 64, 64))])
+def test_dw_fwd_toeplitz_mfma_experiment_matches_the_valu_kernel(C, shape, monkeypatch):
+    """csrc/dw_toeplitz.hip (experiment, C3D_DW_TZ=1): same output and per-sample statistics as the default kernel up
+    to the bf16 rounding of its MFMA operands (activations after BN+ReLU and weights)."""
+    _need_gpu()
+    from change3d_amd import ops
+    B, H, W = shape
+    T, dtype = 3, torch.bfloat16
+    Cp = ops.cpad(C)
+    a = padc(q(rnd((B, T, H, W, C), 80), dtype), Cp).to(DEV, dtype).contiguous()
+    scale, shift = rnd((C,), 81).abs() + 0.5, rnd((C,), 82, 0.3)
+    ss = torch.cat([padc(scale, Cp), padc(shift, Cp)]).to(DEV)
+    w = rnd((C, 1, 3, 3, 3), 83, 0.3).to(DEV).contiguous()
+    outs = []
+    for tz in ("0", "1"):
+        monkeypatch.setenv("C3D_DW_TZ", tz)
+        b = torch.full((B, T, H, W, Cp), float("nan"), dtype=dtype, device=DEV)
+        nc = torch.zeros(B * Cp * 2, dtype=torch.float64, device=DEV)
+        ops.dw_fwd(a, ss, w, b, nc, B, T, H, W, C, 1, ops.dt_code(dtype))
+        torch.cuda.synchronize()
+        outs.append((b.float().cpu(), nc.cpu()))
+    (b0, n0), (b1, n1) = outs
+    sc = b0.abs().max().item()
+    assert sc > 0.1 and torch.isfinite(b1).all()
+    assert (b0 - b1).abs().max().item() < 3e-2 * sc and (b0 - b1).abs().mean().item() < 3e-3 * sc
+    assert (b1[..., C:] == 0).all()
+    assert torch.allclose(n0, n1, rtol=2e-2, atol=2e-2 * n0.abs().max().item())
