@@ -31,7 +31,7 @@ class PwArgs(C.Structure):
                 ("M", i64), ("gstride", i64), ("rows_per_sample", i64),
                 ("K", i32), ("Kp", i32), ("N", i32), ("Np", i32), ("w_sn", i32), ("w_sk", i32),
                 ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32),
-                ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32), ("fin", BnFin), ("bias", vp)]
+                ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32), ("fin", BnFin), ("bias", vp), ("pro_out", vp)]
 
 
 class PwWgradArgs(C.Structure):

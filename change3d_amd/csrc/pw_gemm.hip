@@ -27,10 +27,12 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   const c3d_pw_args& a = *args;
   if (a.M <= 0 || (a.Kp & 7) || (a.Np & 7) || a.K > a.Kp || a.N > a.Np) return C3D_E_BADARG;
   const bool wide = a.Kp > 224 || a.Np > 224 || a.bias != nullptr;
-  if (wide && (a.Kp > 1024 || a.Np > 1024 || a.fin.ticket || a.fin.sums)) return C3D_E_UNSUPPORTED;
+  if (wide && (a.Kp > 1024 || a.Np > 1024 || a.fin.ticket || a.fin.sums || a.pro_out)) return C3D_E_UNSUPPORTED;
+  if (a.pro_out && (a.pro_mode != C3D_PRO_AFFINE2 || a.row_mode != C3D_ROWS_DENSE)) return C3D_E_BADARG;
   if (a.pro_mode == C3D_PRO_AFFINE2 && !a.x2) return C3D_E_BADARG;
   if (a.pro_mode != C3D_PRO_NONE && !a.pro_p && !(a.pro_mode == C3D_PRO_AFFINE2 && a.fin.sums)) return C3D_E_BADARG;
-  if (a.fin.sums && a.pro_mode == C3D_PRO_AFFINE2 && (!a.fin.gamma || !a.fin.mr)) return C3D_E_BADARG;
+  if (a.fin.sums && a.pro_mode == C3D_PRO_AFFINE2 && !a.fin.training && (!a.fin.gamma || !a.fin.mr)) return C3D_E_BADARG;
+  if (a.fin.sums && a.pro_mode == C3D_PRO_AFFINE2 && a.fin.training && (!a.fin.gamma || !a.fin.beta || !a.fin.ss)) return C3D_E_BADARG;
   if (a.epi_mode == C3D_EPI_STATS && !a.stats) return C3D_E_BADARG;
   if (a.epi_mode == C3D_EPI_SWISH_SE_BWD &&
       (!a.stats || !a.e1 || !a.epi_p || !a.epi_q || a.rows_per_sample <= 0 || (!wide && (a.rows_per_sample & 15))))

@@ -440,7 +440,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       MM::store8(Ws + i, z);
     }
-    if (PRO == C3D_PRO_AFFINE2 && a.fin.sums) {
+    if (PRO == C3D_PRO_AFFINE2 && a.fin.sums && a.fin.training) {
+      // forward residual add fused into this GEMM's prologue (pro_out): A|B = scale|shift of the previous block's
+      // BatchNorm_c rebuilt from its completed sums (csrc/bn_fin.h bn_consume: workgroup 0 owns the saved vectors and
+      // the running statistics), C = 1 for the shortcut operand
+      if (blockIdx.x == 0 && tid == 0 && a.fin.nbt) *a.fin.nbt += 1;
+      c3dfin::bn_consume(a.fin, a.K, Kp, 0, Kp, blockIdx.x == 0, Pp, Pp + Kp, tid, WAVES * 64);
+      for (int c = tid; c < Kp; c += WAVES * 64) Pp[2 * Kp + c] = 1.f;
+    } else if (PRO == C3D_PRO_AFFINE2 && a.fin.sums) {
       // BatchNorm-backward coefficients rebuilt from the producer's completed sums (no c3d_bn_bwd_coef launch in
       // front of this kernel); workgroup 0 also accumulates dgamma / dbeta and writes the vector for other readers
       for (int c = tid; c < Kp; c += WAVES * 64) {
@@ -552,8 +559,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             lds_ld8(Pp + Kp + v_ * 8, cB);
             lds_ld8(Pp + 2 * Kp + v_ * 8, cC);
             const bool real = tl_ < t1 && ((tl_ << 4) + row_) < M32;
+            if (a.pro_out) {
+              // y = relu(bn_c(c) + shortcut) of the previous residual block, in the association of c3d_block_out_fwd
+              // (bit-identical), also written out: the next block's shortcut and the backward pass read it
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = real ? fmaf(cA[e], f[e], fmaf(cC[e], f2[e], cB[e])) : 0.f;
+              for (int e = 0; e < 8; ++e) f[e] = real ? fmaxf(fmaf(f[e], cA[e], cB[e]) + fmaf(f2[e], cC[e], 0.f), 0.f) : 0.f;
+              if (real) Vec8<T>::store(reinterpret_cast<T*>(a.pro_out) + (int64_t)((tl_ << 4) + row_) * Kp + v_ * 8, f);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] = real ? fmaf(cA[e], f[e], fmaf(cC[e], f2[e], cB[e])) : 0.f;
+            }
           }
           MM::store8(Xs + (slot_s[j] * 16 + row_) * KL + v_ * 8, f);
         }
@@ -933,6 +948,7 @@ int dispatch_mode(const c3d_pw_args& a, hipStream_t s) {
   if (pro == C3D_PRO_BN_SE_SWISH && epi == C3D_EPI_STORE) return dispatch_nt<T, C3D_PRO_BN_SE_SWISH, C3D_EPI_STORE>(a, s);
   if (pro == C3D_PRO_BN_SE_SWISH && epi == C3D_EPI_STATS) return dispatch_nt<T, C3D_PRO_BN_SE_SWISH, C3D_EPI_STATS>(a, s);
   if (pro == C3D_PRO_AFFINE2 && epi == C3D_EPI_STORE) return dispatch_nt<T, C3D_PRO_AFFINE2, C3D_EPI_STORE>(a, s);
+  if (pro == C3D_PRO_AFFINE2 && epi == C3D_EPI_STATS) return dispatch_nt<T, C3D_PRO_AFFINE2, C3D_EPI_STATS>(a, s);
   if (pro == C3D_PRO_AFFINE2 && epi == C3D_EPI_SWISH_SE_BWD) return dispatch_nt<T, C3D_PRO_AFFINE2, C3D_EPI_SWISH_SE_BWD>(a, s);
   if (pro == C3D_PRO_AFFINE2 && epi == C3D_EPI_ADD) return dispatch_nt<T, C3D_PRO_AFFINE2, C3D_EPI_ADD>(a, s);
   if (pro == C3D_PRO_NONE && epi == C3D_EPI_ADD) return dispatch_nt<T, C3D_PRO_NONE, C3D_EPI_ADD>(a, s);

@@ -341,6 +341,12 @@ bool fin_consumer() {
   return on;
 }
 
+// C3D_FUSE_RESIDUAL=0: separate residual-add launches (c3d_block_out_fwd_fin) instead of the next block's conv_a prologue
+bool fuse_residual() {
+  static const bool on = !(getenv("C3D_FUSE_RESIDUAL") && atoi(getenv("C3D_FUSE_RESIDUAL")) == 0);
+  return on;
+}
+
 inline c3d_bn_fin fin_consume(const double* sums, const c3d_bn_ptrs& bn, double count, float momentum, float eps,
                               float* ss, float* mr) {
   c3d_bn_fin f = fin_fwd(nullptr, bn, 1, count, momentum, eps, ss, mr);
@@ -491,6 +497,9 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
   HIPRC(hipMemsetAsync(at(ws, P.fwd_acc_off), 0, P.fwd_acc_bytes, st));
   const int epi = tr ? C3D_EPI_STATS : C3D_EPI_STORE;
   const void* cur = x;
+  // Residual add of block i fused into conv_a of block i+1 (c3d_pw_args.pro_out): pending operands of block i
+  struct Pending { const void* c; const void* sc; c3d_bn_fin fin; void* y; bool on; } pend;
+  std::memset(&pend, 0, sizeof(pend));
   for (int i = 0; i < d->n_blocks; ++i) {
     const c3d_block_desc& k = d->blocks[i];
     const BlkGeom& G = P.g[i];
@@ -508,7 +517,13 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
     uint32_t* tick = atT<uint32_t>(ws, F.tick);
     const bool fold = tr && fold_fin();   // (eval mode has no statistics: the finalize launches build scale/shift)
     // conv_a (1x1x1) + BN_a statistics
-    {
+    if (pend.on) {   // y(i-1) = relu(bn_c(c) + shortcut) computed on load, written out, and fed to the GEMM
+      PwCall p(pend.c, k.w_a, a, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
+      p.a.x2 = pend.sc; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.fin = pend.fin; p.a.pro_p = pend.fin.ss; p.a.pro_out = pend.y;
+      p.a.epi_mode = epi; p.a.stats = sums_a;
+      RC(c3d_pw_gemm(&p.a, st));
+      pend.on = false;
+    } else {
       PwCall p(cur, k.w_a, a, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
       p.a.epi_mode = epi; p.a.stats = sums_a;
       if (fold) p.a.fin = fin_fwd(tick + 0, k.bn_a, tr, (double)G.M, d->momentum, d->eps, ss_a, mr_a);
@@ -561,7 +576,14 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       }
       scp = sc;
     }
-    if (cons) {
+    // the next block's conv_a can take over this block's residual add when that block reads dense rows of y
+    // (stride 1 inside a stage), its kernels are the narrow bf16 ones, and the shortcut carries no BatchNorm
+    const bool fuse_next = cons && fuse_residual() && i + 1 < d->n_blocks && mode != SC_BN && dt == C3D_DT_BF16 &&
+                           G.Cop <= 224 && P.g[i + 1].Cip <= 224 && d->blocks[i + 1].stride == 1 && !d->blocks[i + 1].has_sc_conv;
+    if (fuse_next) {
+      pend.c = c; pend.sc = scp; pend.y = y; pend.on = true;
+      pend.fin = fin_consume(sums_c, k.bn_c, (double)G.Mo, d->momentum, d->eps, ss_c, mr_c);
+    } else if (cons) {
       const c3d_bn_fin fc = fin_consume(sums_c, k.bn_c, (double)G.Mo, d->momentum, d->eps, ss_c, mr_c);
       c3d_bn_fin f1;
       if (mode == SC_BN) f1 = fin_consume(sums_1, k.bn_sc, (double)G.Mo, d->momentum, d->eps, ss_1, mr_1);

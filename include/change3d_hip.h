@@ -109,6 +109,9 @@ typedef struct c3d_pw_args {
                          /* dgamma / dbeta into fin.running_mean / fin.running_var and writes fin.ss if non-NULL) */
                          /* instead of read from pro_p (narrow kernel only: K, N <= 224, no bias).                */
   const float* bias;     /* optional bias[N] added before the epilogue (linear layers of the caption decoder)  */
+  void* pro_out;         /* C3D_PRO_AFFINE2, dense rows, narrow kernel: relu(A*x + B + C*x2) is what enters the GEMM  */
+                         /* AND is written here [M][Kp] (the residual add of the previous block fused into conv_a:    */
+                         /* x = c, x2 = shortcut, fin.training = 1 + fin.sums = BatchNorm_c's 16-stripe sums, C = 1)  */
 } c3d_pw_args;
 
 /* K, N <= 224 run the wave-private-tile kernel (pw_gemm_impl.h); wider layers (X3D res5: 432 inner channels; the
