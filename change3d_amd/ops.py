@@ -240,11 +240,12 @@ def fin_bwd(tick, idx, bn, count, coef, mr):
 def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, pro_p=None,
             pro_gate=None, epi_mode=EPI_STORE, e1=None, epi_p=None, epi_gate=None, epi_q=None, stats=None,
             rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, res_mode=0,
-            x_ptr=None, e1_ptr=None, fin=None, bias=None):
+            x_ptr=None, e1_ptr=None, fin=None, bias=None, pro_out=None):
     a = L.PwArgs()
     if fin is not None:
         a.fin = fin
     a.bias = _p(bias)
+    a.pro_out = _p(pro_out)
     a.x = x_ptr if x_ptr is not None else _p(x)
     a.x2 = _p(x2)
     a.y = _p(y)

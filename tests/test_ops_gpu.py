@@ -682,3 +682,49 @@ def test_dw_fwd_toeplitz_mfma_experiment_matches_the_valu_kernel(C, shape, monke
     assert (b0 - b1).abs().max().item() < 3e-2 * sc and (b0 - b1).abs().mean().item() < 3e-3 * sc
     assert (b1[..., C:] == 0).all()
     assert torch.allclose(n0, n1, rtol=2e-2, atol=2e-2 * n0.abs().max().item())
+
+
+@pytest.mark.parametrize("Cin,Cinner,M", [(96, 216, 3000), (48, 108, 5003), (24, 54, 8192)])
+def test_residual_add_fused_into_conv_a_is_bit_identical(Cin, Cinner, M):
+    """conv_a with the previous block's residual add in its prologue (c3d_pw_args.pro_out + fin, bf16) against
+    c3d_block_out_fwd_fin followed by the plain conv_a: identical y, conv output, BN_a statistics, BatchNorm_c vectors
+    and running statistics."""
+    _need_gpu()
+    from change3d_amd import ops
+    dtype = torch.bfloat16
+    dt = ops.dt_code(dtype)
+    Cp, Np = ops.cpad(Cin), ops.cpad(Cinner)
+    c = padc(q(rnd((M, Cin), 100), dtype), Cp).to(DEV, dtype).contiguous()
+    s = padc(q(rnd((M, Cin), 101), dtype), Cp).to(DEV, dtype).contiguous()
+    w = rnd((Cinner, Cin), 102, 0.2).to(DEV).contiguous()
+    g_ = torch.Generator().manual_seed(103)
+    sums = torch.zeros(16, 2, Cin, dtype=torch.float64)
+    sums[:, 0] = torch.randn(16, Cin, generator=g_, dtype=torch.float64) * M / 64
+    sums[:, 1] = (torch.rand(16, Cin, generator=g_, dtype=torch.float64) + 0.5) * M / 8
+    sums = sums.to(DEV)
+
+    def bn():
+        m = torch.nn.BatchNorm3d(Cin)
+        with torch.no_grad():
+            m.weight.copy_(rnd((Cin,), 104).abs() + 0.5); m.bias.copy_(rnd((Cin,), 105, 0.3))
+        return m.to(DEV)
+
+    outs = []
+    for fused in (False, True):
+        m = bn()
+        ss, mr = torch.full((2 * Cp,), float("nan"), device=DEV), torch.full((2 * Cp,), float("nan"), device=DEV)
+        y = torch.full((M, Cp), float("nan"), dtype=dtype, device=DEV)
+        a = torch.full((M, Np), float("nan"), dtype=dtype, device=DEV)
+        st = torch.zeros(16 * 2 * Cinner, dtype=torch.float64, device=DEV)
+        fin = ops.fin_consume(sums, m, float(M), ss, mr)
+        if fused:
+            ops.pw_gemm(c, w, a, M=M, K=Cin, N=Cinner, w_sn=Cin, w_sk=1, dtype=dt, x2=s, pro_mode=ops.PRO_AFFINE2, pro_p=ss,
+                        epi_mode=ops.EPI_STATS, stats=st, fin=fin, pro_out=y)
+        else:
+            ops.block_out_fwd_fin(c, fin, s, None, 1, y, M, Cin, dt)
+            ops.pw_gemm(y, w, a, M=M, K=Cin, N=Cinner, w_sn=Cin, w_sk=1, dtype=dt, epi_mode=ops.EPI_STATS, stats=st)
+        torch.cuda.synchronize()
+        outs.append((y, a, st, ss, mr, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()))
+    for i, (x0, x1) in enumerate(zip(*outs)):
+        assert torch.equal(x0, x1), i
+    assert torch.isfinite(outs[1][1].float()).all() and outs[1][0].float().abs().max() > 0 and int(outs[1][7]) == 1
