@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
       const bool all_real = vmask == (1u << WG_RPT) - 1u;
       int rows_n[WG_RPT];    // sample of each row (swish gate); the thread's rows are consecutive
       bool one_sample = true;
-      if (swish && a.q_gate) {
+      if (swish && a.q_gate && vmask) {   // (a thread without a real row must not index the gate: m0 / rps may be >= B)
         const int64_t m0 = tile * MT + rg * WG_RPT;
         const int64_t rps = a.rows_per_sample;
         if (gn < 0 || m0 < (int64_t)gn * rps || m0 >= (int64_t)(gn + 1) * rps) {   // rarely: the cached sample moved on
