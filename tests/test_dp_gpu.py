@@ -91,3 +91,61 @@ def test_world2_real_backward_hook_allreduce_equals_mean_of_single_rank_grads(dt
           f"overlapped tail bucket = {f0.size - split} of {f0.size} floats")
     # single-rank reruns differ only by f32 leaf-gradient atomics (test_step_is_reproducible: < 2e-5)
     assert worst < 1e-4, worst
+
+
+def _rccl_worker(port, q):
+    """One rank, backend nccl (= RCCL): the group has a single member, but GradSync is told world = 2 so that the
+    overlapped tail all-reduce, the head all-reduce and the stream fences actually run through RCCL."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from change3d_amd import synthetic as synth
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.utils import BCEDiceLoss
+    from change3d_amd.parallel import setup_data_parallel
+    args = synth.make_args(size=SIZE)
+    args.act_dtype = torch.bfloat16
+    net = Trainer(args)
+    net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25))
+    net = net.to(dev).train()
+    arena, sync = setup_data_parallel(net, dev, overlap=True)
+    sync.world = 2                                                    # force the collective path (sum over 1 rank, / 2)
+    net.encoder.x3d.blocks[3].post_backward = sync.launch_tail
+    pre, post, tgt = (t.to(dev) for t in synth.synth_batch(BATCH, SIZE, seed=0))
+    out = []
+    for it in range(3):                                               # several steps: the comm stream is reused
+        arena.zero_grad()
+        BCEDiceLoss(net.update_bcd(pre, post), tgt).backward()
+        fired = sync._tail_launched
+        sync.finish()
+        torch.cuda.synchronize()
+        out.append((fired, arena.flat_grad.cpu().numpy().copy()))
+    q.put((dist.get_backend(), out))
+    dist.destroy_process_group()
+
+
+def test_overlapped_allreduce_through_rccl_single_rank():
+    """The real backend: `torch.distributed` "nccl" (RCCL) on the GPU.  With one member the sum is the identity, so the
+    averaged buffer must be exactly half of the gradient -- what is exercised is RCCL initialisation, the all-reduce of
+    the tail bucket on the communication stream from inside backward, the head all-reduce, and the stream fences."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import torch.multiprocessing as mp
+    dev = torch.device("cuda", 0)
+    arena, _, _ = _local_step(0, dev, torch.bfloat16, sync_setup=False)
+    torch.cuda.synchronize()
+    ref = arena.flat_grad.cpu().numpy().astype(np.float64)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29700 + (os.getpid() % 2000), q))
+    p.start()
+    backend, out = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and backend == "nccl"
+    for fired, flat in out:
+        assert fired, "the stage hook did not launch the tail bucket"
+        err = np.linalg.norm(flat.astype(np.float64) - 0.5 * ref) / np.linalg.norm(0.5 * ref)
+        assert err < 1e-4, err
