@@ -22,8 +22,9 @@
 // per 32x32x16-channel tile: staging 11 us, MFMA + statistics 8.4 us, gather 7.5 us = 27 us for 49 k outputs, against
 // ~20 us for the same outputs in the VALU kernel (two workgroups per CU overlapping each other).  The matrix time is
 // not the problem (336 MFMAs = 2.2 us); with ONE wave per SIMD (131 KB of planes per workgroup) nothing overlaps the
-// two transposes, and batching the loads / LDS reads per phase did not move them.  What the next attempt needs is in
-// two workgroups per CU (8-channel planes) or producer waves for the transposes.
+// two transposes, and batching the loads / LDS reads per phase did not move them.  C3D_DW_TZ_NCH=8 (8-channel planes,
+// 65 KB, TWO workgroups per CU) measures 344 / 127 / 76 us: occupancy is not the cure either (and 16-byte pieces of
+// each pixel row cost the 128x128 stage dearly).  Next: in-kernel clocks on the three phases.
 #include "common.h"
 #include "dw_toeplitz.h"
 #include <cstdlib>
@@ -37,7 +38,6 @@ constexpr int PH = TS + 2, PW = 40;    // plane rows (halo), row stride in eleme
 constexpr int TT = 3;
 constexpr int PLANE_E = TT * PH * PW;  // 4080 elements
 constexpr int PLANE_B = PLANE_E * 2 + 16;   // bytes, +16: the two channel octets of a pixel fall on different banks
-constexpr int NCH = 16;                // channels per workgroup
 constexpr int NTHR = 256;
 constexpr int OW = TS;                 // output plane row stride (elements)
 
@@ -55,12 +55,15 @@ __device__ __forceinline__ float wave_sum64(float v) {
   return v;
 }
 
+template <int NCH>
 __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ss,
                                                          const float* __restrict__ w, bf16_t* __restrict__ y,
                                                          double* __restrict__ nc, const Geom g, const int walkers, const int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* planes = smem;                                        // [NCH][PLANE_B]
-  float* lss = reinterpret_cast<float*>(smem + NCH * PLANE_B + 64);    // scale[16] | shift[16]
+  float* lss = reinterpret_cast<float*>(smem + NCH * PLANE_B + 64);    // scale[NCH] | shift[NCH]
+  constexpr int CPW = NCH / 4;       // channels per wave
+  constexpr int NV = NCH / 8;        // channel octets per pixel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, gq = lane >> 4;
   const int c0 = blockIdx.y * NCH;
@@ -68,8 +71,8 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
   // (an XCD-aware 1-D order that puts the channel groups of one walker on one L2 was measured: no gain for the 128x128
   //  stage, and the walker count rounded to whole XCD rows left CUs idle for the others)
   if (tid < 2 * NCH) {
-    const int c = c0 + (tid & 15);
-    lss[tid] = c < g.C ? ss[(tid >> 4) * g.Cp + c] : 0.f;
+    const int c = c0 + (tid % NCH);
+    lss[tid] = c < g.C ? ss[(tid / NCH) * g.Cp + c] : 0.f;
   }
   // (the 16 bytes behind each plane are read -- never used, their Toeplitz coefficients are zero -- and zeroed below)
 
@@ -81,15 +84,15 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
   }
   __syncthreads();
   // ---- Toeplitz weight fragments of this wave's 4 channels: A[m = x_out][k = x_in] = w[kx = k - m], k = 8*gq + j
-  u32x4 A[4][3][3];
+  u32x4 A[CPW][3][3];
   const int s0 = n - 8 * gq;        // element j of this lane's window holds w[kx = j - s0]
 #pragma unroll
-  for (int ci = 0; ci < 4; ++ci) {
+  for (int ci = 0; ci < CPW; ++ci) {
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
-        const float* wp = wl + (wave * 4 + ci) * 27 + kt * 9 + ky * 3;
+        const float* wp = wl + (wave * CPW + ci) * 27 + kt * 9 + ky * 3;
         const uint32_t b0 = f32_to_bf16(wp[0]), b1 = f32_to_bf16(wp[1]), b2 = f32_to_bf16(wp[2]);
         uint32_t h[8];
 #pragma unroll
@@ -112,19 +115,19 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
     const int y0 = ty * TS, x0 = tx * TS;
     // ---- stage: group-item = (t, plane row py, group of 8 plane columns, channel octet); the loads of TWO passes
     //      (16 x 16 B per thread) are issued before the first conversion (one wave per SIMD: nothing else hides them)
-    constexpr int NGI = TT * PH * 5 * 2;
+    constexpr int NGI = TT * PH * 5 * NV;
     constexpr int NPASS = (NGI + NTHR - 1) / NTHR;   // 4
     if (!(dbg & 1)) {
 #pragma unroll
-      for (int p0 = 0; p0 < NPASS; p0 += 2) {
+      for (int p0 = 0; p0 < (NPASS + 1) / 2 * 2; p0 += 2) {
         uint4 raw[2][8];
         int st_v[2], st_xg[2], st_py[2], st_t[2];
         bool st_row[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int gi = (p0 + u) * NTHR + tid;
-          const int v = gi & 1;
-          int q = gi >> 1;
+          const int v = gi % NV;
+          int q = gi / NV;
           const int xg = q % 5; q /= 5;
           const int py = q % PH, t = q / PH;
           const int gy = y0 - 1 + py;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
           const int v = st_v[u], xg = st_xg[u], py = st_py[u], t = st_t[u];
           float sc[8], sh[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { sc[e] = lss[8 * v + e]; sh[e] = lss[16 + 8 * v + e]; }
+          for (int e = 0; e < 8; ++e) { sc[e] = lss[8 * v + e]; sh[e] = lss[NCH + 8 * v + e]; }
           uint32_t P[8][4];   // [channel e][pixel pair]
 #pragma unroll
           for (int jp = 0; jp < 4; ++jp) {
@@ -175,12 +178,14 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
     }
     __syncthreads();
     // ---- MFMA: this wave's 4 channels, 2x2 blocks of 16x16 outputs, 3 frames
-    float cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
+    float cs1[CPW], cs2[CPW];
+#pragma unroll
+    for (int ci = 0; ci < CPW; ++ci) { cs1[ci] = 0.f; cs2[ci] = 0.f; }
     if (!(dbg & 2))
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci) {
-      const int c = c0 + wave * 4 + ci;
-      const unsigned char* pl = planes + (size_t)(wave * 4 + ci) * PLANE_B;
+    for (int ci = 0; ci < CPW; ++ci) {
+      const int c = c0 + wave * CPW + ci;
+      const unsigned char* pl = planes + (size_t)(wave * CPW + ci) * PLANE_B;
       uint32_t outp[4][TT][2];
       float s1 = 0.f, s2 = 0.f;
       // all nine B fragments of a block are requested before its first MFMA, the next block's while it computes
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
       }
 #undef TZ_LOAD
       // the channel's input plane is dead now (same wave, LDS operations complete in order): results over it
-      unsigned char* op = planes + (size_t)(wave * 4 + ci) * PLANE_B;
+      unsigned char* op = planes + (size_t)(wave * CPW + ci) * PLANE_B;
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk) {
         const int yb = blk >> 1, xb = blk & 1;
@@ -247,11 +252,11 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) {
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci) { cs1[ci] += __shfl_xor(cs1[ci], o, 64); cs2[ci] += __shfl_xor(cs2[ci], o, 64); }
+        for (int ci = 0; ci < CPW; ++ci) { cs1[ci] += __shfl_xor(cs1[ci], o, 64); cs2[ci] += __shfl_xor(cs2[ci], o, 64); }
       }
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci) {
-        const int c = c0 + wave * 4 + ci;
+      for (int ci = 0; ci < CPW; ++ci) {
+        const int c = c0 + wave * CPW + ci;
         if (lane == 0 && c < g.C) {
           atomicAdd(nc + ((size_t)b * g.Cp + c) * 2, (double)cs1[ci]);
           atomicAdd(nc + ((size_t)b * g.Cp + c) * 2 + 1, (double)cs2[ci]);
@@ -261,15 +266,15 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
     __syncthreads();
     // ---- gather: (t, row, group of 8 columns, channel octet): 8 channels x 8 pixels -> 8 pixel vectors; the LDS
     //      reads of all passes are issued first
-    constexpr int NGO = TT * TS * 4 * 2;
-    constexpr int NGP = NGO / NTHR;   // 3
+    constexpr int NGO = TT * TS * 4 * NV;
+    constexpr int NGP = (NGO + NTHR - 1) / NTHR;
     if (!(dbg & 4)) {
       uint4 R[NGP][8];
 #pragma unroll
       for (int u = 0; u < NGP; ++u) {
         const int gi = u * NTHR + tid;
-        const int v = gi & 1, xg = (gi >> 1) & 3, q = gi >> 3;
-        const int py = q % TS, t = q / TS;
+        const int v = gi % NV, xg = (gi / NV) & 3, q = gi / (4 * NV);
+        const int py = q % TS, t = (q / TS) % TT;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           R[u][e] = *reinterpret_cast<const uint4*>(planes + (size_t)(8 * v + e) * PLANE_B + ((size_t)(t * TS + py) * OW + 8 * xg) * 2);
@@ -277,10 +282,10 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
 #pragma unroll
       for (int u = 0; u < NGP; ++u) {
         const int gi = u * NTHR + tid;
-        const int v = gi & 1, xg = (gi >> 1) & 3, q = gi >> 3;
+        const int v = gi % NV, xg = (gi / NV) & 3, q = gi / (4 * NV);
         const int py = q % TS, t = q / TS;
         const int gy = y0 + py;
-        if (t < g.T && gy < g.H && c0 + 8 * v < g.Cp) {
+        if (gi < NGO && t < g.T && gy < g.H && c0 + 8 * v < g.Cp) {
           bf16_t* rowp = y + ((((size_t)b * g.T + t) * g.H + gy) * g.W) * g.Cp + c0 + 8 * v;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -309,26 +314,34 @@ bool c3d_dw_toeplitz_enabled() {
   return e && atoi(e) == 1;
 }
 
-int c3d_dw333_fwd_toeplitz(const void* x, const float* ss, const float* w, void* y, double* nc, int B, int T, int H, int W,
-                           int C, int Cp, hipStream_t s) {
-  if (T > TT || T < 1) return C3D_E_UNSUPPORTED;
-  const Geom g{B, T, H, W, C, Cp};
+template <int NCH>
+static int tz_launch(const void* x, const float* ss, const float* w, void* y, double* nc, const Geom& g, hipStream_t s) {
   const size_t lds = (size_t)NCH * PLANE_B + 64 + 2 * NCH * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_tz_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_tz_kernel<NCH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int groups = (Cp + NCH - 1) / NCH;
-  const int nitems = B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
-  int walkers = 256 / groups;               // one workgroup per CU
+  const int groups = (g.Cp + NCH - 1) / NCH;
+  const int nitems = g.B * ((g.H + TS - 1) / TS) * ((g.W + TS - 1) / TS);
+  int walkers = (NCH == 16 ? 256 : 512) / groups;     // one (16 channels) or two (8 channels) workgroups per CU
   if (walkers < 1) walkers = 1;
   if (walkers > nitems) walkers = nitems;
   static const int env_w = getenv("C3D_DW_TZ_WALKERS") ? atoi(getenv("C3D_DW_TZ_WALKERS")) : 0;
   if (env_w > 0) walkers = env_w < nitems ? env_w : nitems;
-  dw_fwd_tz_kernel<<<dim3(walkers, groups), NTHR, lds, s>>>(reinterpret_cast<const bf16_t*>(x), ss, w,
-                                                          reinterpret_cast<bf16_t*>(y), nc, g, walkers, getenv("C3D_DW_TZ_DBG") ? atoi(getenv("C3D_DW_TZ_DBG")) : 0);
+  dw_fwd_tz_kernel<NCH><<<dim3(walkers, groups), NTHR, lds, s>>>(reinterpret_cast<const bf16_t*>(x), ss, w,
+                                                               reinterpret_cast<bf16_t*>(y), nc, g, walkers,
+                                                               getenv("C3D_DW_TZ_DBG") ? atoi(getenv("C3D_DW_TZ_DBG")) : 0);
   return 0;
+}
+
+int c3d_dw333_fwd_toeplitz(const void* x, const float* ss, const float* w, void* y, double* nc, int B, int T, int H, int W,
+                           int C, int Cp, hipStream_t s) {
+  if (T > TT || T < 1) return C3D_E_UNSUPPORTED;
+  const Geom g{B, T, H, W, C, Cp};
+  const char* e = getenv("C3D_DW_TZ_NCH");   // 16 (one workgroup per CU) or 8 (two)
+  if (e && atoi(e) == 8) return tz_launch<8>(x, ss, w, y, nc, g, s);
+  return tz_launch<16>(x, ss, w, y, nc, g, s);
 }
