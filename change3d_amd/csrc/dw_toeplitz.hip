@@ -58,7 +58,8 @@ __device__ __forceinline__ float wave_sum64(float v) {
 template <int NCH>
 __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ss,
                                                          const float* __restrict__ w, bf16_t* __restrict__ y,
-                                                         double* __restrict__ nc, const Geom g, const int walkers, const int dbg) {
+                                                         double* __restrict__ nc, const Geom g, const int walkers, const int dbg,
+                                                         unsigned long long* __restrict__ clk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* planes = smem;                                        // [NCH][PLANE_B]
   float* lss = reinterpret_cast<float*>(smem + NCH * PLANE_B + 64);    // scale[NCH] | shift[NCH]
@@ -66,6 +67,10 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
   constexpr int NV = NCH / 8;        // channel octets per pixel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, gq = lane >> 4;
+  // phase clocks (C3D_DW_TZ_CLK=1): s_memtime deltas summed per wave, added to clk[phase] at the end
+  unsigned long long ck[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ck_last = clk ? __builtin_amdgcn_s_memtime() : 0;
+#define TZCK(i) if (clk) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ck[i] += t_ - ck_last; ck_last = t_; }
   const int c0 = blockIdx.y * NCH;
   const int walker = blockIdx.x;
   // (an XCD-aware 1-D order that puts the channel groups of one walker on one L2 was measured: no gain for the 128x128
@@ -113,6 +118,7 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
     const int b = item / (tiles_y * tiles_x), tl = item - b * tiles_y * tiles_x;
     const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
+    TZCK(9)
     // ---- stage: group-item = (t, plane row py, group of 8 plane columns, channel octet); the loads of TWO passes
     //      (16 x 16 B per thread) are issued before the first conversion (one wave per SIMD: nothing else hides them)
     constexpr int NGI = TT * PH * 5 * NV;
@@ -143,6 +149,9 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
             raw[u][j] = ok ? val : make_uint4(0, 0, 0, 0);
           }
         }
+        TZCK(0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TZCK(1)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int gi = (p0 + u) * NTHR + tid;
@@ -174,9 +183,11 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
             *reinterpret_cast<uint4*>(dst) = make_uint4(P[e][0], P[e][1], P[e][2], P[e][3]);
           }
         }
+        TZCK(2)
       }
     }
     __syncthreads();
+    TZCK(3)
     // ---- MFMA: this wave's 4 channels, 2x2 blocks of 16x16 outputs, 3 frames
     float cs1[CPW], cs2[CPW];
 #pragma unroll
@@ -248,6 +259,7 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
       }
       cs1[ci] = s1; cs2[ci] = s2;
     }
+    TZCK(4)
     if (nc) {   // the eight wave reductions run interleaved (a chain of six dependent cross-lane steps each)
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) {
@@ -263,7 +275,9 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
         }
       }
     }
+    TZCK(5)
     __syncthreads();
+    TZCK(6)
     // ---- gather: (t, row, group of 8 columns, channel octet): 8 channels x 8 pixels -> 8 pixel vectors; the LDS
     //      reads of all passes are issued first
     constexpr int NGO = TT * TS * 4 * NV;
@@ -279,6 +293,7 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
         for (int e = 0; e < 8; ++e)
           R[u][e] = *reinterpret_cast<const uint4*>(planes + (size_t)(8 * v + e) * PLANE_B + ((size_t)(t * TS + py) * OW + 8 * xg) * 2);
       }
+      TZCK(7)
 #pragma unroll
       for (int u = 0; u < NGP; ++u) {
         const int gi = u * NTHR + tid;
@@ -303,7 +318,14 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
         }
       }
     }
+    TZCK(8)
     __syncthreads();
+  }
+#undef TZCK
+  if (clk && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) atomicAdd(clk + i, ck[i]);
+    atomicAdd(clk + 10, 1ull);
   }
 }
 
@@ -312,6 +334,14 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
 bool c3d_dw_toeplitz_enabled() {
   const char* e = getenv("C3D_DW_TZ");   // read per call (tests toggle it inside one process)
   return e && atoi(e) == 1;
+}
+
+// C3D_DW_TZ_CLK=1: device buffer of 11 counters (10 phases + waves), read back by c3d_debug_tz_clock
+static unsigned long long* tz_clk_buffer() {
+  static unsigned long long* buf = nullptr;
+  static const bool on = getenv("C3D_DW_TZ_CLK") && atoi(getenv("C3D_DW_TZ_CLK")) == 1;
+  if (on && !buf && hipMalloc(&buf, 16 * sizeof(unsigned long long)) == hipSuccess) hipMemset(buf, 0, 16 * sizeof(unsigned long long));
+  return on ? buf : nullptr;
 }
 
 template <int NCH>
@@ -333,7 +363,8 @@ static int tz_launch(const void* x, const float* ss, const float* w, void* y, do
   if (env_w > 0) walkers = env_w < nitems ? env_w : nitems;
   dw_fwd_tz_kernel<NCH><<<dim3(walkers, groups), NTHR, lds, s>>>(reinterpret_cast<const bf16_t*>(x), ss, w,
                                                                reinterpret_cast<bf16_t*>(y), nc, g, walkers,
-                                                               getenv("C3D_DW_TZ_DBG") ? atoi(getenv("C3D_DW_TZ_DBG")) : 0);
+                                                               getenv("C3D_DW_TZ_DBG") ? atoi(getenv("C3D_DW_TZ_DBG")) : 0,
+                                                               tz_clk_buffer());
   return 0;
 }
 
@@ -344,4 +375,14 @@ int c3d_dw333_fwd_toeplitz(const void* x, const float* ss, const float* w, void*
   const char* e = getenv("C3D_DW_TZ_NCH");   // 16 (one workgroup per CU) or 8 (two)
   if (e && atoi(e) == 8) return tz_launch<8>(x, ss, w, y, nc, g, s);
   return tz_launch<16>(x, ss, w, y, nc, g, s);
+}
+
+// (diagnosis) copies the phase counters to `out[11]` and clears them; returns 0 when C3D_DW_TZ_CLK is not set
+extern "C" __attribute__((visibility("default"))) int c3d_debug_tz_clock(unsigned long long* out) {
+  unsigned long long* b = tz_clk_buffer();
+  if (!b) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(out, b, 11 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  hipMemset(b, 0, 16 * sizeof(unsigned long long));
+  return 1;
 }
