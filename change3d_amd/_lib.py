@@ -31,7 +31,11 @@ class PwArgs(C.Structure):
                 ("M", i64), ("gstride", i64), ("rows_per_sample", i64),
                 ("K", i32), ("Kp", i32), ("N", i32), ("Np", i32), ("w_sn", i32), ("w_sk", i32),
                 ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32),
-                ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32), ("fin", BnFin), ("bias", vp), ("pro_out", vp)]
+                ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32), ("fin", BnFin), ("bias", vp), ("pro_out", vp), ("w_img", vp)]
+
+
+class PwPackDesc(C.Structure):
+    _fields_ = [("w", vp), ("img", vp), ("N", i32), ("Np", i32), ("K", i32), ("Kp", i32), ("w_sn", i32), ("w_sk", i32)]
 
 
 class PwWgradArgs(C.Structure):
@@ -70,6 +74,8 @@ SIGNATURES = {
     "c3d_build_info": (C.c_char_p, []),
     "c3d_device_cus": (i32, []),
     "c3d_pw_gemm": (i32, [C.POINTER(PwArgs), vp]),
+    "c3d_pw_weight_image_bytes": (i64, [i32, i32, i32]),
+    "c3d_pw_pack_weights": (i32, [C.POINTER(PwPackDesc), i32, i32, vp]),
     "c3d_pw_wgrad_ws_floats": (i64, [i32, i32]),
     "c3d_pw_wgrad": (i32, [C.POINTER(PwWgradArgs), vp]),
     "c3d_bn_finalize": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp]),

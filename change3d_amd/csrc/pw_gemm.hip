@@ -1,5 +1,6 @@
 // Pointwise-convolution row GEMM: C entry point and the bf16 (throughput) instantiations.  The kernel lives in
 // pw_gemm_impl.h; the f32 (parity) instantiations are compiled in pw_gemm_f32.hip.
+#include <cstring>
 #include "pw_gemm_impl.h"
 
 // f32 instantiations (pw_gemm_f32.hip); library-internal
@@ -22,6 +23,82 @@ extern "C" int c3d_debug_pw_clock(unsigned long long* out, int reset) {   // out
 
 int c3d_detail_pw_gemm_wide(const c3d_pw_args* args, void* stream);   // pw_wide.hip
 
+// ------------------------------------------------------------------------------------------ weight images
+namespace {
+
+// (NT, KL) of the narrow kernel for a padded shape: dispatch_nt's buckets and pw_gemm_kernel's KL
+bool pw_img_geom(int Np, int Kp, int dtype, int& NT, int& KL, int& esz) {
+  if (Kp <= 0 || Np <= 0 || Kp > 224 || Np > 224 || (Kp & 7) || (Np & 7)) return false;
+  const int nt = (Np + 15) / 16;
+  NT = nt <= 2 ? 2 : nt <= 4 ? 4 : nt <= 7 ? 7 : 14;
+  if (dtype == C3D_DT_BF16) {
+    KL = (Kp + Mma<bf16_t>::KSTEP - 1) / Mma<bf16_t>::KSTEP * Mma<bf16_t>::KSTEP + Mma<bf16_t>::KPAD; esz = 2;
+  } else if (dtype == C3D_DT_F32) {
+    KL = (Kp + Mma<float>::KSTEP - 1) / Mma<float>::KSTEP * Mma<float>::KSTEP + Mma<float>::KPAD; esz = 4;
+  } else {
+    return false;
+  }
+  return true;
+}
+
+struct PackOne { const float* w; void* img; int N, K, sn, sk, NT, KL; };
+struct PackArgs { PackOne d[C3D_PW_PACK_MAX]; };
+
+// one thread = 4 consecutive k of one image row (8-byte store bf16, 16-byte store f32); blockIdx.y = image
+template <typename T>
+__global__ __launch_bounds__(256) void pw_pack_kernel(const PackArgs P) {
+  typedef Mma<T> MM;
+  const PackOne& d = P.d[blockIdx.y];
+  const int kq = d.KL >> 2, total = d.NT * 16 * kq;
+  for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < total; i += (int)(gridDim.x * blockDim.x)) {
+    const int n = i / kq, k0 = (i - n * kq) * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + e;
+      v[e] = (n < d.N && k < d.K) ? d.w[(size_t)n * d.sn + (size_t)k * d.sk] : 0.f;
+    }
+    typename MM::lds_t* dst = reinterpret_cast<typename MM::lds_t*>(d.img) + (size_t)n * d.KL + k0;
+    if (sizeof(typename MM::lds_t) == 2)
+      *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    else
+      *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t c3d_pw_weight_image_bytes(int32_t Np, int32_t Kp, int32_t dtype) {
+  int NT, KL, esz;
+  if (!pw_img_geom(Np, Kp, dtype, NT, KL, esz)) return 0;
+  return (int64_t)NT * 16 * KL * esz;
+}
+
+extern "C" int c3d_pw_pack_weights(const c3d_pw_pack_desc* descs, int32_t n, int32_t dtype, void* stream) {
+  if (n < 0 || (n > 0 && !descs)) return C3D_E_BADARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int base = 0; base < n; base += C3D_PW_PACK_MAX) {
+    const int m = n - base < C3D_PW_PACK_MAX ? n - base : C3D_PW_PACK_MAX;
+    PackArgs P;
+    std::memset(&P, 0, sizeof(P));
+    int most = 0;
+    for (int i = 0; i < m; ++i) {
+      const c3d_pw_pack_desc& d = descs[base + i];
+      int NT, KL, esz;
+      if (!d.w || !d.img || ((uintptr_t)d.img & 15) || d.N <= 0 || d.K <= 0 || d.N > d.Np || d.K > d.Kp) return C3D_E_BADARG;
+      if (!pw_img_geom(d.Np, d.Kp, dtype, NT, KL, esz)) return C3D_E_UNSUPPORTED;
+      P.d[i] = PackOne{d.w, d.img, d.N, d.K, d.w_sn, d.w_sk, NT, KL};
+      const int groups = NT * 16 * (KL >> 2);
+      if (groups > most) most = groups;
+    }
+    const dim3 grid((unsigned)((most + 255) / 256), (unsigned)m);
+    if (dtype == C3D_DT_BF16) pw_pack_kernel<bf16_t><<<grid, 256, 0, s>>>(P);
+    else pw_pack_kernel<float><<<grid, 256, 0, s>>>(P);
+    C3D_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
 extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   if (!args || !args->x || !args->y || !args->w) return C3D_E_BADARG;
   const c3d_pw_args& a = *args;
@@ -41,6 +118,7 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   if (a.pro_mode == C3D_PRO_BN_SE_SWISH && a.pro_gate && a.rows_per_sample <= 0) return C3D_E_BADARG;
   if (a.pro_mode == C3D_PRO_BN_SE_SWISH && a.pro_gate && !wide && (a.rows_per_sample & 15)) return C3D_E_BADARG;
   if (a.M >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
+  if (a.w_img && ((uintptr_t)a.w_img & 15)) return C3D_E_BADARG;
   if (wide) return c3d_detail_pw_gemm_wide(args, stream);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = C3D_E_BADARG;

@@ -227,6 +227,9 @@ __device__ __forceinline__ void lds_ld8(const float* p, float (&f)[8]) {
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
+typedef __attribute__((address_space(3))) void* pw_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* pw_glb_ptr_t;
+
 // Weight matrix (f32, any strides) -> LDS image Ws[n][k] in the MFMA operand type.  VW = floats per global load
 // along the contiguous dimension, KC = that dimension is K (then the VW elements are adjacent in LDS too: one
 // 8-byte / 16-byte write).  All of a thread's loads are issued before the first LDS write: one round trip.
@@ -436,9 +439,28 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   // ---- stage weights: zero fill, then vectorised fill along W's contiguous dimension -------
   {
     const int wtot = NT * 16 * KL;  // elements, multiple of 8
-    for (int i = tid * 8; i < wtot; i += WAVES * 64 * 8) {
-      float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      MM::store8(Ws + i, z);
+    const bool img = a.w_img != nullptr;
+    if (img) {
+      // Packed image (c3d_pw_pack_weights): the LDS layout itself, copied by LDS-DMA in 1 KB chunks per wave -- no
+      // zero fill, no f32 -> operand-type conversion, no scattered 2-byte LDS writes for the transposed (data-gradient)
+      // orientation, half the bytes.  Every workgroup of the launch reads the same image at the same moment: the
+      // chunk order is rotated by the workgroup index so that the requests spread over the L2 channels.
+      const int wbytes = wtot * (int)sizeof(lds_t);
+      const int nchunk = (wbytes + 1023) >> 10;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(a.w_img);
+      const int rot = (int)blockIdx.x % nchunk;
+      for (int c = wave; c < nchunk; c += WAVES) {
+        int r = c + rot;
+        if (r >= nchunk) r -= nchunk;
+        const int off = r * 1024 + lane * 16;
+        if (off < wbytes)
+          __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)(src + off), (pw_lds_ptr_t)(smem + L.w_off + r * 1024), 16, 0, 0);
+      }
+    } else {
+      for (int i = tid * 8; i < wtot; i += WAVES * 64 * 8) {
+        float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        MM::store8(Ws + i, z);
+      }
     }
     if (PRO == C3D_PRO_AFFINE2 && a.fin.sums && a.fin.training) {
       // forward residual add fused into this GEMM's prologue (pro_out): A|B = scale|shift of the previous block's
@@ -460,20 +482,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       for (int i = tid; i < np; i += WAVES * 64) Pp[i] = a.pro_p[i];
     }
     CLK(10)
-    __syncthreads();
-    CLK(11)
-    const bool kc = (a.w_sk == 1);
-    const int CL = kc ? a.K : a.N, OLn = kc ? a.N : a.K;
-    const int ostride = kc ? a.w_sn : a.w_sk;
-    if ((CL & 3) == 0 && (ostride & 3) == 0 && ((uintptr_t)a.w & 15) == 0) {
-      if (kc) stage_weights<T, 4, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-      else stage_weights<T, 4, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-    } else if ((CL & 1) == 0 && (ostride & 1) == 0 && ((uintptr_t)a.w & 7) == 0) {
-      if (kc) stage_weights<T, 2, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-      else stage_weights<T, 2, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+    if (img) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA chunks (and the first tile's rows, issued earlier)
     } else {
-      if (kc) stage_weights<T, 1, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-      else stage_weights<T, 1, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+      __syncthreads();
+      CLK(11)
+      const bool kc = (a.w_sk == 1);
+      const int CL = kc ? a.K : a.N, OLn = kc ? a.N : a.K;
+      const int ostride = kc ? a.w_sn : a.w_sk;
+      if ((CL & 3) == 0 && (ostride & 3) == 0 && ((uintptr_t)a.w & 15) == 0) {
+        if (kc) stage_weights<T, 4, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+        else stage_weights<T, 4, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+      } else if ((CL & 1) == 0 && (ostride & 1) == 0 && ((uintptr_t)a.w & 7) == 0) {
+        if (kc) stage_weights<T, 2, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+        else stage_weights<T, 2, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+      } else {
+        if (kc) stage_weights<T, 1, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+        else stage_weights<T, 1, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+      }
     }
     CLK(12)
     __syncthreads();

@@ -49,7 +49,16 @@ struct BlkFwd {   // byte offsets into ws_fwd
   size_t ss_a, mr_a, ss_b, mr_b, gate, hid, ss_c, mr_c, ss_1, mr_1;   // f32 vectors
   size_t sums_a, nc_b, sums_c, sums_1;                          // f64 accumulators
   size_t tick;                                                  // u32 [4] last-workgroup tickets (a, c, shortcut)
+  // pointwise weights as LDS images (c3d_pw_pack_weights): forward orientation and transposed (data gradient);
+  // SIZE_MAX where the narrow GEMM kernel does not take the shape
+  size_t img_a, img_at, img_c, img_ct, img_s, img_st;
 };
+
+// C3D_PW_IMG=0: every GEMM workgroup converts the f32 weights itself (the path before the images existed)
+bool use_pw_img() {
+  static const bool on = !(getenv("C3D_PW_IMG") && atoi(getenv("C3D_PW_IMG")) == 0);
+  return on;
+}
 
 // Ring depth of the backward temporaries: block i shares its slot with block i+R, so the side stream (weight gradients)
 // may run up to R-1 blocks behind the data-gradient chain before the main stream has to wait for it.
@@ -139,6 +148,18 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
     F.tick = cf.take(16);
   }
   P.fwd_acc_bytes = cf.off - P.fwd_acc_off;
+  for (int i = 0; i < n; ++i) {
+    const BlkGeom& G = P.g[i];
+    BlkFwd& F = P.f[i];
+    auto img = [&](int Np, int Kp) -> size_t {
+      const int64_t b = c3d_pw_weight_image_bytes(Np, Kp, d->dtype);
+      return b > 0 ? cf.take((size_t)b) : SIZE_MAX;
+    };
+    F.img_a = img(G.Cip, G.Cinp); F.img_at = img(G.Cinp, G.Cip);
+    F.img_c = img(G.Cop, G.Cip); F.img_ct = img(G.Cip, G.Cop);
+    F.img_s = G.sc_conv ? img(G.Cop, G.Cinp) : SIZE_MAX;
+    F.img_st = G.sc_conv ? img(G.Cinp, G.Cop) : SIZE_MAX;
+  }
   P.fwd_total = cf.off;
   // ---- backward workspace: bwd_ring() ring slots of big temporaries (the side stream may lag the data-gradient chain
   //      by ring-1 blocks), per-block f32 coefficient vectors, one f64 accumulator region, the split-K scratch of
@@ -495,6 +516,29 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
   static int whatif_calls = 0;
   const WhatIf wi(&whatif_calls);
   HIPRC(hipMemsetAsync(at(ws, P.fwd_acc_off), 0, P.fwd_acc_bytes, st));
+  // Weight images of the whole stage in one launch per 64 images: the f32 master weights change once per optimizer
+  // step, the four (six with a shortcut convolution) GEMMs of a block read them in ~256 workgroups each.  The backward
+  // pass of this forward reads the transposed images from the same workspace.
+  const bool wimg = use_pw_img();
+  auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
+  if (wimg) {
+    std::vector<c3d_pw_pack_desc> pk;
+    auto add = [&](const float* w, size_t off, int N, int K, int sn, int sk) {
+      if (off != SIZE_MAX) pk.push_back(c3d_pw_pack_desc{w, at(ws, off), N, cpad(N), K, cpad(K), sn, sk});
+    };
+    for (int i = 0; i < d->n_blocks; ++i) {
+      const c3d_block_desc& k = d->blocks[i];
+      const BlkGeom& G = P.g[i];
+      const BlkFwd& F = P.f[i];
+      add(k.w_a, F.img_a, G.Ci, G.Cin, G.Cin, 1);
+      add(k.w_c, F.img_c, G.Co, G.Ci, G.Ci, 1);
+      if (G.sc_conv) add(k.w_sc, F.img_s, G.Co, G.Cin, G.Cin, 1);
+      add(k.w_a, F.img_at, G.Cin, G.Ci, 1, G.Cin);
+      add(k.w_c, F.img_ct, G.Ci, G.Co, 1, G.Ci);
+      if (G.sc_conv) add(k.w_sc, F.img_st, G.Cin, G.Co, 1, G.Cin);
+    }
+    RC(c3d_pw_pack_weights(pk.data(), (int32_t)pk.size(), dt, st));
+  }
   const int epi = tr ? C3D_EPI_STATS : C3D_EPI_STORE;
   const void* cur = x;
   // Residual add of block i fused into conv_a of block i+1 (c3d_pw_args.pro_out): pending operands of block i
@@ -520,12 +564,12 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
     if (pend.on) {   // y(i-1) = relu(bn_c(c) + shortcut) computed on load, written out, and fed to the GEMM
       PwCall p(pend.c, k.w_a, a, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
       p.a.x2 = pend.sc; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.fin = pend.fin; p.a.pro_p = pend.fin.ss; p.a.pro_out = pend.y;
-      p.a.epi_mode = epi; p.a.stats = sums_a;
+      p.a.epi_mode = epi; p.a.stats = sums_a; p.a.w_img = imgp(F.img_a);
       RC(c3d_pw_gemm(&p.a, st));
       pend.on = false;
     } else {
       PwCall p(cur, k.w_a, a, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
-      p.a.epi_mode = epi; p.a.stats = sums_a;
+      p.a.epi_mode = epi; p.a.stats = sums_a; p.a.w_img = imgp(F.img_a);
       if (fold) p.a.fin = fin_fwd(tick + 0, k.bn_a, tr, (double)G.M, d->momentum, d->eps, ss_a, mr_a);
       RC(c3d_pw_gemm(&p.a, st));
     }
@@ -549,7 +593,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
     {
       PwCall p(b, k.w_c, c, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
       p.a.pro_mode = C3D_PRO_BN_SE_SWISH; p.a.pro_p = ss_b; p.a.pro_gate = gate; p.a.rows_per_sample = rps;
-      p.a.epi_mode = epi; p.a.stats = sums_c;
+      p.a.epi_mode = epi; p.a.stats = sums_c; p.a.w_img = imgp(F.img_c);
       if (fold) p.a.fin = fin_fwd(tick + 1, k.bn_c, tr, (double)G.Mo, d->momentum, d->eps, ss_c, mr_c);
       RC(c3d_pw_gemm(&p.a, st));
     }
@@ -562,7 +606,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
     if (G.sc_conv) {
       PwCall p(cur, k.w_sc, sc, G.Mo, G.Cin, G.Co, G.Cin, 1, dt);
       p.a.row_mode = G.s == 2 ? C3D_ROWS_STRIDE2 : C3D_ROWS_DENSE; p.a.H = G.H; p.a.W = G.W;
-      p.a.epi_mode = G.sc_bn ? epi : C3D_EPI_STORE; p.a.stats = sums_1;
+      p.a.epi_mode = G.sc_bn ? epi : C3D_EPI_STORE; p.a.stats = sums_1; p.a.w_img = imgp(F.img_s);
       if (fold && G.sc_bn) p.a.fin = fin_fwd(tick + 2, k.bn_sc, tr, (double)G.Mo, d->momentum, d->eps, ss_1, mr_1);
       RC(c3d_pw_gemm(&p.a, st));
       if (G.sc_bn) {
@@ -607,6 +651,8 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   const WhatIf wi(&whatif_calls);
   HIPRC(hipMemsetAsync(at(wb, P.bwd_acc_off), 0, P.bwd_acc_bytes, st));
   float* wgws = atT<float>(wb, P.wgrad_ws);
+  const bool wimg = use_pw_img();   // transposed weight images written by this step's c3d_stage_fwd (training mode)
+  auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
   const void* cur_dy = dy;
   std::deque<uint64_t> lag;   // side-stream marks of the blocks whose ring slots are still in flight
   for (int i = d->n_blocks - 1; i >= 0; --i) {
@@ -665,7 +711,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       p.a.x2 = c; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_c;
       if (consb) p.a.fin = fin_coef_consume(dsums_c, k.bn_c, (double)G.Mo, mr_c, true);
       p.a.epi_mode = C3D_EPI_SWISH_SE_BWD; p.a.e1 = b; p.a.epi_p = ss_b; p.a.epi_gate = gate; p.a.epi_q = mr_b;
-      p.a.stats = nc3; p.a.rows_per_sample = rps;
+      p.a.stats = nc3; p.a.rows_per_sample = rps; p.a.w_img = imgp(F.img_ct);
       RC(c3d_pw_gemm(&p.a, st));
     }
     if (!wgc_early) RC(side_run(st, wgrad_c));
@@ -691,6 +737,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     if (G.sc_conv) {
       const int rm = G.s == 2 ? C3D_ROWS_STRIDE2 : C3D_ROWS_DENSE;
       PwCall p(g, k.w_sc, dxs, G.Mo, G.Co, G.Cin, 1, G.Cin, dt);
+      p.a.w_img = imgp(F.img_st);
       if (scbn) {
         if (!fold && !consb && !wi.skip(0))
           RC(c3d_bn_bwd_coef(dsums_1, 1, (double)G.Mo, k.bn_sc.gamma, mr_1, G.Co, G.Cop, coef_1, k.bn_sc.dgamma,
@@ -725,6 +772,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       p.a.x2 = a; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_a;
       if (consb) p.a.fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, true);
       p.a.epi_mode = C3D_EPI_ADD; p.a.e1 = res; p.a.res_mode = res_mode; p.a.H = G.H; p.a.W = G.W;
+      p.a.w_img = imgp(F.img_at);
       RC(c3d_pw_gemm(&p.a, st));
     }
     if (!wgc_early) RC(side_run(st, wgrad_a));

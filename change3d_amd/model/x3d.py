@@ -236,7 +236,7 @@ def _n_acc_bwd(blk, B):
     return 4 * blk.cout + B * cpad(blk.cinner) * 3 + S * 2 * blk.cinner + 2   # upper bound (shortcut BN or not)
 
 
-def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None):
+def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None, imgs=None):
     """x: [B,T,H,W,Cin] contiguous.  Returns (y, saved-for-backward dict)."""
     dev, dt = x.device, ops.dt_code(act_dtype)
     b2 = blk.branch2
@@ -260,7 +260,9 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None):
 
     a = torch.empty((M, Cip), dtype=act_dtype, device=dev)
     ss_a, mr_a = _f32(2 * Cip, dev), _f32(2 * Cip, dev)
+    wi = (lambda conv, tr: imgs.get((id(conv), tr))) if imgs else (lambda conv, tr: None)   # packed weight images
     ops.pw_gemm(x, b2.conv_a.weight, a, M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt, epi_mode=epi, stats=sums_a,
+                w_img=wi(b2.conv_a, False),
                 fin=ops.fin_fwd(tick, 0, b2.norm_a, training, M, ss_a, mr_a) if fold else None)
     if not fold:
         ops.bn_finalize(sums_a, M, b2.norm_a, Ci, ss_a, mr_a, training, stripes=S)
@@ -276,6 +278,7 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None):
     ss_c, mr_c = _f32(2 * Cop, dev), _f32(2 * Cop, dev)
     ops.pw_gemm(b, b2.conv_c.weight, c, M=Mo, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH,
                 pro_p=ss_b, pro_gate=gate, rows_per_sample=T * Ho * Wo, epi_mode=epi, stats=sums_c,
+                w_img=wi(b2.conv_c, False),
                 fin=ops.fin_fwd(tick, 1, b2.norm_c, training, Mo, ss_c, mr_c) if fold else None)
     if not fold:
         ops.bn_finalize(sums_c, Mo, b2.norm_c, Co, ss_c, mr_c, training, stripes=S)
@@ -287,7 +290,7 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None):
             ss_1, mr_1 = _f32(2 * Cop, dev), _f32(2 * Cop, dev)
         ops.pw_gemm(x, blk.branch1_conv.weight, sc, M=Mo, K=Cin, N=Co, w_sn=Cin, w_sk=1, dtype=dt,
                     row_mode=ops.ROWS_STRIDE2 if s == 2 else ops.ROWS_DENSE, H=H, W=W,
-                    epi_mode=epi if has_bn1 else ops.EPI_STORE, stats=sums_1,
+                    epi_mode=epi if has_bn1 else ops.EPI_STORE, stats=sums_1, w_img=wi(blk.branch1_conv, False),
                     fin=ops.fin_fwd(tick, 2, blk.branch1_norm, training, Mo, ss_1, mr_1) if (fold and has_bn1) else None)
         if has_bn1:
             if not fold:
@@ -305,7 +308,7 @@ def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None):
     return y, saved
 
 
-def _block_backward(blk, dy, sv, act_dtype, pool=None):
+def _block_backward(blk, dy, sv, act_dtype, pool=None, imgs=None):
     """dy: [B,T,Ho,Wo,Co] contiguous.  Returns dx [B,T,H,W,Cin]; parameter grads accumulate in .grad."""
     dev, dt = dy.device, ops.dt_code(act_dtype)
     b2 = blk.branch2
@@ -343,7 +346,9 @@ def _block_backward(blk, dy, sv, act_dtype, pool=None):
         ops.bn_bwd_coef(dsums_c, Mo, b2.norm_c, sv["mr_c"], Co, coef_c)
     # ---- conv_c (data + weight), Swish / SE backward in the epilogue
     t1 = torch.empty((Mo, Cip), dtype=act_dtype, device=dev)
+    wi = (lambda conv: imgs.get((id(conv), True))) if imgs else (lambda conv: None)   # transposed weight images
     ops.pw_gemm(g, b2.conv_c.weight, t1, M=Mo, K=Co, N=Ci, w_sn=1, w_sk=Ci, dtype=dt, x2=c, pro_mode=ops.PRO_AFFINE2,
+                w_img=wi(b2.conv_c),
                 pro_p=coef_c, epi_mode=ops.EPI_SWISH_SE_BWD, e1=b, epi_p=sv["ss_b"], epi_gate=sv["gate"], epi_q=sv["mr_b"], stats=nc3,
                 rows_per_sample=T * Ho * Wo)
     gw_c = ops.grad_of(b2.conv_c.weight)
@@ -378,12 +383,14 @@ def _block_backward(blk, dy, sv, act_dtype, pool=None):
             if not fold:
                 ops.bn_bwd_coef(dsums_1, Mo, blk.branch1_norm, sv["mr_1"], Co, coef_1)
             ops.pw_gemm(g, blk.branch1_conv.weight, dxs, M=Mo, K=Co, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=sc,
+                        w_img=wi(blk.branch1_conv),
                         pro_mode=ops.PRO_AFFINE2, pro_p=coef_1)
             gw_1 = ops.grad_of(blk.branch1_conv.weight)
             ops.side_run(lambda: ops.pw_wgrad(g, x, gw_1, M=Mo, K=Cin, N=Co, dw_sn=Cin, dw_sk=1,
                                           dtype=dt, p2=sc, p_coef=coef_1, row_mode=rm, H=H, W=W), g, x, sc, coef_1)
         else:
-            ops.pw_gemm(g, blk.branch1_conv.weight, dxs, M=Mo, K=Co, N=Cin, w_sn=1, w_sk=Cin, dtype=dt)
+            ops.pw_gemm(g, blk.branch1_conv.weight, dxs, M=Mo, K=Co, N=Cin, w_sn=1, w_sk=Cin, dtype=dt,
+                        w_img=wi(blk.branch1_conv))
             gw_1 = ops.grad_of(blk.branch1_conv.weight)
             ops.side_run(lambda: ops.pw_wgrad(g, x, gw_1, M=Mo, K=Cin, N=Co, dw_sn=Cin, dw_sk=1,
                                           dtype=dt, row_mode=rm, H=H, W=W), g, x)
@@ -391,12 +398,36 @@ def _block_backward(blk, dy, sv, act_dtype, pool=None):
     else:
         res, res_mode = g, 0
     # ---- conv_a (data + weight); the shortcut gradient is added in the epilogue
-    ops.pw_gemm(t2, b2.conv_a.weight, dx, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=a,
+    ops.pw_gemm(t2, b2.conv_a.weight, dx, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=a, w_img=wi(b2.conv_a),
                 pro_mode=ops.PRO_AFFINE2, pro_p=coef_a, epi_mode=ops.EPI_ADD, e1=res, res_mode=res_mode, H=H, W=W)
     gw_a = ops.grad_of(b2.conv_a.weight)
     ops.side_run(lambda: ops.pw_wgrad(t2, x, gw_a, M=M, K=Cin, N=Ci, dw_sn=Cin, dw_sk=1, dtype=dt, p2=a,
                                   p_coef=coef_a), t2, x, a, coef_a)
     return dx
+
+
+def _pack_stage_images(stage):
+    """LDS images of the stage's pointwise weights, both orientations, in one buffer and one launch per 64
+    (`c3d_pw_pack_weights`; the C++ stage driver does the same inside `c3d_stage_fwd`).  Keys: (id(conv), transposed)."""
+    dt = ops.dt_code(stage.act_dtype)
+    plan, total = [], 0
+    for blk in stage.res_blocks:
+        for conv, n_out, n_in in ((blk.branch2.conv_a, blk.cinner, blk.cin), (blk.branch2.conv_c, blk.cout, blk.cinner),
+                                  (blk.branch1_conv, blk.cout, blk.cin)):
+            if conv is None:
+                continue
+            for tr in (False, True):
+                N, K, sn, sk = (n_in, n_out, 1, n_in) if tr else (n_out, n_in, n_in, 1)
+                nb = ops.pw_weight_image_bytes(N, K, dt)
+                if nb:
+                    plan.append((conv, tr, N, K, sn, sk, total, nb))
+                    total += (nb + 255) // 256 * 256
+    if not plan:
+        return None
+    buf = torch.empty(total, dtype=torch.uint8, device=plan[0][0].weight.device)
+    imgs = {(id(conv), tr): buf[off:off + nb] for conv, tr, N, K, sn, sk, off, nb in plan}
+    ops.pw_pack_weights([(conv.weight, imgs[(id(conv), tr)], N, K, sn, sk) for conv, tr, N, K, sn, sk, off, nb in plan], dt)
+    return imgs
 
 
 class _StageFnPy(torch.autograd.Function):
@@ -411,12 +442,13 @@ class _StageFnPy(torch.autograd.Function):
         keep = any(ctx.needs_input_grad)  # (also True under no_grad: this per-kernel path is for profiling only)
         saved = []
         pool = _AccPool(sum(_n_acc_fwd(blk, B) for blk in stage.res_blocks), cur.device)
+        imgs = _pack_stage_images(stage) if ops.PW_IMG else None
         for blk in stage.res_blocks:
-            cur, sv = _block_forward(blk, cur, B, T, H, W, stage.training, stage.act_dtype, pool)
+            cur, sv = _block_forward(blk, cur, B, T, H, W, stage.training, stage.act_dtype, pool, imgs)
             H, W = sv["dims"][4], sv["dims"][5]
             if keep:
                 saved.append(sv)
-        ctx.stage, ctx.saved, ctx.x_dtype = stage, saved, x.dtype
+        ctx.stage, ctx.saved, ctx.x_dtype, ctx.imgs = stage, saved, x.dtype, imgs
         return to_logical(cur)
 
     @staticmethod
@@ -426,7 +458,7 @@ class _StageFnPy(torch.autograd.Function):
         pool = _AccPool(sum(_n_acc_bwd(blk, dy.shape[0]) for blk in stage.res_blocks), cur.device)
         prev_mark = None   # side-stream weight gradients may lag the data-gradient chain by one block
         for blk, sv in zip(reversed(list(stage.res_blocks)), reversed(saved)):
-            cur = _block_backward(blk, cur, sv, stage.act_dtype, pool)
+            cur = _block_backward(blk, cur, sv, stage.act_dtype, pool, ctx.imgs)
             ops.side_run(lambda: None, dict(sv))   # keep the saved activations alive until the side work is done
             sv.clear()
             if prev_mark is not None:

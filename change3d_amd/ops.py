@@ -202,6 +202,7 @@ def grad_of(p):
 
 # ----------------------------------------------------------------------------- pointwise GEMM
 FOLD_FIN = os.environ.get("C3D_FOLD_FIN", "0") == "1"   # BatchNorm finalisation by the producers' last workgroup (measured slower: off)
+PW_IMG = os.environ.get("C3D_PW_IMG", "1") != "0"       # pointwise weights as packed LDS images (c3d_pw_pack_weights), once per stage pass
 
 
 def fin_fwd(tick, idx, bn, training, count, ss, mr):
@@ -240,8 +241,9 @@ def fin_bwd(tick, idx, bn, count, coef, mr):
 def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, pro_p=None,
             pro_gate=None, epi_mode=EPI_STORE, e1=None, epi_p=None, epi_gate=None, epi_q=None, stats=None,
             rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, res_mode=0,
-            x_ptr=None, e1_ptr=None, fin=None, bias=None, pro_out=None):
+            x_ptr=None, e1_ptr=None, fin=None, bias=None, pro_out=None, w_img=None):
     a = L.PwArgs()
+    a.w_img = _p(w_img)
     if fin is not None:
         a.fin = fin
     a.bias = _p(bias)
@@ -259,6 +261,19 @@ def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, 
     a.row_mode, a.rpg, a.H, a.W = row_mode, rpg, H, W
     a.pro_mode, a.epi_mode, a.res_mode, a.dtype = pro_mode, epi_mode, res_mode, dtype
     _launch(_detail("c3d_pw_gemm", a), a.M * (a.Kp * (2 if x2 is not None else 1) + a.Np * (2 if (e1 is not None or e1_ptr is not None) else 1)) * _es(dtype), L.lib().c3d_pw_gemm, C.byref(a), _stream())
+
+
+def pw_weight_image_bytes(N, K, dtype):
+    """Bytes of the LDS image of an (N, K) pointwise weight for `c3d_pw_args.w_img` (0: shape not taken)."""
+    return int(L.lib().c3d_pw_weight_image_bytes(cpad(N), cpad(K), dtype))
+
+
+def pw_pack_weights(items, dtype):
+    """items: (w, img, N, K, w_sn, w_sk) tuples; one launch per 64 images (`c3d_pw_pack_weights`)."""
+    descs = (L.PwPackDesc * len(items))()
+    for d, (w, img, N, K, sn, sk) in zip(descs, items):
+        d.w, d.img, d.N, d.Np, d.K, d.Kp, d.w_sn, d.w_sk = _p(w), _p(img), N, cpad(N), K, cpad(K), sn, sk
+    _launch("c3d_pw_pack_weights", 0, L.lib().c3d_pw_pack_weights, descs, len(items), dtype, _stream())
 
 
 _wgrad_ws = {}

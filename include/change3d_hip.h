@@ -112,12 +112,30 @@ typedef struct c3d_pw_args {
   void* pro_out;         /* C3D_PRO_AFFINE2, dense rows, narrow kernel: relu(A*x + B + C*x2) is what enters the GEMM  */
                          /* AND is written here [M][Kp] (the residual add of the previous block fused into conv_a:    */
                          /* x = c, x2 = shortcut, fin.training = 1 + fin.sums = BatchNorm_c's 16-stripe sums, C = 1)  */
+  const void* w_img;     /* optional: image of `w` made by c3d_pw_pack_weights for the same (N, Np, K, Kp, w_sn, w_sk,  */
+                         /* dtype).  The narrow kernel then copies it into LDS (one 16-byte DMA per lane) instead of     */
+                         /* converting and scattering the f32 weights in every workgroup; same results bit for bit.     */
+                         /* `w` must still be given (the block-tiled kernel reads it).                                  */
 } c3d_pw_args;
 
 /* K, N <= 224 run the wave-private-tile kernel (pw_gemm_impl.h); wider layers (X3D res5: 432 inner channels; the
  * caption decoder's 192 -> 576 / vocabulary projections) or a non-NULL bias run the block-tiled kernel of
  * pw_wide.hip with the same prologues / epilogues (row modes DENSE and STRIDE2; no in-kernel finalisation). */
 int c3d_pw_gemm(const c3d_pw_args* args, void* stream);
+
+/* Weight images for c3d_pw_args.w_img: the narrow kernel's LDS operand layout ([NT*16][Kpad+pad] in the MFMA operand
+ * type, zero padded) written once per weight VERSION instead of rebuilt by each of the ~256 workgroups of each launch
+ * (the f32 master weights change once per optimizer step; a block's four GEMMs per step read two weights, each in two
+ * orientations).  c3d_pw_weight_image_bytes returns 0 for shapes the narrow kernel does not take (Kp or Np > 224).
+ * One launch packs up to C3D_PW_PACK_MAX images (descriptors travel as kernel arguments). */
+typedef struct c3d_pw_pack_desc {
+  const float* w;        /* element (n,k) at w[n*w_sn + k*w_sk] */
+  void* img;             /* c3d_pw_weight_image_bytes(Np, Kp, dtype) bytes, 16-byte aligned */
+  int32_t N, Np, K, Kp, w_sn, w_sk;
+} c3d_pw_pack_desc;
+#define C3D_PW_PACK_MAX 64
+int64_t c3d_pw_weight_image_bytes(int32_t Np, int32_t Kp, int32_t dtype);
+int c3d_pw_pack_weights(const c3d_pw_pack_desc* descs, int32_t n, int32_t dtype, void* stream);
 
 /* Weight gradient of the same family:
  *     dW[n, k] += sum_m P(m, n) * Q(m, k),  P = prologue_p(p, p2),  Q = prologue_q(q)

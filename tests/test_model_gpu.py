@@ -623,10 +623,12 @@ def test_e2e_bf16_tracks_f32():
             assert torch.isfinite(p.grad).all(), n
 
 
-def test_folded_batchnorm_launches_are_bit_identical_end_to_end(tmp_path):
-    """Default library (BatchNorm finalisation / backward coefficients rebuilt by their consumers, csrc/bn_fin.h) vs
-    C3D_FIN_CONSUMER=0 (246 separate launches per step): the bf16 train step produces the same loss, gradients,
-    running statistics and num_batches_tracked to the last bit."""
+@pytest.mark.parametrize("knob", ["C3D_FIN_CONSUMER", "C3D_PW_IMG"])
+def test_folded_batchnorm_launches_are_bit_identical_end_to_end(tmp_path, knob):
+    """Default library (BatchNorm finalisation / backward coefficients rebuilt by their consumers, csrc/bn_fin.h;
+    pointwise weights read as packed LDS images, c3d_pw_pack_weights) vs C3D_FIN_CONSUMER=0 (246 separate launches
+    per step) and vs C3D_PW_IMG=0 (every GEMM workgroup converts the f32 weights itself): the bf16 train step produces
+    the same loss, gradients, running statistics and num_batches_tracked to the last bit."""
     _need_gpu()
     import subprocess
     import sys
@@ -634,7 +636,7 @@ def test_folded_batchnorm_launches_are_bit_identical_end_to_end(tmp_path):
     outs = []
     for mode in ("1", "0"):
         f = str(tmp_path / f"step_{mode}.pt")
-        env = dict(os.environ, C3D_FIN_CONSUMER=mode)
+        env = dict(os.environ, **{knob: mode})
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "dump_step.py"), f, "64", "3"], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -728,3 +728,61 @@ def test_residual_add_fused_into_conv_a_is_bit_identical(Cin, Cinner, M):
     for i, (x0, x1) in enumerate(zip(*outs)):
         assert torch.equal(x0, x1), i
     assert torch.isfinite(outs[1][1].float()).all() and outs[1][0].float().abs().max() > 0 and int(outs[1][7]) == 1
+
+
+# --------------------------------------------------------------------------- packed weight images
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("K,N,transposed", [(24, 54, False), (54, 24, True), (96, 216, False), (216, 96, True),
+                                            (48, 108, True), (108, 48, False), (192, 192, False), (24, 24, True),
+                                            (12, 20, False)])
+def test_pw_gemm_with_packed_weight_image_is_bit_identical(dtype, K, N, transposed):
+    """`c3d_pw_args.w_img` (LDS image written once by c3d_pw_pack_weights, copied by LDS-DMA) against the path
+    where every workgroup converts the f32 weights itself: same bytes out, both weight orientations (forward:
+    w[n*K + k]; data gradient: w[k*N + n]), ragged row counts, channel counts that need padding."""
+    _need_gpu()
+    from change3d_amd import ops
+    M = 16 * 53 + 7
+    Kp, Np = ops.cpad(K), ops.cpad(N)
+    dt = ops.dt_code(dtype)
+    x = padc(q(rnd((M, K), 31), dtype), Kp).to(DEV, dtype).contiguous()
+    if transposed:
+        w = rnd((K, N), 32, 0.2).to(DEV)      # conv weight [out = K][in = N] read as W^T
+        sn, sk = 1, N
+    else:
+        w = rnd((N, K), 32, 0.2).to(DEV)
+        sn, sk = K, 1
+    nbytes = ops.pw_weight_image_bytes(N, K, dt)
+    assert nbytes > 0 and nbytes % 16 == 0
+    img = torch.full((nbytes + 64,), 0x7F, dtype=torch.uint8, device=DEV)   # +64: the pack kernel must stay inside
+    ops.pw_pack_weights([(w, img, N, K, sn, sk)], dt)
+    torch.cuda.synchronize()
+    assert (img[nbytes:] == 0x7F).all(), "pack kernel wrote past the image"
+    outs = []
+    for wi in (None, img):
+        y = torch.full((M, Np), float("nan"), dtype=dtype, device=DEV)
+        stats = torch.zeros(ops.STAT_STRIPES * 2 * N, dtype=torch.float64, device=DEV)
+        ops.pw_gemm(x, w, y, M=M, K=K, N=N, w_sn=sn, w_sk=sk, dtype=dt, epi_mode=ops.EPI_STATS, stats=stats, w_img=wi)
+        torch.cuda.synchronize()
+        outs.append((y.clone(), stats.view(ops.STAT_STRIPES, -1).sum(0).clone()))
+    assert torch.equal(outs[0][0].view(torch.uint8), outs[1][0].view(torch.uint8)), "output differs with the weight image"
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-12, atol=1e-9)
+    ref = x[:, :K].float().cpu() @ (w.cpu() if transposed else w.cpu().t())
+    close(outs[1][0][:, :N], ref, dtype, "y", scale=ref.abs().max().item())
+
+
+def test_pw_pack_weights_many_images_in_one_call():
+    """More images than one launch carries (C3D_PW_PACK_MAX = 64): each image equals its single-image packing."""
+    _need_gpu()
+    from change3d_amd import ops
+    dt = ops.dt_code(torch.bfloat16)
+    shapes = [(24 + 8 * (i % 5), 216 - 8 * (i % 7)) for i in range(70)]
+    ws = [rnd((n, k), 100 + i, 0.3).to(DEV) for i, (n, k) in enumerate(shapes)]
+    sizes = [ops.pw_weight_image_bytes(n, k, dt) for n, k in shapes]
+    together = [torch.zeros(s, dtype=torch.uint8, device=DEV) for s in sizes]
+    ops.pw_pack_weights([(w, im, n, k, k, 1) for w, im, (n, k) in zip(ws, together, shapes)], dt)
+    for i in (0, 1, 33, 63, 64, 69):
+        alone = torch.zeros(sizes[i], dtype=torch.uint8, device=DEV)
+        ops.pw_pack_weights([(ws[i], alone, shapes[i][0], shapes[i][1], shapes[i][1], 1)], dt)
+        torch.cuda.synchronize()
+        assert torch.equal(alone, together[i]), f"image {i}"
+    assert ops.pw_weight_image_bytes(432, 192, dt) == 0      # wide shapes have no image (block-tiled kernel)

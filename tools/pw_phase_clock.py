@@ -68,18 +68,25 @@ def main():
         coef3, coefo = torch.rand(3 * Cip, device=DEV), torch.rand(3 * Co, device=DEV)
         nc3 = torch.zeros(B * Cip * 3, dtype=torch.float64, device=DEV)
         rps = T * H * H
+        ia = iat = ic = ict = None
+        if ops.PW_IMG:   # packed weight images (the product path); C3D_PW_IMG=0: every workgroup converts the f32 weights
+            mk = lambda N, K: torch.empty(ops.pw_weight_image_bytes(N, K, dt), dtype=torch.uint8, device=DEV)  # noqa: E731
+            ia, iat, ic, ict = mk(Ci, Cin), mk(Cin, Ci), mk(Co, Ci), mk(Ci, Co)
+            ops.pw_pack_weights([(wa, ia, Ci, Cin, Cin, 1), (wa, iat, Cin, Ci, 1, Cin), (wc, ic, Co, Ci, Ci, 1),
+                                 (wc, ict, Ci, Co, 1, Ci)], dt)
         cases = {
             "conv_a fwd   NONE+STATS": lambda: ops.pw_gemm(x, wa, a_, M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt,
-                                                           epi_mode=ops.EPI_STATS, stats=stats),
+                                                           epi_mode=ops.EPI_STATS, stats=stats, w_img=ia),
             "conv_c fwd   SWISH+STATS": lambda: ops.pw_gemm(b_, wc, c_, M=M, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt,
                                                             pro_mode=ops.PRO_BN_SE_SWISH, pro_p=ss, pro_gate=gate,
-                                                            rows_per_sample=rps, epi_mode=ops.EPI_STATS, stats=stats),
+                                                            rows_per_sample=rps, epi_mode=ops.EPI_STATS, stats=stats, w_img=ic),
             "conv_c bwd-d AFFINE2+SWISH_SE_BWD": lambda: ops.pw_gemm(
                 c_, wc, a_, M=M, K=Co, N=Ci, w_sn=1, w_sk=Ci, dtype=dt, x2=c_, pro_mode=ops.PRO_AFFINE2, pro_p=coefo,
-                epi_mode=ops.EPI_SWISH_SE_BWD, e1=b_, epi_p=ss, epi_gate=gate, epi_q=ss, stats=nc3, rows_per_sample=rps),
+                epi_mode=ops.EPI_SWISH_SE_BWD, e1=b_, epi_p=ss, epi_gate=gate, epi_q=ss, stats=nc3, rows_per_sample=rps,
+                w_img=ict),
             "conv_a bwd-d AFFINE2+ADD": lambda: ops.pw_gemm(a_, wa, x, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=b_,
                                                             pro_mode=ops.PRO_AFFINE2, pro_p=coef3, epi_mode=ops.EPI_ADD,
-                                                            e1=c_, res_mode=0),
+                                                            e1=c_, res_mode=0, w_img=iat),
         }
         for name, fn in cases.items():
             if only and not any(o in f"s{st} {name}" for o in only):
