@@ -58,7 +58,7 @@ def main():
           out = [{"entry": e, "calls": c, "total_ms": round(t / 1e6, 3), "avg_us": round(t / c / 1e3, 2)}
                  for e, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])]
           json.dump({"source": "rocprofv3 --kernel-trace --stats -- " + cmd,
-                     "note": "all launches of the run (5 warm-up + 20 timed eager steps, 1 eager profile step)",
+                     "note": "all launches of the run (python bench.py: 40 settling + 5 warm-up + 20 timed steps through the stage driver, 2 per-kernel profile steps = 67 steps)",
                      "by_entry": out,
                      "top_kernels": [{"name": r["Name"][:160], "calls": int(r["Calls"]),
                                       "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
