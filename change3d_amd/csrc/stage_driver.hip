@@ -66,7 +66,9 @@ constexpr int BWD_RING_MAX = 4;
 int bwd_ring() {
   static const int r = [] {
     const char* s = getenv("C3D_BWD_RING");
-    const int v = s ? atoi(s) : 2;   // measured on MI355X (B=32 bf16): 2, 3, 4 slots -> 34.04 / 34.10 / 34.32 ms per step
+    // measured on MI355X (B=32 bf16): 2, 3, 4 slots -> 34.04 / 34.10 / 34.32 ms per step before the weight gradients were
+    // forked ahead of their data gradients; 32.62 / 32.45 ms for 2 / 3 slots after (three interleaved repeats each)
+    const int v = s ? atoi(s) : 3;
     return v < 2 ? 2 : (v > BWD_RING_MAX ? BWD_RING_MAX : v);
   }();
   return r;
