@@ -2,6 +2,7 @@
 #include "common.h"
 #include "../../include/change3d_hip.h"
 #include "pw_common.h"
+#include "launch_hints.h"
 #include "bn_fin.h"
 #include <cstdlib>
 
@@ -451,6 +452,14 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   static const int cap_env = getenv("C3D_WG_BLOCKS") ? atoi(getenv("C3D_WG_BLOCKS")) : 0;  // tuning knob
   int64_t cap = device_cus() < WGRAD_MAX_PARTS ? device_cus() : WGRAD_MAX_PARTS;
   if (cap_env > 0 && cap_env <= WGRAD_MAX_PARTS) cap = cap_env;
+  else if (c3d_side_launch) {
+    // beside the data-gradient chain (stage driver's side stream): three quarters of the CUs.  This single-round
+    // kernel at full width holds every CU for its whole duration (launch_hints.h); measured on MI355X, B=32 bf16,
+    // 60-step runs: 256 / 208 / 192 / 176 / 160 / 128 workgroups -> 32.52 / 32.08 / 31.84 / 32.11 / 32.48 / 32.87 ms
+    static const int side_env = getenv("C3D_PWWG_SIDE_WGS") ? atoi(getenv("C3D_PWWG_SIDE_WGS")) : 0;
+    const int64_t side_cap = side_env > 0 ? side_env : (int64_t)device_cus() * 3 / 4;
+    if (side_cap < cap) cap = side_cap;
+  }
   const int taps = a.taps > 1 ? a.taps : 1;
   if (taps > 1 && cap > WGRAD_MAX_PARTS / taps) cap = WGRAD_MAX_PARTS / taps;   // the workspace holds MAX_PARTS slabs
   if (blocks > cap) blocks = cap;

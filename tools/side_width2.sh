@@ -1,5 +1,4 @@
 #!/bin/bash
-# sweep of the side-stream kernel widths / ring depth (interleaved with the default configuration)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
@@ -9,14 +8,15 @@ run() { local label=$1; shift; env "$@" python bench.py --no-cpu-baseline --no-k
 import json; d=json.load(open('gpurun_out/sw_$label.json')); print('$label', d['value'], d['ms_per_step'], d['config']['host_enqueue_ms_per_step'])"; }
 run warm A=1
 run base A=1
-run pw224 C3D_WG_BLOCKS=224
+run pw208 C3D_WG_BLOCKS=208
 run pw192 C3D_WG_BLOCKS=192
-run dw96 C3D_DWWG_SIDE_WGS=96
-run dw112 C3D_DWWG_SIDE_WGS=112
+run pw176 C3D_WG_BLOCKS=176
+run pw160 C3D_WG_BLOCKS=160
 run base2 A=1
-run dw144 C3D_DWWG_SIDE_WGS=144
-run dw160 C3D_DWWG_SIDE_WGS=160
-run ring2 C3D_BWD_RING=2
-run ring4 C3D_BWD_RING=4
-run prio C3D_SIDE_PRIO=1
+run pw144 C3D_WG_BLOCKS=144
+run pw128 C3D_WG_BLOCKS=128
+run pw192_dw112 C3D_WG_BLOCKS=192 C3D_DWWG_SIDE_WGS=112
+run pw192_dw144 C3D_WG_BLOCKS=192 C3D_DWWG_SIDE_WGS=144
+run pw176_dw144 C3D_WG_BLOCKS=176 C3D_DWWG_SIDE_WGS=144
+run pw192_ring2 C3D_WG_BLOCKS=192 C3D_BWD_RING=2
 run base3 A=1
