@@ -722,15 +722,19 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
                           k.se_w2, gate, hid, G.Cr, cA, cC, cB, k.bn_b.dgamma, k.bn_b.dbeta, k.dse_w1, k.dse_b1,
                           k.dse_w2, k.dse_b2, st));
     // ---- depthwise conv_b
+    // (the depthwise weight gradient needs the coefficients, not the data gradient: forked first; C3D_DWWG_EARLY=0 forks it after)
+    auto wgrad_b = [&](hipStream_t s2) {
+      return c3d_dw333_wgrad(t1, b, cA, cB, cC, a, ss_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, s2);
+    };
+    static const bool dwwg_early = !(getenv("C3D_DWWG_EARLY") && atoi(getenv("C3D_DWWG_EARLY")) == 0);
+    if (dwwg_early) RC(side_run(st, wgrad_b));
     if (fold) {
       const c3d_bn_fin fa = fin_bwd(tick + 1, k.bn_a, (double)G.M, coef_a, mr_a);
       RC(c3d_dw333_bwd_data_fin(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, &fa, st));
     } else {
       RC(c3d_dw333_bwd_data(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
     }
-    RC(side_run(st, [&](hipStream_t s2) {
-      return c3d_dw333_wgrad(t1, b, cA, cB, cC, a, ss_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, s2);
-    }));
+    if (!dwwg_early) RC(side_run(st, wgrad_b));
     if (!fold && !consb && !wi.skip(0))
       RC(c3d_bn_bwd_coef(dsums_a, 1, (double)G.M, k.bn_a.gamma, mr_a, G.Ci, G.Cip, coef_a, k.bn_a.dgamma, k.bn_a.dbeta, st));
     // ---- shortcut branch
