@@ -1661,7 +1661,11 @@ int launch_bwd_data_t(const void* t1, const void* bb, const float* cA, const flo
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
   // walk length: long enough to amortise the prologue and pipeline the loads, short enough for ~2 workgroups per CU
   static const int env_tpw = getenv("C3D_DWBD_TPW") ? atoi(getenv("C3D_DWBD_TPW")) : 0;
-  int tpw = 16;   // measured best: 16 / 16 / 8 tiles for the 128x128 / 64x64 / 32x32 stages (~2 workgroups per CU)
+  // measured best with the GPU to itself: 16 / 16 / 8 tiles for the 128x128 / 64x64 / 32x32 stages (~2 workgroups per
+  // CU); in the train step this kernel shares the CUs with the side stream's weight gradients and shorter walks win
+  // (finer units for the dispatcher): 8 everywhere -> 31.66 -> 31.46 ms, 32.08 -> 31.92 ms per step on two boxes
+  // (4: no better, 32: +1.3 ms; non-powers of two +0.4-0.9 ms)
+  int tpw = 8;
   while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 7L * device_cus() / 4) tpw >>= 1;
   if (env_tpw > 0) tpw = env_tpw;
   if (tpw > ntiles) tpw = ntiles;

@@ -1,17 +1,19 @@
+#!/bin/bash
+# environment-knob sweep around the defaults (each label: one 60-step bench), defaults interleaved
+set -u
 cd "${GRAFT_REPO_ROOT:-.}"
-run() { v=$(env "$@" python bench.py --no-cpu-baseline --no-kernel-profile 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])"); echo "$* -> $v"; }
-run X=1
-run C3D_WG_BLOCKS=192
-run C3D_WG_BLOCKS=384
-run C3D_WG_BLOCKS=512
-run C3D_PW_FORCE8=2
-run C3D_DWBD_TPW=4
-run C3D_DWBD_TPW=8
-run C3D_DWBD_TPW=16
-run C3D_DW_TPW=4
-run C3D_DW_TPW=8
-run C3D_DW_TPW=16
-run C3D_BOB_GRID=256
-run C3D_BOB_GRID=512
-run C3D_WG_MT=64
-run X=2
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+run() { local label=$1; shift; env "$@" timeout 300 python bench.py --no-cpu-baseline --no-kernel-profile --steps 60 --warmup 10 2> gpurun_out/ks_$label.err | tail -1 > gpurun_out/ks_$label.json
+  python -c "
+import json; d=json.load(open('gpurun_out/ks_$label.json')); print('$label', d['value'], d['ms_per_step'])" || tail -3 gpurun_out/ks_$label.err; }
+run warm A=1
+run base A=1
+run dwbd_tpw8 C3D_DWBD_TPW=8
+run dwbd_tpw12 C3D_DWBD_TPW=12
+run dwbd_tpw6 C3D_DWBD_TPW=6
+run base2 A=1
+run dwbd_tpw8b C3D_DWBD_TPW=8
+run dwbd_tpw10 C3D_DWBD_TPW=10
+run dwbd8_dwf12 C3D_DWBD_TPW=8 C3D_DW_TPW=12
+run base3 A=1
