@@ -414,7 +414,11 @@ int c3d_stage_ws_bytes(const c3d_stage_desc* d, int64_t* ws_fwd_bytes, int64_t* 
                        int64_t* dx_bytes);
 /* x: [B][T][H][W][cpad(cin)] channels-last, storage dtype.  y: stage output (also re-read by backward).      */
 int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws_fwd, void* y, void* stream);
-/* dy: gradient of y (same layout); dx: gradient of x (written).  x / y / ws_fwd as given to c3d_stage_fwd.   */
+/* dy: gradient of y (same layout); dx: gradient of x (written).  x / y / ws_fwd as given to c3d_stage_fwd.
+ * The weight gradients (c3d_pw_wgrad, c3d_dw333_wgrad) are launched on the library's side stream, each forked ahead
+ * of the data-gradient kernel that reads the same operands, with their grids capped at 3/4 and 1/2 of the CUs so
+ * that the data-gradient chain always finds free CUs (csrc/launch_hints.h); ws_bwd holds a ring of three blocks'
+ * temporaries, so the side stream may lag the chain by two blocks.                                              */
 int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void* y, const void* dy, void* ws_fwd, void* ws_bwd,
                   void* dx, void* stream);
 int c3d_side_join(void* stream);
