@@ -1,0 +1,428 @@
+// Depthwise 3x3x3 Conv3d backward, stride 1: DATA gradient and WEIGHT gradient from ONE staged tile
+// (conv_b of the X3D bottleneck, reference model/x3d.py:184-193; autograd's convolution_backward computes both
+// from the same two operands).
+//
+// Round 2 ran two kernels per block: c3d_dw333_bwd_data staged db = A*t1 + B[n] + C*b (+halo) and read the `a`
+// rows for the ReLU mask; c3d_dw333_wgrad (side stream) read t1, b and a AGAIN (10.2 GB of the 98 GB a B=32 step
+// moved, 4.1 ms of kernel time) and spent most of its VALU time re-doing the same conversions.  With the tile
+// of db (+halo) in LDS and the centre pixel's relu(bn_a(a)) in registers both gradients are the same LDS reads:
+//
+//     d a_in[i]  = sum_k db[i + 1 - k] * w[k]            (per dimension, zero padding)
+//     d w[k]     = sum_i db[i + 1 - k] * a_in[i]
+//
+// so the weight gradient costs one more FMA per tap and pixel and no memory traffic at all.
+//
+// Mapping: workgroup = 8x8 pixels x 32 channels, 512 threads; thread = (pixel, 4 channels, all T frames):
+// 27 x 4 weight-gradient partial sums live in registers for the whole tile walk (a thread with 8 channels would
+// need 216), reduced once per workgroup through LDS (dump [tap][thread], 64-term sums in fixed order) and added to
+// dw with f32 atomics.  The staged tile is double buffered: one barrier per tile.
+#include "pw_common.h"   // device_cus()
+#include "dw_common.h"
+#include "../../include/change3d_hip.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int FB_TH = 8, FB_TW = 8, FB_DH = FB_TH + 2, FB_DW = FB_TW + 2, FB_NTHR = 512;
+
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  typedef uint4 type;
+  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+};
+template <> struct Raw8<float> {
+  struct type { float4 a, b; };
+  static __device__ __forceinline__ type load(const float* p) {
+    type t; t.a = *reinterpret_cast<const float4*>(p); t.b = *reinterpret_cast<const float4*>(p + 4); return t;
+  }
+  static __device__ __forceinline__ void cvt(const type& v, float (&f)[8]) {
+    f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w; f[4] = v.b.x; f[5] = v.b.y; f[6] = v.b.z; f[7] = v.b.w;
+  }
+};
+// 4-channel half vectors: what a thread owns of a pixel
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16_t> {
+  typedef uint2 type;
+  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ void cvt(const type& v, float (&f)[4]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&f)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+  }
+};
+template <> struct Raw4<float> {
+  typedef float4 type;
+  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void cvt(const type& v, float (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+  static __device__ __forceinline__ void store(float* p, const float (&f)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+};
+
+__device__ __forceinline__ void lds4(const float* p, float (&f)[4]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+}
+
+__device__ __forceinline__ void lds8(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// empty asm that "modifies" the accumulators: their FMAs cannot be sunk below it, later LDS reads not hoisted above
+template <int TT> __device__ __forceinline__ void pin_acc(f32x2_t (&a)[TT][2]);
+template <> __device__ __forceinline__ void pin_acc<3>(f32x2_t (&a)[3][2]) {
+  asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]) : : "memory");
+}
+template <> __device__ __forceinline__ void pin_acc<5>(f32x2_t (&a)[5][2]) {
+  asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]),
+               "+v"(a[3][1]), "+v"(a[4][0]), "+v"(a[4][1]) : : "memory");
+}
+// (the weight-gradient partial sums of one (ky, kx) step: temporal taps kt = 0, 1, 2)
+__device__ __forceinline__ void pin_dw(f32x2_t (&a0)[2], f32x2_t (&a1)[2], f32x2_t (&a2)[2]) {
+  asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a1[0]), "+v"(a1[1]), "+v"(a2[0]), "+v"(a2[1]));
+}
+
+template <typename T, int TT>
+__global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
+    const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
+    const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
+    const T* __restrict__ a, const float* __restrict__ ss_a, const float* __restrict__ mr_a, T* __restrict__ t2,
+    double* __restrict__ dsums, float* __restrict__ dw, const DwGeom g, const int tiles_per_wg) {
+  typedef Raw8<T> R8;
+  typedef Raw4<T> R4;
+  constexpr int NI = TT * FB_DH * FB_DW * DW_CV;          // staged 8-channel vectors per tile
+  constexpr int SL = (NI + FB_NTHR - 1) / FB_NTHR;        // prefetch slots per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);             // [27][32]
+  float* cf = wl + 27 * 32;                               // [7][32]: cA, cB(sample), cC, sa, sb, ma, ra
+  float4* tile = reinterpret_cast<float4*>(cf + 7 * 32);  // [2 buffers][2 half-vector planes][NI]
+
+  const int tid = threadIdx.x;
+  const int h = tid >> 8;                                 // channel half of the vector (wave-uniform)
+  const int cv = tid & (DW_CV - 1);
+  const int pix = (tid & 255) >> 2;
+  const int px = pix & (FB_TW - 1), py = pix >> 3;
+
+  const int tiles_x = (g.W + FB_TW - 1) / FB_TW, tiles_y = (g.H + FB_TH - 1) / FB_TH;
+  const int ntiles = tiles_x * tiles_y;
+  const int gx = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
+  const ChunkOrder co = chunk_order((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), gx * g.B);
+  if (co.group < 0) return;
+  const int b = co.group / gx, tg = co.group % gx;
+  const int c0 = co.chunk * DW_CV * 8;
+  const int cb8 = c0 + cv * 8;                            // the 8-channel vector this thread stages
+  const int cb4 = cb8 + h * 4;                            // the 4 channels this thread owns
+  const bool c_ok = cb8 < g.Cp;                           // (Cp is a multiple of 8: both halves exist or neither)
+
+  for (int i = tid; i < 27 * 32; i += FB_NTHR) {
+    const int tap = i >> 5, c = c0 + (i & 31);
+    wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
+  }
+  for (int i = tid; i < 7 * 32; i += FB_NTHR) {
+    const int k = i >> 5, c = c0 + (i & 31);
+    float v = 0.f;
+    if (c < g.Cp) {
+      v = k == 0 ? coefA[c] : k == 1 ? coefB[(size_t)b * g.Cp + c] : k == 2 ? coefC[c] : k == 3 ? ss_a[c]
+        : k == 4 ? ss_a[g.Cp + c] : k == 5 ? mr_a[c] : mr_a[g.Cp + c];
+    }
+    cf[i] = v;
+  }
+
+  // BN_a-backward sums (sum t2, sum t2*ahat): f32 per thread over its walk (tiles_per_wg x T terms), f64 from the
+  // cross-thread reduction on (the sums of the two terms nearly cancel on some channels: d gamma needs the digits)
+  float S1[4], S2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { S1[j] = 0.f; S2[j] = 0.f; }
+  f32x2_t dwa[27][2];   // weight-gradient partial sums of this thread's 4 channels, as register pairs (v_pk_fma_f32)
+#pragma unroll
+  for (int k = 0; k < 27; ++k) { dwa[k][0] = f32x2_t{0.f, 0.f}; dwa[k][1] = f32x2_t{0.f, 0.f}; }
+
+  // per-slot staging descriptors, computed once (offset relative to the tile origin; (row, column) in the tile)
+  typename R8::type r1[SL], r2[SL];
+  typename R4::type ar[TT];
+  unsigned vmask = 0;
+  int rel[SL], yx[SL];
+#pragma unroll
+  for (int sl = 0; sl < SL; ++sl) {
+    const int i_ = tid + sl * FB_NTHR;
+    const int p_ = i_ / DW_CV;
+    const int ix_ = p_ % FB_DW, q_ = p_ / FB_DW;
+    const int iy_ = q_ % FB_DH, t_ = q_ / FB_DH;
+    const bool use_ = i_ < NI && c_ok && t_ < g.T;
+    rel[sl] = ((t_ * g.H + iy_) * g.W + ix_) * g.Cp + cb8;
+    yx[sl] = use_ ? (iy_ | (ix_ << 16)) : 0x7fff7fff;
+  }
+  const int orel = (py * g.W + px) * g.Cp + cb4, ofr = g.H * g.W * g.Cp;   // lane offset in a tile, frame stride
+#define FB_ISSUE(TL)                                                                              \
+  {                                                                                               \
+    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                         \
+    const int dy0_ = ty_ * FB_TH - 1, dx0_ = tx_ * FB_TW - 1;                                     \
+    const int64_t tb_ = ((((int64_t)b * g.T) * g.H + dy0_) * g.W + dx0_) * g.Cp;  /* wave-uniform */ \
+    const T* t1b_ = t1 + tb_;                                                                     \
+    const T* bbb_ = bb + tb_;                                                                     \
+    vmask = 0;                                                                                    \
+    _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                           \
+      const unsigned gy_ = (unsigned)(dy0_ + (yx[sl] & 0xffff));                                  \
+      const unsigned gx_ = (unsigned)(dx0_ + (yx[sl] >> 16));                                     \
+      if (gy_ < (unsigned)g.H && gx_ < (unsigned)g.W) {                                           \
+        r1[sl] = R8::load(t1b_ + rel[sl]);                                                        \
+        r2[sl] = R8::load(bbb_ + rel[sl]);                                                        \
+        vmask |= 1u << sl;                                                                        \
+      }                                                                                           \
+    }                                                                                             \
+    if (c_ok && ty_ * FB_TH + py < g.H && tx_ * FB_TW + px < g.W) {                               \
+      const T* ab_ = a + ((((int64_t)b * g.T) * g.H + ty_ * FB_TH) * g.W + tx_ * FB_TW) * g.Cp;   \
+      _Pragma("unroll") for (int t = 0; t < TT; ++t)                                              \
+        if (t < g.T) ar[t] = R4::load(ab_ + (orel + t * ofr));                                    \
+    }                                                                                             \
+  }
+
+  const int tl0 = tg * tiles_per_wg;
+  int tl1 = tl0 + tiles_per_wg;
+  if (tl1 > ntiles) tl1 = ntiles;
+  if (tl0 < tl1) FB_ISSUE(tl0)
+  __syncthreads();   // wl / cf staged
+
+  for (int tl = tl0; tl < tl1; ++tl) {
+    const int tx = tl % tiles_x, ty = tl / tiles_x;
+    const int y0 = ty * FB_TH, x0 = tx * FB_TW;
+    float4* tb = tile + (size_t)((tl - tl0) & 1) * 2 * NI;
+    // ---- stage db = A*t1 + B[n] + C*b (zero outside the image) as two f32 half-vector planes
+    {
+      float cA[8], cB[8], cC[8];
+      lds8(cf + 0 * 32 + cv * 8, cA);
+      lds8(cf + 1 * 32 + cv * 8, cB);
+      lds8(cf + 2 * 32 + cv * 8, cC);
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        const int i = tid + sl * FB_NTHR;
+        if (i < NI) {
+          float f[8];
+          if ((vmask >> sl) & 1u) {
+            float f2[8];
+            R8::cvt(r1[sl], f);
+            R8::cvt(r2[sl], f2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j]));
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.f;
+          }
+          tb[i] = make_float4(f[0], f[1], f[2], f[3]);            // i = p * DW_CV + cv
+          tb[NI + i] = make_float4(f[4], f[5], f[6], f[7]);
+        }
+      }
+    }
+    // ---- this thread's centre pixel: a_in = relu(bn_a(a)) for the weight gradient and the mask
+    const bool p_ok = c_ok && y0 + py < g.H && x0 + px < g.W;
+    typename R4::type arc[TT];
+    f32x2_t ain[TT][2];
+    float sa[4], sb[4];
+    lds4(cf + 3 * 32 + cv * 8 + h * 4, sa);
+    lds4(cf + 4 * 32 + cv * 8 + h * 4, sb);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      if (p_ok && t < g.T) {
+        arc[t] = ar[t];
+        float av[4];
+        R4::cvt(arc[t], av);
+        ain[t][0] = f32x2_t{fmaxf(fmaf(av[0], sa[0], sb[0]), 0.f), fmaxf(fmaf(av[1], sa[1], sb[1]), 0.f)};
+        ain[t][1] = f32x2_t{fmaxf(fmaf(av[2], sa[2], sb[2]), 0.f), fmaxf(fmaf(av[3], sa[3], sb[3]), 0.f)};
+      } else {
+        ain[t][0] = f32x2_t{0.f, 0.f}; ain[t][1] = f32x2_t{0.f, 0.f};
+      }
+    }
+    if (tl + 1 < tl1) FB_ISSUE(tl + 1)
+    __syncthreads();
+
+    // ---- 27 taps: one LDS read feeds the data gradient (x weight) and the weight gradient (x a_in)
+    f32x2_t acc[TT][2];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) { acc[t][0] = f32x2_t{0.f, 0.f}; acc[t][1] = f32x2_t{0.f, 0.f}; }
+    // lowest-address tap (ky = kx = 2) as base: every other tap is a non-negative immediate offset of the ds_read
+    const float4* tp = tb + (size_t)h * NI + (py * FB_DW + px) * DW_CV + cv;
+    // software pipeline over the nine (ky, kx) steps: the LDS reads of step s+1 are issued before the FMAs of step s
+    // (with two waves per SIMD the ~130-clock LDS latency of a step was exposed nine times per tile)
+    float4 wq[2][3], hq[2][TT];
+#define FB_LOAD(S, SLOT)                                                                                          \
+  {                                                                                                               \
+    constexpr int ky_ = (S) / 3, kx_ = (S) % 3;                                                                   \
+    _Pragma("unroll") for (int kt = 0; kt < 3; ++kt)                                                             \
+      wq[SLOT][kt] = *reinterpret_cast<const float4*>(wl + (kt * 9 + (S)) * 32 + cv * 8 + h * 4);                \
+    _Pragma("unroll") for (int to = 0; to < TT; ++to)                                                            \
+      hq[SLOT][to] = tp[((to * FB_DH + (2 - ky_)) * FB_DW + (2 - kx_)) * DW_CV];                                 \
+  }
+#define FB_STEP(S, SLOT)                                                                                          \
+  {                                                                                                               \
+    _Pragma("unroll") for (int to = 0; to < TT; ++to) {                                                          \
+      const f32x2_t v0 = {hq[SLOT][to].x, hq[SLOT][to].y}, v1 = {hq[SLOT][to].z, hq[SLOT][to].w};                 \
+      _Pragma("unroll") for (int kt = 0; kt < 3; ++kt) {                                                         \
+        const int ti = to + kt - 1;   /* in[ti] <-> out[to] through temporal tap kt */                            \
+        if (ti >= 0 && ti < TT) {                                                                                 \
+          const f32x2_t w0 = {wq[SLOT][kt].x, wq[SLOT][kt].y}, w1 = {wq[SLOT][kt].z, wq[SLOT][kt].w};             \
+          acc[ti][0] = __builtin_elementwise_fma(v0, w0, acc[ti][0]);                                             \
+          acc[ti][1] = __builtin_elementwise_fma(v1, w1, acc[ti][1]);                                             \
+          dwa[kt * 9 + (S)][0] = __builtin_elementwise_fma(v0, ain[ti][0], dwa[kt * 9 + (S)][0]);                 \
+          dwa[kt * 9 + (S)][1] = __builtin_elementwise_fma(v1, ain[ti][1], dwa[kt * 9 + (S)][1]);                 \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+    /* pin the schedule: the data-gradient accumulators are only consumed under `p_ok` below and the weight-     \
+       gradient sums at the end of the walk, so the compiler sinks their FMAs and keeps the LDS reads of ALL     \
+       nine steps live until then (216 registers, spills) */                                                      \
+    pin_acc<TT>(acc);                                                                                             \
+    pin_dw(dwa[(S)], dwa[9 + (S)], dwa[18 + (S)]);                                                                \
+  }
+    FB_LOAD(0, 0)
+    FB_LOAD(1, 1) FB_STEP(0, 0)
+    FB_LOAD(2, 0) FB_STEP(1, 1)
+    FB_LOAD(3, 1) FB_STEP(2, 0)
+    FB_LOAD(4, 0) FB_STEP(3, 1)
+    FB_LOAD(5, 1) FB_STEP(4, 0)
+    FB_LOAD(6, 0) FB_STEP(5, 1)
+    FB_LOAD(7, 1) FB_STEP(6, 0)
+    FB_LOAD(8, 0) FB_STEP(7, 1)
+    FB_STEP(8, 0)
+#undef FB_LOAD
+#undef FB_STEP
+    // ---- mask, store t2, BN_a-backward sums
+    if (p_ok) {
+      float ma[4], ra[4];
+      lds4(cf + 5 * 32 + cv * 8 + h * 4, ma);
+      lds4(cf + 6 * 32 + cv * 8 + h * 4, ra);
+      T* ob = t2 + ((((int64_t)b * g.T) * g.H + y0) * g.W + x0) * g.Cp;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (t < g.T) {
+          float av[4], o[4];
+          R4::cvt(arc[t], av);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = round_as<T>(ain[t][j >> 1][j & 1] > 0.f ? acc[t][j >> 1][j & 1] : 0.f);
+            o[j] = d;
+            S1[j] += d; S2[j] += d * ((av[j] - ma[j]) * ra[j]);
+          }
+          R4::store(ob + (orel + t * ofr), o);
+        }
+      }
+    }
+  }
+#undef FB_ISSUE
+
+  // ---- flush the BN_a-backward sums: lanes of equal cv inside a wave, then the four waves of each half
+  const int lane = tid & 63, wave = tid >> 6;
+  double* red64 = reinterpret_cast<double*>(tile);   // [8 waves][DW_CV][8]; the tile buffers are dead now
+  __syncthreads();
+  double D1[4], D2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    D1[j] = (double)S1[j]; D2[j] = (double)S2[j];
+#pragma unroll
+    for (int o = DW_CV; o < 64; o <<= 1) {
+      D1[j] += __shfl_xor(D1[j], o, 64);
+      D2[j] += __shfl_xor(D2[j], o, 64);
+    }
+  }
+  if (lane < DW_CV) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red64[(wave * DW_CV + lane) * 8 + j] = D1[j];
+      red64[(wave * DW_CV + lane) * 8 + 4 + j] = D2[j];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int v = tid >> 4, r = tid & 15;
+    const int hh = r >> 3, which = (r >> 2) & 1, j = r & 3;
+    double sacc = 0.0;
+    for (int wv = hh * 4; wv < hh * 4 + 4; ++wv) sacc += red64[(wv * DW_CV + v) * 8 + which * 4 + j];
+    const int c = c0 + v * 8 + hh * 4 + j;
+    if (c < g.C) atomicAdd(dsums + (size_t)which * g.C + c, sacc);
+  }
+  // ---- weight gradient: dump [tap][thread] per channel-of-four, 64-pixel sums in fixed order, f32 atomics
+  if (dw == nullptr) return;
+  float* dump = reinterpret_cast<float*>(tile);      // 27 * 512 floats = 55 KB <= 2 * 2 * NI * 16 B
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 27; ++k) dump[k * FB_NTHR + tid] = dwa[k][j >> 1][j & 1];
+    __syncthreads();
+    if (tid < 27 * 8 * 2) {
+      const int o = tid >> 1, part = tid & 1;
+      const int tap = o >> 3, v = o & 3, hh = (o >> 2) & 1;
+      const float* src = dump + tap * FB_NTHR + hh * 256 + part * 32 * DW_CV + v;
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) s += src[k * DW_CV];
+      s += __shfl_xor(s, 1, 64);
+      const int c = c0 + v * 8 + hh * 4 + j;
+      if (part == 0 && c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, s);
+    }
+  }
+}
+
+template <typename T, int TT>
+int launch_fused_t(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const float* w,
+                   const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw,
+                   const DwGeom& g, hipStream_t stream) {
+  constexpr int NI = TT * FB_DH * FB_DW * DW_CV;
+  const size_t lds = (27 * 32 + 7 * 32) * sizeof(float) + (size_t)2 * 2 * NI * sizeof(float4);
+  static_assert((size_t)2 * 2 * NI * sizeof(float4) >= (size_t)27 * FB_NTHR * sizeof(float), "dump region");
+  if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_fused_kernel<T, TT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int ntiles = ((g.W + FB_TW - 1) / FB_TW) * ((g.H + FB_TH - 1) / FB_TH);
+  const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
+  // one 512-thread workgroup is resident per CU: a walk amortises the weight-gradient flush (~3 us) and pipelines the
+  // loads; short enough for ~2 rounds of workgroups (C3D_DWBF_TPW: tuning knob)
+  static const int env_tpw = getenv("C3D_DWBF_TPW") ? atoi(getenv("C3D_DWBF_TPW")) : 0;
+  // measured on MI355X (B=32 bf16 step, side stream on): 4 / 8 / 16 / 32 / 64 tiles -> 32.9 / 31.3 / 30.6 / 30.4 / 31.2 ms
+  // (12, 24: +0.3..1.2 ms -- ragged last groups)
+  // -> the longest walk that still gives (almost) every CU a workgroup: 16 / 32 / 32 tiles for the 32x32 / 64x64 / 128x128 stages
+  static const int env_max = getenv("C3D_DWBF_MAX") ? atoi(getenv("C3D_DWBF_MAX")) : 32;
+  int tpw = env_max;
+  while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 85L * device_cus() / 100) tpw >>= 1;
+  if (env_tpw > 0) tpw = env_tpw;
+  if (tpw > ntiles) tpw = ntiles;
+  dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
+  dw_bwd_fused_kernel<T, TT><<<grid, dim3(FB_NTHR), lds, stream>>>(
+      reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, w, reinterpret_cast<const T*>(a),
+      ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, dw, g, tpw);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int c3d_dw333_bwd_fused(const void* t1, const void* b, const float* coefA, const float* coefB,
+                                   const float* coefC, const float* w, const void* a, const float* ss_a,
+                                   const float* mr_a, void* t2, double* dsums, float* dw, int32_t B, int32_t T,
+                                   int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t dtype, void* stream) {
+  DwGeom g{B, T, H, W, H, W, C, Cp, 1};
+  if (!t1 || !b || !coefA || !coefB || !coefC || !w || !a || !ss_a || !mr_a || !t2 || !dsums || !dw || !geom_ok(g))
+    return C3D_E_BADARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == C3D_DT_F32)
+    return T <= 3 ? launch_fused_t<float, 3>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s)
+                  : launch_fused_t<float, 5>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s);
+  if (dtype == C3D_DT_BF16)
+    return T <= 3 ? launch_fused_t<bf16_t, 3>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s)
+                  : launch_fused_t<bf16_t, 5>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s);
+  return C3D_E_BADARG;
+}

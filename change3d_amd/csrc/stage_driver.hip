@@ -727,6 +727,12 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       return c3d_dw333_wgrad(t1, b, cA, cB, cC, a, ss_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, s2);
     };
     static const bool dwwg_early = !(getenv("C3D_DWWG_EARLY") && atoi(getenv("C3D_DWWG_EARLY")) == 0);
+    // stride 1: data gradient and weight gradient in ONE pass over t1, b, a (csrc/dw_bwd_fused.hip); C3D_DW_FUSED=0: the pair
+    static const bool dw_fused_on = !(getenv("C3D_DW_FUSED") && atoi(getenv("C3D_DW_FUSED")) == 0);
+    const bool dw_fused = dw_fused_on && G.s == 1 && !fold;
+    if (dw_fused) {
+      RC(c3d_dw333_bwd_fused(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, dt, st));
+    } else {
     if (dwwg_early) RC(side_run(st, wgrad_b));
     if (fold) {
       const c3d_bn_fin fa = fin_bwd(tick + 1, k.bn_a, (double)G.M, coef_a, mr_a);
@@ -735,6 +741,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       RC(c3d_dw333_bwd_data(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
     }
     if (!dwwg_early) RC(side_run(st, wgrad_b));
+    }
     if (!fold && !consb && !wi.skip(0))
       RC(c3d_bn_bwd_coef(dsums_a, 1, (double)G.M, k.bn_a.gamma, mr_a, G.Ci, G.Cip, coef_a, k.bn_a.dgamma, k.bn_a.dbeta, st));
     // ---- shortcut branch

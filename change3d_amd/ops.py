@@ -373,6 +373,13 @@ def dw_wgrad(t1, b, cA, cB, cC, a, ss_a, dw, B, T, H, W, C_, stride, dtype):
                                     C_, cpad(C_), stride, dtype, _stream())
 
 
+def dw_bwd_fused(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, dw, B, T, H, W, C_, dtype):
+    """Stride-1 depthwise backward: data gradient, BatchNorm_a-backward sums and weight gradient in one pass."""
+    _launch("c3d_dw333_bwd_fused", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_fused,
+            _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2), _p(dsums), _p(dw),
+            B, T, H, W, C_, cpad(C_), dtype, _stream())
+
+
 # ----------------------------------------------------------------------------- elementwise
 def block_out_fwd(c, ss_c, shortcut, ss_1, mode, y, M, Cp, dtype):
     _launch("c3d_block_out_fwd", M * Cp * (3 if shortcut is not None else 2) * _es(dtype), L.lib().c3d_block_out_fwd, _p(c), _p(ss_c), _p(shortcut), _p(ss_1), mode, _p(y), M, Cp, dtype,

@@ -231,6 +231,13 @@ int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const flo
                     const float* coefC, const void* a, const float* ss_a, float* dw, int32_t B, int32_t T,
                     int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
                     void* stream);
+/* Stride 1: bwd_data AND wgrad from one staged tile of db (csrc/dw_bwd_fused.hip) -- what autograd's
+ * convolution_backward returns for conv_b (reference model/x3d.py:184-193) in one pass over t1, b and a: t2 and dsums
+ * exactly as c3d_dw333_bwd_data writes them, dw += as c3d_dw333_wgrad (f32 atomics).  Stride-2 blocks keep the pair. */
+int c3d_dw333_bwd_fused(const void* t1, const void* b, const float* coefA, const float* coefB,
+                        const float* coefC, const float* w, const void* a, const float* ss_a,
+                        const float* mr_a, void* t2, double* dsums, float* dw, int32_t B, int32_t T,
+                        int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Res-block output y = relu(bn_c(c) + shortcut) (reference model/x3d.py:326-327; also the
