@@ -15,6 +15,8 @@ EPI_STORE, EPI_STATS, EPI_SWISH_SE_BWD, EPI_ADD = 0, 1, 2, 3
 ROWS_DENSE, ROWS_FRAME, ROWS_STRIDE2, ROWS_S2SHIFT = 0, 1, 2, 3
 SC_NONE, SC_IDENTITY, SC_BN, SC_RAW = 0, 1, 2, 3
 STAT_STRIPES = 16
+OPT_SIDE_STREAM, OPT_STEM_MFMA, OPT_CONVT_MFMA = 0, 1, 2
+STAGE_SEPARATE_FINALIZE, STAGE_NO_WEIGHT_IMAGES, STAGE_SEPARATE_RESIDUAL = 1, 2, 4
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -62,9 +64,14 @@ class BlockDesc(C.Structure):
                 ("dse_w1", vp), ("dse_b1", vp), ("dse_w2", vp), ("dse_b2", vp)]
 
 
+class ProfRow(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", i32), ("reserved", i32), ("ms_total", f32), ("reserved2", f32),
+                ("bytes_total", f64)]
+
+
 class StageDesc(C.Structure):
     _fields_ = [("n_blocks", i32), ("B", i32), ("T", i32), ("H", i32), ("W", i32), ("dtype", i32),
-                ("training", i32), ("reserved", i32), ("momentum", f32), ("eps", f32),
+                ("training", i32), ("flags", i32), ("momentum", f32), ("eps", f32),
                 ("blocks", C.POINTER(BlockDesc))]
 
 
@@ -137,6 +144,9 @@ SIGNATURES = {
     "c3d_stage_fwd": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp]),
     "c3d_stage_bwd": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp, vp, vp, vp]),
     "c3d_side_join": (i32, [vp]),
+    "c3d_set_option": (i32, [i32, i32]),
+    "c3d_prof_begin": (i32, [i32]),
+    "c3d_prof_end": (i32, [C.POINTER(ProfRow), i32, C.POINTER(i32)]),
     "c3d_stage_fold_bytes": (i32, [C.POINTER(StageDesc), C.POINTER(i64), C.POINTER(i64)]),
     "c3d_stage_fold_bn": (i32, [C.POINTER(StageDesc), vp, vp]),
     "c3d_stage_fwd_folded": (i32, [C.POINTER(StageDesc), vp, vp, vp, vp, vp]),
@@ -167,6 +177,10 @@ def lib():
                 raise Change3DHipError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
+        # host-side convenience (the library itself never reads the environment): C3D_WGRAD_SIDE=0 keeps the weight
+        # gradients on the caller's stream, e.g. for one-kernel-at-a-time rocprofv3 traces of unmodified commands
+        if os.environ.get("C3D_WGRAD_SIDE", "1") == "0":
+            handle.c3d_set_option(OPT_SIDE_STREAM, 0)
         _lib = handle
     return _lib
 

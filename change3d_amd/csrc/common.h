@@ -90,6 +90,23 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __device__ __forceinline__ int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
 
 // Host-side helpers -----------------------------------------------------------------------
+// Tuning knobs (walk lengths, grid caps, experiment switches): the environment is consulted only in the instrumented
+// build (hipcc -DC3D_TUNING: `python __graft_entry__.py --tuning` -> lib/libchange3d_hip_tune.so, loaded through
+// C3D_LIB).  The product library compiles every knob to its measured-best default and never reads the environment;
+// what a caller may legitimately choose at run time is an explicit C-ABI option (c3d_set_option, c3d_stage_desc.flags).
+#include <cstdlib>
+inline const char* c3d_env(const char* name) {
+#ifdef C3D_TUNING
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+inline int c3d_knob(const char* name, int dflt) {
+  const char* s = c3d_env(name);
+  return s ? atoi(s) : dflt;
+}
 #define C3D_CHECK_LAUNCH()                                   \
   do {                                                       \
     hipError_t e_ = hipGetLastError();                       \

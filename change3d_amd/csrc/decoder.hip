@@ -9,6 +9,7 @@
 // The weight gradient of the transposed conv runs on the MFMA weight-gradient kernel
 // (c3d_pw_wgrad with C3D_ROWS_S2SHIFT addressing), the bias gradient on c3d_col_sum.
 #include "common.h"
+#include "launch_hints.h"
 #include <cstdlib>
 #include "../../include/change3d_hip.h"
 
@@ -372,14 +373,11 @@ __global__ __launch_bounds__(HD_TH * HD_TW) void head_bwd_kernel(
 
 }  // namespace
 
-// bf16 (throughput) path: MFMA kernels in convt_mfma.hip (C3D_CONVT_MFMA=0 keeps the scalar kernels for A/B runs)
+// bf16 (throughput) path: MFMA kernels in convt_mfma.hip (c3d_set_option(C3D_OPT_CONVT_MFMA, 0) keeps the scalar kernels: parity tests)
 int c3d_detail_convt_fwd_bf16(const void* in, const float* w, const float* bias, const void* skip, int64_t skip_bstride, void* out,
                               int B, int h, int wd, int C, hipStream_t st);
 int c3d_detail_convt_bwd_data_bf16(const void* dout, const float* w, void* din, int B, int h, int wd, int C, hipStream_t st);
-static bool convt_mfma_on() {
-  static const bool on = !(getenv("C3D_CONVT_MFMA") && atoi(getenv("C3D_CONVT_MFMA")) == 0);
-  return on;
-}
+static bool convt_mfma_on() { return c3d_option_convt_mfma != 0; }
 
 extern "C" int c3d_convT4s2_fwd(const void* in, const float* w, const float* bias, const void* skip,
                                 int64_t skip_bstride, void* out, int32_t B, int32_t h, int32_t wd, int32_t C,
@@ -479,7 +477,7 @@ extern "C" int c3d_head3x3_bwd(const float* dout, const float* prob, const void*
   if (!dout || !x || !w || !dx || !dw || B <= 0 || C != HD_C || NC <= 0 || NC > HD_MAXNC) return C3D_E_BADARG;
   if (has_sigmoid && !prob) return C3D_E_BADARG;
   const int ntiles = ((W + HD_TW - 1) / HD_TW) * ((H + HD_TH - 1) / HD_TH);
-  static const int env_tpw = getenv("C3D_HEAD_TPW") ? atoi(getenv("C3D_HEAD_TPW")) : 0;   // tuning knob
+  static const int env_tpw = c3d_env("C3D_HEAD_TPW") ? atoi(c3d_env("C3D_HEAD_TPW")) : 0;   // tuning knob
   int tpw = env_tpw > 0 ? env_tpw : 16;    // long walks: every workgroup ends with 216*NC same-address global atomics
   while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * B < 2L * 256) tpw >>= 1;            // ... but keep >= 2 per CU
   if (tpw > ntiles) tpw = ntiles;

@@ -391,11 +391,11 @@ int launch_fused_t(const void* t1, const void* bb, const float* cA, const float*
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
   // one 512-thread workgroup is resident per CU: a walk amortises the weight-gradient flush (~3 us) and pipelines the
   // loads; short enough for ~2 rounds of workgroups (C3D_DWBF_TPW: tuning knob)
-  static const int env_tpw = getenv("C3D_DWBF_TPW") ? atoi(getenv("C3D_DWBF_TPW")) : 0;
+  static const int env_tpw = c3d_env("C3D_DWBF_TPW") ? atoi(c3d_env("C3D_DWBF_TPW")) : 0;
   // measured on MI355X (B=32 bf16 step, side stream on): 4 / 8 / 16 / 32 / 64 tiles -> 32.9 / 31.3 / 30.6 / 30.4 / 31.2 ms
   // (12, 24: +0.3..1.2 ms -- ragged last groups)
   // -> the longest walk that still gives (almost) every CU a workgroup: 16 / 32 / 32 tiles for the 32x32 / 64x64 / 128x128 stages
-  static const int env_max = getenv("C3D_DWBF_MAX") ? atoi(getenv("C3D_DWBF_MAX")) : 32;
+  static const int env_max = c3d_env("C3D_DWBF_MAX") ? atoi(c3d_env("C3D_DWBF_MAX")) : 32;
   int tpw = env_max;
   while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 85L * device_cus() / 100) tpw >>= 1;
   if (env_tpw > 0) tpw = env_tpw;

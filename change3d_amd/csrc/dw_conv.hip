@@ -16,7 +16,9 @@
 #include "bn_fin.h"
 #include "dw_common.h"
 #include "launch_hints.h"
-#include "dw_toeplitz.h"
+#ifdef C3D_TUNING
+#include "dw_toeplitz.h"   // Toeplitz-MFMA forward experiment (slower; instrumented build only)
+#endif
 #include "../../include/change3d_hip.h"
 #include <cstdlib>
 #include <cstring>
@@ -26,8 +28,8 @@ thread_local int c3d_side_launch = 0;
 // Workgroups of the (single-round) depthwise weight-gradient kernels: every CU when the kernel has the GPU to itself,
 // half of them when the stage driver runs it beside the data-gradient chain (launch_hints.h).
 static long dw_wgrad_target_wgs() {
-  static const int env_wgs = getenv("C3D_DWWG_WGS") ? atoi(getenv("C3D_DWWG_WGS")) : 0;
-  static const int env_side = getenv("C3D_DWWG_SIDE_WGS") ? atoi(getenv("C3D_DWWG_SIDE_WGS")) : 0;
+  static const int env_wgs = c3d_env("C3D_DWWG_WGS") ? atoi(c3d_env("C3D_DWWG_WGS")) : 0;
+  static const int env_side = c3d_env("C3D_DWWG_SIDE_WGS") ? atoi(c3d_env("C3D_DWWG_SIDE_WGS")) : 0;
   if (env_wgs > 0) return env_wgs;
   if (c3d_side_launch) return env_side > 0 ? env_side : device_cus() / 2;
   return device_cus();
@@ -1559,7 +1561,7 @@ int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, doubl
   // measured best: 16 / 8 / 4 tiles for the 128x128 / 64x64 / 32x32 stages = ~2 workgroups per CU, and
   // never fewer than 4 tiles (the prefetch pipeline needs a walk)
   while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks_ * g.B < 2L * device_cus()) tpw >>= 1;
-  if (const char* e = getenv("C3D_DW_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;  // tuning knob
+  if (const char* e = c3d_env("C3D_DW_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;  // tuning knob
   if (tpw > ntiles) tpw = ntiles;
   dim3 grid(chunk_order_grid((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), (long)((ntiles + tpw - 1) / tpw) * g.B));
   c3d_bn_fin f0;
@@ -1591,7 +1593,7 @@ int launch_fwd_t(const void* x, const float* ss, const float* w, void* y, double
   }
   const int ntiles = ((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH);
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
-  static const int env_tpw = getenv("C3D_DWF1_TPW") ? atoi(getenv("C3D_DWF1_TPW")) : 0;
+  static const int env_tpw = c3d_env("C3D_DWF1_TPW") ? atoi(c3d_env("C3D_DWF1_TPW")) : 0;
   int tpw = 8;   // no prefetch in this kernel: the walk only amortises the weight staging and the statistics flush
   while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 2L * device_cus()) tpw >>= 1;   // swept: 8 is best
   if (env_tpw > 0) tpw = env_tpw;
@@ -1632,7 +1634,7 @@ int launch_bwd_data_t(const void* t1, const void* bb, const float* cA, const flo
   const int ntiles = ((g.W + TW - 1) / TW) * ((g.H + TH - 1) / TH);
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
   // walk length: long enough to amortise the prologue and pipeline the loads, short enough for ~2 workgroups per CU
-  static const int env_tpw = getenv("C3D_DWBD_TPW") ? atoi(getenv("C3D_DWBD_TPW")) : 0;
+  static const int env_tpw = c3d_env("C3D_DWBD_TPW") ? atoi(c3d_env("C3D_DWBD_TPW")) : 0;
   // measured best with the GPU to itself: 16 / 16 / 8 tiles for the 128x128 / 64x64 / 32x32 stages (~2 workgroups per
   // CU); in the train step this kernel shares the CUs with the side stream's weight gradients and shorter walks win
   // (finer units for the dispatcher): 8 everywhere -> 31.66 -> 31.46 ms, 32.08 -> 31.92 ms per step on two boxes
@@ -1769,10 +1771,12 @@ extern "C" int c3d_dw333_fwd(const void* x, const float* ss, const float* w, voi
   DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
   if (!x || !ss || !w || !y || !geom_ok(g)) return C3D_E_BADARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#ifdef C3D_TUNING
   if (stride == 1 && dtype == C3D_DT_BF16 && T <= 3 && c3d_dw_toeplitz_enabled()) {   // matrix-core kernel (dw_toeplitz.hip)
     const int rc = c3d_dw333_fwd_toeplitz(x, ss, w, y, nc_sums, B, T, H, W, C, Cp, s);
     if (rc != C3D_E_UNSUPPORTED) { if (rc == 0) C3D_CHECK_LAUNCH(); return rc; }
   }
+#endif
   if (stride == 1) {  // v2 mapping (wave = channel vector, lane = x-strip)
     int rc = C3D_E_UNSUPPORTED;
     if (dtype == C3D_DT_F32) rc = T <= 3 ? launch_fwd_v2<float, 3>(x, ss, w, y, nc_sums, g, s)
@@ -1796,7 +1800,11 @@ extern "C" int c3d_dw333_fwd_fin(const void* x, const c3d_bn_fin* fin, const flo
   DwGeom g{B, T, H, W, (H - 1) / (stride > 0 ? stride : 1) + 1, (W - 1) / (stride > 0 ? stride : 1) + 1, C, Cp, stride};
   if (!x || !w || !y || !geom_ok(g)) return C3D_E_BADARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#ifdef C3D_TUNING
   const bool tz = stride == 1 && dtype == C3D_DT_BF16 && T <= 3 && c3d_dw_toeplitz_enabled();
+#else
+  const bool tz = false;
+#endif
   if (!tz && stride == 1 && (dtype == C3D_DT_F32 || dtype == C3D_DT_BF16)) {
     int rc;
     if (dtype == C3D_DT_F32) rc = T <= 3 ? launch_fwd_v2<float, 3>(x, fin->ss, w, y, nc_sums, g, s, fin)
@@ -1853,8 +1861,8 @@ extern "C" int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA
     return stride == 1 ? launch_wgrad<float, 1>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s)
                        : launch_wgrad<float, 2>(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
   if (dtype == C3D_DT_BF16) {
-    static const bool no_dma = getenv("C3D_DWWG_NODMA") != nullptr;
-    static const bool no_dot2 = getenv("C3D_DWWG_NODOT2") != nullptr;
+    static const bool no_dma = c3d_env("C3D_DWWG_NODMA") != nullptr;
+    static const bool no_dot2 = c3d_env("C3D_DWWG_NODOT2") != nullptr;
     if (!no_dma && !no_dot2 && stride == 1) {
       const int rc = launch_wgrad_dot2(t1, b, coefA, coefB, coefC, a, ss_a, dw, g, s);
       if (rc != C3D_E_UNSUPPORTED) return rc;

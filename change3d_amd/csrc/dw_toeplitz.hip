@@ -332,14 +332,14 @@ __global__ __launch_bounds__(NTHR) void dw_fwd_tz_kernel(const bf16_t* __restric
 }  // namespace
 
 bool c3d_dw_toeplitz_enabled() {
-  const char* e = getenv("C3D_DW_TZ");   // read per call (tests toggle it inside one process)
+  const char* e = c3d_env("C3D_DW_TZ");   // read per call (tests toggle it inside one process)
   return e && atoi(e) == 1;
 }
 
 // C3D_DW_TZ_CLK=1: device buffer of 11 counters (10 phases + waves), read back by c3d_debug_tz_clock
 static unsigned long long* tz_clk_buffer() {
   static unsigned long long* buf = nullptr;
-  static const bool on = getenv("C3D_DW_TZ_CLK") && atoi(getenv("C3D_DW_TZ_CLK")) == 1;
+  static const bool on = c3d_env("C3D_DW_TZ_CLK") && atoi(c3d_env("C3D_DW_TZ_CLK")) == 1;
   if (on && !buf && hipMalloc(&buf, 16 * sizeof(unsigned long long)) == hipSuccess) hipMemset(buf, 0, 16 * sizeof(unsigned long long));
   return on ? buf : nullptr;
 }
@@ -359,11 +359,11 @@ static int tz_launch(const void* x, const float* ss, const float* w, void* y, do
   int walkers = (NCH == 16 ? 256 : 512) / groups;     // one (16 channels) or two (8 channels) workgroups per CU
   if (walkers < 1) walkers = 1;
   if (walkers > nitems) walkers = nitems;
-  static const int env_w = getenv("C3D_DW_TZ_WALKERS") ? atoi(getenv("C3D_DW_TZ_WALKERS")) : 0;
+  static const int env_w = c3d_env("C3D_DW_TZ_WALKERS") ? atoi(c3d_env("C3D_DW_TZ_WALKERS")) : 0;
   if (env_w > 0) walkers = env_w < nitems ? env_w : nitems;
   dw_fwd_tz_kernel<NCH><<<dim3(walkers, groups), NTHR, lds, s>>>(reinterpret_cast<const bf16_t*>(x), ss, w,
                                                                reinterpret_cast<bf16_t*>(y), nc, g, walkers,
-                                                               getenv("C3D_DW_TZ_DBG") ? atoi(getenv("C3D_DW_TZ_DBG")) : 0,
+                                                               c3d_env("C3D_DW_TZ_DBG") ? atoi(c3d_env("C3D_DW_TZ_DBG")) : 0,
                                                                tz_clk_buffer());
   return 0;
 }
@@ -372,7 +372,7 @@ int c3d_dw333_fwd_toeplitz(const void* x, const float* ss, const float* w, void*
                            int C, int Cp, hipStream_t s) {
   if (T > TT || T < 1) return C3D_E_UNSUPPORTED;
   const Geom g{B, T, H, W, C, Cp};
-  const char* e = getenv("C3D_DW_TZ_NCH");   // 16 (one workgroup per CU) or 8 (two)
+  const char* e = c3d_env("C3D_DW_TZ_NCH");   // 16 (one workgroup per CU) or 8 (two)
   if (e && atoi(e) == 8) return tz_launch<8>(x, ss, w, y, nc, g, s);
   return tz_launch<16>(x, ss, w, y, nc, g, s);
 }

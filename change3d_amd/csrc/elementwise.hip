@@ -258,7 +258,7 @@ int block_out_fwd_launch(const void* c, const float* ss_c, const void* shortcut,
   // grid stride must stay a multiple of G: blk is, so any grid works.  With the finalisation folded in every
   // workgroup starts with a ~1.5 us dependent prologue: ONE round of workgroups (4 per CU), each walking the rows.
   int grid = ew_grid(nvec, blk);
-  static const int env_grid = getenv("C3D_BOF_GRID") ? atoi(getenv("C3D_BOF_GRID")) : 0;   // tuning knob
+  static const int env_grid = c3d_env("C3D_BOF_GRID") ? atoi(c3d_env("C3D_BOF_GRID")) : 0;   // tuning knob
   if (fin_c && grid > (env_grid > 0 ? env_grid : 1024)) grid = env_grid > 0 ? env_grid : 1024;
   EW_DISPATCH(dtype,
               (block_out_fwd_kernel<float><<<grid, blk, 0, s>>>(
@@ -308,7 +308,7 @@ extern "C" int c3d_block_out_bwd_fin(const void* dy, const void* y, const void* 
   const int G = Cp / 8, blk = ew_block(G);
   const int64_t nvec = M * G;
   int grid = ew_grid(nvec, blk);
-  static const int env_cap = getenv("C3D_BOB_GRID") ? atoi(getenv("C3D_BOB_GRID")) : 0;
+  static const int env_cap = c3d_env("C3D_BOB_GRID") ? atoi(c3d_env("C3D_BOB_GRID")) : 0;
   // every workgroup ends with an LDS reduction and G*24 same-address f64 atomics: measured on MI355X
   // 128/256/384/512/1024/2048 workgroups -> 2.55/1.70/1.59/1.68/2.22/3.07 ms per step
   const int cap = env_cap > 0 ? env_cap : 384;

@@ -9,3 +9,7 @@
 // The pointwise weight gradient takes 3/4 of the CUs in the same situation (256 -> 192 workgroups: 32.43 -> 31.69 ms;
 // profiles/r02_side_stream_width_final.json).
 extern thread_local int c3d_side_launch;
+
+// c3d_set_option (stage_driver.hip): kernel-family selectors with a parity test between the two implementations
+extern int c3d_option_stem_mfma;    // 1: stem on the matrix cores (stem_mfma.hip), 0: scalar-FMA kernels (stem.hip)
+extern int c3d_option_convt_mfma;   // 1: bf16 ConvTranspose2d on the matrix cores (convt_mfma.hip), 0: decoder.hip's

@@ -921,13 +921,13 @@ int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
   int64_t tpw = (tiles + blocks * WAVES - 1) / (blocks * WAVES);
   // Whole iterations only when that does not idle CUs: 6144 tiles over 2048 waves is 3 per wave; rounding
   // to 4 (tpi = 2) left 64 of 256 CUs without a workgroup (stage-3 K=96 layers, -20 % per launch).
-  static const int round_iters = getenv("C3D_PW_ROUND") ? atoi(getenv("C3D_PW_ROUND")) : 0;
+  static const int round_iters = c3d_env("C3D_PW_ROUND") ? atoi(c3d_env("C3D_PW_ROUND")) : 0;
   const int64_t tpw_r = (tpw + L.tpi - 1) / L.tpi * L.tpi;
   const int64_t blocks_r = (tiles + tpw_r * WAVES - 1) / (tpw_r * WAVES);
   if (round_iters || blocks_r * 16 >= blocks * 15) tpw = tpw_r;
   blocks = (tiles + tpw * WAVES - 1) / (tpw * WAVES);
   L.tiles_per_wave = (int)tpw;
-  static const int fsm = getenv("C3D_PW_FLUSH_SHFL") ? atoi(getenv("C3D_PW_FLUSH_SHFL")) : 0;   // tuning knob (measured: no gain)
+  static const int fsm = c3d_env("C3D_PW_FLUSH_SHFL") ? atoi(c3d_env("C3D_PW_FLUSH_SHFL")) : 0;   // tuning knob (measured: no gain)
   L.flush_shuffle_max = fsm;
   pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE><<<dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream>>>(a, L);
   C3D_CHECK_LAUNCH();
@@ -946,7 +946,7 @@ int launch_pw(const c3d_pw_args& a, hipStream_t stream) {
   // prefer 8 waves per workgroup (one weight copy per 8 waves) when LDS allows it
   PwLaunch L;
   size_t lds = 0;
-  static const int force8 = getenv("C3D_PW_FORCE8") ? atoi(getenv("C3D_PW_FORCE8")) : 0;  // tuning knob
+  static const int force8 = c3d_env("C3D_PW_FORCE8") ? atoi(c3d_env("C3D_PW_FORCE8")) : 0;  // tuning knob
   const bool e1_epi = EPI == C3D_EPI_SWISH_SE_BWD || EPI == C3D_EPI_ADD;  // epilogues with exposed companion loads
   if (force8 >= 0 && plan_pw<T, NT, PRO, EPI, 8>(a, L, lds) &&
       (L.tpi * ((((a.Kp >> 3) + 3) >> 2)) >= 4 || lds <= 80 * 1024 || force8 == 2 || (force8 == 1 && e1_epi)))

@@ -415,7 +415,7 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   const int maxG = (a.Np > a.Kp ? a.Np : a.Kp) >> 3;
   int MT = (256 / maxG) * WG_RPT / 32 * 32;
   if (MT > WG_MAXMT) MT = WG_MAXMT;
-  static const int mt_env = getenv("C3D_WG_MT") ? atoi(getenv("C3D_WG_MT")) : 0;  // tuning knob
+  static const int mt_env = c3d_env("C3D_WG_MT") ? atoi(c3d_env("C3D_WG_MT")) : 0;  // tuning knob
   if (mt_env >= 32 && mt_env < MT) MT = mt_env / 32 * 32;
   if (MT < 32) return C3D_E_UNSUPPORTED;
   size_t lds = 0;
@@ -449,14 +449,14 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   }
   const int64_t tiles = (a.M + MT - 1) / MT;
   int64_t blocks = (tiles + 3) / 4;  // >= 4 tiles per workgroup when there is enough work
-  static const int cap_env = getenv("C3D_WG_BLOCKS") ? atoi(getenv("C3D_WG_BLOCKS")) : 0;  // tuning knob
+  static const int cap_env = c3d_env("C3D_WG_BLOCKS") ? atoi(c3d_env("C3D_WG_BLOCKS")) : 0;  // tuning knob
   int64_t cap = device_cus() < WGRAD_MAX_PARTS ? device_cus() : WGRAD_MAX_PARTS;
   if (cap_env > 0 && cap_env <= WGRAD_MAX_PARTS) cap = cap_env;
   else if (c3d_side_launch) {
     // beside the data-gradient chain (stage driver's side stream): three quarters of the CUs.  This single-round
     // kernel at full width holds every CU for its whole duration (launch_hints.h); measured on MI355X, B=32 bf16,
     // 60-step runs: 256 / 208 / 192 / 176 / 160 / 128 workgroups -> 32.52 / 32.08 / 31.84 / 32.11 / 32.48 / 32.87 ms
-    static const int side_env = getenv("C3D_PWWG_SIDE_WGS") ? atoi(getenv("C3D_PWWG_SIDE_WGS")) : 0;
+    static const int side_env = c3d_env("C3D_PWWG_SIDE_WGS") ? atoi(c3d_env("C3D_PWWG_SIDE_WGS")) : 0;
     const int64_t side_cap = side_env > 0 ? side_env : (int64_t)device_cus() * 3 / 4;
     if (side_cap < cap) cap = side_cap;
   }

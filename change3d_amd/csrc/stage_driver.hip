@@ -11,7 +11,9 @@
 #include "../../include/change3d_hip.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include "common.h"
 #include "launch_hints.h"
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -54,18 +56,12 @@ struct BlkFwd {   // byte offsets into ws_fwd
   size_t img_a, img_at, img_c, img_ct, img_s, img_st;
 };
 
-// C3D_PW_IMG=0: every GEMM workgroup converts the f32 weights itself (the path before the images existed)
-bool use_pw_img() {
-  static const bool on = !(getenv("C3D_PW_IMG") && atoi(getenv("C3D_PW_IMG")) == 0);
-  return on;
-}
-
 // Ring depth of the backward temporaries: block i shares its slot with block i+R, so the side stream (weight gradients)
 // may run up to R-1 blocks behind the data-gradient chain before the main stream has to wait for it.
 constexpr int BWD_RING_MAX = 4;
 int bwd_ring() {
   static const int r = [] {
-    const char* s = getenv("C3D_BWD_RING");
+    const char* s = c3d_env("C3D_BWD_RING");
     // measured on MI355X (B=32 bf16): 2, 3, 4 slots -> 34.04 / 34.10 / 34.32 ms per step before the weight gradients were
     // forked ahead of their data gradients; 32.62 / 32.45 ms for 2 / 3 slots after (three interleaved repeats each)
     const int v = s ? atoi(s) : 3;
@@ -215,6 +211,30 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ per-launch profile
+// c3d_prof_begin / c3d_prof_end (include/change3d_hip.h): every kernel the driver enqueues is bracketed by a HIP event
+// pair on the stream it is launched on and billed its algorithmic bytes, so bench.py's per-kernel table and `roofline`
+// block are taken through THIS launch sequence (round 2 took them through a second, Python, copy of it).
+struct ProfRec { char name[64]; hipEvent_t e0, e1; double bytes; };
+std::vector<ProfRec> g_prof;
+int g_prof_flags = -1;   // < 0: off; bit 0: weight gradients inline on the main stream; bit 1: names carry shape / mode
+
+template <typename F>
+int prof_call(const char* name, double bytes, hipStream_t s, F&& fn) {
+  if (g_prof_flags < 0) return fn();
+  ProfRec r;
+  std::snprintf(r.name, sizeof(r.name), "%s", name);
+  r.bytes = bytes;
+  HIPRC(hipEventCreate(&r.e0));
+  HIPRC(hipEventCreate(&r.e1));
+  HIPRC(hipEventRecord(r.e0, s));
+  const int rc = fn();
+  HIPRC(hipEventRecord(r.e1, s));
+  g_prof.push_back(r);
+  return rc;
+}
+inline bool prof_detail() { return g_prof_flags >= 0 && (g_prof_flags & 2); }
+
 // ------------------------------------------------------------------------------------------ side stream
 struct SideCtx {
   hipStream_t side = nullptr;
@@ -237,10 +257,8 @@ struct SideCtx {
 std::mutex g_mu;
 SideCtx g_side[16];
 
-bool side_enabled() {
-  static const bool on = !(getenv("C3D_WGRAD_SIDE") && atoi(getenv("C3D_WGRAD_SIDE")) == 0);
-  return on;
-}
+int g_side_on = 1;        // c3d_set_option(C3D_OPT_SIDE_STREAM, ...)
+bool side_enabled() { return g_side_on != 0 && !(g_prof_flags >= 0 && (g_prof_flags & 1)); }
 
 SideCtx* side_ctx() {
   int dev = 0;
@@ -248,7 +266,7 @@ SideCtx* side_ctx() {
   SideCtx& c = g_side[dev];
   if (!c.side) {
     // C3D_SIDE_PRIO=1: lowest stream priority for the weight-gradient stream (A/B knob)
-    static const bool low = getenv("C3D_SIDE_PRIO") && atoi(getenv("C3D_SIDE_PRIO")) == 1;
+    static const bool low = c3d_env("C3D_SIDE_PRIO") && atoi(c3d_env("C3D_SIDE_PRIO")) == 1;
     int lo = 0, hi = 0;
     if (low && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) {
       if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
@@ -322,58 +340,19 @@ struct WgCall {
   }
 };
 
-// C3D_FOLD_FIN=1: BatchNorm finalisation by the LAST WORKGROUP of the statistics producers (csrc/bn_fin.h) instead of
-// separate c3d_bn_finalize / c3d_bn_bwd_coef launches.  Default OFF -- measured on MI355X (B=32, bf16, round 2,
-// profiles/r02_fold_finalize_ab.json): 166 launches of 6.5 us disappear (-1.07 ms) but the producers grow by
-// 8-13 us per launch (+1.70 ms: pw_gemm +0.86, dw333_bwd_data +0.53, block_out_bwd +0.32): the hand-off is a chain of
-// memory-side round trips (statistics atomics -> vmcnt(0) -> ticket atomic -> acquire -> sc1 loads of the sums), each
-// ~2 us on this chip, serialised at the tail of the last workgroup -- MORE than a kernel boundary plus a 6 us kernel.
-bool fold_fin() {
-  static const bool on = getenv("C3D_FOLD_FIN") && atoi(getenv("C3D_FOLD_FIN")) == 1;
-  return on;
-}
-
-// C3D_WHATIF=<bits>: TIMING EXPERIMENTS ONLY (results are wrong on purpose; tools/whatif.sh).  After the first 8 calls
-// of each driver entry (so that every buffer holds finite values from a regular pass): bit 0 skips the plain
-// BatchNorm finalize / backward-coefficient launches, bit 1 the SE finalize launches (forward), bit 3 the SE coefficient launches (backward), bit 2 the
-// residual add + ReLU launches (forward) -- upper bounds for what folding those launches into neighbours could win.
-int whatif_bits() {
-  static const int bits = getenv("C3D_WHATIF") ? atoi(getenv("C3D_WHATIF")) : 0;
-  return bits;
-}
-struct WhatIf {
-  int bits;
-  explicit WhatIf(int* calls) : bits(0) { if (whatif_bits() && ++*calls > 9) bits = whatif_bits(); }
-  bool skip(int bit) const { return (bits >> bit) & 1; }
-};
-
-inline c3d_bn_fin fin_fwd(uint32_t* ticket, const c3d_bn_ptrs& bn, int training, double count, float momentum, float eps,
-                          float* ss, float* mr) {
-  c3d_bn_fin f;
-  std::memset(&f, 0, sizeof(f));
-  f.ticket = ticket; f.gamma = bn.gamma; f.beta = bn.beta; f.running_mean = bn.running_mean; f.running_var = bn.running_var;
-  f.nbt = training ? bn.num_batches_tracked : nullptr; f.ss = ss; f.mr = mr; f.count = count; f.momentum = momentum;
-  f.eps = eps; f.training = training;
-  return f;
-}
-
-// C3D_FIN_CONSUMER=0: separate c3d_bn_finalize launches in front of the depthwise forward and the residual add (the
-// default folds them into those kernels' prologues: csrc/bn_fin.h bn_consume)
-bool fin_consumer() {
-  static const bool on = !(getenv("C3D_FIN_CONSUMER") && atoi(getenv("C3D_FIN_CONSUMER")) == 0);
-  return on;
-}
-
-// C3D_FUSE_RESIDUAL=0: separate residual-add launches (c3d_block_out_fwd_fin) instead of the next block's conv_a prologue
-bool fuse_residual() {
-  static const bool on = !(getenv("C3D_FUSE_RESIDUAL") && atoi(getenv("C3D_FUSE_RESIDUAL")) == 0);
-  return on;
-}
+// c3d_stage_desc.flags (include/change3d_hip.h): the unfused launch sequences, kept callable so that the fused ones can
+// be tested bit for bit against them (tests/test_model_gpu.py) -- the default (flags = 0) is the measured-best sequence
+inline bool fin_consumer(const c3d_stage_desc* d) { return !(d->flags & C3D_STAGE_SEPARATE_FINALIZE); }
+inline bool fuse_residual(const c3d_stage_desc* d) { return !(d->flags & C3D_STAGE_SEPARATE_RESIDUAL); }
+inline bool use_pw_img(const c3d_stage_desc* d) { return !(d->flags & C3D_STAGE_NO_WEIGHT_IMAGES); }
 
 inline c3d_bn_fin fin_consume(const double* sums, const c3d_bn_ptrs& bn, double count, float momentum, float eps,
                               float* ss, float* mr) {
-  c3d_bn_fin f = fin_fwd(nullptr, bn, 1, count, momentum, eps, ss, mr);
-  f.sums = sums;
+  c3d_bn_fin f;
+  std::memset(&f, 0, sizeof(f));
+  f.gamma = bn.gamma; f.beta = bn.beta; f.running_mean = bn.running_mean; f.running_var = bn.running_var;
+  f.nbt = bn.num_batches_tracked; f.ss = ss; f.mr = mr; f.count = count; f.momentum = momentum; f.eps = eps;
+  f.training = 1; f.sums = sums;
   return f;
 }
 
@@ -385,14 +364,6 @@ inline c3d_bn_fin fin_coef_consume(const double* dsums, const c3d_bn_ptrs& bn, d
   std::memset(&f, 0, sizeof(f));
   f.sums = dsums; f.gamma = bn.gamma; f.mr = const_cast<float*>(mr); f.count = count;
   if (accumulate) { f.running_mean = bn.dgamma; f.running_var = bn.dbeta; }
-  return f;
-}
-
-inline c3d_bn_fin fin_bwd(uint32_t* ticket, const c3d_bn_ptrs& bn, double count, float* coef, const float* mr) {
-  c3d_bn_fin f;
-  std::memset(&f, 0, sizeof(f));
-  f.ticket = ticket; f.gamma = bn.gamma; f.running_mean = bn.dgamma; f.running_var = bn.dbeta; f.ss = coef;
-  f.mr = const_cast<float*>(mr); f.count = count;
   return f;
 }
 
@@ -509,19 +480,45 @@ extern "C" int c3d_stage_saved(const c3d_stage_desc* d, int32_t blk, const char*
 
 extern "C" int c3d_side_join(void* stream) { return side_join(reinterpret_cast<hipStream_t>(stream), UINT64_MAX); }
 
+// ---- profiled launches -------------------------------------------------------------------------------------
+namespace {
+
+int pw_launch(const c3d_pw_args& a, hipStream_t st) {
+  const double bytes = (double)a.M * ((double)a.Kp * (a.x2 ? 2 : 1) + (double)a.Np * (a.e1 ? 2 : 1) + (a.pro_out ? a.Kp : 0)) *
+                       (double)es(a.dtype);
+  char nm[64];
+  if (prof_detail())
+    std::snprintf(nm, sizeof(nm), "c3d_pw_gemm[M=%lld K=%d N=%d pro=%d epi=%d rows=%d]", (long long)a.M, a.K, a.N, a.pro_mode,
+                  a.epi_mode, a.row_mode);
+  else
+    std::snprintf(nm, sizeof(nm), "c3d_pw_gemm");
+  return prof_call(nm, bytes, st, [&] { return c3d_pw_gemm(&a, st); });
+}
+
+int wg_launch(const c3d_pw_wgrad_args& a, hipStream_t st) {
+  const double bytes = (double)a.M * ((double)a.Np * (a.p2 ? 2 : 1) + (double)a.Kp) * (double)es(a.dtype);
+  char nm[64];
+  if (prof_detail())
+    std::snprintf(nm, sizeof(nm), "c3d_pw_wgrad[M=%lld K=%d N=%d q=%d rows=%d]", (long long)a.M, a.K, a.N, a.q_mode, a.row_mode);
+  else
+    std::snprintf(nm, sizeof(nm), "c3d_pw_wgrad");
+  return prof_call(nm, bytes, st, [&] { return c3d_pw_wgrad(&a, st); });
+}
+
+}  // namespace
+
 extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, void* y_out, void* stream) {
   Plan P;
   RC(make_plan(d, P));
   if (!x || !ws || !y_out) return C3D_E_BADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int dt = d->dtype, tr = d->training ? 1 : 0, B = d->B, T = d->T;
-  static int whatif_calls = 0;
-  const WhatIf wi(&whatif_calls);
+  const double e = (double)es(dt);
   HIPRC(hipMemsetAsync(at(ws, P.fwd_acc_off), 0, P.fwd_acc_bytes, st));
   // Weight images of the whole stage in one launch per 64 images: the f32 master weights change once per optimizer
   // step, the four (six with a shortcut convolution) GEMMs of a block read them in ~256 workgroups each.  The backward
   // pass of this forward reads the transposed images from the same workspace.
-  const bool wimg = use_pw_img();
+  const bool wimg = use_pw_img(d);
   auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
   if (wimg) {
     std::vector<c3d_pw_pack_desc> pk;
@@ -539,7 +536,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       add(k.w_c, F.img_ct, G.Ci, G.Co, 1, G.Ci);
       if (G.sc_conv) add(k.w_sc, F.img_st, G.Cin, G.Co, 1, G.Cin);
     }
-    RC(c3d_pw_pack_weights(pk.data(), (int32_t)pk.size(), dt, st));
+    RC(prof_call("c3d_pw_pack_weights", 0.0, st, [&] { return c3d_pw_pack_weights(pk.data(), (int32_t)pk.size(), dt, st); }));
   }
   const int epi = tr ? C3D_EPI_STATS : C3D_EPI_STORE;
   const void* cur = x;
@@ -560,48 +557,50 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
     double* sums_a = atT<double>(ws, F.sums_a); double* nc_b = atT<double>(ws, F.nc_b);
     double* sums_c = atT<double>(ws, F.sums_c); double* sums_1 = atT<double>(ws, F.sums_1);
     const int64_t rps = (int64_t)T * G.Ho * G.Wo;
-    uint32_t* tick = atT<uint32_t>(ws, F.tick);
-    const bool fold = tr && fold_fin();   // (eval mode has no statistics: the finalize launches build scale/shift)
     // conv_a (1x1x1) + BN_a statistics
     if (pend.on) {   // y(i-1) = relu(bn_c(c) + shortcut) computed on load, written out, and fed to the GEMM
       PwCall p(pend.c, k.w_a, a, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
       p.a.x2 = pend.sc; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.fin = pend.fin; p.a.pro_p = pend.fin.ss; p.a.pro_out = pend.y;
       p.a.epi_mode = epi; p.a.stats = sums_a; p.a.w_img = imgp(F.img_a);
-      RC(c3d_pw_gemm(&p.a, st));
+      RC(pw_launch(p.a, st));
       pend.on = false;
     } else {
       PwCall p(cur, k.w_a, a, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
       p.a.epi_mode = epi; p.a.stats = sums_a; p.a.w_img = imgp(F.img_a);
-      if (fold) p.a.fin = fin_fwd(tick + 0, k.bn_a, tr, (double)G.M, d->momentum, d->eps, ss_a, mr_a);
-      RC(c3d_pw_gemm(&p.a, st));
+      RC(pw_launch(p.a, st));
     }
     // conv_b (depthwise 3x3x3, BN_a + ReLU on load) + per-sample statistics; BN_b + SE.  BN_a is finalised by the
-    // depthwise kernel's own prologue (or by a separate launch: eval mode, last-workgroup mode, C3D_FIN_CONSUMER=0)
-    const bool cons = tr && !fold && fin_consumer() && !(whatif_bits() & 5);
+    // depthwise kernel's own prologue (or by a separate launch: eval mode, C3D_FIN_CONSUMER=0)
+    const bool cons = tr && fin_consumer(d);
+    const double dw_bytes = ((double)G.M + (double)G.Mo) * G.Cip * e;
     if (cons) {
       const c3d_bn_fin fa = fin_consume(sums_a, k.bn_a, (double)G.M, d->momentum, d->eps, ss_a, mr_a);
-      RC(c3d_dw333_fwd_fin(a, &fa, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+      RC(prof_call("c3d_dw333_fwd", dw_bytes, st, [&] {
+        return c3d_dw333_fwd_fin(a, &fa, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st); }));
     } else {
-      if (!fold && !wi.skip(0))
-        RC(c3d_bn_finalize(sums_a, S, (double)G.M, k.bn_a.gamma, k.bn_a.beta, k.bn_a.running_mean, k.bn_a.running_var,
-                           tr ? k.bn_a.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr, ss_a, mr_a, st));
-      RC(c3d_dw333_fwd(a, ss_a, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+      RC(prof_call("c3d_bn_finalize", 0.0, st, [&] {
+        return c3d_bn_finalize(sums_a, S, (double)G.M, k.bn_a.gamma, k.bn_a.beta, k.bn_a.running_mean, k.bn_a.running_var,
+                               tr ? k.bn_a.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr, ss_a, mr_a, st); }));
+      RC(prof_call("c3d_dw333_fwd", dw_bytes, st, [&] {
+        return c3d_dw333_fwd(a, ss_a, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st); }));
     }
-    if (!wi.skip(1))
-    RC(c3d_bn_se_finalize(nc_b, B, (double)rps, k.bn_b.gamma, k.bn_b.beta, k.bn_b.running_mean, k.bn_b.running_var,
-                          tr ? k.bn_b.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr,
-                          G.se ? k.se_w1 : nullptr, k.se_b1, k.se_w2, k.se_b2, G.Cr, ss_b, mr_b, gate, hid, st));
+    RC(prof_call("c3d_bn_se_finalize", 0.0, st, [&] {
+      return c3d_bn_se_finalize(nc_b, B, (double)rps, k.bn_b.gamma, k.bn_b.beta, k.bn_b.running_mean, k.bn_b.running_var,
+                                tr ? k.bn_b.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr,
+                                G.se ? k.se_w1 : nullptr, k.se_b1, k.se_w2, k.se_b2, G.Cr, ss_b, mr_b, gate, hid, st); }));
     // conv_c (BN_b * SE gate, Swish on load) + BN_c statistics
     {
       PwCall p(b, k.w_c, c, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
       p.a.pro_mode = C3D_PRO_BN_SE_SWISH; p.a.pro_p = ss_b; p.a.pro_gate = gate; p.a.rows_per_sample = rps;
       p.a.epi_mode = epi; p.a.stats = sums_c; p.a.w_img = imgp(F.img_c);
-      if (fold) p.a.fin = fin_fwd(tick + 1, k.bn_c, tr, (double)G.Mo, d->momentum, d->eps, ss_c, mr_c);
-      RC(c3d_pw_gemm(&p.a, st));
+      RC(pw_launch(p.a, st));
     }
-    if (!cons && !fold && !wi.skip(0))
-      RC(c3d_bn_finalize(sums_c, S, (double)G.Mo, k.bn_c.gamma, k.bn_c.beta, k.bn_c.running_mean, k.bn_c.running_var,
-                         tr ? k.bn_c.num_batches_tracked : nullptr, d->momentum, d->eps, G.Co, G.Cop, tr, ss_c, mr_c, st));
+    auto finalize = [&](const double* sums, const c3d_bn_ptrs& bn, int C, int Cp, float* ss, float* mr) {
+      return prof_call("c3d_bn_finalize", 0.0, st, [&] {
+        return c3d_bn_finalize(sums, S, (double)G.Mo, bn.gamma, bn.beta, bn.running_mean, bn.running_var,
+                               tr ? bn.num_batches_tracked : nullptr, d->momentum, d->eps, C, Cp, tr, ss, mr, st); });
+    };
+    if (!cons) RC(finalize(sums_c, k.bn_c, G.Co, G.Cop, ss_c, mr_c));
     // shortcut
     int mode = SC_IDENTITY;
     const void* scp = cur;
@@ -609,13 +608,9 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       PwCall p(cur, k.w_sc, sc, G.Mo, G.Cin, G.Co, G.Cin, 1, dt);
       p.a.row_mode = G.s == 2 ? C3D_ROWS_STRIDE2 : C3D_ROWS_DENSE; p.a.H = G.H; p.a.W = G.W;
       p.a.epi_mode = G.sc_bn ? epi : C3D_EPI_STORE; p.a.stats = sums_1; p.a.w_img = imgp(F.img_s);
-      if (fold && G.sc_bn) p.a.fin = fin_fwd(tick + 2, k.bn_sc, tr, (double)G.Mo, d->momentum, d->eps, ss_1, mr_1);
-      RC(c3d_pw_gemm(&p.a, st));
+      RC(pw_launch(p.a, st));
       if (G.sc_bn) {
-        if (!cons && !fold && !wi.skip(0))
-          RC(c3d_bn_finalize(sums_1, S, (double)G.Mo, k.bn_sc.gamma, k.bn_sc.beta, k.bn_sc.running_mean,
-                             k.bn_sc.running_var, tr ? k.bn_sc.num_batches_tracked : nullptr, d->momentum, d->eps,
-                             G.Co, G.Cop, tr, ss_1, mr_1, st));
+        if (!cons) RC(finalize(sums_1, k.bn_sc, G.Co, G.Cop, ss_1, mr_1));
         mode = SC_BN;
       } else {
         mode = SC_RAW;
@@ -624,8 +619,9 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
     }
     // the next block's conv_a can take over this block's residual add when that block reads dense rows of y
     // (stride 1 inside a stage), its kernels are the narrow bf16 ones, and the shortcut carries no BatchNorm
-    const bool fuse_next = cons && fuse_residual() && i + 1 < d->n_blocks && mode != SC_BN && dt == C3D_DT_BF16 &&
+    const bool fuse_next = cons && fuse_residual(d) && i + 1 < d->n_blocks && mode != SC_BN && dt == C3D_DT_BF16 &&
                            G.Cop <= 224 && P.g[i + 1].Cip <= 224 && d->blocks[i + 1].stride == 1 && !d->blocks[i + 1].has_sc_conv;
+    const double bo_bytes = (double)G.Mo * G.Cop * 3 * e;
     if (fuse_next) {
       pend.c = c; pend.sc = scp; pend.y = y; pend.on = true;
       pend.fin = fin_consume(sums_c, k.bn_c, (double)G.Mo, d->momentum, d->eps, ss_c, mr_c);
@@ -633,11 +629,13 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       const c3d_bn_fin fc = fin_consume(sums_c, k.bn_c, (double)G.Mo, d->momentum, d->eps, ss_c, mr_c);
       c3d_bn_fin f1;
       if (mode == SC_BN) f1 = fin_consume(sums_1, k.bn_sc, (double)G.Mo, d->momentum, d->eps, ss_1, mr_1);
-      RC(c3d_block_out_fwd_fin(c, &fc, scp, mode == SC_BN ? &f1 : nullptr, mode, y, G.Mo, G.Co, G.Cop, dt, st));
-    } else if (!wi.skip(2)) {
-      RC(c3d_block_out_fwd(c, ss_c, scp, ss_1, mode, y, G.Mo, G.Cop, dt, st));
+      RC(prof_call("c3d_block_out_fwd", bo_bytes, st, [&] {
+        return c3d_block_out_fwd_fin(c, &fc, scp, mode == SC_BN ? &f1 : nullptr, mode, y, G.Mo, G.Co, G.Cop, dt, st); }));
+    } else {
+      RC(prof_call("c3d_block_out_fwd", bo_bytes, st, [&] {
+        return c3d_block_out_fwd(c, ss_c, scp, ss_1, mode, y, G.Mo, G.Cop, dt, st); }));
     }
-    cur = wi.skip(2) ? c : y;
+    cur = y;
   }
   return 0;
 }
@@ -649,11 +647,10 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   if (!x || !y_out || !dy || !ws || !wb || !dx_out) return C3D_E_BADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int dt = d->dtype, B = d->B, T = d->T;
-  static int whatif_calls = 0;
-  const WhatIf wi(&whatif_calls);
+  const double e = (double)es(dt);
   HIPRC(hipMemsetAsync(at(wb, P.bwd_acc_off), 0, P.bwd_acc_bytes, st));
   float* wgws = atT<float>(wb, P.wgrad_ws);
-  const bool wimg = use_pw_img();   // transposed weight images written by this step's c3d_stage_fwd (training mode)
+  const bool wimg = use_pw_img(d);   // transposed weight images written by this step's c3d_stage_fwd (training mode)
   auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
   const void* cur_dy = dy;
   std::deque<uint64_t> lag;   // side-stream marks of the blocks whose ring slots are still in flight
@@ -679,71 +676,54 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     double* nc3 = atT<double>(wb, Bk.nc3); double* dsums_a = atT<double>(wb, Bk.dsums_a);
     const int64_t rps = (int64_t)T * G.Ho * G.Wo;
     const bool scbn = G.sc_bn;
-    // ---- y = relu(bn_c(c) + shortcut)
-    uint32_t* tick = atT<uint32_t>(wb, Bk.tick);
-    const bool fold = fold_fin();
     // BatchNorm-backward coefficients rebuilt by their consumers (narrow bf16 kernels; csrc/bn_fin.h) instead of
     // c3d_bn_bwd_coef launches
-    const bool consb = !fold && fin_consumer() && !(whatif_bits() & 1) && dt == C3D_DT_BF16 && G.Cip <= 224 && G.Cop <= 224 &&
-                       G.Cinp <= 224;
-    if (fold) {
-      const c3d_bn_fin fc = fin_bwd(tick + 0, k.bn_c, (double)G.Mo, coef_c, mr_c);
-      const c3d_bn_fin f1 = scbn ? fin_bwd(tick + 0, k.bn_sc, (double)G.Mo, coef_1, mr_1) : c3d_bn_fin{};
-      RC(c3d_block_out_bwd_fin(cur_dy, y, c, scbn ? sc : nullptr, g, mr_c, scbn ? mr_1 : nullptr, dsums_c,
-                               scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, &fc, scbn ? &f1 : nullptr, st));
-    } else {
-      RC(c3d_block_out_bwd(cur_dy, y, c, scbn ? sc : nullptr, g, mr_c, scbn ? mr_1 : nullptr, dsums_c,
-                           scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, st));
-      if (!consb && !wi.skip(0))
-      RC(c3d_bn_bwd_coef(dsums_c, 1, (double)G.Mo, k.bn_c.gamma, mr_c, G.Co, G.Cop, coef_c, k.bn_c.dgamma, k.bn_c.dbeta, st));
-    }
+    const bool consb = fin_consumer(d) && dt == C3D_DT_BF16 && G.Cip <= 224 && G.Cop <= 224 && G.Cinp <= 224;
+    auto coef = [&](const double* dsums, double count, const c3d_bn_ptrs& bn, const float* mr, int C, int Cp, float* out) {
+      return prof_call("c3d_bn_bwd_coef", 0.0, st, [&] {
+        return c3d_bn_bwd_coef(dsums, 1, count, bn.gamma, mr, C, Cp, out, bn.dgamma, bn.dbeta, st); });
+    };
+    // ---- y = relu(bn_c(c) + shortcut)
+    RC(prof_call("c3d_block_out_bwd", (double)G.Mo * G.Cop * (scbn ? 5 : 4) * e, st, [&] {
+      return c3d_block_out_bwd(cur_dy, y, c, scbn ? sc : nullptr, g, mr_c, scbn ? mr_1 : nullptr, dsums_c,
+                               scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, st); }));
+    if (!consb) RC(coef(dsums_c, (double)G.Mo, k.bn_c, mr_c, G.Co, G.Cop, coef_c));
     // ---- conv_c data gradient, Swish / SE backward in the epilogue; weight gradient on the side stream (it needs
-    //      coef_c, not the data gradient: it is forked BEFORE the data-gradient launch; C3D_WGC_EARLY=0 forks it after)
-    auto wgrad_c = [&](hipStream_t s2) {
+    //      coef_c, not the data gradient: it is forked BEFORE the data-gradient launch)
+    RC(side_run(st, [&](hipStream_t s2) {
       WgCall w(g, b, k.dw_c, wgws, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
       w.a.p2 = c; w.a.p_coef = coef_c; w.a.q_mode = C3D_PRO_BN_SE_SWISH; w.a.q_ss = ss_b; w.a.q_gate = gate;
       w.a.rows_per_sample = rps;
       if (consb) w.a.p_fin = fin_coef_consume(dsums_c, k.bn_c, (double)G.Mo, mr_c, false);
-      return c3d_pw_wgrad(&w.a, s2);
-    };
-    static const bool wgc_early = !(getenv("C3D_WGC_EARLY") && atoi(getenv("C3D_WGC_EARLY")) == 0);
-    if (wgc_early) RC(side_run(st, wgrad_c));
+      return wg_launch(w.a, s2);
+    }));
     {
       PwCall p(g, k.w_c, t1, G.Mo, G.Co, G.Ci, 1, G.Ci, dt);
       p.a.x2 = c; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_c;
       if (consb) p.a.fin = fin_coef_consume(dsums_c, k.bn_c, (double)G.Mo, mr_c, true);
       p.a.epi_mode = C3D_EPI_SWISH_SE_BWD; p.a.e1 = b; p.a.epi_p = ss_b; p.a.epi_gate = gate; p.a.epi_q = mr_b;
       p.a.stats = nc3; p.a.rows_per_sample = rps; p.a.w_img = imgp(F.img_ct);
-      RC(c3d_pw_gemm(&p.a, st));
+      RC(pw_launch(p.a, st));
     }
-    if (!wgc_early) RC(side_run(st, wgrad_c));
-    if (!wi.skip(3))
-    RC(c3d_se_bn_bwd_coef(nc3, nc_b, B, (double)rps, k.bn_b.gamma, mr_b, ss_b, G.Ci, G.Cip, G.se ? k.se_w1 : nullptr,
-                          k.se_w2, gate, hid, G.Cr, cA, cC, cB, k.bn_b.dgamma, k.bn_b.dbeta, k.dse_w1, k.dse_b1,
-                          k.dse_w2, k.dse_b2, st));
-    // ---- depthwise conv_b
-    // (the depthwise weight gradient needs the coefficients, not the data gradient: forked first; C3D_DWWG_EARLY=0 forks it after)
-    auto wgrad_b = [&](hipStream_t s2) {
-      return c3d_dw333_wgrad(t1, b, cA, cB, cC, a, ss_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, s2);
-    };
-    static const bool dwwg_early = !(getenv("C3D_DWWG_EARLY") && atoi(getenv("C3D_DWWG_EARLY")) == 0);
-    // stride 1: data gradient and weight gradient in ONE pass over t1, b, a (csrc/dw_bwd_fused.hip); C3D_DW_FUSED=0: the pair
-    static const bool dw_fused_on = !(getenv("C3D_DW_FUSED") && atoi(getenv("C3D_DW_FUSED")) == 0);
-    const bool dw_fused = dw_fused_on && G.s == 1 && !fold;
-    if (dw_fused) {
-      RC(c3d_dw333_bwd_fused(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, dt, st));
+    RC(prof_call("c3d_se_bn_bwd_coef", 0.0, st, [&] {
+      return c3d_se_bn_bwd_coef(nc3, nc_b, B, (double)rps, k.bn_b.gamma, mr_b, ss_b, G.Ci, G.Cip, G.se ? k.se_w1 : nullptr,
+                                k.se_w2, gate, hid, G.Cr, cA, cC, cB, k.bn_b.dgamma, k.bn_b.dbeta, k.dse_w1, k.dse_b1,
+                                k.dse_w2, k.dse_b2, st); }));
+    // ---- depthwise conv_b.  Stride 1: data gradient and weight gradient in ONE pass over t1, b, a
+    //      (csrc/dw_bwd_fused.hip).  Stride 2 (first block of a stage): the pair, the weight gradient forked first on
+    //      the side stream (it needs the coefficients, not the data gradient).
+    if (G.s == 1) {
+      RC(prof_call("c3d_dw333_bwd_fused", ((double)G.Mo * 2 + (double)G.M * 2) * G.Cip * e, st, [&] {
+        return c3d_dw333_bwd_fused(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, dt, st); }));
     } else {
-    if (dwwg_early) RC(side_run(st, wgrad_b));
-    if (fold) {
-      const c3d_bn_fin fa = fin_bwd(tick + 1, k.bn_a, (double)G.M, coef_a, mr_a);
-      RC(c3d_dw333_bwd_data_fin(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, &fa, st));
-    } else {
-      RC(c3d_dw333_bwd_data(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st));
+      RC(side_run(st, [&](hipStream_t s2) {
+        return prof_call("c3d_dw333_wgrad", ((double)G.Mo * 2 + (double)G.M) * G.Cip * e, s2, [&] {
+          return c3d_dw333_wgrad(t1, b, cA, cB, cC, a, ss_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, s2); });
+      }));
+      RC(prof_call("c3d_dw333_bwd_data", ((double)G.Mo * 2 + (double)G.M * 2) * G.Cip * e, st, [&] {
+        return c3d_dw333_bwd_data(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st); }));
     }
-    if (!dwwg_early) RC(side_run(st, wgrad_b));
-    }
-    if (!fold && !consb && !wi.skip(0))
-      RC(c3d_bn_bwd_coef(dsums_a, 1, (double)G.M, k.bn_a.gamma, mr_a, G.Ci, G.Cip, coef_a, k.bn_a.dgamma, k.bn_a.dbeta, st));
+    if (!consb) RC(coef(dsums_a, (double)G.M, k.bn_a, mr_a, G.Ci, G.Cip, coef_a));
     // ---- shortcut branch
     const void* res = g;
     int res_mode = 0;
@@ -752,13 +732,11 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       PwCall p(g, k.w_sc, dxs, G.Mo, G.Co, G.Cin, 1, G.Cin, dt);
       p.a.w_img = imgp(F.img_st);
       if (scbn) {
-        if (!fold && !consb && !wi.skip(0))
-          RC(c3d_bn_bwd_coef(dsums_1, 1, (double)G.Mo, k.bn_sc.gamma, mr_1, G.Co, G.Cop, coef_1, k.bn_sc.dgamma,
-                             k.bn_sc.dbeta, st));
+        if (!consb) RC(coef(dsums_1, (double)G.Mo, k.bn_sc, mr_1, G.Co, G.Cop, coef_1));
         p.a.x2 = sc; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_1;
         if (consb) p.a.fin = fin_coef_consume(dsums_1, k.bn_sc, (double)G.Mo, mr_1, true);
       }
-      RC(c3d_pw_gemm(&p.a, st));
+      RC(pw_launch(p.a, st));
       RC(side_run(st, [&](hipStream_t s2) {
         WgCall w(g, xin, k.dw_sc, wgws, G.Mo, G.Cin, G.Co, G.Cin, 1, dt);
         if (scbn) {
@@ -766,34 +744,75 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
           if (consb) w.a.p_fin = fin_coef_consume(dsums_1, k.bn_sc, (double)G.Mo, mr_1, false);
         }
         w.a.row_mode = rm; w.a.H = G.H; w.a.W = G.W;
-        return c3d_pw_wgrad(&w.a, s2);
+        return wg_launch(w.a, s2);
       }));
       res = dxs;
       res_mode = G.s == 2 ? 1 : 0;
     }
     // ---- conv_a data gradient (+ shortcut gradient in the epilogue) and weight gradient (forked first: it needs the
     //      coefficients, not the data gradient)
-    auto wgrad_a = [&](hipStream_t s2) {
+    RC(side_run(st, [&](hipStream_t s2) {
       WgCall w(t2, xin, k.dw_a, wgws, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
       w.a.p2 = a; w.a.p_coef = coef_a;
       if (consb) w.a.p_fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, false);
-      return c3d_pw_wgrad(&w.a, s2);
-    };
-    if (wgc_early) RC(side_run(st, wgrad_a));
+      return wg_launch(w.a, s2);
+    }));
     {
       PwCall p(t2, k.w_a, dx, G.M, G.Ci, G.Cin, 1, G.Cin, dt);
       p.a.x2 = a; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_a;
       if (consb) p.a.fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, true);
       p.a.epi_mode = C3D_EPI_ADD; p.a.e1 = res; p.a.res_mode = res_mode; p.a.H = G.H; p.a.W = G.W;
       p.a.w_img = imgp(F.img_at);
-      RC(c3d_pw_gemm(&p.a, st));
+      RC(pw_launch(p.a, st));
     }
-    if (!wgc_early) RC(side_run(st, wgrad_a));
     // the side stream may lag by ring-1 blocks: block i-1 reuses the ring slot of block i-1+ring
     lag.push_back(side_mark());
     if ((int)lag.size() >= bwd_ring()) { RC(side_join(st, lag.front())); lag.pop_front(); }
     cur_dy = dx;
   }
+  return 0;
+}
+
+// ---- profile / runtime switches --------------------------------------------------------------------------------
+int c3d_option_stem_mfma = 1, c3d_option_convt_mfma = 1;   // read by stem.hip / decoder.hip (launch_hints.h)
+
+extern "C" int c3d_set_option(int32_t option, int32_t value) {
+  switch (option) {
+    case C3D_OPT_SIDE_STREAM: g_side_on = value ? 1 : 0; return 0;
+    case C3D_OPT_STEM_MFMA: c3d_option_stem_mfma = value ? 1 : 0; return 0;
+    case C3D_OPT_CONVT_MFMA: c3d_option_convt_mfma = value ? 1 : 0; return 0;
+    default: return C3D_E_BADARG;
+  }
+}
+
+extern "C" int c3d_prof_begin(int32_t flags) {
+  for (ProfRec& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof.clear();
+  g_prof_flags = flags & 3;
+  return 0;
+}
+
+extern "C" int c3d_prof_end(c3d_prof_row* rows, int32_t cap, int32_t* n_rows) {
+  g_prof_flags = -1;
+  if (!n_rows || (cap > 0 && !rows)) return C3D_E_BADARG;
+  HIPRC(hipDeviceSynchronize());
+  int n = 0;
+  for (ProfRec& r : g_prof) {
+    float ms = 0.f;
+    HIPRC(hipEventElapsedTime(&ms, r.e0, r.e1));
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    int j = 0;
+    while (j < n && std::strncmp(rows[j].name, r.name, sizeof(rows[j].name)) != 0) ++j;
+    if (j == n) {
+      if (n >= cap) continue;   // table full: the row is dropped (callers pass cap >= 256)
+      std::memset(&rows[n], 0, sizeof(rows[n]));
+      std::snprintf(rows[n].name, sizeof(rows[n].name), "%s", r.name);
+      ++n;
+    }
+    rows[j].launches += 1; rows[j].ms_total += ms; rows[j].bytes_total += r.bytes;
+  }
+  g_prof.clear();
+  *n_rows = n;
   return 0;
 }
 

@@ -451,7 +451,7 @@ extern "C" int c3d_stem_fwd(const float* x, const float* w_t, const float* w_xy,
   StemGeom g{B, T, H, W};
   const size_t lds = (27 * ST_C + 5 * ST_C + 6 * 3 * 16 + (size_t)ST_CI * T * ST_IH * ST_IW) * sizeof(float);
   const int ntiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
-  static const int env_tpw = getenv("C3D_STEM_FWD_TPW") ? atoi(getenv("C3D_STEM_FWD_TPW")) : 0;   // tuning knob
+  static const int env_tpw = c3d_env("C3D_STEM_FWD_TPW") ? atoi(c3d_env("C3D_STEM_FWD_TPW")) : 0;   // tuning knob
   int tpw = 16;
   while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * B < 1024) tpw >>= 1;   // keep ~4 workgroups per CU
   if (env_tpw > 0) tpw = env_tpw;
@@ -480,7 +480,7 @@ extern "C" int c3d_stem_bwd_dv(const float* x, const float* w_t, const float* w_
   const int ntiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
   // one workgroup (6 waves, ~216 VGPRs) fits per CU and each ends with 120 same-address atomics: walks as long as
   // 2 workgroups per CU allow
-  static const int env_tpw = getenv("C3D_STEM_DV_TPW") ? atoi(getenv("C3D_STEM_DV_TPW")) : 0;   // tuning knob
+  static const int env_tpw = c3d_env("C3D_STEM_DV_TPW") ? atoi(c3d_env("C3D_STEM_DV_TPW")) : 0;   // tuning knob
   int tpw = 64;
   while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * B < 2L * 256) tpw >>= 1;
   if (env_tpw > 0) tpw = env_tpw;

@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-bool c3d_stem_mfma_enabled();   // C3D_STEM_MFMA=0 selects the scalar-FMA kernels
+bool c3d_stem_mfma_enabled();   // c3d_set_option(C3D_OPT_STEM_MFMA, 0) selects the scalar-FMA kernels
 int c3d_stem_fwd_mfma(const float* x, const float* w_t, const float* w_xy, void* u, double* sums, int B, int T, int H,
                       int W, int dtype, hipStream_t s);
 int c3d_stem_bwd_dv_mfma(const float* x, const float* w_t, const float* w_xy, const void* g0, const void* u,

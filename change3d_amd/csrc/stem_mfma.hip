@@ -19,6 +19,7 @@
 //                perception frames (3 outputs per pixel: VALU)
 #include "common.h"
 #include "stem_mfma.h"
+#include "launch_hints.h"
 #include <cstdlib>
 #include "../../include/change3d_hip.h"
 
@@ -525,7 +526,7 @@ template <typename T, int TT>
 int fwd_t(const float* x, const float* w_t, const float* w_xy, void* u, double* sums, const Geom& g, hipStream_t s) {
   const size_t lds = (2 * 4 * 2 * 32 + (size_t)SCI * TT * IHW) * sizeof(float);
   const int ntiles = ((g.W + TW - 1) / TW) * ((g.H + TH - 1) / TH);
-  static const int env_tpw = getenv("C3D_STEM_FWD_TPW") ? atoi(getenv("C3D_STEM_FWD_TPW")) : 0;   // tuning knob
+  static const int env_tpw = c3d_env("C3D_STEM_FWD_TPW") ? atoi(c3d_env("C3D_STEM_FWD_TPW")) : 0;   // tuning knob
   int tpw = 8;
   while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * g.B < 1024) tpw >>= 1;   // keep ~4 workgroups per CU
   if (env_tpw > 0) tpw = env_tpw;
@@ -539,7 +540,7 @@ int dv_t(const float* x, const float* w_t, const float* w_xy, const void* g0, co
          float* dw_xy, const Geom& g, hipStream_t s) {
   const size_t lds = (4 * 5 * 32 + (size_t)SCI * TT * IHW) * sizeof(float);
   const int ntiles = ((g.W + TW - 1) / TW) * ((g.H + TH - 1) / TH);
-  static const int env_tpw = getenv("C3D_STEM_DV_TPW") ? atoi(getenv("C3D_STEM_DV_TPW")) : 0;   // tuning knob
+  static const int env_tpw = c3d_env("C3D_STEM_DV_TPW") ? atoi(c3d_env("C3D_STEM_DV_TPW")) : 0;   // tuning knob
   int tpw = 16;   // every workgroup ends with 120 same-address atomics
   while (tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * g.B < 2L * 256) tpw >>= 1;
   if (env_tpw > 0) tpw = env_tpw;
@@ -588,10 +589,7 @@ int wx_t(const float* x, const float* w_t, const void* dv, float* dw_t, float* d
 
 }  // namespace
 
-bool c3d_stem_mfma_enabled() {
-  const char* e = getenv("C3D_STEM_MFMA");   // read per call: tools/stem_compare.py toggles it inside one process
-  return !(e && atoi(e) == 0);
-}
+bool c3d_stem_mfma_enabled() { return c3d_option_stem_mfma != 0; }
 
 int c3d_stem_fwd_mfma(const float* x, const float* w_t, const float* w_xy, void* u, double* sums, int B, int T, int H,
                       int W, int dtype, hipStream_t s) {

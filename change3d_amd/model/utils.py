@@ -313,6 +313,7 @@ class FusedAdam:
         return lr, bc1, bc2s
 
     def launch(self, lr=0.0, bc1=1.0, bc2s=1.0):
+        ops.bump_weights_version()   # in-place parameter update: folded-BatchNorm copies made earlier are stale
         g = self.param_groups[0]
         b1, b2 = g["betas"]
         a = self.arena

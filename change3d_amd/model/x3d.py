@@ -211,269 +211,11 @@ class X3DResBlock(nn.Module):
         self.branch2 = b2
 
 
-class _AccPool:
-    """One zero-filled f64 buffer per stage pass; blocks take their accumulator sets from it (one fill
-    kernel per stage instead of one per block)."""
-
-    def __init__(self, n, dev):
-        self.buf, self.off = torch.zeros(n, dtype=torch.float64, device=dev), 0
-
-    def take(self, n):
-        v = self.buf[self.off:self.off + n]
-        self.off += n
-        assert self.off <= self.buf.numel()
-        return v
-
-
-def _n_acc_fwd(blk, B):
-    S = ops.STAT_STRIPES
-    return (S * 2 * blk.cinner + B * cpad(blk.cinner) * 2 + S * 2 * blk.cout
-            + (S * 2 * blk.cout if blk.branch1_norm is not None else 0) + 2)
-
-
-def _n_acc_bwd(blk, B):
-    S = ops.STAT_STRIPES
-    return 4 * blk.cout + B * cpad(blk.cinner) * 3 + S * 2 * blk.cinner + 2   # upper bound (shortcut BN or not)
-
-
-def _block_forward(blk, x, B, T, H, W, training, act_dtype, pool=None, imgs=None):
-    """x: [B,T,H,W,Cin] contiguous.  Returns (y, saved-for-backward dict)."""
-    dev, dt = x.device, ops.dt_code(act_dtype)
-    b2 = blk.branch2
-    Cin, Ci, Co, s = blk.cin, blk.cinner, blk.cout, blk.stride
-    Cip, Cop = cpad(Ci), cpad(Co)
-    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
-    M, Mo = B * T * H * W, B * T * Ho * Wo
-    se = b2.norm_b[1] if blk.use_se else None
-    has_bn1 = blk.branch1_norm is not None
-    # f64 accumulators in one zeroed buffer
-    S = ops.STAT_STRIPES  # pointwise-GEMM statistics are accumulated in S striped sets
-    n_acc = S * 2 * Ci + B * Cip * 2 + S * 2 * Co + (S * 2 * Co if has_bn1 else 0) + 2
-    acc = pool.take(n_acc) if pool is not None else torch.zeros(n_acc, dtype=torch.float64, device=dev)
-    sums_a, o = acc[:S * 2 * Ci], S * 2 * Ci
-    nc_b, o = acc[o:o + B * Cip * 2], o + B * Cip * 2
-    sums_c, o = acc[o:o + S * 2 * Co], o + S * 2 * Co
-    sums_1 = acc[o:o + S * 2 * Co] if has_bn1 else None
-    tick = acc[n_acc - 2:].view(torch.int32)   # last-workgroup tickets (zeroed with the accumulators)
-    fold = training and ops.FOLD_FIN           # BatchNorm finalised by the producer's last workgroup
-    epi = ops.EPI_STATS if training else ops.EPI_STORE
-
-    a = torch.empty((M, Cip), dtype=act_dtype, device=dev)
-    ss_a, mr_a = _f32(2 * Cip, dev), _f32(2 * Cip, dev)
-    wi = (lambda conv, tr: imgs.get((id(conv), tr))) if imgs else (lambda conv, tr: None)   # packed weight images
-    ops.pw_gemm(x, b2.conv_a.weight, a, M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt, epi_mode=epi, stats=sums_a,
-                w_img=wi(b2.conv_a, False),
-                fin=ops.fin_fwd(tick, 0, b2.norm_a, training, M, ss_a, mr_a) if fold else None)
-    if not fold:
-        ops.bn_finalize(sums_a, M, b2.norm_a, Ci, ss_a, mr_a, training, stripes=S)
-
-    b = torch.empty((Mo, Cip), dtype=act_dtype, device=dev)
-    ops.dw_fwd(a, ss_a, b2.conv_b.weight, b, nc_b, B, T, H, W, Ci, s, dt)
-    ss_b, mr_b = _f32(2 * Cip, dev), _f32(2 * Cip, dev)
-    gate = _f32(B * Cip, dev) if se is not None else None
-    hid = _f32(B * se.block[0].weight.shape[0], dev) if se is not None else None
-    ops.bn_se_finalize(nc_b, B, T * Ho * Wo, b2.norm_b[0], se, Ci, ss_b, mr_b, gate, hid, training)
-
-    c = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
-    ss_c, mr_c = _f32(2 * Cop, dev), _f32(2 * Cop, dev)
-    ops.pw_gemm(b, b2.conv_c.weight, c, M=Mo, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH,
-                pro_p=ss_b, pro_gate=gate, rows_per_sample=T * Ho * Wo, epi_mode=epi, stats=sums_c,
-                w_img=wi(b2.conv_c, False),
-                fin=ops.fin_fwd(tick, 1, b2.norm_c, training, Mo, ss_c, mr_c) if fold else None)
-    if not fold:
-        ops.bn_finalize(sums_c, Mo, b2.norm_c, Co, ss_c, mr_c, training, stripes=S)
-
-    ss_1 = mr_1 = None
-    if blk.branch1_conv is not None:
-        sc = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
-        if has_bn1:
-            ss_1, mr_1 = _f32(2 * Cop, dev), _f32(2 * Cop, dev)
-        ops.pw_gemm(x, blk.branch1_conv.weight, sc, M=Mo, K=Cin, N=Co, w_sn=Cin, w_sk=1, dtype=dt,
-                    row_mode=ops.ROWS_STRIDE2 if s == 2 else ops.ROWS_DENSE, H=H, W=W,
-                    epi_mode=epi if has_bn1 else ops.EPI_STORE, stats=sums_1, w_img=wi(blk.branch1_conv, False),
-                    fin=ops.fin_fwd(tick, 2, blk.branch1_norm, training, Mo, ss_1, mr_1) if (fold and has_bn1) else None)
-        if has_bn1:
-            if not fold:
-                ops.bn_finalize(sums_1, Mo, blk.branch1_norm, Co, ss_1, mr_1, training, stripes=S)
-            mode = ops.SC_BN
-        else:
-            mode = ops.SC_RAW
-    else:
-        sc, mode = x, ops.SC_IDENTITY
-    y = torch.empty((B, T, Ho, Wo, Cop), dtype=act_dtype, device=dev)
-    ops.block_out_fwd(c, ss_c, sc, ss_1, mode, y, Mo, Cop, dt)
-    saved = dict(x=x, a=a, b=b, c=c, sc=sc if blk.branch1_conv is not None else None, y=y, ss_a=ss_a, mr_a=mr_a,
-                 ss_b=ss_b, mr_b=mr_b, gate=gate, hid=hid, mr_c=mr_c, mr_1=mr_1, nc_b=nc_b, mode=mode,
-                 dims=(B, T, H, W, Ho, Wo))
-    return y, saved
-
-
-def _block_backward(blk, dy, sv, act_dtype, pool=None, imgs=None):
-    """dy: [B,T,Ho,Wo,Co] contiguous.  Returns dx [B,T,H,W,Cin]; parameter grads accumulate in .grad."""
-    dev, dt = dy.device, ops.dt_code(act_dtype)
-    b2 = blk.branch2
-    Cin, Ci, Co, s = blk.cin, blk.cinner, blk.cout, blk.stride
-    Cip, Cop, Cinp = cpad(Ci), cpad(Co), cpad(Cin)
-    B, T, H, W, Ho, Wo = sv["dims"]
-    M, Mo = B * T * H * W, B * T * Ho * Wo
-    se = b2.norm_b[1] if blk.use_se else None
-    mode = sv["mode"]
-    x, a, b, c, sc, y = sv["x"], sv["a"], sv["b"], sv["c"], sv["sc"], sv["y"]
-    S = ops.STAT_STRIPES
-    n_acc = 2 * Co + (2 * Co if mode == ops.SC_BN else 0) + B * Cip * 3 + S * 2 * Ci + 2
-    acc = pool.take(n_acc) if pool is not None else torch.zeros(n_acc, dtype=torch.float64, device=dev)
-    tick = acc[n_acc - 2:].view(torch.int32)
-    fold = ops.FOLD_FIN
-    dsums_c, o = acc[:2 * Co], 2 * Co
-    dsums_1 = None
-    if mode == ops.SC_BN:
-        dsums_1, o = acc[o:o + 2 * Co], o + 2 * Co
-    nc3, o = acc[o:o + B * Cip * 3], o + B * Cip * 3
-    dsums_a = acc[o:o + S * 2 * Ci]
-
-    # ---- y = relu(bn_c(c) + shortcut)
-    g = torch.empty((Mo, Cop), dtype=act_dtype, device=dev)
-    coef_c = _f32(3 * Cop, dev)
-    coef_1 = _f32(3 * Cop, dev) if mode == ops.SC_BN else None
-    if fold:
-        ops.block_out_bwd_fin(dy, y, c, sc if mode == ops.SC_BN else None, g, sv["mr_c"],
-                              sv["mr_1"] if mode == ops.SC_BN else None, dsums_c, dsums_1, Mo, Co, dt,
-                              ops.fin_bwd(tick, 0, b2.norm_c, Mo, coef_c, sv["mr_c"]),
-                              ops.fin_bwd(tick, 0, blk.branch1_norm, Mo, coef_1, sv["mr_1"]) if mode == ops.SC_BN else None)
-    else:
-        ops.block_out_bwd(dy, y, c, sc if mode == ops.SC_BN else None, g, sv["mr_c"],
-                          sv["mr_1"] if mode == ops.SC_BN else None, dsums_c, dsums_1, Mo, Co, dt)
-        ops.bn_bwd_coef(dsums_c, Mo, b2.norm_c, sv["mr_c"], Co, coef_c)
-    # ---- conv_c (data + weight), Swish / SE backward in the epilogue
-    t1 = torch.empty((Mo, Cip), dtype=act_dtype, device=dev)
-    wi = (lambda conv: imgs.get((id(conv), True))) if imgs else (lambda conv: None)   # transposed weight images
-    ops.pw_gemm(g, b2.conv_c.weight, t1, M=Mo, K=Co, N=Ci, w_sn=1, w_sk=Ci, dtype=dt, x2=c, pro_mode=ops.PRO_AFFINE2,
-                w_img=wi(b2.conv_c),
-                pro_p=coef_c, epi_mode=ops.EPI_SWISH_SE_BWD, e1=b, epi_p=sv["ss_b"], epi_gate=sv["gate"], epi_q=sv["mr_b"], stats=nc3,
-                rows_per_sample=T * Ho * Wo)
-    gw_c = ops.grad_of(b2.conv_c.weight)
-    ops.side_run(lambda: ops.pw_wgrad(g, b, gw_c, M=Mo, K=Ci, N=Co, dw_sn=Ci, dw_sk=1, dtype=dt, p2=c,
-                                  p_coef=coef_c, q_mode=ops.PRO_BN_SE_SWISH, q_ss=sv["ss_b"], q_gate=sv["gate"],
-                                  rows_per_sample=T * Ho * Wo),
-             g, b, c, coef_c, sv["ss_b"], sv["gate"])
-    cA, cC, cB = _f32(Cip, dev), _f32(Cip, dev), _f32(B * Cip, dev)
-    ops.se_bn_bwd_coef(nc3, sv["nc_b"], B, T * Ho * Wo, b2.norm_b[0], sv["mr_b"], sv["ss_b"], se, sv["gate"],
-                       sv["hid"], Ci, cA, cC, cB)
-    # ---- depthwise conv_b
-    t2 = torch.empty((M, Cip), dtype=act_dtype, device=dev)
-    # (c3d_dw333_bwd, the single-pass fused variant, is exported and tested but currently slower than
-    # the split pair on MI355X — LDS-read bound; see DESIGN.md "what comes next")
-    coef_a = _f32(3 * Cip, dev)
-    if fold:
-        ops.dw_bwd_data_fin(t1, b, cA, cB, cC, b2.conv_b.weight, a, sv["ss_a"], sv["mr_a"], t2, dsums_a, B, T, H, W, Ci, s, dt,
-                            ops.fin_bwd(tick, 1, b2.norm_a, M, coef_a, sv["mr_a"]))
-    else:
-        ops.dw_bwd_data(t1, b, cA, cB, cC, b2.conv_b.weight, a, sv["ss_a"], sv["mr_a"], t2, dsums_a, B, T, H, W, Ci, s, dt)
-    gw_b = ops.grad_of(b2.conv_b.weight)
-    ops.side_run(lambda: ops.dw_wgrad(t1, b, cA, cB, cC, a, sv["ss_a"], gw_b, B, T, H, W, Ci, s, dt),
-             t1, b, cA, cB, cC, a, sv["ss_a"])
-    if not fold:
-        ops.bn_bwd_coef(dsums_a, M, b2.norm_a, sv["mr_a"], Ci, coef_a, stripes=1)
-    # ---- shortcut branch
-    dx = torch.empty((B, T, H, W, Cinp), dtype=act_dtype, device=dev)
-    if blk.branch1_conv is not None:
-        rm = ops.ROWS_STRIDE2 if s == 2 else ops.ROWS_DENSE
-        dxs = torch.empty((Mo, Cinp), dtype=act_dtype, device=dev)
-        if mode == ops.SC_BN:
-            if not fold:
-                ops.bn_bwd_coef(dsums_1, Mo, blk.branch1_norm, sv["mr_1"], Co, coef_1)
-            ops.pw_gemm(g, blk.branch1_conv.weight, dxs, M=Mo, K=Co, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=sc,
-                        w_img=wi(blk.branch1_conv),
-                        pro_mode=ops.PRO_AFFINE2, pro_p=coef_1)
-            gw_1 = ops.grad_of(blk.branch1_conv.weight)
-            ops.side_run(lambda: ops.pw_wgrad(g, x, gw_1, M=Mo, K=Cin, N=Co, dw_sn=Cin, dw_sk=1,
-                                          dtype=dt, p2=sc, p_coef=coef_1, row_mode=rm, H=H, W=W), g, x, sc, coef_1)
-        else:
-            ops.pw_gemm(g, blk.branch1_conv.weight, dxs, M=Mo, K=Co, N=Cin, w_sn=1, w_sk=Cin, dtype=dt,
-                        w_img=wi(blk.branch1_conv))
-            gw_1 = ops.grad_of(blk.branch1_conv.weight)
-            ops.side_run(lambda: ops.pw_wgrad(g, x, gw_1, M=Mo, K=Cin, N=Co, dw_sn=Cin, dw_sk=1,
-                                          dtype=dt, row_mode=rm, H=H, W=W), g, x)
-        res, res_mode = dxs, (1 if s == 2 else 0)
-    else:
-        res, res_mode = g, 0
-    # ---- conv_a (data + weight); the shortcut gradient is added in the epilogue
-    ops.pw_gemm(t2, b2.conv_a.weight, dx, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=a, w_img=wi(b2.conv_a),
-                pro_mode=ops.PRO_AFFINE2, pro_p=coef_a, epi_mode=ops.EPI_ADD, e1=res, res_mode=res_mode, H=H, W=W)
-    gw_a = ops.grad_of(b2.conv_a.weight)
-    ops.side_run(lambda: ops.pw_wgrad(t2, x, gw_a, M=M, K=Cin, N=Ci, dw_sn=Cin, dw_sk=1, dtype=dt, p2=a,
-                                  p_coef=coef_a), t2, x, a, coef_a)
-    return dx
-
-
-def _pack_stage_images(stage):
-    """LDS images of the stage's pointwise weights, both orientations, in one buffer and one launch per 64
-    (`c3d_pw_pack_weights`; the C++ stage driver does the same inside `c3d_stage_fwd`).  Keys: (id(conv), transposed)."""
-    dt = ops.dt_code(stage.act_dtype)
-    plan, total = [], 0
-    for blk in stage.res_blocks:
-        for conv, n_out, n_in in ((blk.branch2.conv_a, blk.cinner, blk.cin), (blk.branch2.conv_c, blk.cout, blk.cinner),
-                                  (blk.branch1_conv, blk.cout, blk.cin)):
-            if conv is None:
-                continue
-            for tr in (False, True):
-                N, K, sn, sk = (n_in, n_out, 1, n_in) if tr else (n_out, n_in, n_in, 1)
-                nb = ops.pw_weight_image_bytes(N, K, dt)
-                if nb:
-                    plan.append((conv, tr, N, K, sn, sk, total, nb))
-                    total += (nb + 255) // 256 * 256
-    if not plan:
-        return None
-    buf = torch.empty(total, dtype=torch.uint8, device=plan[0][0].weight.device)
-    imgs = {(id(conv), tr): buf[off:off + nb] for conv, tr, N, K, sn, sk, off, nb in plan}
-    ops.pw_pack_weights([(conv.weight, imgs[(id(conv), tr)], N, K, sn, sk) for conv, tr, N, K, sn, sk, off, nb in plan], dt)
-    return imgs
-
-
-class _StageFnPy(torch.autograd.Function):
-    """Per-kernel launch path (one ctypes call per kernel): used when per-kernel profiling / tracing is on
-    (`ops.PROFILE`, `ops.TRACE`) or `C3D_PY_STAGE=1`; the product path is `_StageFn` (C++ stage driver)."""
-
-    @staticmethod
-    def forward(ctx, x, anchor, stage):
-        ops.require_gpu(x, "stage input")
-        B, C, T, H, W = x.shape
-        cur = to_ndhwc(x.detach()).to(stage.act_dtype)
-        keep = any(ctx.needs_input_grad)  # (also True under no_grad: this per-kernel path is for profiling only)
-        saved = []
-        pool = _AccPool(sum(_n_acc_fwd(blk, B) for blk in stage.res_blocks), cur.device)
-        imgs = _pack_stage_images(stage) if ops.PW_IMG else None
-        for blk in stage.res_blocks:
-            cur, sv = _block_forward(blk, cur, B, T, H, W, stage.training, stage.act_dtype, pool, imgs)
-            H, W = sv["dims"][4], sv["dims"][5]
-            if keep:
-                saved.append(sv)
-        ctx.stage, ctx.saved, ctx.x_dtype, ctx.imgs = stage, saved, x.dtype, imgs
-        return to_logical(cur)
-
-    @staticmethod
-    def backward(ctx, dy):
-        stage, saved = ctx.stage, ctx.saved
-        cur = to_ndhwc(dy).to(stage.act_dtype)
-        pool = _AccPool(sum(_n_acc_bwd(blk, dy.shape[0]) for blk in stage.res_blocks), cur.device)
-        prev_mark = None   # side-stream weight gradients may lag the data-gradient chain by one block
-        for blk, sv in zip(reversed(list(stage.res_blocks)), reversed(saved)):
-            cur = _block_backward(blk, cur, sv, stage.act_dtype, pool, ctx.imgs)
-            ops.side_run(lambda: None, dict(sv))   # keep the saved activations alive until the side work is done
-            sv.clear()
-            if prev_mark is not None:
-                ops.side_join(prev_mark)
-            prev_mark = ops.side_mark()
-        if stage.post_backward is not None:  # data-parallel hook: this stage's grads must be final
-            ops.side_join()
-            stage.post_backward()
-        return to_logical(cur).to(ctx.x_dtype), None, None
-
-
 class _StageFn(torch.autograd.Function):
     """One residual stage = ONE C call forward and ONE backward (`c3d_stage_fwd` / `c3d_stage_bwd`,
-    csrc/stage_driver.hip): the launch sequence of `_block_forward` / `_block_backward` above runs in C++ over a
-    single workspace; weight gradients go to the driver's side stream."""
+    csrc/stage_driver.hip): the per-block launch sequence runs in C++ over a single workspace; weight gradients go
+    to the driver's side stream.  This is the only launch path: per-kernel profiles are taken by the driver itself
+    (`ops.profile_begin`, `c3d_prof_begin`)."""
 
     @staticmethod
     def forward(ctx, x, anchor, stage, grad_mode):
@@ -487,7 +229,13 @@ class _StageFn(torch.autograd.Function):
         # needs_input_grad reports requires_grad of the inputs even under torch.no_grad(); the caller's grad mode
         # (grad mode is always off inside Function.forward) is passed in explicitly
         keep = grad_mode and any(ctx.needs_input_grad)
+        if keep and not stage.training:
+            # eval-mode BatchNorm under autograd (frozen-BN fine-tuning): its backward is dx = gamma*rstd*g, not the
+            # batch-statistics form the backward kernels implement -- refuse instead of returning wrong gradients
+            raise NotImplementedError("gradients through an eval()-mode residual stage are not implemented (the backward "
+                                      "kernels implement train-mode BatchNorm); call .train() or run under torch.no_grad()")
         bn0 = stage.res_blocks[0].branch2.norm_a
+        bind.desc.flags = int(stage.driver_flags)
         bind.refresh(B, T, H, W, ops.dt_code(act), stage.training, float(bn0.momentum), float(bn0.eps), with_grads=False)
         ws_bytes, _, y_bytes, _ = bind.sizes()
         last = stage.res_blocks[-1]
@@ -500,9 +248,9 @@ class _StageFn(torch.autograd.Function):
             fold_bytes, ws_eval = ops.stage_fold_sizes(bind)
             if stage._fold is None or stage._fold.numel() != fold_bytes or stage._fold.device != x.device:
                 stage._fold, stage._fold_valid = torch.empty(fold_bytes, dtype=torch.uint8, device=x.device), False
-            if not stage._fold_valid:
+            if not stage._fold_valid or stage._fold_version != ops.weights_version():
                 ops.stage_fold_bn(bind, stage._fold)
-                stage._fold_valid = True
+                stage._fold_valid, stage._fold_version = True, ops.weights_version()
             ws = torch.empty(ws_eval, dtype=torch.uint8, device=x.device)
             ops.stage_fwd_folded(bind, stage._fold, xin, ws, y)
             return to_logical(y)
@@ -515,11 +263,15 @@ class _StageFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         stage, ws, xin, y = ctx.stage, ctx.saved_ws, ctx.xin, ctx.y
+        if ws is None:
+            raise RuntimeError("Trying to backward through a residual stage a second time: its saved activations were "
+                               "released by the first backward pass (retain_graph is not supported by the stage driver)")
         B, T, H, W = ctx.dims
         act = stage.act_dtype
         dyc = to_ndhwc(dy).to(act)
         bind = stage.binding()
         bn0 = stage.res_blocks[0].branch2.norm_a
+        bind.desc.flags = int(stage.driver_flags)
         bind.refresh(B, T, H, W, ops.dt_code(act), True, float(bn0.momentum), float(bn0.eps), with_grads=True)
         _, wb_bytes, _, dx_bytes = bind.sizes()
         wb = torch.empty(wb_bytes, dtype=torch.uint8, device=dy.device)
@@ -536,9 +288,6 @@ class _StageFn(torch.autograd.Function):
         return to_logical(dx).to(ctx.x_dtype), None, None, None
 
 
-PY_STAGE = os.environ.get("C3D_PY_STAGE", "0") == "1"
-
-
 class X3DResStage(nn.Module):
     """`blocks[1..4]` (reference model/x3d.py:331-412)."""
 
@@ -551,10 +300,13 @@ class X3DResStage(nn.Module):
         self.post_backward = None
         self._binding = None
         # eval / no-grad forward with BatchNorm folded into the conv weights.  The folded copy is rebuilt lazily
-        # after every train()/eval() switch and load_state_dict(); code that edits parameters or running statistics
-        # by hand while the module stays in eval mode must call invalidate_folded_bn().
+        # after every train()/eval() switch, load_state_dict(), .to(), and whenever the library's own in-place
+        # writers ran since it was made (FusedAdam / broadcast_module_state / ParamArena bump ops.weights_version());
+        # code that edits parameters or running statistics by hand while the module stays in eval mode must call
+        # invalidate_folded_bn().
         self.fold_bn_eval = os.environ.get("C3D_FOLD_BN", "1") != "0"
-        self._fold, self._fold_valid = None, False
+        self._fold, self._fold_valid, self._fold_version = None, False, -1
+        self.driver_flags = 0   # c3d_stage_desc.flags (ops.STAGE_*): the unfused launch sequences, for parity tests
 
     def invalidate_folded_bn(self):
         self._fold_valid = False
@@ -578,9 +330,6 @@ class X3DResStage(nn.Module):
         return self._binding
 
     def forward(self, x):
-        per_kernel = PY_STAGE or ops.PROFILE is not None or ops.TRACE is not None
-        if per_kernel:
-            return _StageFnPy.apply(x, self.res_blocks[0].branch2.conv_a.weight, self)
         return _StageFn.apply(x, self.res_blocks[0].branch2.conv_a.weight, self, torch.is_grad_enabled())
 
 

@@ -11,6 +11,8 @@ import os
 import torch
 
 from . import _lib as L
+from ._lib import (OPT_CONVT_MFMA, OPT_SIDE_STREAM, OPT_STEM_MFMA, STAGE_NO_WEIGHT_IMAGES, STAGE_SEPARATE_FINALIZE,  # noqa: F401
+                   STAGE_SEPARATE_RESIDUAL)
 from ._lib import (DT_BF16, DT_F32, EPI_ADD, EPI_STATS, EPI_STORE, EPI_SWISH_SE_BWD, PRO_AFFINE2,  # noqa: F401
                    PRO_BN_SE_SWISH, PRO_NONE, ROWS_DENSE, ROWS_FRAME, ROWS_S2SHIFT, ROWS_STRIDE2, SC_BN,
                    SC_IDENTITY, SC_NONE, SC_RAW, STAT_STRIPES)
@@ -70,24 +72,57 @@ def require_gpu(t, what="input"):
 PROFILE = None  # dict: kernel name -> list of (start_event, end_event, algorithmic_bytes) when enabled
 
 
-def profile_begin():
-    global PROFILE
+def profile_begin(serial=True, detail=False):
+    """Per-kernel HIP-event profile of everything launched until `profile_end()`: the wrappers below time their own
+    launches, the C++ stage driver times the launches it enqueues itself (`c3d_prof_begin`).  serial: weight
+    gradients run inline on the launch stream, so an event pair brackets exactly one kernel."""
+    global PROFILE, PROFILE_DETAIL, _prof_side_was, SIDE_STREAM
     PROFILE = {}
+    PROFILE_DETAIL = detail
+    _prof_side_was = SIDE_STREAM
+    if serial:
+        SIDE_STREAM = False
+    L.check(L.lib().c3d_prof_begin((1 if serial else 0) | (2 if detail else 0)), "c3d_prof_begin")
 
 
 def profile_end():
     """Returns {name: dict(launches, ms_total, bytes_total)} and disables profiling."""
-    global PROFILE
+    global PROFILE, PROFILE_DETAIL, SIDE_STREAM
     prof, PROFILE = PROFILE, None
-    torch.cuda.synchronize()
+    PROFILE_DETAIL = False
+    SIDE_STREAM = _prof_side_was
+    rows = (L.ProfRow * 512)()
+    n = C.c_int32(0)
+    L.check(L.lib().c3d_prof_end(rows, 512, C.byref(n)), "c3d_prof_end")   # synchronises the device
     out = {}
     for name, recs in (prof or {}).items():
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
         out[name] = dict(launches=len(recs), ms_total=ms, bytes_total=float(sum(b for _, _, b in recs)))
+    for r in rows[:n.value]:
+        d = out.setdefault(r.name.decode(), dict(launches=0, ms_total=0.0, bytes_total=0.0))
+        d["launches"] += r.launches
+        d["ms_total"] += r.ms_total
+        d["bytes_total"] += r.bytes_total
     return out
 
 
-PROFILE_DETAIL = False  # profile keys carry the GEMM shape/mode (tools/profile_shapes.py)
+_prof_side_was = True
+PROFILE_DETAIL = False  # profile keys carry the GEMM shape/mode (bench.py --kernel-table)
+
+
+# ---------------------------------------------------------------------------- weights version
+# Bumped by everything in this package that writes parameters or BatchNorm buffers IN PLACE without going through
+# nn.Module hooks (FusedAdam.launch, broadcast_module_state, ParamArena placement): X3DResStage compares it with the
+# version its folded-BatchNorm weights were built from, so an eval forward never runs on stale folded weights.
+_weights_version = [0]
+
+
+def weights_version():
+    return _weights_version[0]
+
+
+def bump_weights_version():
+    _weights_version[0] += 1
 
 
 # ---------------------------------------------------------------------------- side stream
@@ -100,6 +135,11 @@ SIDE_STREAM = os.environ.get("C3D_WGRAD_SIDE", "1") != "0"
 _side_streams = {}
 _side_pending = []      # (seq, done_event, tensors kept alive until the event has been waited for)
 _side_state = {"seq": 0}
+
+
+def set_option(option, value):
+    """Run-time options of the library (include/change3d_hip.h: C3D_OPT_*)."""
+    L.check(L.lib().c3d_set_option(int(option), int(value)), "c3d_set_option")
 
 
 def side_run(fn, *tensors):
@@ -201,22 +241,6 @@ def grad_of(p):
 
 
 # ----------------------------------------------------------------------------- pointwise GEMM
-FOLD_FIN = os.environ.get("C3D_FOLD_FIN", "0") == "1"   # BatchNorm finalisation by the producers' last workgroup (measured slower: off)
-PW_IMG = os.environ.get("C3D_PW_IMG", "1") != "0"       # pointwise weights as packed LDS images (c3d_pw_pack_weights), once per stage pass
-
-
-def fin_fwd(tick, idx, bn, training, count, ss, mr):
-    """c3d_bn_fin for a forward statistics producer (include/change3d_hip.h); tick: zeroed int32 tensor."""
-    f = L.BnFin()
-    f.ticket = tick.data_ptr() + 4 * idx
-    f.gamma, f.beta = _p(bn.weight), _p(bn.bias)
-    f.running_mean, f.running_var = _p(bn.running_mean), _p(bn.running_var)
-    f.nbt = _p(bn.num_batches_tracked) if training else None
-    f.ss, f.mr, f.count = _p(ss), _p(mr), float(count)
-    f.momentum, f.eps, f.training = float(bn.momentum), float(bn.eps), 1 if training else 0
-    return f
-
-
 def fin_consume(sums, bn, count, ss, mr):
     """c3d_bn_fin for the consumer-side finalisation (c3d_dw333_fwd_fin / c3d_block_out_fwd_fin): `sums` are the
     completed f64 [16][2][C] statistics of an earlier launch."""
@@ -226,15 +250,6 @@ def fin_consume(sums, bn, count, ss, mr):
     f.running_mean, f.running_var, f.nbt = _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked)
     f.ss, f.mr, f.count = _p(ss), _p(mr), float(count)
     f.momentum, f.eps, f.training = float(bn.momentum), float(bn.eps), 1
-    return f
-
-
-def fin_bwd(tick, idx, bn, count, coef, mr):
-    f = L.BnFin()
-    f.ticket = tick.data_ptr() + 4 * idx
-    f.gamma = _p(bn.weight)
-    f.running_mean, f.running_var = _p(grad_of(bn.weight)), _p(grad_of(bn.bias))   # carry dgamma / dbeta
-    f.ss, f.mr, f.count = _p(coef), _p(mr), float(count)
     return f
 
 

@@ -17,6 +17,7 @@ the head of the buffer follows at the end.  The payload is latency-bound on xGMI
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .model.utils import ParamArena, hot_path_named_params
 
 _EARLY = ("encoder.x3d.blocks.3.", "encoder.fc.3.", "decoder")
@@ -79,6 +80,7 @@ def broadcast_module_state(module, src=0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+    ops.bump_weights_version()   # in-place writes: folded-BatchNorm weights built before this are stale
 
 
 def setup_data_parallel(trainer, device, overlap=True, group=None):

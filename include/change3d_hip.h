@@ -406,12 +406,20 @@ typedef struct c3d_block_desc {
   float* dse_w1; float* dse_b1; float* dse_w2; float* dse_b2;
 } c3d_block_desc;
 
+/* c3d_stage_desc.flags: the unfused launch sequences stay callable so that the fused ones are testable against them
+ * bit for bit (tests/test_model_gpu.py::test_folded_batchnorm_launches_are_bit_identical_end_to_end).                */
+enum {
+  C3D_STAGE_SEPARATE_FINALIZE = 1,   /* c3d_bn_finalize / c3d_bn_bwd_coef launches instead of the consumers' prologues     */
+  C3D_STAGE_NO_WEIGHT_IMAGES = 2,    /* every GEMM workgroup converts the f32 weights itself (no c3d_pw_pack_weights)      */
+  C3D_STAGE_SEPARATE_RESIDUAL = 4    /* c3d_block_out_fwd launches instead of the next block's conv_a prologue             */
+};
+
 typedef struct c3d_stage_desc {
   int32_t n_blocks;
   int32_t B, T, H, W;                          /* stage INPUT extent; block 0 applies the stride        */
   int32_t dtype;                               /* activation storage type                               */
   int32_t training;                            /* 1: batch statistics (+ running-stat update), 0: eval  */
-  int32_t reserved;
+  int32_t flags;                               /* C3D_STAGE_* (0 = the fused, measured-best launch sequence) */
   float momentum, eps;                         /* BatchNorm3d momentum / eps (0.1 / 1e-5)               */
   const c3d_block_desc* blocks;                /* HOST array of n_blocks descriptors                    */
 } c3d_stage_desc;
@@ -429,6 +437,28 @@ int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws_fwd, void* y,
 int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void* y, const void* dy, void* ws_fwd, void* ws_bwd,
                   void* dx, void* stream);
 int c3d_side_join(void* stream);
+/* Run-time options of the library (process-wide; not thread-safe; all default to 1).  These are the ONLY run-time
+ * switches: the product library never reads the environment (tuning knobs exist in the -DC3D_TUNING build only).
+ *   C3D_OPT_SIDE_STREAM : 0 = weight gradients inline on the caller's stream (needed when the step is captured in a HIP
+ *                         graph, and for one-kernel-at-a-time traces)
+ *   C3D_OPT_STEM_MFMA   : 0 = scalar-FMA stem kernels (csrc/stem.hip) instead of the matrix-core ones (bit-identical
+ *                         u / dv / dx: tests/test_model_gpu.py::test_stem_mfma_kernels_equal_the_scalar_kernels)
+ *   C3D_OPT_CONVT_MFMA  : 0 = scalar ConvTranspose2d kernels on the bf16 path too                                  */
+enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2 };
+int c3d_set_option(int32_t option, int32_t value);
+/* Per-launch profile of the stage driver: between c3d_prof_begin and c3d_prof_end every kernel c3d_stage_fwd /
+ * c3d_stage_bwd enqueue is bracketed by a HIP event pair on its launch stream and billed its algorithmic bytes
+ * (the tensors it must read / write once).  flags bit 0: weight gradients inline on the main stream (an event pair
+ * then brackets exactly one kernel), bit 1: pointwise rows are keyed by shape and mode.  c3d_prof_end synchronises
+ * the device and returns one row per kernel entry (aggregated).  Not thread-safe; meant for bench.py / tools.      */
+typedef struct c3d_prof_row {
+  char name[64];
+  int32_t launches, reserved;
+  float ms_total, reserved2;
+  double bytes_total;
+} c3d_prof_row;
+int c3d_prof_begin(int32_t flags);
+int c3d_prof_end(c3d_prof_row* rows, int32_t cap, int32_t* n_rows);
 /* Eval / inference (reference scripts/train_BCD.py:92-154 `val()` under model.eval() + torch.no_grad()): BatchNorm
  * folded into the convolution weights.  c3d_stage_fold_bn writes, once per set of weights, W' = W * gamma/sqrt(var+eps)
  * (rows of conv_a / conv_b / conv_c / branch1_conv) and the remaining per-channel biases into `fold`

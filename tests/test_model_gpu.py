@@ -339,8 +339,8 @@ def test_e2e_vs_oracle_conditioned_weights_every_gradient(task):
 @pytest.mark.parametrize("T,dtype,shape", [(3, torch.float32, (2, 64, 64)), (5, torch.float32, (2, 40, 72)),
                                            (3, torch.bfloat16, (3, 128, 128)), (4, torch.bfloat16, (1, 17, 70)),
                                            (5, torch.bfloat16, (2, 64, 64))])
-def test_stem_mfma_kernels_equal_the_scalar_kernels(T, dtype, shape, monkeypatch):
-    """csrc/stem_mfma.hip against csrc/stem.hip through the same C entry points (C3D_STEM_MFMA is read per call):
+def test_stem_mfma_kernels_equal_the_scalar_kernels(T, dtype, shape):
+    """csrc/stem_mfma.hip against csrc/stem.hip through the same C entry points (c3d_set_option C3D_OPT_STEM_MFMA):
     u, dv and the input gradient are BIT-identical (v_mfma_f32_16x16x4_f32 accumulates k in order, like the FMA chain);
     sums that go through atomics or a different partial-sum grouping (statistics, weight gradients) agree to 2e-6."""
     _need_gpu()
@@ -349,7 +349,7 @@ def test_stem_mfma_kernels_equal_the_scalar_kernels(T, dtype, shape, monkeypatch
     dt = ops.dt_code(dtype)
 
     def run(mfma):
-        monkeypatch.setenv("C3D_STEM_MFMA", "1" if mfma else "0")
+        ops.set_option(ops.OPT_STEM_MFMA, 1 if mfma else 0)
         g = torch.Generator().manual_seed(3)
         x = torch.randn(B, 3, T, H, W, generator=g).to(DEV)
         w_t = (torch.randn(24, 3, 1, 3, 3, generator=g) * 0.3).to(DEV)
@@ -371,7 +371,10 @@ def test_stem_mfma_kernels_equal_the_scalar_kernels(T, dtype, shape, monkeypatch
         torch.cuda.synchronize()
         return dict(u=u, dv=dv, dP=dP), dict(sums=sums, dw_xy=dw_xy, dw_t=dw_t, dw_t2=dw_t2, dPs=dPs)
 
-    (ea, sa), (eb, sb) = run(True), run(False)
+    try:
+        (ea, sa), (eb, sb) = run(True), run(False)
+    finally:
+        ops.set_option(ops.OPT_STEM_MFMA, 1)
     for k in ea:
         assert torch.equal(ea[k], eb[k]), k
     for k in sa:
@@ -623,24 +626,36 @@ def test_e2e_bf16_tracks_f32():
             assert torch.isfinite(p.grad).all(), n
 
 
-@pytest.mark.parametrize("knob", ["C3D_FIN_CONSUMER", "C3D_PW_IMG"])
-def test_folded_batchnorm_launches_are_bit_identical_end_to_end(tmp_path, knob):
-    """Default library (BatchNorm finalisation / backward coefficients rebuilt by their consumers, csrc/bn_fin.h;
-    pointwise weights read as packed LDS images, c3d_pw_pack_weights) vs C3D_FIN_CONSUMER=0 (246 separate launches
-    per step) and vs C3D_PW_IMG=0 (every GEMM workgroup converts the f32 weights itself): the bf16 train step produces
-    the same loss, gradients, running statistics and num_batches_tracked to the last bit."""
+@pytest.mark.parametrize("flag", ["STAGE_SEPARATE_FINALIZE", "STAGE_NO_WEIGHT_IMAGES", "STAGE_SEPARATE_RESIDUAL"])
+def test_folded_batchnorm_launches_are_bit_identical_end_to_end(flag):
+    """Default launch sequence (BatchNorm finalisation / backward coefficients rebuilt by their consumers, csrc/bn_fin.h;
+    pointwise weights read as packed LDS images, c3d_pw_pack_weights; residual add in the next block's conv_a) vs the
+    unfused sequences of c3d_stage_desc.flags (246 separate finalize launches per step / every GEMM workgroup converts
+    the f32 weights itself / c3d_block_out_fwd launches): the bf16 train step produces the same loss, gradients, running
+    statistics and num_batches_tracked to the last bit."""
     _need_gpu()
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import contextlib
+    import io
+    from change3d_amd import ops, synthetic as synth
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.utils import BCEDiceLoss
+    from change3d_amd.model.x3d import X3DResStage
     outs = []
-    for mode in ("1", "0"):
-        f = str(tmp_path / f"step_{mode}.pt")
-        env = dict(os.environ, **{knob: mode})
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dump_step.py"), f, "64", "3"], env=env,
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(torch.load(f))
+    for flags in (0, getattr(ops, flag)):
+        args = synth.make_args(size=64, act_dtype=torch.bfloat16)
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            net = Trainer(args)
+        net.load_state_dict(synth.synth_state_dict(net, seed=5, mask_margin=0.25, branch_gain=0.1))
+        net = net.to(DEV).train()
+        for m in net.modules():
+            if isinstance(m, X3DResStage):
+                m.driver_flags = flags
+        pre, post, tgt = (t.to(DEV) for t in synth.synth_batch(3, 64, seed=2))
+        loss = BCEDiceLoss(net.update_bcd(pre, post), tgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append({"loss": loss.detach().cpu(), "grads": {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None},
+                     "bufs": {n: b.cpu() for n, b in net.named_buffers()}})
     a, b = outs
     assert torch.equal(a["loss"], b["loss"]) and torch.isfinite(a["loss"])
     assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 400
