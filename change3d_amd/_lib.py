@@ -127,8 +127,11 @@ SIGNATURES = {
     "c3d_cossim_bwd": (i32, [vp, vp, vp, vp, i64, i32, i64, i64, i64, i64, i64, vp, vp, vp]),
     "c3d_adam_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
     "c3d_confusion2": (i32, [vp, vp, i64, vp, vp]),
+    "c3d_hist2d": (i32, [vp, vp, i64, i32, vp, vp]),
     "c3d_build_clip": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "c3d_bcd_preprocess": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "c3d_scd_label_preprocess": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "c3d_cc_preprocess": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "c3d_cap_embed_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, i32, vp]),
     "c3d_cap_embed_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, i32, vp]),
     "c3d_cap_dropout": (i32, [vp, vp, i64, i32, f32, C.c_uint64, i32, vp]),

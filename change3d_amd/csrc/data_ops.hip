@@ -111,6 +111,71 @@ extern "C" int c3d_build_clip(const float* pre, const float* post, const float* 
   return 0;
 }
 
+// SCD labels (reference data/transforms.py:300-326 SCDTransforms.random_flip / random_exchange, :341-357 to_tensor;
+// scripts/train_SCD.py:207-213 `.long()`): label u8 [B][H][W][3] = (pre classes, post classes, change) with the same
+// flip / exchange flags as the image (c3d_bcd_preprocess handles the image: the 6-channel arithmetic is identical)
+// -> int64 [B][3][H][W]; an exchange swaps the two class maps.
+__global__ __launch_bounds__(256) void scd_label_kernel(const uint8_t* __restrict__ lab, const uint8_t* __restrict__ flags,
+                                                        int64_t* __restrict__ out, int B, int H, int W) {
+  const int64_t total = (int64_t)B * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const int64_t r = i / W;
+    const int y = (int)(r % H), b = (int)(r / H);
+    const bool fy = flags && flags[b * 3 + 0], fx = flags && flags[b * 3 + 1], ex = flags && flags[b * 3 + 2];
+    const uint8_t* p = lab + (((int64_t)b * H + (fy ? H - 1 - y : y)) * W + (fx ? W - 1 - x : x)) * 3;
+    const int64_t plane = (int64_t)H * W, o = (int64_t)b * 3 * plane + (int64_t)y * W + x;
+    out[o] = p[ex ? 1 : 0];
+    out[o + plane] = p[ex ? 0 : 1];
+    out[o + 2 * plane] = p[2];
+  }
+}
+
+// Change-captioning image pairs (reference data/dataset.py:411-424 CaptionDataset.__getitem__ + scripts/train_CC.py:466-469
+// transforms.Normalize): img u8 [B][2][3][H][W] (planar, as the HDF5 file stores them) -> pre, post f32 [B][3][H][W] =
+// Normalize(FloatTensor(u8 / 255.)) through a 3 x 256 table built by the HOST with exactly that arithmetic (f64 division,
+// rounded to f32, then f32 sub / div), so every value is bit-identical to the reference's; swap[b] != 0 exchanges the
+// pair (the TRAIN split's p = 0.3 augmentation).  8 B read / 32 B written per 4 pixels and plane.
+__global__ __launch_bounds__(256) void cc_preprocess_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ swap,
+                                                            const float* __restrict__ lut, float* __restrict__ pre,
+                                                            float* __restrict__ post, int B, int64_t hw4) {
+  __shared__ float tab[3 * 256];
+  for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) tab[i] = lut[i];
+  __syncthreads();
+  const int64_t total = (int64_t)B * 6 * hw4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = i % hw4;
+    const int pc = (int)((i / hw4) % 6), b = (int)(i / (hw4 * 6));   // pc = image (0 / 1) * 3 + channel
+    const uchar4 v = reinterpret_cast<const uchar4*>(img)[i];
+    const float* t = tab + (pc % 3) * 256;
+    const bool second = (pc >= 3) != (swap && swap[b]);
+    float* dst = (second ? post : pre) + ((int64_t)b * 3 + pc % 3) * hw4 * 4 + q * 4;
+    *reinterpret_cast<float4*>(dst) = make_float4(t[v.x], t[v.y], t[v.z], t[v.w]);
+  }
+}
+
+extern "C" int c3d_scd_label_preprocess(const uint8_t* label3, const uint8_t* flags, int64_t* out, int32_t B, int32_t H,
+                                        int32_t W, void* stream) {
+  if (!label3 || !out || B <= 0 || H <= 0 || W <= 0) return C3D_E_BADARG;
+  int64_t grid = ((int64_t)B * H * W + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  scd_label_kernel<<<dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(label3, flags, out, B, H, W);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_cc_preprocess(const uint8_t* img, const uint8_t* swap, const float* lut, float* pre, float* post,
+                                 int32_t B, int32_t H, int32_t W, void* stream) {
+  if (!img || !lut || !pre || !post || B <= 0 || H <= 0 || W <= 0 || (((int64_t)H * W) & 3)) return C3D_E_BADARG;
+  const int64_t hw4 = (int64_t)H * W / 4;
+  int64_t grid = ((int64_t)B * 6 * hw4 + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  cc_preprocess_kernel<<<dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(img, swap, lut, pre, post,
+                                                                                                     B, hw4);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int c3d_bcd_preprocess(const uint8_t* image6, const uint8_t* label, const uint8_t* flags, const float* mean6,
                                   const float* std6, float* pre, float* post, float* label_out, int32_t B, int32_t H,
                                   int32_t W, void* stream) {

@@ -39,8 +39,14 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
   lds_t* Xs = reinterpret_cast<lds_t*>(smem);                       // [64][KL]
   lds_t* Ws = Xs + WB_M * KL;                                       // [112][KL]
   float* Os = reinterpret_cast<float*>(Ws + WB_N * KL);             // [64][OL]
-  float* red = Os + WB_M * OL;                                      // STATS: [18][112][2]; SWISH_SE_BWD: [5][112][3]
-  float* Pp = red + WB_SLOTS * WB_N * 3;                            // prologue parameters [3][Kp] (scale|shift or A|B|C)
+  float* red = Os + WB_M * OL;                                      // SWISH_SE_BWD: [5][112][3] 64-bit fixed-point sums
+  float* Pp = red + WB_SLOTS * WB_N * 3 * 2;                        // prologue parameters [3][Kp] (scale|shift or A|B|C)
+  // SWISH_SE_BWD: the per-(sample, channel) sums of the workgroup are accumulated in 2^-40 FIXED POINT (64-bit integer LDS
+  // atomics): integer addition is associative, so the sums -- and through the BatchNorm / SE coefficients built from them
+  // the whole data gradient below res5 -- do not depend on the order in which the row groups arrive.  (f32 LDS atomics
+  // here made the CC encoder gradient differ by ~1e-2 between two identical bf16 runs: the sum t1*bhat nearly cancels.)
+  unsigned long long* red64 = reinterpret_cast<unsigned long long*>(red);
+  constexpr double FIX = 1099511627776.0;   // 2^40: resolution 9e-13, range +-8e6
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * WB_M;
   const int n0 = (int)blockIdx.y * WB_N;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
     *reinterpret_cast<float4*>(d) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
   }
   if (EPI == C3D_EPI_SWISH_SE_BWD) {
-    for (int i = tid; i < WB_SLOTS * WB_N * 3; i += 256) red[i] = 0.f;
+    for (int i = tid; i < WB_SLOTS * WB_N * 3; i += 256) red64[i] = 0ull;
   }
   __syncthreads();
   // ---- fused epilogue: thread = (column vector v, row group rg)
@@ -159,8 +165,10 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
     if (cur_slot >= 0 && cur_slot < WB_SLOTS) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float* d = red + ((size_t)cur_slot * WB_N + v * 8 + j) * 3;
-        atomicAdd(d, s0[j]); atomicAdd(d + 1, s1[j]); atomicAdd(d + 2, s2[j]);
+        unsigned long long* d = red64 + ((size_t)cur_slot * WB_N + v * 8 + j) * 3;
+        atomicAdd(d, (unsigned long long)__double2ll_rn((double)s0[j] * FIX));
+        atomicAdd(d + 1, (unsigned long long)__double2ll_rn((double)s1[j] * FIX));
+        atomicAdd(d + 2, (unsigned long long)__double2ll_rn((double)s2[j] * FIX));
         s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f;
       }
     }
@@ -241,7 +249,8 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
     for (int i = tid; i < WB_SLOTS * WB_N * 3; i += 256) {
       const int which = i % 3, c = (i / 3) % WB_N, slot = i / (3 * WB_N);
       const int64_t n = n_first + slot;
-      if (n <= nmax && n0 + c < Np && red[i] != 0.f) atomicAdd(a.stats + ((size_t)n * Np + n0 + c) * 3 + which, (double)red[i]);
+      const long long fx = (long long)red64[i];
+      if (n <= nmax && n0 + c < Np && fx != 0) atomicAdd(a.stats + ((size_t)n * Np + n0 + c) * 3 + which, (double)fx * (1.0 / FIX));
     }
   }
 }
@@ -252,7 +261,7 @@ int launch_wide(const c3d_pw_args& a, hipStream_t st) {
   constexpr int KC = sizeof(T) == 2 ? 64 : 32;
   constexpr int KL = KC + MM::KPAD;
   const size_t lds = (size_t)(WB_M + WB_N) * KL * sizeof(typename MM::lds_t) + (size_t)WB_M * (WB_N + 4) * 4 +
-                     (size_t)WB_SLOTS * WB_N * 3 * 4 + (size_t)3 * a.Kp * 4;
+                     (size_t)WB_SLOTS * WB_N * 3 * 8 + (size_t)3 * a.Kp * 4;
   dim3 grid((unsigned)((a.M + WB_M - 1) / WB_M), (unsigned)((a.Np + WB_N - 1) / WB_N));
   pw_wide_kernel<T, PRO, EPI><<<grid, 256, lds, st>>>(a);
   C3D_CHECK_LAUNCH();

@@ -323,6 +323,34 @@ extern "C" int c3d_confusion2(const float* prob, const float* target, int64_t n,
   return 0;
 }
 
+// n x n joint histogram hist[a][b] of two integer label maps (SCD validation: prediction x label, reference
+// model/utils.py:313-345 fast_hist / get_hist: np.bincount(n * a[k] + b[k]) over k = (0 <= a < n)).  Workgroup-local
+// counts in LDS, one 64-bit atomic per bin and workgroup.  Pairs with b outside [0, n) -- numpy's reshape would raise
+// there -- are counted in hist[n*n] so that the host wrapper can raise too.
+constexpr int HIST_MAXN = 16;
+__global__ __launch_bounds__(256) void hist2d_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t n_elems,
+                                                     int n, unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int h[HIST_MAXN * HIST_MAXN + 1];
+  for (int i = threadIdx.x; i <= n * n; i += blockDim.x) h[i] = 0u;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t av = a[i], bv = b[i];
+    if (av >= 0 && av < n) atomicAdd(&h[(bv >= 0 && bv < n) ? (int)(av * n + bv) : n * n], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= n * n; i += blockDim.x)
+    if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+extern "C" int c3d_hist2d(const int64_t* a, const int64_t* b, int64_t n_elems, int32_t n, unsigned long long* hist,
+                          void* stream) {
+  if (!a || !b || !hist || n_elems <= 0 || n < 1 || n > HIST_MAXN) return C3D_E_BADARG;
+  // (a workgroup's LDS counters are 32-bit: at most 2^32 - 1 elements per workgroup; 1024 workgroups cover 2^42)
+  hist2d_kernel<<<grid_for(n_elems, 256, 1024), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(a, b, n_elems, n, hist);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int c3d_abi_version(void) { return 1; }
 extern "C" const char* c3d_build_info(void) { return "change3d_hip gfx950 (MI355X) hipcc " __VERSION__; }
 

@@ -7,6 +7,8 @@ gradient arena and a fused Adam (`scripts/train_BCD.py:284-290` hyper-parameters
 import math
 import os
 
+import numpy as np
+
 import torch
 import torch.nn as nn
 
@@ -359,3 +361,139 @@ def clip_gradient(optimizer, grad_clip):
         for param in group["params"]:
             if param.grad is not None:
                 param.grad.data.clamp_(-grad_clip, grad_clip)
+
+
+# ------------------------------------------------------------------------------ validation metrics (SCD / CC scripts)
+class AverageMeter:
+    """reference model/utils.py:278-310 (imported by scripts/train_SCD.py:22-32 and scripts/train_CC.py:22-23):
+    `average()` = sum(val * weight) / sum(count)."""
+
+    def __init__(self):
+        self.initialized, self.val, self.avg, self.sum, self.count = False, None, None, None, None
+
+    def initialize(self, val, count, weight):
+        self.val, self.avg, self.count, self.sum, self.initialized = val, val, count, val * weight, True
+
+    def update(self, val, count=1, weight=1):
+        if not self.initialized:
+            self.initialize(val, count, weight)
+        else:
+            self.add(val, count, weight)
+
+    def add(self, val, count, weight):
+        self.val = val
+        self.count += count
+        self.sum += val * weight
+        self.avg = self.sum / self.count
+
+    def value(self):
+        return self.val
+
+    def average(self):
+        return self.avg
+
+
+def accuracy(pred, label, ignore_zero=False):
+    """reference model/utils.py:313-319: fraction of the valid pixels (label >= 0, or > 0) where pred == label, and the
+    number of valid pixels.  numpy arrays or torch tensors (device tensors stay on the device: one read-back of two
+    scalars)."""
+    valid = (label > 0) if ignore_zero else (label >= 0)
+    acc_sum = (valid * (pred == label)).sum()
+    valid_sum = valid.sum()
+    if isinstance(valid_sum, torch.Tensor):
+        acc_sum, valid_sum = (int(v) for v in torch.stack([acc_sum, valid_sum]).tolist())
+    return float(acc_sum) / (valid_sum + 1e-10), valid_sum
+
+
+class SCDHistogram:
+    """Joint (prediction x label) histogram of the SCD validation loop (reference model/utils.py:321-355: fast_hist /
+    get_hist summed over every (pred, label) pair of the epoch), accumulated ON THE DEVICE by `c3d_hist2d`: the reference
+    moves every mask to the host each iteration; here one n*n read-back happens in `scores()`."""
+
+    def __init__(self, num_class, device):
+        self.n = int(num_class)
+        self.hist = torch.zeros(self.n * self.n + 1, dtype=torch.int64, device=device)
+
+    def update(self, pred, label):
+        pred, label = pred.reshape(-1).to(torch.int64).contiguous(), label.reshape(-1).to(torch.int64).contiguous()
+        if pred.numel() != label.numel():
+            raise AssertionError("The size of prediction and target must be the same")
+        ops.hist2d(pred, label, self.n, self.hist)
+
+    def matrix(self):
+        h = self.hist.cpu().numpy()
+        if h[-1] != 0:
+            raise ValueError(f"{int(h[-1])} label values outside [0, {self.n}) in the SCD validation histogram")
+        return h[:-1].reshape(self.n, self.n).astype(np.float64)
+
+    def scores(self):
+        return scd_scores_from_hist(self.matrix())
+
+
+def _cal_kappa(hist):
+    """reference model/utils.py:330-342."""
+    if hist.sum() == 0:
+        return 0
+    po = np.diag(hist).sum() / hist.sum()
+    pe = np.matmul(hist.sum(1), hist.sum(0).T) / hist.sum() ** 2
+    return 0 if pe == 1 else (po - pe) / (1 - pe)
+
+
+def scd_scores_from_hist(hist):
+    """(Fscd, mIoU, SeK) from the num_class x num_class histogram: reference model/utils.py:356-378 (float64 host
+    arithmetic, same order of operations)."""
+    hist = np.asarray(hist, dtype=np.float64)
+    c2 = np.zeros((2, 2))
+    c2[0][0] = hist[0][0]
+    c2[0][1] = hist.sum(1)[0] - hist[0][0]
+    c2[1][0] = hist.sum(0)[0] - hist[0][0]
+    c2[1][1] = hist[1:, 1:].sum()
+    hist_n0 = hist.copy()
+    hist_n0[0][0] = 0
+    kappa_n0 = _cal_kappa(hist_n0)
+    iu = np.diag(c2) / (c2.sum(1) + c2.sum(0) - np.diag(c2))
+    sek = (kappa_n0 * math.exp(iu[1])) / math.e
+    pixel_sum = hist.sum()
+    change_pred_sum = pixel_sum - hist.sum(1)[0].sum()
+    change_label_sum = pixel_sum - hist.sum(0)[0].sum()
+    sc_tp = np.diag(hist[1:, 1:]).sum()
+    precision, recall = sc_tp / change_pred_sum, sc_tp / change_label_sum
+    fscd = 2.0 / (1.0 / precision + 1.0 / recall) if precision > 0 and recall > 0 else 0.0   # scipy.stats.hmean of the two
+    return fscd, (iu[0] + iu[1]) / 2, sek
+
+
+def SCDD_eval_all(preds, labels, num_class):
+    """reference model/utils.py:345-378: lists of per-image prediction / label maps -> (Fscd, mIoU, SeK).  Device tensors
+    are histogrammed by `c3d_hist2d`; numpy arrays (the reference's calling convention) by np.bincount."""
+    if len(preds) and isinstance(preds[0], torch.Tensor) and preds[0].is_cuda:
+        acc = SCDHistogram(num_class, preds[0].device)
+        for p, l in zip(preds, labels):
+            if tuple(p.shape) != tuple(l.shape):
+                raise AssertionError("The size of prediction and target must be the same")
+            acc.update(p, l)
+        return acc.scores()
+    hist = np.zeros((num_class, num_class))
+    for p, l in zip(preds, labels):
+        p, l = np.asarray(p), np.asarray(l)
+        assert set(np.unique(p)).issubset({0, 1, 2, 3, 4, 5, 6}), "unrecognized label number"
+        assert p.shape == l.shape, "The size of prediction and target must be the same"
+        a, b = p.flatten(), l.flatten()
+        k = (a >= 0) & (a < num_class)
+        hist += np.bincount(num_class * a[k].astype(int) + b[k], minlength=num_class ** 2).reshape(num_class, num_class)
+    return scd_scores_from_hist(hist)
+
+
+def caption_accuracy(scores, targets, k):
+    """reference model/utils.py:493-507: top-k accuracy (percent) of packed (rows, vocab) scores against (rows,) targets."""
+    batch_size = targets.size(0)
+    _, ind = scores.topk(k, 1, True, True)
+    correct = ind.eq(targets.view(-1, 1).expand_as(ind))
+    return correct.view(-1).float().sum().item() * (100.0 / batch_size)
+
+
+def eval_caption_score(references, hypotheses):
+    """reference model/utils.py:509-536: BLEU / METEOR / ROUGE-L / CIDEr through pycocoevalcap (java METEOR scorer).  Host-side
+    string scoring, outside the hot path (out of scope); the name exists so that
+    `from model.utils import ... eval_caption_score` (reference scripts/train_CC.py:22-23) resolves through the drop-in."""
+    raise NotImplementedError("caption text metrics (pycocoevalcap: BLEU/METEOR/ROUGE/CIDEr) are not part of the MI355X hot path; "
+                              "score the decoded captions with the reference's own eval_caption_score")

@@ -540,6 +540,11 @@ def confusion2(prob, target, cm4):
     _launch("c3d_confusion2", prob.numel() * 8, L.lib().c3d_confusion2, _p(prob), _p(target), prob.numel(), _p(cm4), _stream())
 
 
+def hist2d(a, b, n, hist):
+    """hist (uint64-as-int64 [n*n + 1], device) += joint histogram of the int64 label maps a (rows) and b (columns)."""
+    _launch("c3d_hist2d", a.numel() * 16, L.lib().c3d_hist2d, _p(a), _p(b), a.numel(), n, _p(hist), _stream())
+
+
 # ------------------------------------------------------------------------------ stage driver
 class StageBinding:
     """ctypes descriptor (include/change3d_hip.h: c3d_stage_desc) of one residual stage, bound to the tensors of
@@ -666,6 +671,16 @@ def stage_bwd(binding, x, y, dy, ws, wb, dx):
 def bcd_preprocess(image6, label, flags, mean6, std6, pre, post, label_out, B, H, W):
     _launch("c3d_bcd_preprocess", B * H * W * (7 + 28), L.lib().c3d_bcd_preprocess, _p(image6), _p(label), _p(flags),
             _p(mean6), _p(std6), _p(pre), _p(post), _p(label_out), B, H, W, _stream())
+
+
+def scd_label_preprocess(label3, flags, out, B, H, W):
+    _launch("c3d_scd_label_preprocess", B * H * W * (3 + 24), L.lib().c3d_scd_label_preprocess, _p(label3), _p(flags), _p(out),
+            B, H, W, _stream())
+
+
+def cc_preprocess(img, swap, lut, pre, post, B, H, W):
+    _launch("c3d_cc_preprocess", B * H * W * (6 + 24), L.lib().c3d_cc_preprocess, _p(img), _p(swap), _p(lut), _p(pre), _p(post),
+            B, H, W, _stream())
 
 
 def build_clip(pre, post, frames, clip, B, K, H, W):

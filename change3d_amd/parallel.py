@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .model.utils import ParamArena, hot_path_named_params
+from .model.utils import ParamArena, cc_named_params, hot_path_named_params
 
 _EARLY = ("encoder.x3d.blocks.3.", "encoder.fc.3.", "decoder")
 
@@ -92,3 +92,41 @@ def setup_data_parallel(trainer, device, overlap=True, group=None):
     if overlap and sync.world > 1:
         trainer.encoder.x3d.blocks[3].post_backward = sync.launch_tail
     return arena, sync
+
+
+class GradSyncGroup:
+    """Several flat buffers exchanged as one unit (change captioning: the encoder's and the decoder's Adam own
+    separate arenas, reference scripts/train_CC.py:436-458)."""
+
+    def __init__(self, syncs):
+        self.syncs = list(syncs)
+        self.world = self.syncs[0].world
+
+    def launch_tail(self):
+        for s in self.syncs:
+            s.launch_tail()
+
+    def finish(self):
+        for s in self.syncs:
+            s.finish()
+
+
+def setup_data_parallel_cc(trainer, device, overlap=True, group=None):
+    """Change-captioning path (CC row: 5.65 M gradient-bearing parameters = 22.6 MB): returns
+    ((enc_arena, enc_sync), (dec_arena, dec_sync), both) where `both.finish()` completes the exchange.
+
+    Backward runs decoder -> res5 -> res4 -> ... -> stem, so when `blocks[4]` (res5) returns from backward the WHOLE
+    decoder arena and res5 (2.9 M of the encoder's 4.4 M parameters) are final: the encoder arena is ordered
+    [stem .. res4 | res5] and the hook at the end of res5's backward launches both buckets -- 4.2 M of the 5.65 M floats --
+    on the communication streams while res4 .. stem backward (most of the backward pass) still run."""
+    enc_named, dec_named = cc_named_params(trainer)
+    tail = "encoder.x3d.blocks.4."
+    late = [(n, p) for n, p in enc_named if not n.startswith(tail)]
+    early = [(n, p) for n, p in enc_named if n.startswith(tail)]
+    enc_arena, dec_arena = ParamArena(late + early, device), ParamArena(dec_named, device)
+    enc_sync = GradSync(enc_arena, len(late), group=group)
+    dec_sync = GradSync(dec_arena, 0, group=group)          # split 0: the whole decoder buffer is the overlapped bucket
+    both = GradSyncGroup([dec_sync, enc_sync])
+    if overlap and enc_sync.world > 1:
+        trainer.encoder.x3d.blocks[4].post_backward = both.launch_tail
+    return (enc_arena, enc_sync), (dec_arena, dec_sync), both

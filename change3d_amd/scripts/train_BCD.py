@@ -144,9 +144,11 @@ def trainValidate(args):
         cur_iter += len(train_loader)
         if epoch == 0:
             continue
-        loss_val, score_val = val(args, test_loader, model, epoch)
+        # rank 0 validates (BatchNorm running statistics are per rank by design; the checkpoint holds rank 0's, so
+        # its score is the one that describes the saved model); the other ranks go on and meet it at the next exchange
         if args.rank != 0:
             continue
+        loss_val, score_val = val(args, test_loader, model, epoch)
         logger.write("\n%d\t\t%.4f\t\t%.4f\t\t%.4f\t\t%.4f\t\t%.4f" % (
             epoch, score_val["Kappa"], score_val["IoU"], score_val["F1"], score_val["recall"], score_val["precision"]))
         logger.flush()

@@ -23,13 +23,16 @@ if ROOT not in sys.path:
 from change3d_amd import synthetic as synth  # noqa: E402
 from change3d_amd.model.caption_decoder import packed_cross_entropy  # noqa: E402
 from change3d_amd.model.trainer import Trainer  # noqa: E402
-from change3d_amd.model.utils import FusedAdam, ParamArena, cc_named_params, clip_gradient  # noqa: E402
+from change3d_amd.model.utils import FusedAdam, clip_gradient  # noqa: E402
+from change3d_amd.parallel import broadcast_module_state, setup_data_parallel_cc  # noqa: E402
 
 
 def build(args, device):
     model = Trainer(args).to(device)
-    enc_named, dec_named = cc_named_params(model)
-    enc_arena, dec_arena = ParamArena(enc_named, device), ParamArena(dec_named, device)
+    broadcast_module_state(model)
+    # one flat buffer per optimizer; under torch.distributed.run both are all-reduced from inside backward (the decoder's
+    # and res5's buckets when res5's backward returns: change3d_amd/parallel.py::setup_data_parallel_cc)
+    (enc_arena, _), (dec_arena, _), args.grad_sync = setup_data_parallel_cc(model, device)
     # reference scripts/train_CC.py:436-458 (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8)
     enc_opt = FusedAdam(enc_arena, args.encoder_lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
     dec_opt = FusedAdam(dec_arena, args.decoder_lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
@@ -46,6 +49,7 @@ def train_step(args, model, enc_opt, dec_opt, imgs_a, imgs_b, caps, caplens):
     dec_opt.zero_grad()
     enc_opt.zero_grad()
     loss.backward()
+    args.grad_sync.finish()          # data-parallel: mean over ranks of the local gradients (no-op on one rank)
     if args.grad_clip is not None:
         clip_gradient(dec_opt, args.grad_clip)
         clip_gradient(enc_opt, args.grad_clip)
@@ -97,19 +101,24 @@ def main():
         raise SystemExit("--dataset must name a change-captioning set (contains 'CC')")
     args.act_dtype = torch.bfloat16 if args.act_dtype == "bf16" else torch.float32
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
     torch.manual_seed(16)
     model, enc_opt, dec_opt = build(args, device)
     model.train()
-    pre, post, _ = (t.to(device) for t in synth.synth_batch(args.batch_size, args.in_height, seed=0))
-    caps, caplens = (t.to(device) for t in synth.synth_captions(args.batch_size, seed=0, vocab_size=args.vocab_size))
+    pre, post, _ = (t.to(device) for t in synth.synth_batch(args.batch_size, args.in_height, seed=rank))
+    caps, caplens = (t.to(device) for t in synth.synth_captions(args.batch_size, seed=rank, vocab_size=args.vocab_size))
     start = time.time()
     for i in range(args.max_steps):
         loss, stats = train_step(args, model, enc_opt, dec_opt, pre, post, caps, caplens)
-        if i % args.print_freq == 0 or i == args.max_steps - 1:
+        if rank == 0 and (i % args.print_freq == 0 or i == args.max_steps - 1):
             s = stats.cpu()
             print(f"step: {i}/{args.max_steps} Loss: {loss.item():.4f} Top-1 Accuracy: {100.0 * s[2].item() / max(s[1].item(), 1):.4f} "
                   f"Batch_time: {(time.time() - start) / (i + 1):.4f}s")
-    if args.eval_pairs:
+    if args.eval_pairs and rank == 0:
         n = args.eval_pairs
         ep, eq, _ = (t.to(device) for t in synth.synth_batch(n, args.in_height, seed=1))
         start_id, end_id = args.vocab_size - 2, args.vocab_size - 1            # synthetic word map: <start>, <end> last

@@ -26,8 +26,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from change3d_amd.model.trainer import Trainer  # noqa: E402
-from change3d_amd.model.utils import (BCEDiceLoss, ChangeSimilarity, CrossEntropyLoss2d, FusedAdam,  # noqa: E402
-                                      adjust_learning_rate)
+from change3d_amd.model.utils import (AverageMeter, BCEDiceLoss, ChangeSimilarity, CrossEntropyLoss2d, FusedAdam,  # noqa: E402
+                                      SCDHistogram, adjust_learning_rate)
 from change3d_amd.parallel import broadcast_module_state, setup_data_parallel  # noqa: E402
 
 
@@ -95,6 +95,43 @@ def train(args, loader, model, optimizer, sync, epoch, max_batches, cur_iter=0):
     return float(torch.stack(losses).mean()), float(torch.stack(accs).mean()), lr
 
 
+@torch.no_grad()
+def val(args, val_loader, model, seg_loss=None, sim_loss=None):
+    """reference scripts/train_SCD.py:104-178: eval-mode forward, the same loss composition, per-sample semantic
+    accuracy (`model/utils.py:313-319` on `argmax * change` vs `label * change`, averaged over the two dates) and
+    Fscd / mIoU / SeK from the joint histogram of every (prediction, label) pair (`SCDD_eval_all`, :345-378).  The
+    reference moves all masks to the host every iteration; here the histogram and the accuracies are accumulated on the
+    device (`c3d_hist2d`) and read back once.  Returns (Fscd, IoU_mean, Sek, acc_meter, val_loss) like the reference."""
+    model.eval()
+    seg_loss = seg_loss or CrossEntropyLoss2d(ignore_index=0)
+    sim_loss = sim_loss or ChangeSimilarity()
+    dev = next(model.parameters()).device
+    hist = SCDHistogram(args.num_class, dev)
+    losses, accs = [], []
+    start = time.time()
+    for imgs, labels in val_loader:
+        pre, post, labels = imgs[:, 0:3].to(dev).float(), imgs[:, 3:6].to(dev).float(), labels.to(dev)
+        masks = model.update_scd(pre, post)
+        loss, pre_label, post_label, _ = scd_loss(seg_loss, sim_loss, masks, labels)
+        losses.append(loss)
+        chg = (masks[2] > 0.5).squeeze(1).long()
+        pa, pb = masks[0].argmax(1) * chg, masks[1].argmax(1) * chg
+        # accuracy(pred, label): every pixel is valid (label >= 0); per sample, mean of the two dates (:158-163)
+        accs.append(0.5 * ((pa == pre_label).float().flatten(1).mean(1) + (pb == post_label).float().flatten(1).mean(1)))
+        hist.update(pa, pre_label)
+        hist.update(pb, post_label)
+    val_loss, acc_meter = AverageMeter(), AverageMeter()
+    for l in torch.stack(losses).cpu().numpy():
+        val_loss.update(l)
+    for a in torch.cat(accs).cpu().tolist():
+        acc_meter.update(a)
+    Fscd, IoU_mean, Sek = hist.scores()
+    if getattr(args, "rank", 0) == 0:
+        print(f"{time.time() - start:.1f}s Val loss: {val_loss.average():.2f} Fscd: {Fscd * 100:.2f} IoU: {IoU_mean * 100:.2f} "
+              f"Sek: {Sek * 100:.2f} Accuracy: {acc_meter.average() * 100:.2f}")
+    return Fscd, IoU_mean, Sek, acc_meter, val_loss
+
+
 def trainValidate(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.rank = int(os.environ.get("RANK", "0"))
@@ -118,6 +155,9 @@ def trainValidate(args):
         cur_iter += len(loader)
         if args.rank == 0:
             print(f"Epoch {epoch}: train loss {loss_tr:.4f}  acc {acc_tr:.4f}  lr {lr:.6f}")
+            if args.val_pairs > 0:   # rank 0 validates on its own BatchNorm statistics (the ones a checkpoint would hold)
+                vl = SyntheticSCDLoader(args.val_pairs, min(args.batch_size, args.val_pairs), args.in_height, args.num_class, seed=5)
+                val(args, vl, model)
     if world > 1:
         dist.destroy_process_group()
 
@@ -137,6 +177,7 @@ def build_parser():
     p.add_argument("--pretrained", default="./pretrained/X3D_L.pyth")
     p.add_argument("--gpu_id", default=0, type=int)
     p.add_argument("--synthetic_pairs", type=int, default=256)
+    p.add_argument("--val_pairs", type=int, default=0, help="validate on this many synthetic pairs after every epoch")
     p.add_argument("--act_dtype", choices=["f32", "bf16"], default="bf16")
     return p
 

@@ -332,6 +332,10 @@ int c3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   const float* hparams_dev, float lr, float bias_correction1, float bias_correction2_sqrt,
                   float beta1, float beta2, float eps, float weight_decay, void* stream);
 int c3d_confusion2(const float* prob, const float* target, int64_t n, unsigned long long* cm4, void* stream);
+/* SCD validation (reference scripts/train_SCD.py:104-178, model/utils.py:313-378 fast_hist / get_hist / SCDD_eval_all):
+ * hist[a*n + b] += #{i : a[i] == a, b[i] == b} for 0 <= a < n (a = prediction, b = label; int64 device arrays), n <= 16;
+ * hist has n*n + 1 u64 slots, the last one counts pairs whose b is outside [0, n) (numpy would raise there).        */
+int c3d_hist2d(const int64_t* a, const int64_t* b, int64_t n_elems, int32_t n, unsigned long long* hist, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * SCD losses.  Logits are f32 NCHW views: element (b, c, p) at
@@ -371,6 +375,16 @@ int c3d_build_clip(const float* pre, const float* post, const float* frames, flo
 int c3d_bcd_preprocess(const uint8_t* image6, const uint8_t* label, const uint8_t* flags, const float* mean6,
                        const float* std6, float* pre, float* post, float* label_out, int32_t B, int32_t H,
                        int32_t W, void* stream);
+/* SCD labels (reference data/transforms.py:300-326, 341-357; scripts/train_SCD.py:207-213): label3 u8 [B][H][W][3] =
+ * (pre classes, post classes, change), same flags as the image pass -> int64 [B][3][H][W]; an exchange swaps the two
+ * class maps.  The SCD image goes through c3d_bcd_preprocess (same 6-channel arithmetic, label = NULL).             */
+int c3d_scd_label_preprocess(const uint8_t* label3, const uint8_t* flags, int64_t* out, int32_t B, int32_t H, int32_t W,
+                             void* stream);
+/* Change-captioning pairs (reference data/dataset.py:411-424, scripts/train_CC.py:466-469): img u8 [B][2][3][H][W] ->
+ * pre, post f32 [B][3][H][W] = lut[channel][u8] (the host builds the 3 x 256 table with the reference's own arithmetic:
+ * Normalize(FloatTensor(u8 / 255.))); swap u8 [B] or NULL exchanges the pair.  H*W % 4 == 0.                        */
+int c3d_cc_preprocess(const uint8_t* img, const uint8_t* swap, const float* lut, float* pre, float* post, int32_t B,
+                      int32_t H, int32_t W, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Residual-stage step driver: ONE call enqueues every kernel of `blocks[i](x)` for a whole X3D residual

@@ -394,6 +394,43 @@ def run_cc_beam():
     print(f"[gen_golden] wrote {path}")
 
 
+def run_metrics():
+    """SCD / CC validation metrics through the REAL reference functions (model/utils.py: accuracy, SCDD_eval_all,
+    caption_accuracy, AverageMeter) on seeded label maps / score matrices -> tests/golden/scd_metrics.npz; the
+    restatement (oracle/metrics.py) is asserted identical first."""
+    from oracle import metrics as om_
+    _, mu, _ = ref_import.import_reference()
+    rng = np.random.default_rng(7)
+    nc, n_img, S = 7, 6, 48
+    labels = [rng.integers(0, nc, size=(S, S)).astype(np.int64) * (rng.random((S, S)) < 0.4) for _ in range(n_img)]
+    preds = [np.where(rng.random((S, S)) < 0.7, l, rng.integers(0, nc, size=(S, S))).astype(np.int64) for l in labels]
+    ref_scores = mu.SCDD_eval_all(preds, labels, nc)
+    ora_scores = om_.SCDD_eval_all(preds, labels, nc)
+    assert tuple(float(v) for v in ref_scores) == tuple(float(v) for v in ora_scores), (ref_scores, ora_scores)
+    accs = np.array([mu.accuracy(p, l)[0] for p, l in zip(preds, labels)])
+    assert np.array_equal(accs, np.array([om_.accuracy(p, l)[0] for p, l in zip(preds, labels)]))
+    accs_nz = np.array([mu.accuracy(p, l, ignore_zero=True)[0] for p, l in zip(preds, labels)])
+    hist = np.zeros((nc, nc))
+    for p, l in zip(preds, labels):
+        hist += mu.get_hist(p, l, nc)
+    m_ref, m_ora = mu.AverageMeter(), om_.AverageMeter()
+    for v in accs:
+        m_ref.update(float(v)); m_ora.update(float(v))
+    assert m_ref.average() == m_ora.average()
+    g = torch.Generator().manual_seed(3)
+    scores = torch.randn(97, 53, generator=g)
+    targets = torch.randint(0, 53, (97,), generator=g)
+    scores[torch.arange(0, 97, 3), targets[::3]] += 6.0
+    cap = np.array([mu.caption_accuracy(scores, targets, k) for k in (1, 5)])
+    assert np.array_equal(cap, np.array([om_.caption_accuracy(scores, targets, k) for k in (1, 5)]))
+    path = os.path.join(GOLDEN_DIR, "scd_metrics.npz")
+    np.savez_compressed(path, preds=np.stack(preds).astype(np.int8), labels=np.stack(labels).astype(np.int8), num_class=np.int64(nc),
+                        scores=np.array(ref_scores, dtype=np.float64), hist=hist, acc=accs, acc_ignore_zero=accs_nz,
+                        acc_meter=np.float64(m_ref.average()), cap_scores=scores.numpy(), cap_targets=targets.numpy(), cap_acc=cap)
+    print(f"[gen_golden] wrote {path}: Fscd {ref_scores[0]:.6f} mIoU {ref_scores[1]:.6f} SeK {ref_scores[2]:.6f}, "
+          f"caption top-1/5 {cap[0]:.3f}/{cap[1]:.3f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", type=int, nargs="+", default=[64, 256])
@@ -401,11 +438,14 @@ def main():
     ap.add_argument("--scd-only", action="store_true", help="only regenerate the SCD fixture")
     ap.add_argument("--cc-only", action="store_true", help="only regenerate the CC fixtures")
     ap.add_argument("--cc-beam", action="store_true", help="only regenerate the CC beam-search fixture")
+    ap.add_argument("--metrics", action="store_true", help="only regenerate the SCD / CC validation-metric fixture")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     if a.cc_beam:
         return run_cc_beam()
+    if a.metrics:
+        return run_metrics()
     if not a.scd_only and not a.cc_only:
         for s in a.sizes:
             run(s, a.batch)

@@ -297,12 +297,19 @@ def test_create_x3d_accepts_the_reference_default_callables_and_exports_creators
 
 def test_dropin_import_paths_resolve_to_the_mirrors():
     """`PYTHONPATH=change3d_amd/dropin` makes the reference's own import lines (scripts/train_BCD.py:20-28,
-    model/trainer.py:14-17) resolve to this package."""
+    scripts/train_SCD.py:22-32, scripts/train_CC.py:20-23, model/trainer.py:14-17) resolve to this package."""
     import subprocess
     code = ("from model.trainer import Trainer, Encoder; from model.x3d import create_x3d; "
             "from model.change_decoder import ChangeDecoder; "
             "from model.utils import adjust_learning_rate, BCEDiceLoss, load_checkpoint, setup_logger, weight_init; "
             "from utils.metric_tool import ConfuseMatrixMeter; import change3d_amd.model.trainer as t; "
+            # scripts/train_SCD.py:22-32
+            "from model.utils import (adjust_learning_rate, BCEDiceLoss, CrossEntropyLoss2d, ChangeSimilarity, AverageMeter, "
+            "load_checkpoint, setup_logger, accuracy, SCDD_eval_all); "
+            # scripts/train_CC.py:20-23, model/trainer.py:16
+            "from model.utils import AverageMeter, clip_gradient, adjust_learning_rate, caption_accuracy, eval_caption_score; "
+            "from model.caption_decoder import CaptionDecoder; import change3d_amd.model.caption_decoder as cd; "
+            "assert CaptionDecoder is cd.CaptionDecoder; "
             "assert Trainer is t.Trainer; print('ok')")
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "change3d_amd", "dropin") + os.pathsep + ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/")
@@ -545,3 +552,121 @@ def test_oracle_stage_shapes_and_flops_match_the_survey():
     assert abs(g["pw"] - 11.11) < 0.02 and abs(g["dw"] - 2.38) < 0.01, g
     assert abs(g["dense"] - 0.28) < 0.01 and abs(g["convT"] - 0.45) < 0.01, g
     assert abs(sum(g.values()) - 14.225) < 0.02, g
+
+
+# ------------------------------------------------------------- round-3: validation metrics, CC data-parallel wiring
+def test_metric_oracle_and_mirror_match_the_reference_fixture(golden_dir):
+    """tests/golden/scd_metrics.npz was produced by the REAL reference functions (oracle/gen_golden.py::run_metrics:
+    model/utils.py accuracy / get_hist / SCDD_eval_all / AverageMeter / caption_accuracy): the restatement
+    (oracle/metrics.py) and the mirror (change3d_amd/model/utils.py, host path) reproduce every number exactly."""
+    from oracle import metrics as om_
+    from change3d_amd.model import utils as mu
+    G = np.load(os.path.join(golden_dir, "scd_metrics.npz"))
+    nc = int(G["num_class"])
+    preds, labels = [p.astype(np.int64) for p in G["preds"]], [l.astype(np.int64) for l in G["labels"]]
+    for impl in (om_, mu):
+        assert tuple(float(v) for v in impl.SCDD_eval_all(preds, labels, nc)) == tuple(G["scores"].tolist()), impl.__name__
+        assert np.array_equal(np.array([impl.accuracy(p, l)[0] for p, l in zip(preds, labels)]), G["acc"])
+        assert np.array_equal(np.array([impl.accuracy(p, l, ignore_zero=True)[0] for p, l in zip(preds, labels)]), G["acc_ignore_zero"])
+        m = impl.AverageMeter()
+        for v in G["acc"]:
+            m.update(float(v))
+        assert m.average() == float(G["acc_meter"]) and m.value() == float(G["acc"][-1])
+        sc, tg = torch.from_numpy(G["cap_scores"]), torch.from_numpy(G["cap_targets"])
+        assert np.array_equal(np.array([impl.caption_accuracy(sc, tg, k) for k in (1, 5)]), G["cap_acc"])
+    assert tuple(mu.scd_scores_from_hist(G["hist"])) == tuple(G["scores"].tolist())
+    # torch tensors (what the device loop hands over) give the same accuracy as numpy arrays
+    a_t = mu.accuracy(torch.from_numpy(preds[0]), torch.from_numpy(labels[0]))
+    assert a_t[0] == float(G["acc"][0])
+    with pytest.raises(NotImplementedError):
+        mu.eval_caption_score([], [])
+
+
+def test_metric_oracle_equals_imported_reference():
+    from oracle import metrics as om_, ref_import
+    if not ref_import.reference_available():
+        pytest.skip("reference tree not present (build container only)")
+    _, mu, _ = ref_import.import_reference()
+    rng = np.random.default_rng(123)
+    for nc in (7, 5):
+        labels = [rng.integers(0, nc, size=(33, 41)).astype(np.int64) for _ in range(4)]
+        preds = [np.where(rng.random((33, 41)) < 0.6, l, rng.integers(0, nc, size=(33, 41))).astype(np.int64) for l in labels]
+        assert tuple(map(float, mu.SCDD_eval_all(preds, labels, nc))) == tuple(map(float, om_.SCDD_eval_all(preds, labels, nc)))
+        for p, l in zip(preds, labels):
+            assert mu.accuracy(p, l) == om_.accuracy(p, l) and mu.accuracy(p, l, True) == om_.accuracy(p, l, True)
+    assert float(mu.cal_kappa(np.zeros((3, 3)))) == float(om_.cal_kappa(np.zeros((3, 3)))) == 0.0
+
+
+def test_input_pipeline_oracles_are_self_consistent():
+    """oracle/transforms.py restates the SCD / CC tensor-side transforms (the GPU tests compare the HIP kernels with
+    them bit for bit); here: flips and exchanges are involutions, the exchange swaps the class maps, and the CC table the
+    product builds (change3d_amd/data/transforms.py::cc_normalize_table) IS the restated per-pixel arithmetic."""
+    from oracle import transforms as ot
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(10, 12, 6), dtype=np.uint8)
+    lab = rng.integers(0, 7, size=(10, 12, 3), dtype=np.uint8)
+    mean, std = [0.5] * 6, [0.5] * 6
+    i0, l0 = ot.scd_transform_sample(img, lab, (0, 0, 0), mean, std)
+    i1, l1 = ot.scd_transform_sample(img, lab, (1, 1, 1), mean, std)
+    assert np.array_equal(i1[:3, ::-1, ::-1], i0[3:]) and np.array_equal(i1[3:, ::-1, ::-1], i0[:3])
+    assert np.array_equal(l1[0, ::-1, ::-1], l0[1]) and np.array_equal(l1[1, ::-1, ::-1], l0[0]) and np.array_equal(l1[2, ::-1, ::-1], l0[2])
+    assert l0.dtype == np.int64 and i0.dtype == np.float32
+    from change3d_amd.data.transforms import cc_normalize_table
+    lut = cc_normalize_table().numpy()
+    pair = rng.integers(0, 256, size=(2, 3, 8, 8), dtype=np.uint8)
+    t = ot.cc_transform_sample(pair, swap=False)
+    assert np.array_equal(t, np.stack([np.stack([lut[c][pair[i, c]] for c in range(3)]) for i in range(2)]))
+    assert np.array_equal(ot.cc_transform_sample(pair, swap=True), t[::-1])
+
+
+def _cc_ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from change3d_amd import synthetic as synth
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.parallel import broadcast_module_state, setup_data_parallel_cc
+    torch.manual_seed(200 + rank)
+    net = Trainer(synth.make_cc_args(size=32, vocab_size=51, dropout=0.0))
+    broadcast_module_state(net)
+    (enc_arena, enc_sync), (dec_arena, dec_sync), both = setup_data_parallel_cc(net, torch.device("cpu"), overlap=True)
+    assert both.world == world and enc_sync.split > 0 and dec_sync.split == 0
+    hook = net.encoder.x3d.blocks[4].post_backward
+    assert hook is not None and net.encoder.x3d.blocks[3].post_backward is None
+    g = torch.Generator().manual_seed(rank)
+    local = []
+    for arena in (enc_arena, dec_arena):
+        arena.zero_grad()
+        arena.flat_grad.copy_(torch.randn(arena.numel, generator=g))
+        local.append(arena.flat_grad.clone())
+    hook()                       # from the end of res5's backward: the decoder buffer and the res5 tail
+    assert enc_sync._tail_launched and dec_sync._tail_launched
+    both.finish()
+    # every encoder parameter of res5 sits in the overlapped tail, nothing else does
+    tail_names = [n for n, o in zip(enc_arena.names, enc_arena.offsets) if o >= enc_sync.split]
+    assert tail_names and all(n.startswith("encoder.x3d.blocks.4.") for n in tail_names)
+    assert not any(n.startswith("encoder.x3d.blocks.4.") for n, o in zip(enc_arena.names, enc_arena.offsets) if o < enc_sync.split)
+    q.put((rank, [a.flat_grad.numpy().copy() for a in (enc_arena, dec_arena)], [l.numpy() for l in local]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_cc_two_arena_allreduce_is_mean_of_local_grads():
+    """Change captioning exchanges TWO flat buffers (encoder / decoder Adam): both are launched by the hook at the end of
+    res5's backward (`setup_data_parallel_cc`) and completed by one `finish()`; result = mean over ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_cc_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, f0, l0), (_, f1, l1) = res
+    for k in range(2):
+        assert np.array_equal(f0[k], f1[k])
+        assert np.allclose(f0[k], 0.5 * (l0[k] + l1[k]), rtol=1e-6, atol=1e-7)
