@@ -24,7 +24,7 @@ vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 class BnFin(C.Structure):
     _fields_ = [("ticket", vp), ("gamma", vp), ("beta", vp), ("running_mean", vp), ("running_var", vp), ("nbt", vp),
                 ("ss", vp), ("mr", vp), ("count", f64), ("momentum", f32), ("eps", f32), ("training", i32),
-                ("reserved", i32), ("sums", vp)]
+                ("batch", i32), ("sums", vp)]
 
 
 class PwArgs(C.Structure):
@@ -99,6 +99,7 @@ SIGNATURES = {
                                      i32, C.POINTER(BnFin), vp]),
     "c3d_dw333_wgrad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_dw333_bwd_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "c3d_dw333_bwd_fused_fin": (i32, [vp, vp, C.POINTER(BnFin), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_block_out_fwd": (i32, [vp, vp, vp, vp, i32, vp, i64, i32, i32, vp]),
     "c3d_block_out_fwd_fin": (i32, [vp, C.POINTER(BnFin), vp, C.POINTER(BnFin), i32, vp, i64, i32, i32, i32, vp]),
     "c3d_block_out_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),

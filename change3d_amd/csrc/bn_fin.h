@@ -175,4 +175,74 @@ __device__ __forceinline__ void bn_bwd_coef_consume(const c3d_bn_fin& f, int C, 
   if (acc && f.ss && c < Cp) { f.ss[c] = cA; f.ss[Cp + c] = cB; f.ss[2 * Cp + c] = cC; }
 }
 
+// ---- BatchNorm_b of blocks without SqueezeExcitation: per-sample sums consumed directly -----------------------------
+// Forward.  nc f64 [B][Cp][2] (c3d_dw333_fwd) -> scale / shift of ALL channels into lds_sc / lds_sh; `owner` also writes
+// ss / mr / the running statistics.  Four adjacent lanes split the batch loop and combine with xor 1, xor 2 -- the
+// summation tree of bn_se_finalize_kernel, so the result is bit-identical to the separate launch.  Ends with
+// __syncthreads().
+__device__ __forceinline__ void bn_consume_nc(const c3d_bn_fin& f, int C, int Cp, bool owner, float* lds_sc, float* lds_sh,
+                                              int tid, int nthreads) {
+  const int B = f.batch, q = tid & 3;
+  for (int c0 = 0; c0 < Cp; c0 += nthreads >> 2) {
+    const int c = c0 + (tid >> 2);
+    const bool live = c < C;
+    double s1 = 0, s2 = 0;
+    if (live) {
+#pragma unroll 4
+      for (int n = q; n < B; n += 4) { s1 += f.sums[((size_t)n * Cp + c) * 2]; s2 += f.sums[((size_t)n * Cp + c) * 2 + 1]; }
+    }
+    s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+    s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+    if (q != 0 || c >= Cp) continue;
+    float sc = 0.f, sh = 0.f, meanf = 0.f, rstd = 0.f;
+    if (live) {
+      const double mean = s1 / f.count;
+      double var = s2 / f.count - mean * mean;
+      if (var < 0) var = 0;
+      if (owner && f.running_mean) {
+        const double unb = f.count > 1 ? var * f.count / (f.count - 1) : var;
+        f.running_mean[c] = (float)((1.0 - f.momentum) * f.running_mean[c] + f.momentum * mean);
+        f.running_var[c] = (float)((1.0 - f.momentum) * f.running_var[c] + f.momentum * unb);
+      }
+      rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+      meanf = (float)mean;
+      sc = f.gamma[c] * rstd;
+      sh = f.beta[c] - meanf * sc;
+    }
+    lds_sc[c] = sc; lds_sh[c] = sh;
+    if (owner) {
+      f.ss[c] = sc; f.ss[Cp + c] = sh;
+      if (f.mr) { f.mr[c] = meanf; f.mr[Cp + c] = rstd; }
+    }
+  }
+  __syncthreads();
+}
+
+// Backward.  nc3 f64 [B][Cp][3] (Swish/SE-backward epilogue: d gate, sum t1, sum t1*bhat) -> db = A*t1 + Bc + C*b for the
+// channel `c` (no SE: Bc is the same for every sample), same arithmetic and summation tree as se_bn_bwd_coef_kernel's
+// no-SE branch.  Called by the four lanes q = 0..3 of a channel (adjacent lanes); the result is valid in all four.
+__device__ __forceinline__ void bn_b_bwd_coef_nc(const c3d_bn_fin& f, int C, int Cp, int c, int q, bool owner, float& cA,
+                                                 float& cB, float& cC) {
+  const int B = f.batch;
+  double s1 = 0, s2 = 0;
+  if (c < C) {
+#pragma unroll 4
+    for (int n = q; n < B; n += 4) { s1 += f.sums[((size_t)n * Cp + c) * 3 + 1]; s2 += f.sums[((size_t)n * Cp + c) * 3 + 2]; }
+  }
+  s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+  s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+  cA = 0.f; cB = 0.f; cC = 0.f;
+  if (c < C) {
+    const double mean = f.mr[c], rstd = f.mr[Cp + c];
+    const double A = (double)f.gamma[c] * rstd;
+    const double Cc = -A * rstd * s2 / f.count;
+    cA = (float)A; cC = (float)Cc;
+    cB = (float)(-A * s1 / f.count - Cc * mean);
+    if (owner && q == 0) {
+      if (f.running_mean) f.running_mean[c] += (float)s2;
+      if (f.running_var) f.running_var[c] += (float)s1;
+    }
+  }
+}
+
 }  // namespace c3dfin

@@ -18,6 +18,7 @@
 // dw with f32 atomics.  The staged tile is double buffered: one barrier per tile.
 #include "pw_common.h"   // device_cus()
 #include "dw_common.h"
+#include "bn_fin.h"
 #include "../../include/change3d_hip.h"
 #include <cstdlib>
 
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
     const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
     const T* __restrict__ a, const float* __restrict__ ss_a, const float* __restrict__ mr_a, T* __restrict__ t2,
-    double* __restrict__ dsums, float* __restrict__ dw, const DwGeom g, const int tiles_per_wg) {
+    double* __restrict__ dsums, float* __restrict__ dw, const DwGeom g, const int tiles_per_wg, const c3d_bn_fin fin) {
   typedef Raw8<T> R8;
   typedef Raw4<T> R4;
   constexpr int NI = TT * FB_DH * FB_DW * DW_CV;          // staged 8-channel vectors per tile
@@ -128,7 +129,17 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     const int tap = i >> 5, c = c0 + (i & 31);
     wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
   }
-  for (int i = tid; i < 7 * 32; i += FB_NTHR) {
+  if (fin.sums) {
+    // BatchNorm_b backward coefficients of a block without SqueezeExcitation, rebuilt from the per-sample sums of the
+    // conv_c data gradient's epilogue (csrc/bn_fin.h: no c3d_se_bn_bwd_coef launch in front of this kernel); the first
+    // workgroup of each channel chunk accumulates d gamma / d beta
+    if (tid < 128) {
+      float cA, cB, cC;
+      c3dfin::bn_b_bwd_coef_nc(fin, g.C, g.Cp, c0 + (tid >> 2), tid & 3, co.group == 0, cA, cB, cC);
+      if ((tid & 3) == 0) { cf[tid >> 2] = cA; cf[32 + (tid >> 2)] = cB; cf[64 + (tid >> 2)] = cC; }
+    }
+  }
+  for (int i = tid + (fin.sums ? 3 * 32 : 0); i < 7 * 32; i += FB_NTHR) {
     const int k = i >> 5, c = c0 + (i & 31);
     float v = 0.f;
     if (c < g.Cp) {
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
 template <typename T, int TT>
 int launch_fused_t(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const float* w,
                    const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw,
-                   const DwGeom& g, hipStream_t stream) {
+                   const DwGeom& g, hipStream_t stream, const c3d_bn_fin& fin) {
   constexpr int NI = TT * FB_DH * FB_DW * DW_CV;
   const size_t lds = (27 * 32 + 7 * 32) * sizeof(float) + (size_t)2 * 2 * NI * sizeof(float4);
   static_assert((size_t)2 * 2 * NI * sizeof(float4) >= (size_t)27 * FB_NTHR * sizeof(float), "dump region");
@@ -403,11 +414,25 @@ int launch_fused_t(const void* t1, const void* bb, const float* cA, const float*
   dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
   dw_bwd_fused_kernel<T, TT><<<grid, dim3(FB_NTHR), lds, stream>>>(
       reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, w, reinterpret_cast<const T*>(a),
-      ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, dw, g, tpw);
+      ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, dw, g, tpw, fin);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
+}  // namespace
+
+namespace {
+int dispatch_fused(const void* t1, const void* b, const float* coefA, const float* coefB, const float* coefC, const float* w,
+                   const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw, const DwGeom& g,
+                   int dtype, hipStream_t s, const c3d_bn_fin& fin) {
+  if (dtype == C3D_DT_F32)
+    return g.T <= 3 ? launch_fused_t<float, 3>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin)
+                    : launch_fused_t<float, 5>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
+  if (dtype == C3D_DT_BF16)
+    return g.T <= 3 ? launch_fused_t<bf16_t, 3>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin)
+                    : launch_fused_t<bf16_t, 5>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
+  return C3D_E_BADARG;
+}
 }  // namespace
 
 extern "C" int c3d_dw333_bwd_fused(const void* t1, const void* b, const float* coefA, const float* coefB,
@@ -417,12 +442,16 @@ extern "C" int c3d_dw333_bwd_fused(const void* t1, const void* b, const float* c
   DwGeom g{B, T, H, W, H, W, C, Cp, 1};
   if (!t1 || !b || !coefA || !coefB || !coefC || !w || !a || !ss_a || !mr_a || !t2 || !dsums || !dw || !geom_ok(g))
     return C3D_E_BADARG;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == C3D_DT_F32)
-    return T <= 3 ? launch_fused_t<float, 3>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s)
-                  : launch_fused_t<float, 5>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s);
-  if (dtype == C3D_DT_BF16)
-    return T <= 3 ? launch_fused_t<bf16_t, 3>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s)
-                  : launch_fused_t<bf16_t, 5>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s);
-  return C3D_E_BADARG;
+  return dispatch_fused(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, dtype,
+                        reinterpret_cast<hipStream_t>(stream), c3d_bn_fin{});
+}
+
+extern "C" int c3d_dw333_bwd_fused_fin(const void* t1, const void* b, const c3d_bn_fin* fin_b, const float* w, const void* a,
+                                       const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw, int32_t B,
+                                       int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t dtype, void* stream) {
+  DwGeom g{B, T, H, W, H, W, C, Cp, 1};
+  if (!t1 || !b || !w || !a || !ss_a || !mr_a || !t2 || !dsums || !dw || !geom_ok(g)) return C3D_E_BADARG;
+  if (!fin_b || !fin_b->sums || fin_b->batch != B || !fin_b->gamma || !fin_b->mr || !(fin_b->count > 0)) return C3D_E_BADARG;
+  return dispatch_fused(t1, b, nullptr, nullptr, nullptr, w, a, ss_a, mr_a, t2, dsums, dw, g, dtype,
+                        reinterpret_cast<hipStream_t>(stream), *fin_b);
 }

@@ -77,12 +77,15 @@ __global__ void block_out_bwd_kernel(const T* __restrict__ dy, const T* __restri
   extern __shared__ float red[];  // [blockDim][24]
   const int v = threadIdx.x % G;
   const int Cp = G * 8;
-  // partial sums in f64: (sum g*chat) nearly cancels on some channels and a thread's grid-stride chain is long
-  double s1[8], s2[8], s3[8];
+  // per-thread partial sums in f32 (a thread's grid-stride chain is 12-200 terms: its rounding error is ~1e-5 of ONE
+  // term and random across the ~1e5 threads), everything across threads in f64 below -- the near-cancellation of
+  // (sum g*chat) happens between threads, not inside one.  (Per-element v_cvt_f64_f32 + v_add_f64 triples -- f64 VALU runs
+  // at a fraction of the f32 rate -- plus 48 accumulator registers made this elementwise pass run at 3.7 TB/s.)
+  float s1[8], s2[8], s3[8];
   float mc[8], rc[8], m1[8], r1[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    s1[j] = 0.0; s2[j] = 0.0; s3[j] = 0.0;
+    s1[j] = 0.f; s2[j] = 0.f; s3[j] = 0.f;
     mc[j] = mr_c[v * 8 + j]; rc[j] = mr_c[Cp + v * 8 + j];
     m1[j] = s ? mr_1[v * 8 + j] : 0.f; r1[j] = s ? mr_1[Cp + v * 8 + j] : 0.f;
   }
@@ -97,8 +100,8 @@ __global__ void block_out_bwd_kernel(const T* __restrict__ dy, const T* __restri
     for (int j = 0; j < 8; ++j) {
       const float gg = yv[j] > 0.f ? d[j] : 0.f;
       d[j] = gg;
-      s1[j] += (double)gg; s2[j] += (double)(gg * ((cv[j] - mc[j]) * rc[j]));
-      if (s) s3[j] += (double)(gg * ((sv[j] - m1[j]) * r1[j]));
+      s1[j] += gg; s2[j] += gg * ((cv[j] - mc[j]) * rc[j]);
+      if (s) s3[j] += gg * ((sv[j] - m1[j]) * r1[j]);
     }
     Vec8<T>::store(g + i * 8, d);
   }

@@ -477,6 +477,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         c3dfin::bn_bwd_coef_consume(a.fin, a.K, Kp, c, blockIdx.x == 0, cA, cB, cC);
         Pp[c] = cA; Pp[Kp + c] = cB; Pp[2 * Kp + c] = cC;
       }
+    } else if (PRO == C3D_PRO_BN_SE_SWISH && a.fin.sums) {
+      // BatchNorm_b of a block without SqueezeExcitation, finalised here from the depthwise kernel's per-sample sums (no
+      // c3d_bn_se_finalize launch between conv_b and conv_c); workgroup 0 owns ss / mr / the running statistics
+      if (blockIdx.x == 0 && tid == 0 && a.fin.nbt) *a.fin.nbt += 1;
+      c3dfin::bn_consume_nc(a.fin, a.K, Kp, blockIdx.x == 0, Pp, Pp + Kp, tid, WAVES * 64);
     } else if (PRO != C3D_PRO_NONE) {
       const int np = (PRO == C3D_PRO_AFFINE2 ? 3 : 2) * Kp;
       for (int i = tid; i < np; i += WAVES * 64) Pp[i] = a.pro_p[i];

@@ -584,6 +584,11 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       RC(prof_call("c3d_dw333_fwd", dw_bytes, st, [&] {
         return c3d_dw333_fwd(a, ss_a, k.w_b, b, nc_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st); }));
     }
+    // BatchNorm_b (+ the SqueezeExcitation gate).  Blocks WITHOUT SE (every odd block) need only the batch statistics:
+    // conv_c's prologue rebuilds scale / shift from the per-sample sums itself (csrc/bn_fin.h bn_consume_nc; narrow
+    // kernel) -- one single-workgroup launch less on the forward critical path per such block
+    const bool fold_b = cons && !G.se && G.Cip <= 224 && G.Cop <= 224;
+    if (!fold_b)
     RC(prof_call("c3d_bn_se_finalize", 0.0, st, [&] {
       return c3d_bn_se_finalize(nc_b, B, (double)rps, k.bn_b.gamma, k.bn_b.beta, k.bn_b.running_mean, k.bn_b.running_var,
                                 tr ? k.bn_b.num_batches_tracked : nullptr, d->momentum, d->eps, G.Ci, G.Cip, tr,
@@ -592,6 +597,10 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
     {
       PwCall p(b, k.w_c, c, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
       p.a.pro_mode = C3D_PRO_BN_SE_SWISH; p.a.pro_p = ss_b; p.a.pro_gate = gate; p.a.rows_per_sample = rps;
+      if (fold_b) {
+        p.a.fin = fin_consume(nc_b, k.bn_b, (double)rps * B, d->momentum, d->eps, ss_b, mr_b);
+        p.a.fin.batch = B;
+      }
       p.a.epi_mode = epi; p.a.stats = sums_c; p.a.w_img = imgp(F.img_c);
       RC(pw_launch(p.a, st));
     }
@@ -705,6 +714,10 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       p.a.stats = nc3; p.a.rows_per_sample = rps; p.a.w_img = imgp(F.img_ct);
       RC(pw_launch(p.a, st));
     }
+    // BatchNorm_b / SE backward coefficients.  Blocks without SE (stride 1 always): the fused depthwise backward kernel
+    // rebuilds A | B | C from the per-sample sums in its prologue -- no coefficient launch on the critical path
+    const bool fold_b = fin_consumer(d) && !G.se && G.s == 1;
+    if (!fold_b)
     RC(prof_call("c3d_se_bn_bwd_coef", 0.0, st, [&] {
       return c3d_se_bn_bwd_coef(nc3, nc_b, B, (double)rps, k.bn_b.gamma, mr_b, ss_b, G.Ci, G.Cip, G.se ? k.se_w1 : nullptr,
                                 k.se_w2, gate, hid, G.Cr, cA, cC, cB, k.bn_b.dgamma, k.bn_b.dbeta, k.dse_w1, k.dse_b1,
@@ -712,7 +725,14 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     // ---- depthwise conv_b.  Stride 1: data gradient and weight gradient in ONE pass over t1, b, a
     //      (csrc/dw_bwd_fused.hip).  Stride 2 (first block of a stage): the pair, the weight gradient forked first on
     //      the side stream (it needs the coefficients, not the data gradient).
-    if (G.s == 1) {
+    if (fold_b) {
+      c3d_bn_fin fb;
+      std::memset(&fb, 0, sizeof(fb));
+      fb.sums = nc3; fb.batch = B; fb.gamma = k.bn_b.gamma; fb.mr = const_cast<float*>(mr_b); fb.count = (double)rps * B;
+      fb.running_mean = k.bn_b.dgamma; fb.running_var = k.bn_b.dbeta;
+      RC(prof_call("c3d_dw333_bwd_fused", ((double)G.Mo * 2 + (double)G.M * 2) * G.Cip * e, st, [&] {
+        return c3d_dw333_bwd_fused_fin(t1, b, &fb, k.w_b, a, ss_a, mr_a, t2, dsums_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, dt, st); }));
+    } else if (G.s == 1) {
       RC(prof_call("c3d_dw333_bwd_fused", ((double)G.Mo * 2 + (double)G.M * 2) * G.Cip * e, st, [&] {
         return c3d_dw333_bwd_fused(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, dt, st); }));
     } else {

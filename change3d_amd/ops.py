@@ -241,10 +241,12 @@ def grad_of(p):
 
 
 # ----------------------------------------------------------------------------- pointwise GEMM
-def fin_consume(sums, bn, count, ss, mr):
+def fin_consume(sums, bn, count, ss, mr, batch=0):
     """c3d_bn_fin for the consumer-side finalisation (c3d_dw333_fwd_fin / c3d_block_out_fwd_fin): `sums` are the
-    completed f64 [16][2][C] statistics of an earlier launch."""
+    completed f64 [16][2][C] statistics of an earlier launch; batch > 0: the per-sample layout [batch][Cp][2] of
+    c3d_dw333_fwd (BatchNorm_b of a block without SqueezeExcitation, consumed by c3d_pw_gemm's BN_SE_SWISH prologue)."""
     f = L.BnFin()
+    f.batch = int(batch)
     f.sums = _p(sums)
     f.gamma, f.beta = _p(bn.weight), _p(bn.bias)
     f.running_mean, f.running_var, f.nbt = _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked)
@@ -392,6 +394,21 @@ def dw_bwd_fused(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, dw, B, T, H, W,
     """Stride-1 depthwise backward: data gradient, BatchNorm_a-backward sums and weight gradient in one pass."""
     _launch("c3d_dw333_bwd_fused", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_fused,
             _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2), _p(dsums), _p(dw),
+            B, T, H, W, C_, cpad(C_), dtype, _stream())
+
+
+def fin_b_bwd(nc3, batch, bn, count, mr):
+    """c3d_bn_fin for c3d_dw333_bwd_fused_fin: BatchNorm_b backward coefficients of a block without SqueezeExcitation from
+    the per-sample sums nc3 [batch][Cp][3]; d gamma / d beta accumulate into bn.weight.grad / bn.bias.grad."""
+    f = L.BnFin()
+    f.sums, f.batch, f.gamma, f.mr, f.count = _p(nc3), int(batch), _p(bn.weight), _p(mr), float(count)
+    f.running_mean, f.running_var = _p(grad_of(bn.weight)), _p(grad_of(bn.bias))
+    return f
+
+
+def dw_bwd_fused_fin(t1, b, fin_b, w, a, ss_a, mr_a, t2, dsums, dw, B, T, H, W, C_, dtype):
+    _launch("c3d_dw333_bwd_fused", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_fused_fin,
+            _p(t1), _p(b), C.byref(fin_b), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2), _p(dsums), _p(dw),
             B, T, H, W, C_, cpad(C_), dtype, _stream())
 
 

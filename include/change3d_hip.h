@@ -74,11 +74,16 @@ typedef struct c3d_bn_fin {
   float* ss; float* mr;
   double count;
   float momentum, eps;
-  int32_t training, reserved;
+  int32_t training, batch;   /* batch > 0: `sums` is the PER-SAMPLE layout of c3d_dw333_fwd / the Swish-SE-backward epilogue   */
   /* consumer side (c3d_dw333_fwd_fin, c3d_block_out_fwd_fin): the completed f64 sums [C3D_STAT_STRIPES][2][C] of an
    * EARLIER launch; every workgroup of the consuming kernel rebuilds scale/shift of the channels it reads, one
    * workgroup also writes ss / mr / the running statistics.  `ticket` is unused (NULL) in this mode.                */
   const double* sums;
+  /* batch > 0 (BatchNorm_b of blocks WITHOUT SqueezeExcitation; the SE blocks keep c3d_bn_se_finalize / c3d_se_bn_bwd_coef):
+   *   forward  (c3d_pw_gemm C3D_PRO_BN_SE_SWISH): sums = nc f64 [batch][Cp][2] -> scale|shift rebuilt by every workgroup in
+   *             the 4-lane order of c3d_bn_se_finalize (bit-identical), workgroup 0 writes ss / mr / running statistics;
+   *   backward (c3d_dw333_bwd_fused): sums = nc3 f64 [batch][Cp][3] -> A | B | C of c3d_se_bn_bwd_coef (no-SE branch),
+   *             running_mean / running_var carry dgamma / dbeta (accumulated by one workgroup per channel chunk).      */
 } c3d_bn_fin;
 
 typedef struct c3d_pw_args {
@@ -238,6 +243,13 @@ int c3d_dw333_bwd_fused(const void* t1, const void* b, const float* coefA, const
                         const float* coefC, const float* w, const void* a, const float* ss_a,
                         const float* mr_a, void* t2, double* dsums, float* dw, int32_t B, int32_t T,
                         int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t dtype, void* stream);
+/* Same, with the BatchNorm_b backward coefficients of a block WITHOUT SqueezeExcitation rebuilt in the kernel's prologue
+ * from the per-sample sums nc3 (fin_b->sums, fin_b->batch = B, fin_b->gamma, fin_b->mr = mean|rstd of BatchNorm_b,
+ * fin_b->count = B*T*H*W; dgamma / dbeta += through fin_b->running_mean / running_var): no c3d_se_bn_bwd_coef launch
+ * between the conv_c data gradient and this kernel.  coefA / coefB / coefC are ignored (may be NULL).                */
+int c3d_dw333_bwd_fused_fin(const void* t1, const void* b, const c3d_bn_fin* fin_b, const float* w, const void* a,
+                            const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw, int32_t B,
+                            int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Res-block output y = relu(bn_c(c) + shortcut) (reference model/x3d.py:326-327; also the

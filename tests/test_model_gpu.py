@@ -276,29 +276,20 @@ def test_e2e_bcd_vs_oracle_size64():
             assert p.grad is None, n
 
 
-@pytest.mark.parametrize("task", ["bcd", "scd"])
-def test_e2e_vs_oracle_conditioned_weights_every_gradient(task):
-    """The default synthetic weights are chaotic (tools/grad_error_report.py: one input rounding moves gradients by
-    ~1e-2), which is why the tests around this one judge errors against the fp32 reference's own distance from fp64.
-    With every residual branch scaled by 0.1 (`branch_gain`: a trained-network-like, well-conditioned stack) fp32
-    rounding stays in the linear regime and the HIP f32 path is compared DIRECTLY with the fp32 oracle: outputs to
-    1e-5, EVERY parameter gradient to 1e-4 relative L2 (measured: worst ~1e-5).
-    The strict form is fragile by nature and is asserted where it holds (BCD).  There are ~120 ReLU layers; when ONE
-    pre-activation lands on the other side of the kink -- a last-bit difference in an early BatchNorm scale is enough --
-    the gradients of ~100 upstream tensors move by 1e-4 .. 1e-3.  tools/dbg_flip.py shows the signature on the SCD case
-    for two stem implementations whose outputs are BIT-identical (tests below) and whose f64 statistics differ in the
-    8th digit: res3.6 norm_a differs from the oracle by 4.3e-6 in channel 48 and by 2e-9 in the other 107 channels.
-    For SCD (T=5: more pre-activations, it happens for this seed) the bound is on the distribution: median < 2e-5,
-    70 % of the tensors < 1e-4, none above 5e-3."""
-    _need_gpu()
+def _conditioned_case(task, wseed):
+    """One (task, weight seed) case of the conditioned-weights comparison: HIP f32 vs the fp32 oracle (its own rounding
+    depends on the CPU thread count -- a ReLU can flip on EITHER side -- so the oracle runs single-threaded here: the
+    case is then deterministic on both sides).  Returns {parameter: gradient rel-L2}."""
     from oracle import model as om, synth
     from change3d_amd.model.trainer import Trainer
     from change3d_amd.model.utils import BCEDiceLoss, hot_path_named_params
+    threads0 = torch.get_num_threads()
+    torch.set_num_threads(1)
     size, batch = 64, 2
     mk = (lambda: om.make_args(size=size)) if task == "bcd" else \
         (lambda: om.make_args(num_perception_frame=3, size=size, dataset="SECOND", num_class=7))
     ref = om.Trainer(mk())
-    sd = synth.synth_state_dict(ref, seed=16, mask_margin=0.25, branch_gain=0.1)
+    sd = synth.synth_state_dict(ref, seed=wseed, mask_margin=0.25, branch_gain=0.1)
     ref.load_state_dict(sd)
     mine = Trainer(mk())
     mine.load_state_dict(sd)
@@ -324,16 +315,48 @@ def test_e2e_vs_oracle_conditioned_weights_every_gradient(task):
     for od, orr in outs:
         assert (od.detach().cpu() - orr.detach()).abs().max().item() < 1e-5 * max(1.0, orr.detach().abs().max().item())
     pref = dict(ref.named_parameters())
-    errs = {n: rel(p.grad, pref[n].grad) for n, p in hot_path_named_params(mine)}
+    torch.set_num_threads(threads0)
+    return {n: rel(p.grad, pref[n].grad) for n, p in hot_path_named_params(mine)}
+
+
+def _summ(task, wseed, errs):
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     over = [n for n, e in errs.items() if e >= 1e-4]
-    print(f"{task} conditioned: worst per-parameter gradient rel-L2 {[(n, f'{e:.1e}') for n, e in worst]}; "
-          f"{len(over)}/{len(errs)} tensors above 1e-4")
-    if task == "bcd":
-        assert worst[0][1] < 1e-4, worst
-    else:
-        med = sorted(errs.values())[len(errs) // 2]
-        assert med < 2e-5 and len(over) <= 0.3 * len(errs) and worst[0][1] < 5e-3, (med, len(over), worst)
+    med = sorted(errs.values())[len(errs) // 2]
+    print(f"{task} conditioned (weight seed {wseed}): worst per-parameter gradient rel-L2 {[(n, f'{e:.1e}') for n, e in worst]}; "
+          f"median {med:.1e}; {len(over)}/{len(errs)} tensors above 1e-4")
+    return worst[0][1], med, len(over)
+
+
+def test_e2e_vs_oracle_conditioned_weights_every_gradient_bcd():
+    """The default synthetic weights are chaotic (tools/grad_error_report.py: one input rounding moves gradients by
+    ~1e-2), which is why the tests around this one judge errors against the fp32 reference's own distance from fp64.
+    With every residual branch scaled by 0.1 (`branch_gain`: a trained-network-like, well-conditioned stack) fp32
+    rounding stays in the linear regime and the HIP f32 path is compared DIRECTLY with the fp32 oracle: outputs to
+    1e-5, EVERY parameter gradient to 1e-4 relative L2 (measured: worst 2e-5)."""
+    _need_gpu()
+    worst, _, _ = _summ("bcd", 16, _conditioned_case("bcd", 16))
+    assert worst < 1e-4, worst
+
+
+def test_e2e_vs_oracle_conditioned_weights_every_gradient_scd():
+    """SCD (T=5, three decoders): the same STRICT bound -- every one of the 490 gradient tensors within 1e-4 of the fp32
+    oracle.  There are ~120 ReLU layers over 5/3 as many elements as BCD; when ONE pre-activation lands on the other side
+    of the kink (a last-bit difference in an early BatchNorm scale is enough, on either side) ~100 upstream tensors move
+    by 1e-4 .. 1e-3 (tools/dbg_flip.py; tools/scan_scd_seed.py: 21 of 24 weight seeds hit one).  The bound is therefore
+    asserted on the three kink-free seeds 23, 26, 27 (worst tensor 1.4e-5 / 1.7e-5 / 1.4e-5 on MI355X) and must hold on at
+    least TWO of them, so that a future last-bit change that flips one ReLU in one case does not hide -- or fake -- a
+    regression; every case (and the kinked default seed 16) must also satisfy the distribution bound: median < 2e-5,
+    70 % of the tensors < 1e-4, none above 5e-3."""
+    _need_gpu()
+    strict_ok = 0
+    for wseed in (23, 26, 27, 16):
+        errs = _conditioned_case("scd", wseed)
+        worst, med, n_over = _summ("scd", wseed, errs)
+        assert med < 2e-5 and n_over <= 0.3 * len(errs) and worst < 5e-3, (wseed, med, n_over, worst)
+        if wseed != 16 and worst < 1e-4:
+            strict_ok += 1
+    assert strict_ok >= 2, f"strict 1e-4 bound holds on {strict_ok} of the 3 kink-free seeds"
 
 
 @pytest.mark.parametrize("T,dtype,shape", [(3, torch.float32, (2, 64, 64)), (5, torch.float32, (2, 40, 72)),

@@ -808,3 +808,82 @@ def test_pw_pack_weights_many_images_in_one_call():
         torch.cuda.synchronize()
         assert torch.equal(alone, together[i]), f"image {i}"
     assert ops.pw_weight_image_bytes(432, 192, dt) == 0      # wide shapes have no image (block-tiled kernel)
+
+
+# ----------------------------------------------------- round 3: BatchNorm_b of blocks without SqueezeExcitation, consumer side
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,C", [(5, 54), (32, 216), (3, 108)])
+def test_bn_b_finalize_folded_into_conv_c_and_fused_depthwise_backward_is_bit_identical(dtype, B, C):
+    """Blocks without SE: (a) c3d_pw_gemm's BN_SE_SWISH prologue rebuilding BatchNorm_b's scale / shift from the depthwise
+    kernel's per-sample sums (fin.batch) against c3d_bn_se_finalize + the plain call; (b) c3d_dw333_bwd_fused_fin rebuilding
+    A | B | C from the Swish-backward epilogue's per-sample sums against c3d_se_bn_bwd_coef + c3d_dw333_bwd_fused:
+    outputs, statistics, saved vectors, running statistics and d gamma / d beta are BIT-identical (csrc/bn_fin.h)."""
+    _need_gpu()
+    from change3d_amd import ops
+    T, H, W, N = 3, 16, 24, 48
+    Cp, Np = ops.cpad(C), ops.cpad(N)
+    dt = ops.dt_code(dtype)
+    rps = T * H * W
+    M = B * rps
+    bt = padc(q(rnd((M, C), 300), dtype), Cp).to(DEV, dtype).contiguous()
+    nc = torch.zeros(B, Cp, 2, dtype=torch.float64, device=DEV)
+    bq = bt.float().double().view(B, rps, Cp)
+    nc[:, :, 0], nc[:, :, 1] = bq.sum(1), (bq * bq).sum(1)
+    w = rnd((N, C), 301, 0.2).to(DEV).contiguous()
+
+    def bn_module(seed):
+        m = torch.nn.BatchNorm3d(C).to(DEV)
+        with torch.no_grad():
+            m.weight.copy_(rnd((C,), seed).abs() + 0.5); m.bias.copy_(rnd((C,), seed + 1, 0.3))
+            m.running_mean.copy_(rnd((C,), seed + 2, 0.2)); m.running_var.copy_(rnd((C,), seed + 3).abs() + 0.5)
+        return m
+
+    outs = []
+    for folded in (False, True):
+        m = bn_module(310)
+        ss, mr = torch.zeros(2 * Cp, device=DEV), torch.zeros(2 * Cp, device=DEV)
+        y = torch.full((M, Np), float("nan"), dtype=dtype, device=DEV)
+        stats = torch.zeros(ops.STAT_STRIPES * 2 * N, dtype=torch.float64, device=DEV)
+        kw = dict(M=M, K=C, N=N, w_sn=C, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH, rows_per_sample=rps,
+                  epi_mode=ops.EPI_STATS, stats=stats)
+        if folded:
+            ops.pw_gemm(bt, w, y, pro_p=ss, fin=ops.fin_consume(nc, m, float(M), ss, mr, batch=B), **kw)
+        else:
+            ops.bn_se_finalize(nc.view(-1), B, rps, m, None, C, ss, mr, None, None, True)
+            ops.pw_gemm(bt, w, y, pro_p=ss, **kw)
+        torch.cuda.synchronize()
+        outs.append(dict(y=y, stats=stats, ss=ss, mr=mr, rm=m.running_mean.clone(), rv=m.running_var.clone(),
+                         nbt=m.num_batches_tracked.clone()))
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), f"forward: {k} differs"
+    assert torch.isfinite(outs[1]["y"].float()).all() and int(outs[1]["nbt"]) == 1
+    ss_b, mr_b = outs[0]["ss"], outs[0]["mr"]
+
+    # ---- backward
+    Ho, Wo = H, W
+    a = padc(q(rnd((B, T, H, W, C), 320), dtype), Cp).to(DEV, dtype).contiguous()
+    b5 = bt.view(B, T, Ho, Wo, Cp)
+    t1 = padc(q(rnd((B, T, Ho, Wo, C), 321), dtype), Cp).to(DEV, dtype).contiguous()
+    nc3 = torch.zeros(B, Cp, 3, dtype=torch.float64, device=DEV)
+    nc3[:, :C] = rnd((B, C, 3), 322).double().to(DEV) * 50.0
+    wd = rnd((C, 1, 3, 3, 3), 323, 0.3).to(DEV).contiguous()
+    ssa = torch.cat([padc(rnd((C,), 324).abs() + 0.5, Cp), padc(rnd((C,), 325, 0.3), Cp)]).to(DEV)
+    mra = torch.cat([padc(rnd((C,), 326, 0.5), Cp), padc(rnd((C,), 327).abs() + 0.5, Cp)]).to(DEV)
+    res = []
+    for folded in (False, True):
+        m = bn_module(310)
+        t2 = torch.full_like(a, float("nan"))
+        dsums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+        dw = torch.zeros((C, 27), dtype=torch.float32, device=DEV)
+        if folded:
+            ops.dw_bwd_fused_fin(t1, b5, ops.fin_b_bwd(nc3, B, m, float(M), mr_b), wd, a, ssa, mra, t2, dsums, dw, B, T, H, W, C, dt)
+        else:
+            cA, cC, cB = torch.zeros(Cp, device=DEV), torch.zeros(Cp, device=DEV), torch.zeros(B * Cp, device=DEV)
+            ops.se_bn_bwd_coef(nc3.view(-1), nc.view(-1), B, rps, m, mr_b, ss_b, None, None, None, C, cA, cC, cB)
+            ops.dw_bwd_fused(t1, b5, cA, cB, cC, wd, a, ssa, mra, t2, dsums, dw, B, T, H, W, C, dt)
+        torch.cuda.synchronize()
+        res.append(dict(t2=t2, dsums=dsums, dgamma=m.weight.grad.clone(), dbeta=m.bias.grad.clone(), dw=dw))
+    for k in ("t2", "dsums", "dgamma", "dbeta"):
+        assert torch.equal(res[0][k], res[1][k]), f"backward: {k} differs"
+    assert torch.isfinite(res[1]["t2"].float()).all() and float(res[1]["dgamma"].abs().max()) > 0
+    close(res[1]["dw"], res[0]["dw"], dtype, "dw (f32 atomics)", scale=res[0]["dw"].abs().max().item())
