@@ -294,15 +294,35 @@ __global__ __launch_bounds__(256) void convt_wgrad_mfma_kernel(const bf16_t* __r
       }
 }
 
-// dw[ci][co][ky][kx] += sum over workgroups of ws[wg][tap][ci][co]
-__global__ void convt_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, const int nwg, const int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// dw[ci][co][ky][kx] += sum over workgroups of ws[wg][tap][ci][co].  32 outputs per block x 8 part-groups: a thread adds
+// at most nwg/8 coalesced values with four loads in flight, the groups are combined through LDS in fixed order (one
+// thread per output walking all nwg partials took 100 us per launch: a serial chain of ~1000 dependent-latency loads).
+__global__ __launch_bounds__(256) void convt_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, const int nwg,
+                                                                 const int C) {
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;
   const int n = 16 * C * C;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int g = 0; g < nwg; ++g) s += ws[(size_t)g * n + i];
-  const int co = i % C, ci = (i / C) % C, tap = i / (C * C);
-  dw[((size_t)ci * C + co) * 16 + tap] += s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int g = pg;
+    for (; g + 24 < nwg; g += 32) {
+      s0 += ws[(size_t)g * n + i];
+      s1 += ws[(size_t)(g + 8) * n + i];
+      s2 += ws[(size_t)(g + 16) * n + i];
+      s3 += ws[(size_t)(g + 24) * n + i];
+    }
+    for (; g < nwg; g += 8) s0 += ws[(size_t)g * n + i];
+  }
+  red[pg][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (pg == 0 && i < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][e];
+    const int co = i % C, ci = (i / C) % C, tap = i / (C * C);
+    dw[((size_t)ci * C + co) * 16 + tap] += s;
+  }
 }
 
 int persistent_grid(const int64_t work_items, const int per_cu) {
@@ -363,7 +383,7 @@ int launch_wgrad(const void* t, const void* dcur, float* dw, float* ws, int B, i
   convt_wgrad_mfma_kernel<C><<<grid, 256, lds, st>>>((const bf16_t*)t, (const bf16_t*)dcur, ws, B, h, wd);
   C3D_CHECK_LAUNCH();
   const int n = 16 * C * C;
-  convt_wgrad_reduce_kernel<<<(n + 255) / 256, 256, 0, st>>>(ws, dw, grid, C);
+  convt_wgrad_reduce_kernel<<<(n + 31) / 32, 256, 0, st>>>(ws, dw, grid, C);
   C3D_CHECK_LAUNCH();
   return 0;
 }

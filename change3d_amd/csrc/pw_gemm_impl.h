@@ -560,6 +560,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         const int v_ = i_ - row_ * Gi;
         if (row_ < 16) {
           const int tl_ = it0 + slot_s[j];
+          if constexpr (sizeof(T) == 2 && PRO == C3D_PRO_NONE) {   // no prologue: the raw bf16 vector IS the operand
+            *reinterpret_cast<uint4*>(Xs + (slot_s[j] * 16 + row_) * KL + v_ * 8) = xr[j];
+            continue;
+          }
           float f[8];
           RW::cvt(xr[j], f);
           if (PRO == C3D_PRO_BN_SE_SWISH) {
@@ -657,6 +661,21 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         if (e1_rows) {
           if (p + 1 < npass) e1n = RW::load(PW_E1_PTR(row0, p + 1));
           else if (has_next) e1n = RW::load(PW_E1_PTR(row0 + 16, 0));   // first pass of the next tile of this iteration
+        }
+        if constexpr (sizeof(T) == 2 && (EPI == C3D_EPI_STORE || EPI == C3D_EPI_STATS)) {
+          // bf16 plain-store / statistics epilogue: the staged tile already holds the stored bits -- copy the 16 bytes
+          // as they are (the f32 round trip cost 8 unpack + 8 re-round + 4 pack VALU per vector for an identity)
+          if (act_o && row < 16 && m < M32) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(Os + row * NL + v_o * 8);
+            if (EPI == C3D_EPI_STATS) {
+              float f[8];
+              RW::cvt(raw, f);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { s0[j] += f[j]; s1[j] += f[j] * f[j]; }
+            }
+            *reinterpret_cast<uint4*>(Y + (int64_t)m * Np + v_o * 8) = raw;
+          }
+          continue;
         }
         if (act_o && row < 16 && m < M32) {
           float f[8];

@@ -277,46 +277,54 @@ def test_e2e_bcd_vs_oracle_size64():
 
 
 def _conditioned_case(task, wseed):
-    """One (task, weight seed) case of the conditioned-weights comparison: HIP f32 vs the fp32 oracle (its own rounding
-    depends on the CPU thread count -- a ReLU can flip on EITHER side -- so the oracle runs single-threaded here: the
-    case is then deterministic on both sides).  Returns {parameter: gradient rel-L2}."""
+    """One (task, weight seed) case of the conditioned-weights comparison: HIP f32 vs the fp32 oracle.  A ReLU can flip on
+    EITHER side: torch-CPU's own f32 rounding depends on its thread count (measured: the BCD seed-16 oracle at 1 thread is
+    5e-4 (median) away from the same oracle at 4 or 16 threads -- and from the HIP path, which agrees with those to 1e-6).
+    The oracle is therefore evaluated at two thread counts and every tensor is judged against the closer one: an oracle-side
+    flip in one evaluation cannot fail (or pass) the case.  Returns {parameter: gradient rel-L2}."""
     from oracle import model as om, synth
     from change3d_amd.model.trainer import Trainer
     from change3d_amd.model.utils import BCEDiceLoss, hot_path_named_params
-    threads0 = torch.get_num_threads()
-    torch.set_num_threads(1)
     size, batch = 64, 2
     mk = (lambda: om.make_args(size=size)) if task == "bcd" else \
         (lambda: om.make_args(num_perception_frame=3, size=size, dataset="SECOND", num_class=7))
-    ref = om.Trainer(mk())
-    sd = synth.synth_state_dict(ref, seed=wseed, mask_margin=0.25, branch_gain=0.1)
-    ref.load_state_dict(sd)
+    sd = synth.synth_state_dict(om.Trainer(mk()), seed=wseed, mask_margin=0.25, branch_gain=0.1)
+    pre, post, tgt = synth.synth_batch(batch, size, seed=0)
+    labels = synth.synth_scd_labels(batch, size, seed=0) if task == "scd" else None
     mine = Trainer(mk())
     mine.load_state_dict(sd)
     mine = mine.to(DEV).train()
-    ref.train()
-    pre, post, tgt = synth.synth_batch(batch, size, seed=0)
     if task == "bcd":
-        pr = ref.update_bcd(pre, post)
-        om.bce_dice_loss(pr, tgt).backward()
-        pd = mine.update_bcd(pre.to(DEV), post.to(DEV))
-        BCEDiceLoss(pd, tgt.to(DEV)).backward()
-        outs = [(pd, pr)]
+        outs_d = [mine.update_bcd(pre.to(DEV), post.to(DEV))]
+        BCEDiceLoss(outs_d[0], tgt.to(DEV)).backward()
     else:
-        labels = synth.synth_scd_labels(batch, size, seed=0)
-        o_r = ref.update_scd(pre, post)
-        om.scd_loss(*o_r, labels).backward()
         from change3d_amd.model.utils import ChangeSimilarity, CrossEntropyLoss2d
         from change3d_amd.scripts.train_SCD import scd_loss
-        o_d = mine.update_scd(pre.to(DEV), post.to(DEV))
-        scd_loss(CrossEntropyLoss2d(ignore_index=0), ChangeSimilarity(), o_d, labels.to(DEV))[0].backward()
-        outs = list(zip(o_d, o_r))
+        outs_d = list(mine.update_scd(pre.to(DEV), post.to(DEV)))
+        scd_loss(CrossEntropyLoss2d(ignore_index=0), ChangeSimilarity(), outs_d, labels.to(DEV))[0].backward()
     torch.cuda.synchronize()
-    for od, orr in outs:
-        assert (od.detach().cpu() - orr.detach()).abs().max().item() < 1e-5 * max(1.0, orr.detach().abs().max().item())
-    pref = dict(ref.named_parameters())
-    torch.set_num_threads(threads0)
-    return {n: rel(p.grad, pref[n].grad) for n, p in hot_path_named_params(mine)}
+    threads0 = torch.get_num_threads()
+    errs = None
+    try:
+        for thr in (1, 4):
+            torch.set_num_threads(thr)
+            ref = om.Trainer(mk())
+            ref.load_state_dict(sd)
+            ref.train()
+            if task == "bcd":
+                outs_r = [ref.update_bcd(pre, post)]
+                om.bce_dice_loss(outs_r[0], tgt).backward()
+            else:
+                outs_r = list(ref.update_scd(pre, post))
+                om.scd_loss(*outs_r, labels).backward()
+            for od, orr in zip(outs_d, outs_r):
+                assert (od.detach().cpu() - orr.detach()).abs().max().item() < 1e-5 * max(1.0, orr.detach().abs().max().item())
+            pref = dict(ref.named_parameters())
+            e = {n: rel(p.grad, pref[n].grad) for n, p in hot_path_named_params(mine)}
+            errs = e if errs is None else {n: min(errs[n], e[n]) for n in e}
+    finally:
+        torch.set_num_threads(threads0)
+    return errs
 
 
 def _summ(task, wseed, errs):
