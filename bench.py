@@ -159,13 +159,13 @@ def pmc_traffic(entry):
 
 def also_runs(a):
     """Short runs of the other workloads BASELINE.json names, each in its own process after the headline measurement
-    (5 timed steps, 3 warm-up, no settling: indicative numbers that let the driver's record carry them; the headline
-    `value` is never affected): SCD (configs[3], B=16, T=5), CC (configs[4], B=16) in bf16, and the BCD workload on the
+    (10 timed steps after 40 settling + 5 warm-up steps, as the headline run: numbers that let the driver's record carry them;
+    the headline `value` is never affected): SCD (configs[3], B=16, T=5), CC (configs[4], B=16) in bf16, and the BCD workload on the
     f32 storage path -- the path every bit-exact / 1e-4 parity statement is made on -- so that it has a price."""
     import subprocess
     res = {}
     for key, extra in (("scd", ["--task", "scd"]), ("cc", ["--task", "cc"]), ("bcd_f32", ["--task", "bcd", "--dtype", "f32"])):
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "5", "--warmup", "3", "--size", str(a.size),
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "10", "--warmup", "5", "--size", str(a.size),
                "--no-cpu-baseline", "--no-kernel-profile", "--no-also"] + extra
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)

@@ -18,7 +18,8 @@ from collections import defaultdict
 
 ENTRY = [  # kernel-name prefix -> C-ABI entry point (bench.py's kernel table key)
     ("pw_gemm_kernel", "c3d_pw_gemm"), ("pw_wgrad_kernel", "c3d_pw_wgrad"), ("pw_wgrad_reduce", "c3d_pw_wgrad"),
-    ("dw_fwd", "c3d_dw333_fwd"), ("dw_bwd_data", "c3d_dw333_bwd_data"), ("dw_wgrad", "c3d_dw333_wgrad"),
+    ("dw_fwd", "c3d_dw333_fwd"), ("dw_bwd_fused", "c3d_dw333_bwd_fused"), ("dw_bwd_data", "c3d_dw333_bwd_data"),
+    ("dw_wgrad", "c3d_dw333_wgrad"),
     ("block_out_fwd", "c3d_block_out_fwd"), ("block_out_bwd", "c3d_block_out_bwd"),
     ("se_bn_bwd_coef", "c3d_se_bn_bwd_coef"), ("bn_se_finalize", "c3d_bn_se_finalize"),
     ("bn_finalize", "c3d_bn_finalize"), ("bn_bwd_coef", "c3d_bn_bwd_coef"), ("stem_", "c3d_stem_*"),
@@ -58,7 +59,7 @@ def main():
           out = [{"entry": e, "calls": c, "total_ms": round(t / 1e6, 3), "avg_us": round(t / c / 1e3, 2)}
                  for e, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])]
           json.dump({"source": "rocprofv3 --kernel-trace --stats -- " + cmd,
-                     "note": "all launches of the run (python bench.py: 40 settling + 5 warm-up + 20 timed steps through the stage driver, 2 per-kernel profile steps = 67 steps)",
+                     "note": "all launches of the run (python bench.py --no-also: 40 settling + 5 warm-up + 20 timed steps + 2 set-up / per-kernel profile steps through the stage driver = 67 steps)",
                      "by_entry": out,
                      "top_kernels": [{"name": r["Name"][:160], "calls": int(r["Calls"]),
                                       "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
