@@ -2,6 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oracle import model as om, synth
+from change3d_amd import ops
 from change3d_amd.model.trainer import Trainer
 from change3d_amd.model.utils import ChangeSimilarity, CrossEntropyLoss2d
 from change3d_amd.scripts.train_SCD import scd_loss
@@ -17,7 +18,7 @@ om.scd_loss(*ref.update_scd(pre, post), labels).backward()
 pref = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
 res = {}
 for m in ("1", "0"):
-    os.environ["C3D_STEM_MFMA"] = m
+    ops.set_option(ops.OPT_STEM_MFMA, int(m))
     mine = Trainer(mk()); mine.load_state_dict(sd); mine = mine.to(DEV).train()
     o_d = mine.update_scd(pre.to(DEV), post.to(DEV))
     scd_loss(CrossEntropyLoss2d(ignore_index=0), ChangeSimilarity(), o_d, labels.to(DEV))[0].backward()

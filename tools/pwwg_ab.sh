@@ -1,7 +1,9 @@
 #!/bin/bash
 # A/B of the side-stream width of the pointwise weight gradient (C3D_PWWG_SIDE_WGS): BCD, SCD, CC, B=16
 set -u
+# environment knobs exist in the instrumented build only (python __graft_entry__.py --tuning)
 cd "${GRAFT_REPO_ROOT:-.}"
+export C3D_LIB=${C3D_LIB:-$(pwd)/change3d_amd/lib/libchange3d_hip_tune.so}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -q -k "pw_wgrad or e2e or res_stage or reproducible" 2>&1 | tail -3

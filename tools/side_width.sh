@@ -1,7 +1,9 @@
 #!/bin/bash
 # sweep of the side-stream kernel widths / ring depth (interleaved with the default configuration)
 set -u
+# environment knobs exist in the instrumented build only (python __graft_entry__.py --tuning)
 cd "${GRAFT_REPO_ROOT:-.}"
+export C3D_LIB=${C3D_LIB:-$(pwd)/change3d_amd/lib/libchange3d_hip_tune.so}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 run() { local label=$1; shift; env "$@" python bench.py --no-cpu-baseline --no-kernel-profile --steps 60 --warmup 10 2> gpurun_out/sw_$label.err | tail -1 > gpurun_out/sw_$label.json

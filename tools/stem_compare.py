@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""MFMA stem kernels vs the scalar-FMA ones on the same inputs (C3D_STEM_MFMA toggled per call)."""
+"""MFMA stem kernels vs the scalar-FMA ones on the same inputs (c3d_set_option C3D_OPT_STEM_MFMA toggled per call)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +7,7 @@ from change3d_amd import ops
 
 DEV = "cuda:0"
 def run(mfma, T, dtype, B=2, H=40, W=72):
-    os.environ["C3D_STEM_MFMA"] = "1" if mfma else "0"
+    ops.set_option(ops.OPT_STEM_MFMA, 1 if mfma else 0)
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, 3, T, H, W, generator=g).to(DEV)
     w_t = (torch.randn(24, 3, 1, 3, 3, generator=g) * 0.3).to(DEV)

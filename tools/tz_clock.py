@@ -2,6 +2,8 @@
 """Phase clocks of the Toeplitz-MFMA depthwise forward experiment (csrc/dw_toeplitz.hip, C3D_DW_TZ_CLK=1)."""
 import ctypes as C, os, sys
 os.environ["C3D_DW_TZ"], os.environ["C3D_DW_TZ_CLK"] = "1", "1"
+# the experiment is linked into the instrumented build only (python __graft_entry__.py --tuning)
+os.environ.setdefault("C3D_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "change3d_amd", "lib", "libchange3d_hip_tune.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from change3d_amd import _lib, ops
