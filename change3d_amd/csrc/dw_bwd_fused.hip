@@ -93,7 +93,52 @@ __device__ __forceinline__ void pin_dw(f32x2_t (&a0)[2], f32x2_t (&a1)[2], f32x2
   asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a1[0]), "+v"(a1[1]), "+v"(a2[0]), "+v"(a2[1]));
 }
 
-template <typename T, int TT>
+// Stride 2 (first block of a stage).  The staged db tile is the same 10 x 10 output-resolution tile; it now covers 16 x 16
+// INPUT pixels: a thread owns the 2x2 quad (2py + cy, 2px + cx) and handles its four pixels one parity class (cy, cx) after
+// the other.  An input pixel receives only the taps of matching parity -- (iy + 1 - ky) must be even -- so the taps of a
+// class, and the dW accumulators they update, are compile-time constants: 1 + 2 + 2 + 4 = 9 (ky, kx) steps per quad, as
+// many as ONE stride-1 pixel, against one staging pass and one barrier.  (A first version with one 8x8 INPUT tile per pass
+// and one class per wave was correct and no faster than the separate kernels: 616 us against 356 + 264 us per block --
+// staging, barrier and flush were paid per 64 input pixels.)
+template <int TT, int CY, int CX>
+__device__ __forceinline__ void fb_taps_s2(const float4* tp, const float* wlp, f32x2_t (&acc)[TT][2], f32x2_t (&dwa)[27][2],
+                                           const f32x2_t (&ain)[TT][2]) {
+#pragma unroll
+  for (int ky = CY ? 0 : 1; ky < 3; ky += 2) {
+#pragma unroll
+    for (int kx = CX ? 0 : 1; kx < 3; kx += 2) {
+      const int lyo = (CY + 1 - ky) / 2 + 1, lxo = (CX + 1 - kx) / 2 + 1;   // db row / column relative to (py, px)
+      f32x2_t wk[3][2];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const float4 wv = *reinterpret_cast<const float4*>(wlp + (kt * 9 + ky * 3 + kx) * 32);
+        wk[kt][0] = f32x2_t{wv.x, wv.y}; wk[kt][1] = f32x2_t{wv.z, wv.w};
+      }
+#pragma unroll
+      for (int to = 0; to < TT; ++to) {
+        const float4 hv = tp[((to * FB_DH + lyo) * FB_DW + lxo) * DW_CV];
+        const f32x2_t v0 = {hv.x, hv.y}, v1 = {hv.z, hv.w};
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+          const int ti = to + kt - 1;
+          if (ti >= 0 && ti < TT) {
+            const int k = kt * 9 + ky * 3 + kx;
+            acc[ti][0] = __builtin_elementwise_fma(v0, wk[kt][0], acc[ti][0]);
+            acc[ti][1] = __builtin_elementwise_fma(v1, wk[kt][1], acc[ti][1]);
+            dwa[k][0] = __builtin_elementwise_fma(v0, ain[ti][0], dwa[k][0]);
+            dwa[k][1] = __builtin_elementwise_fma(v1, ain[ti][1], dwa[k][1]);
+          }
+        }
+      }
+      pin_acc<TT>(acc);
+      pin_dw(dwa[ky * 3 + kx], dwa[9 + ky * 3 + kx], dwa[18 + ky * 3 + kx]);
+      if (CX == 0) break;   // (kx = 1 only)
+    }
+    if (CY == 0) break;     // (ky = 1 only)
+  }
+}
+
+template <typename T, int TT, int S>
 __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
     const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
@@ -114,7 +159,7 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
   const int pix = (tid & 255) >> 2;
   const int px = pix & (FB_TW - 1), py = pix >> 3;
 
-  const int tiles_x = (g.W + FB_TW - 1) / FB_TW, tiles_y = (g.H + FB_TH - 1) / FB_TH;
+  const int tiles_x = (g.W + FB_TW * S - 1) / (FB_TW * S), tiles_y = (g.H + FB_TH * S - 1) / (FB_TH * S);   // tile: 8S x 8S input pixels
   const int ntiles = tiles_x * tiles_y;
   const int gx = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
   const ChunkOrder co = chunk_order((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), gx * g.B);
@@ -170,33 +215,40 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     const int ix_ = p_ % FB_DW, q_ = p_ / FB_DW;
     const int iy_ = q_ % FB_DH, t_ = q_ / FB_DH;
     const bool use_ = i_ < NI && c_ok && t_ < g.T;
-    rel[sl] = ((t_ * g.H + iy_) * g.W + ix_) * g.Cp + cb8;
+    rel[sl] = ((t_ * g.Ho + iy_) * g.Wo + ix_) * g.Cp + cb8;
     yx[sl] = use_ ? (iy_ | (ix_ << 16)) : 0x7fff7fff;
   }
-  const int orel = (py * g.W + px) * g.Cp + cb4, ofr = g.H * g.W * g.Cp;   // lane offset in a tile, frame stride
-#define FB_ISSUE(TL)                                                                              \
+  const int orel = (S * py * g.W + S * px) * g.Cp + cb4, ofr = g.H * g.W * g.Cp;   // lane offset in a tile (class (0,0) pixel), frame stride
+  // raw (t1, b) rows of the db tile of tile TL -> r1 / r2
+#define FB_ISSUE_RAW(TL)                                                                          \
   {                                                                                               \
     const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                         \
     const int dy0_ = ty_ * FB_TH - 1, dx0_ = tx_ * FB_TW - 1;                                     \
-    const int64_t tb_ = ((((int64_t)b * g.T) * g.H + dy0_) * g.W + dx0_) * g.Cp;  /* wave-uniform */ \
+    const int64_t tb_ = ((((int64_t)b * g.T) * g.Ho + dy0_) * g.Wo + dx0_) * g.Cp;  /* wave-uniform */ \
     const T* t1b_ = t1 + tb_;                                                                     \
     const T* bbb_ = bb + tb_;                                                                     \
     vmask = 0;                                                                                    \
     _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                           \
       const unsigned gy_ = (unsigned)(dy0_ + (yx[sl] & 0xffff));                                  \
       const unsigned gx_ = (unsigned)(dx0_ + (yx[sl] >> 16));                                     \
-      if (gy_ < (unsigned)g.H && gx_ < (unsigned)g.W) {                                           \
+      if (gy_ < (unsigned)g.Ho && gx_ < (unsigned)g.Wo) {                                         \
         r1[sl] = R8::load(t1b_ + rel[sl]);                                                        \
         r2[sl] = R8::load(bbb_ + rel[sl]);                                                        \
         vmask |= 1u << sl;                                                                        \
       }                                                                                           \
     }                                                                                             \
-    if (c_ok && ty_ * FB_TH + py < g.H && tx_ * FB_TW + px < g.W) {                               \
-      const T* ab_ = a + ((((int64_t)b * g.T) * g.H + ty_ * FB_TH) * g.W + tx_ * FB_TW) * g.Cp;   \
+  }
+  // this thread's `a` rows (all frames) of its class-(CY, CX) pixel in tile TL -> ar
+#define FB_ISSUE_A(TL, CY, CX)                                                                    \
+  {                                                                                               \
+    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                         \
+    if (c_ok && ty_ * FB_TH * S + S * py + (CY) < g.H && tx_ * FB_TW * S + S * px + (CX) < g.W) { \
+      const T* ab_ = a + ((((int64_t)b * g.T) * g.H + ty_ * FB_TH * S + (CY)) * g.W + tx_ * FB_TW * S + (CX)) * g.Cp; \
       _Pragma("unroll") for (int t = 0; t < TT; ++t)                                              \
         if (t < g.T) ar[t] = R4::load(ab_ + (orel + t * ofr));                                    \
     }                                                                                             \
   }
+#define FB_ISSUE(TL) { FB_ISSUE_RAW(TL) FB_ISSUE_A(TL, 0, 0) }
 
   const int tl0 = tg * tiles_per_wg;
   int tl1 = tl0 + tiles_per_wg;
@@ -206,7 +258,7 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
 
   for (int tl = tl0; tl < tl1; ++tl) {
     const int tx = tl % tiles_x, ty = tl / tiles_x;
-    const int y0 = ty * FB_TH, x0 = tx * FB_TW;
+    const int y0 = ty * FB_TH * S, x0 = tx * FB_TW * S;   // input-resolution origin of the tile
     float4* tb = tile + (size_t)((tl - tl0) & 1) * 2 * NI;
     // ---- stage db = A*t1 + B[n] + C*b (zero outside the image) as two f32 half-vector planes
     {
@@ -234,32 +286,80 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
         }
       }
     }
-    // ---- this thread's centre pixel: a_in = relu(bn_a(a)) for the weight gradient and the mask
-    const bool p_ok = c_ok && y0 + py < g.H && x0 + px < g.W;
+    // ---- one pixel of this thread (class (CY, CX) of its quad; stride 1: the only one): a_in = relu(bn_a(a)) for the
+    // weight gradient and the mask
     typename R4::type arc[TT];
     f32x2_t ain[TT][2];
+    f32x2_t acc[TT][2];
+    bool p_ok;
     float sa[4], sb[4];
     lds4(cf + 3 * 32 + cv * 8 + h * 4, sa);
     lds4(cf + 4 * 32 + cv * 8 + h * 4, sb);
-#pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      if (p_ok && t < g.T) {
-        arc[t] = ar[t];
-        float av[4];
-        R4::cvt(arc[t], av);
-        ain[t][0] = f32x2_t{fmaxf(fmaf(av[0], sa[0], sb[0]), 0.f), fmaxf(fmaf(av[1], sa[1], sb[1]), 0.f)};
-        ain[t][1] = f32x2_t{fmaxf(fmaf(av[2], sa[2], sb[2]), 0.f), fmaxf(fmaf(av[3], sa[3], sb[3]), 0.f)};
-      } else {
-        ain[t][0] = f32x2_t{0.f, 0.f}; ain[t][1] = f32x2_t{0.f, 0.f};
-      }
+#define FB_PRE(CY, CX)                                                                                            \
+  {                                                                                                               \
+    p_ok = c_ok && y0 + S * py + (CY) < g.H && x0 + S * px + (CX) < g.W;                                          \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                             \
+      if (p_ok && t < g.T) {                                                                                      \
+        arc[t] = ar[t];                                                                                           \
+        float av[4];                                                                                              \
+        R4::cvt(arc[t], av);                                                                                      \
+        ain[t][0] = f32x2_t{fmaxf(fmaf(av[0], sa[0], sb[0]), 0.f), fmaxf(fmaf(av[1], sa[1], sb[1]), 0.f)};        \
+        ain[t][1] = f32x2_t{fmaxf(fmaf(av[2], sa[2], sb[2]), 0.f), fmaxf(fmaf(av[3], sa[3], sb[3]), 0.f)};        \
+      } else {                                                                                                    \
+        ain[t][0] = f32x2_t{0.f, 0.f}; ain[t][1] = f32x2_t{0.f, 0.f};                                             \
+      }                                                                                                           \
+      acc[t][0] = f32x2_t{0.f, 0.f}; acc[t][1] = f32x2_t{0.f, 0.f};                                               \
+    }                                                                                                             \
+  }
+    // ---- mask, store t2, BN_a-backward sums
+#define FB_EPI(CY, CX)                                                                                            \
+  if (p_ok) {                                                                                                     \
+    float ma[4], ra[4];                                                                                           \
+    lds4(cf + 5 * 32 + cv * 8 + h * 4, ma);                                                                       \
+    lds4(cf + 6 * 32 + cv * 8 + h * 4, ra);                                                                       \
+    T* ob = t2 + ((((int64_t)b * g.T) * g.H + y0 + (CY)) * g.W + x0 + (CX)) * g.Cp;                               \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                             \
+      if (t < g.T) {                                                                                              \
+        float av[4], o[4];                                                                                        \
+        R4::cvt(arc[t], av);                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+          const float d = round_as<T>(ain[t][j >> 1][j & 1] > 0.f ? acc[t][j >> 1][j & 1] : 0.f);                 \
+          o[j] = d;                                                                                               \
+          S1[j] += d; S2[j] += d * ((av[j] - ma[j]) * ra[j]);                                                     \
+        }                                                                                                         \
+        R4::store(ob + (orel + t * ofr), o);                                                                      \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+    FB_PRE(0, 0)
+    if constexpr (S == 2) {
+      // the next class's `a` rows go out before the next tile's raw rows: vmcnt retires in order, and class (1,0)
+      // is needed three tap steps from now, the raw rows a whole tile from now
+      FB_ISSUE_A(tl, 1, 0)
+      if (tl + 1 < tl1) FB_ISSUE_RAW(tl + 1)
+      __syncthreads();
+      const float4* tp = tb + (size_t)h * NI + (py * FB_DW + px) * DW_CV + cv;
+      const float* wlp = wl + cv * 8 + h * 4;
+      fb_taps_s2<TT, 0, 0>(tp, wlp, acc, dwa, ain);
+      FB_EPI(0, 0)
+      FB_PRE(1, 0)
+      FB_ISSUE_A(tl, 0, 1)
+      fb_taps_s2<TT, 1, 0>(tp, wlp, acc, dwa, ain);
+      FB_EPI(1, 0)
+      FB_PRE(0, 1)
+      FB_ISSUE_A(tl, 1, 1)
+      fb_taps_s2<TT, 0, 1>(tp, wlp, acc, dwa, ain);
+      FB_EPI(0, 1)
+      FB_PRE(1, 1)
+      if (tl + 1 < tl1) FB_ISSUE_A(tl + 1, 0, 0)
+      fb_taps_s2<TT, 1, 1>(tp, wlp, acc, dwa, ain);
+      FB_EPI(1, 1)
+      continue;
     }
     if (tl + 1 < tl1) FB_ISSUE(tl + 1)
     __syncthreads();
 
     // ---- 27 taps: one LDS read feeds the data gradient (x weight) and the weight gradient (x a_in)
-    f32x2_t acc[TT][2];
-#pragma unroll
-    for (int t = 0; t < TT; ++t) { acc[t][0] = f32x2_t{0.f, 0.f}; acc[t][1] = f32x2_t{0.f, 0.f}; }
     // lowest-address tap (ky = kx = 2) as base: every other tap is a non-negative immediate offset of the ds_read
     const float4* tp = tb + (size_t)h * NI + (py * FB_DW + px) * DW_CV + cv;
     // software pipeline over the nine (ky, kx) steps: the LDS reads of step s+1 are issued before the FMAs of step s
@@ -306,29 +406,13 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     FB_STEP(8, 0)
 #undef FB_LOAD
 #undef FB_STEP
-    // ---- mask, store t2, BN_a-backward sums
-    if (p_ok) {
-      float ma[4], ra[4];
-      lds4(cf + 5 * 32 + cv * 8 + h * 4, ma);
-      lds4(cf + 6 * 32 + cv * 8 + h * 4, ra);
-      T* ob = t2 + ((((int64_t)b * g.T) * g.H + y0) * g.W + x0) * g.Cp;
-#pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        if (t < g.T) {
-          float av[4], o[4];
-          R4::cvt(arc[t], av);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float d = round_as<T>(ain[t][j >> 1][j & 1] > 0.f ? acc[t][j >> 1][j & 1] : 0.f);
-            o[j] = d;
-            S1[j] += d; S2[j] += d * ((av[j] - ma[j]) * ra[j]);
-          }
-          R4::store(ob + (orel + t * ofr), o);
-        }
-      }
-    }
+    FB_EPI(0, 0)
   }
+#undef FB_PRE
+#undef FB_EPI
 #undef FB_ISSUE
+#undef FB_ISSUE_RAW
+#undef FB_ISSUE_A
 
   // ---- flush the BN_a-backward sums: lanes of equal cv inside a wave, then the four waves of each half
   const int lane = tid & 63, wave = tid >> 6;
@@ -383,7 +467,7 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
   }
 }
 
-template <typename T, int TT>
+template <typename T, int TT, int S>
 int launch_fused_t(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const float* w,
                    const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw,
                    const DwGeom& g, hipStream_t stream, const c3d_bn_fin& fin) {
@@ -393,12 +477,12 @@ int launch_fused_t(const void* t1, const void* bb, const float* cA, const float*
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_fused_kernel<T, TT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_fused_kernel<T, TT, S>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int ntiles = ((g.W + FB_TW - 1) / FB_TW) * ((g.H + FB_TH - 1) / FB_TH);
+  const int ntiles = ((g.W + FB_TW * S - 1) / (FB_TW * S)) * ((g.H + FB_TH * S - 1) / (FB_TH * S));
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
   // one 512-thread workgroup is resident per CU: a walk amortises the weight-gradient flush (~3 us) and pipelines the
   // loads; short enough for ~2 rounds of workgroups (C3D_DWBF_TPW: tuning knob)
@@ -407,12 +491,12 @@ int launch_fused_t(const void* t1, const void* bb, const float* cA, const float*
   // (12, 24: +0.3..1.2 ms -- ragged last groups)
   // -> the longest walk that still gives (almost) every CU a workgroup: 16 / 32 / 32 tiles for the 32x32 / 64x64 / 128x128 stages
   static const int env_max = c3d_env("C3D_DWBF_MAX") ? atoi(c3d_env("C3D_DWBF_MAX")) : 32;
-  int tpw = env_max;
+  int tpw = env_max / (S * S);   // a stride-2 tile is four pixels per thread
   while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 85L * device_cus() / 100) tpw >>= 1;
   if (env_tpw > 0) tpw = env_tpw;
   if (tpw > ntiles) tpw = ntiles;
   dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
-  dw_bwd_fused_kernel<T, TT><<<grid, dim3(FB_NTHR), lds, stream>>>(
+  dw_bwd_fused_kernel<T, TT, S><<<grid, dim3(FB_NTHR), lds, stream>>>(
       reinterpret_cast<const T*>(t1), reinterpret_cast<const T*>(bb), cA, cB, cC, w, reinterpret_cast<const T*>(a),
       ss_a, mr_a, reinterpret_cast<T*>(t2), dsums, dw, g, tpw, fin);
   C3D_CHECK_LAUNCH();
@@ -425,12 +509,18 @@ namespace {
 int dispatch_fused(const void* t1, const void* b, const float* coefA, const float* coefB, const float* coefC, const float* w,
                    const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw, const DwGeom& g,
                    int dtype, hipStream_t s, const c3d_bn_fin& fin) {
-  if (dtype == C3D_DT_F32)
-    return g.T <= 3 ? launch_fused_t<float, 3>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin)
-                    : launch_fused_t<float, 5>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
-  if (dtype == C3D_DT_BF16)
-    return g.T <= 3 ? launch_fused_t<bf16_t, 3>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin)
-                    : launch_fused_t<bf16_t, 5>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
+#define FB_DISPATCH(TY, S_)                                                                                         \
+  return g.T <= 3 ? launch_fused_t<TY, 3, S_>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin)  \
+                  : launch_fused_t<TY, 5, S_>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
+  if (dtype == C3D_DT_F32) {
+    if (g.stride == 1) { FB_DISPATCH(float, 1) }
+    FB_DISPATCH(float, 2)
+  }
+  if (dtype == C3D_DT_BF16) {
+    if (g.stride == 1) { FB_DISPATCH(bf16_t, 1) }
+    FB_DISPATCH(bf16_t, 2)
+  }
+#undef FB_DISPATCH
   return C3D_E_BADARG;
 }
 }  // namespace
@@ -438,8 +528,9 @@ int dispatch_fused(const void* t1, const void* b, const float* coefA, const floa
 extern "C" int c3d_dw333_bwd_fused(const void* t1, const void* b, const float* coefA, const float* coefB,
                                    const float* coefC, const float* w, const void* a, const float* ss_a,
                                    const float* mr_a, void* t2, double* dsums, float* dw, int32_t B, int32_t T,
-                                   int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t dtype, void* stream) {
-  DwGeom g{B, T, H, W, H, W, C, Cp, 1};
+                                   int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype, void* stream) {
+  if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1))) return C3D_E_UNSUPPORTED;
+  DwGeom g{B, T, H, W, H / stride, W / stride, C, Cp, stride};
   if (!t1 || !b || !coefA || !coefB || !coefC || !w || !a || !ss_a || !mr_a || !t2 || !dsums || !dw || !geom_ok(g))
     return C3D_E_BADARG;
   return dispatch_fused(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, dtype,
@@ -448,8 +539,10 @@ extern "C" int c3d_dw333_bwd_fused(const void* t1, const void* b, const float* c
 
 extern "C" int c3d_dw333_bwd_fused_fin(const void* t1, const void* b, const c3d_bn_fin* fin_b, const float* w, const void* a,
                                        const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw, int32_t B,
-                                       int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t dtype, void* stream) {
-  DwGeom g{B, T, H, W, H, W, C, Cp, 1};
+                                       int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
+                                       void* stream) {
+  if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1))) return C3D_E_UNSUPPORTED;
+  DwGeom g{B, T, H, W, H / stride, W / stride, C, Cp, stride};
   if (!t1 || !b || !w || !a || !ss_a || !mr_a || !t2 || !dsums || !dw || !geom_ok(g)) return C3D_E_BADARG;
   if (!fin_b || !fin_b->sums || fin_b->batch != B || !fin_b->gamma || !fin_b->mr || !(fin_b->count > 0)) return C3D_E_BADARG;
   return dispatch_fused(t1, b, nullptr, nullptr, nullptr, w, a, ss_a, mr_a, t2, dsums, dw, g, dtype,

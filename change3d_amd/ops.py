@@ -390,11 +390,11 @@ def dw_wgrad(t1, b, cA, cB, cC, a, ss_a, dw, B, T, H, W, C_, stride, dtype):
                                     C_, cpad(C_), stride, dtype, _stream())
 
 
-def dw_bwd_fused(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, dw, B, T, H, W, C_, dtype):
-    """Stride-1 depthwise backward: data gradient, BatchNorm_a-backward sums and weight gradient in one pass."""
+def dw_bwd_fused(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, dw, B, T, H, W, C_, dtype, stride=1):
+    """Depthwise backward: data gradient, BatchNorm_a-backward sums and weight gradient in one pass."""
     _launch("c3d_dw333_bwd_fused", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_fused,
             _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2), _p(dsums), _p(dw),
-            B, T, H, W, C_, cpad(C_), dtype, _stream())
+            B, T, H, W, C_, cpad(C_), stride, dtype, _stream())
 
 
 def fin_b_bwd(nc3, batch, bn, count, mr):
@@ -406,10 +406,10 @@ def fin_b_bwd(nc3, batch, bn, count, mr):
     return f
 
 
-def dw_bwd_fused_fin(t1, b, fin_b, w, a, ss_a, mr_a, t2, dsums, dw, B, T, H, W, C_, dtype):
+def dw_bwd_fused_fin(t1, b, fin_b, w, a, ss_a, mr_a, t2, dsums, dw, B, T, H, W, C_, dtype, stride=1):
     _launch("c3d_dw333_bwd_fused", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_fused_fin,
             _p(t1), _p(b), C.byref(fin_b), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2), _p(dsums), _p(dw),
-            B, T, H, W, C_, cpad(C_), dtype, _stream())
+            B, T, H, W, C_, cpad(C_), stride, dtype, _stream())
 
 
 # ----------------------------------------------------------------------------- elementwise

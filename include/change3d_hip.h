@@ -236,20 +236,21 @@ int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const flo
                     const float* coefC, const void* a, const float* ss_a, float* dw, int32_t B, int32_t T,
                     int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
                     void* stream);
-/* Stride 1: bwd_data AND wgrad from one staged tile of db (csrc/dw_bwd_fused.hip) -- what autograd's
- * convolution_backward returns for conv_b (reference model/x3d.py:184-193) in one pass over t1, b and a: t2 and dsums
- * exactly as c3d_dw333_bwd_data writes them, dw += as c3d_dw333_wgrad (f32 atomics).  Stride-2 blocks keep the pair. */
+/* bwd_data AND wgrad from one staged tile of db (csrc/dw_bwd_fused.hip) -- what autograd's convolution_backward returns
+ * for conv_b (reference model/x3d.py:184-193) in one pass over t1, b and a: t2 and dsums exactly as c3d_dw333_bwd_data
+ * writes them, dw += as c3d_dw333_wgrad (f32 atomics).  stride 1 or 2 (stride 2: H and W even).                      */
 int c3d_dw333_bwd_fused(const void* t1, const void* b, const float* coefA, const float* coefB,
                         const float* coefC, const float* w, const void* a, const float* ss_a,
                         const float* mr_a, void* t2, double* dsums, float* dw, int32_t B, int32_t T,
-                        int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t dtype, void* stream);
+                        int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype, void* stream);
 /* Same, with the BatchNorm_b backward coefficients of a block WITHOUT SqueezeExcitation rebuilt in the kernel's prologue
  * from the per-sample sums nc3 (fin_b->sums, fin_b->batch = B, fin_b->gamma, fin_b->mr = mean|rstd of BatchNorm_b,
- * fin_b->count = B*T*H*W; dgamma / dbeta += through fin_b->running_mean / running_var): no c3d_se_bn_bwd_coef launch
- * between the conv_c data gradient and this kernel.  coefA / coefB / coefC are ignored (may be NULL).                */
+ * fin_b->count = B*T*Ho*Wo; dgamma / dbeta += through fin_b->running_mean / running_var): no c3d_se_bn_bwd_coef launch
+ * between the conv_c data gradient and this kernel.                                                                  */
 int c3d_dw333_bwd_fused_fin(const void* t1, const void* b, const c3d_bn_fin* fin_b, const float* w, const void* a,
                             const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw, int32_t B,
-                            int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t dtype, void* stream);
+                            int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Res-block output y = relu(bn_c(c) + shortcut) (reference model/x3d.py:326-327; also the

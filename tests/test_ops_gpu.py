@@ -427,16 +427,16 @@ def test_dw333_fwd_bwd(dtype, stride, C, T):
     ops.dw_wgrad(t1d, b, padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV), ad, ss, dw,
                  B, T, H, W, C, stride, ops.dt_code(dtype))
     close(dw, w_r.grad.view(C, 27), dtype, "dw wgrad", scale=w_r.grad.abs().max().item())
-    if stride == 1:   # one-pass kernel: same t2 / sums as the data-gradient kernel (bit for bit), same dw
-        _check_fused_dw(ops, t1d, b, padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV),
-                        w.to(DEV).contiguous(), ad, ss, mr, t2, dsums, dw, w_r.grad.view(C, 27), B, T, H, W, C, dtype)
+    # one-pass kernel: same t2 / sums as the data-gradient kernel (bit for bit), same dw
+    _check_fused_dw(ops, t1d, b, padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV),
+                    w.to(DEV).contiguous(), ad, ss, mr, t2, dsums, dw, w_r.grad.view(C, 27), B, T, H, W, C, dtype, stride)
 
 
-def _check_fused_dw(ops, t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, dsums, dw, dw_ref, B, T, H, W, C, dtype):
+def _check_fused_dw(ops, t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, dsums, dw, dw_ref, B, T, H, W, C, dtype, stride=1):
     t2f = torch.full_like(ad, float("nan"))
     dsf = torch.zeros_like(dsums)
     dwf = torch.zeros_like(dw)
-    ops.dw_bwd_fused(t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2f, dsf, dwf, B, T, H, W, C, ops.dt_code(dtype))
+    ops.dw_bwd_fused(t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2f, dsf, dwf, B, T, H, W, C, ops.dt_code(dtype), stride)
     torch.cuda.synchronize()
     assert torch.equal(t2f, t2), f"fused t2 differs: max {(t2f.float() - t2.float()).abs().max().item():.3e}"
     sc = dsums.abs().max().item() + 1e-30
@@ -493,8 +493,8 @@ def test_dw333_backward_walks(dtype, B, H, W, C, stride):
     ops.dw_wgrad(t1d, bd, cAd, cBd, cCd, ad, ss, dw, B, T, H, W, C, stride, ops.dt_code(dtype))
     # the reduction runs over B*T*Ho*Wo products: scale the absolute tolerance with its length
     close(dw, w_r.grad.view(C, 27), dtype, "dw wgrad", scale=w_r.grad.abs().max().item())
-    if stride == 1:
-        _check_fused_dw(ops, t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, dsums, dw, w_r.grad.view(C, 27), B, T, H, W, C, dtype)
+    if stride == 1 or (H % 2 == 0 and W % 2 == 0):
+        _check_fused_dw(ops, t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, dsums, dw, w_r.grad.view(C, 27), B, T, H, W, C, dtype, stride)
 
 
 # --------------------------------------------------------------------------- loss / optimizer
