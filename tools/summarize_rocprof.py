@@ -102,6 +102,27 @@ def main():
                    "by_entry_per_step": {e: round(sum(traffic.get(k, {}).get(e, {"bytes_total": 0})["bytes_total"] for k in ("fetch", "write")) / steps) for e in ents},
                    "by_entry": out}, open(os.path.join(root, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 
+    # ---- MFMA utilisation (own --pmc pass; utilisation = MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), the
+    #      normalisation profiles/r01_pmc_mfma.json introduced)
+    f = find(os.path.join(root, "pmc_mfma"), "*counter_collection.csv")
+    if f:
+        agg = defaultdict(lambda: defaultdict(float))
+        disp = defaultdict(set)
+        for r in csv.DictReader(open(f)):
+            e = entry_of(r["Kernel_Name"])
+            agg[e][r["Counter_Name"]] += float(r["Counter_Value"])
+            disp[e].add(r["Dispatch_Id"])
+        kernels = {}
+        for e, c in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0.0)):
+            gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+            kernels[e] = {"dispatches": len(disp[e]), **{k: v for k, v in c.items()},
+                          "mfma_utilisation": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * gui / 8.0), 4) if gui else None}
+        json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace (own pass, side "
+                             "stream off) -- python bench.py --no-cpu-baseline --no-graph --no-kernel-profile --steps 1 --warmup 1",
+                   "note": "B=32 bf16; sums over all dispatches of an entry point's kernels",
+                   "kernels": kernels}, open(os.path.join(root, f"{tag}_pmc_mfma.json"), "w"), indent=1)
+        print("pmc mfma", f)
+
 
 if __name__ == "__main__":
     main()
