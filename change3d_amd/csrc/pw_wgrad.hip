@@ -138,7 +138,12 @@ template <> struct ColBuf<float> {
 // QD: the Q rows are dense and unshifted (row m at m * Kp) -- tile base in scalar registers + a 32-bit lane offset
 // instead of q_row_offset()'s mode switch and 64-bit multiplies per row ("issue next tile" was 18-25 % of a wave's
 // time in this VALU-bound kernel).
-template <typename T, bool HASP2, bool QD>
+// TN x TK: 16x16 output tiles per wave (compile time).  The LDS tiles are padded with zero channel rows up to TN * WN and
+// TK * WK tiles, so the multiply phase has no conditions: every fragment read and MFMA is unconditional (an MFMA on zero
+// rows costs nothing here -- the matrix cores are ~2 % busy), fully unrolled, and the fragments of k-step s+1 are read
+// while step s multiplies.  (Round 2's phase clocks: the runtime-bounded, branchy multiply phase took 2 700 clocks per
+// 128-row tile for FOUR MFMAs per wave on the 24x54 layers.)
+template <typename T, bool HASP2, bool QD, int TN, int TK>
 __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad_args a_in, const int tiles_per_wg,
                                                               const int WN, const int WK, const int MT) {
   c3d_pw_wgrad_args a = a_in;
@@ -153,9 +158,9 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WCLK_DECL
   const int Kp = a.Kp, Np = a.Np;
-  const int NT = (Np + 15) >> 4, KT = (Kp + 15) >> 4;
+  const int NT = TN * WN;   // padded tile counts (>= ceil(Np / 16), ceil(Kp / 16))
   const int ML = MT + MM::MPAD;
-  const size_t buf_elems = (size_t)(NT + KT) * 16 * ML;
+  const size_t buf_elems = (size_t)(TN * WN + TK * WK) * 16 * ML;
   lds_t* base = reinterpret_cast<lds_t*>(smem);
 
   // zero both buffers once (covers the channel-padding rows, which are never written again)
@@ -190,11 +195,11 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
   }
 
   const int wn_i = wave % WN, wk_i = wave / WN;
-  f32x4_t acc[4][4];
+  f32x4_t acc[TN][TK];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TK; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const T* P = reinterpret_cast<const T*>(a.p);
   const T* P2 = reinterpret_cast<const T*>(a.p2);
@@ -325,27 +330,33 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
     WCLK(3)
     __syncthreads();  // the only barrier per tile (LDS tiles are double buffered)
     WCLK(4)
-    for (int ks = 0; ks < MT / MM::KSTEP; ++ks) {
-      typename MM::frag_t pa[4], qb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int nt = wn_i + i * WN;
-        if (nt < NT) pa[i] = MM::load(PT, nt * 16 + (lane & 15), ks, ML, lane);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kt = wk_i + j * WK;
-        if (kt < KT) qb[j] = MM::load(QT, kt * 16 + (lane & 15), ks, ML, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (wn_i + i * WN < NT) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (wk_i + j * WK < KT) acc[i][j] = MM::mma(pa[i], qb[j], acc[i][j]);
-          }
+    {
+      const int KS = MT / MM::KSTEP;
+      const lds_t* pbase = PT + (size_t)(wn_i * 16 + (lane & 15)) * ML;   // tile (wn_i + i * WN) is i * WN * 16 rows on
+      const lds_t* qbase = QT + (size_t)(wk_i * 16 + (lane & 15)) * ML;
+      const int pstep = WN * 16 * ML, qstep = WK * 16 * ML;
+      typename MM::frag_t pa[2][TN], qb[2][TK];
+#define WG_FRAGS(SLOT, KSI)                                                                                  \
+  {                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TN; ++i) pa[SLOT][i] = MM::load(pbase + i * pstep, 0, (KSI), ML, lane); \
+    _Pragma("unroll") for (int j = 0; j < TK; ++j) qb[SLOT][j] = MM::load(qbase + j * qstep, 0, (KSI), ML, lane); \
+  }
+#define WG_MMA(SLOT)                                                                                         \
+  {                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                           \
+      _Pragma("unroll") for (int j = 0; j < TK; ++j) acc[i][j] = MM::mma(pa[SLOT][i], qb[SLOT][j], acc[i][j]); \
+  }
+      WG_FRAGS(0, 0)
+      for (int ks = 0; ks < KS; ks += 2) {
+        if (ks + 1 < KS) WG_FRAGS(1, ks + 1)
+        WG_MMA(0)
+        if (ks + 1 < KS) {
+          if (ks + 2 < KS) WG_FRAGS(0, ks + 2)
+          WG_MMA(1)
         }
       }
+#undef WG_FRAGS
+#undef WG_MMA
     }
     WCLK(5)
   }
@@ -354,13 +365,11 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
   // partials -> workspace [grid][N][K]
   float* wsb = a.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.N * a.K;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TN; ++i) {
     const int nt = wn_i + i * WN;
-    if (nt >= NT) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TK; ++j) {
       const int kt = wk_i + j * WK;
-      if (kt >= KT) continue;
       const int k = kt * 16 + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -407,10 +416,62 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __res
 
 constexpr int WGRAD_MAX_PARTS = 512;
 
+// One instantiation: sets the LDS attribute once, launches.
+template <typename T, bool HASP2, bool QD, int TN, int TK>
+int launch_wgrad_inst(const c3d_pw_wgrad_args& a, dim3 grid, size_t lds, int tpw, int WN, int WK, int MT, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_kernel<T, HASP2, QD, TN, TK>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  pw_wgrad_kernel<T, HASP2, QD, TN, TK><<<grid, dim3(WG_THREADS), lds, stream>>>(a, tpw, WN, WK, MT);
+  return 0;
+}
+
+// Instantiated per-wave tile grids (TN x TK): a launch takes the smallest that covers its ceil(NT / WN) x ceil(KT / WK).
+// Dense rows (all layers of the residual stages): every grid; shifted / strided rows (shortcut convolutions, the
+// transposed-convolution taps): the 4 x 4 one only.
+struct WgInst { int tn, tk; };
+constexpr WgInst WG_INSTS[] = {{1, 1}, {2, 2}, {3, 4}, {4, 3}, {4, 4}};
+
+template <typename T, bool HASP2>
+int launch_wgrad_pick(const c3d_pw_wgrad_args& a, bool qd, int inst, dim3 grid, size_t lds, int tpw, int WN, int WK, int MT,
+                      hipStream_t s) {
+  if (!qd) return launch_wgrad_inst<T, HASP2, false, 4, 4>(a, grid, lds, tpw, WN, WK, MT, s);
+  switch (inst) {
+    case 0: return launch_wgrad_inst<T, HASP2, true, 1, 1>(a, grid, lds, tpw, WN, WK, MT, s);
+    case 1: return launch_wgrad_inst<T, HASP2, true, 2, 2>(a, grid, lds, tpw, WN, WK, MT, s);
+    case 2: return launch_wgrad_inst<T, HASP2, true, 3, 4>(a, grid, lds, tpw, WN, WK, MT, s);
+    case 3: return launch_wgrad_inst<T, HASP2, true, 4, 3>(a, grid, lds, tpw, WN, WK, MT, s);
+    default: return launch_wgrad_inst<T, HASP2, true, 4, 4>(a, grid, lds, tpw, WN, WK, MT, s);
+  }
+}
+
 template <typename T>
 int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   typedef MmaT<T> MM;
   const int NT = (a.Np + 15) >> 4, KT = (a.Kp + 15) >> 4;
+  const int taps = a.taps > 1 ? a.taps : 1;
+  const bool qd = a.row_mode == C3D_ROWS_DENSE && taps == 1;
+  // wave grid: WN*WK = 8 with ceil(NT/WN) <= 4 and ceil(KT/WK) <= 4
+  int WN = 0, WK = 0, tn_need = 0, tk_need = 0;
+  const int cand[4][2] = {{8, 1}, {4, 2}, {2, 4}, {1, 8}};
+  int best = 1 << 30;
+  for (int c = 0; c < 4; ++c) {
+    const int tn = (NT + cand[c][0] - 1) / cand[c][0], tk = (KT + cand[c][1] - 1) / cand[c][1];
+    if (tn > 4 || tk > 4) continue;
+    const int cost = tn * tk * 4 + tn + tk;  // MFMAs dominate, then fragment loads
+    if (cost < best) { best = cost; WN = cand[c][0]; WK = cand[c][1]; tn_need = tn; tk_need = tk; }
+  }
+  if (WN == 0) return C3D_E_UNSUPPORTED;
+  int inst = 4;
+  if (qd) {
+    for (int i = 0; i < 5; ++i)
+      if (WG_INSTS[i].tn >= tn_need && WG_INSTS[i].tk >= tk_need) { inst = i; break; }
+  }
+  const int TNi = qd ? WG_INSTS[inst].tn : 4, TKi = qd ? WG_INSTS[inst].tk : 4;
   // rows per tile: as tall as 256 staging threads per operand allow (WG_RPT rows x 8 channels each)
   const int maxG = (a.Np > a.Kp ? a.Np : a.Kp) >> 3;
   int MT = (256 / maxG) * WG_RPT / 32 * 32;
@@ -420,33 +481,10 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   if (MT < 32) return C3D_E_UNSUPPORTED;
   size_t lds = 0;
   for (; MT >= 32; MT -= 32) {
-    lds = (size_t)2 * (NT + KT) * 16 * (MT + MM::MPAD) * sizeof(typename MM::lds_t);
+    lds = (size_t)2 * (TNi * WN + TKi * WK) * 16 * (MT + MM::MPAD) * sizeof(typename MM::lds_t);   // padded tile rows
     if (lds <= 160 * 1024) break;
   }
   if (MT < 32) return C3D_E_UNSUPPORTED;
-  // wave grid: WN*WK = 8 with ceil(NT/WN) <= 4 and ceil(KT/WK) <= 4
-  int WN = 0, WK = 0;
-  const int cand[4][2] = {{8, 1}, {4, 2}, {2, 4}, {1, 8}};
-  int best = 1 << 30;
-  for (int c = 0; c < 4; ++c) {
-    const int tn = (NT + cand[c][0] - 1) / cand[c][0], tk = (KT + cand[c][1] - 1) / cand[c][1];
-    if (tn > 4 || tk > 4) continue;
-    const int cost = tn * tk * 4 + tn + tk;  // MFMAs dominate, then fragment loads
-    if (cost < best) { best = cost; WN = cand[c][0]; WK = cand[c][1]; }
-  }
-  if (WN == 0) return C3D_E_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const void* fns[4] = {reinterpret_cast<const void*>(&pw_wgrad_kernel<T, true, true>),
-                          reinterpret_cast<const void*>(&pw_wgrad_kernel<T, true, false>),
-                          reinterpret_cast<const void*>(&pw_wgrad_kernel<T, false, true>),
-                          reinterpret_cast<const void*>(&pw_wgrad_kernel<T, false, false>)};
-    for (int i = 0; i < 4; ++i) {
-      hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-    }
-    attr_set = true;
-  }
   const int64_t tiles = (a.M + MT - 1) / MT;
   int64_t blocks = (tiles + 3) / 4;  // >= 4 tiles per workgroup when there is enough work
   static const int cap_env = c3d_env("C3D_WG_BLOCKS") ? atoi(c3d_env("C3D_WG_BLOCKS")) : 0;  // tuning knob
@@ -460,21 +498,15 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
     const int64_t side_cap = side_env > 0 ? side_env : (int64_t)device_cus() * 3 / 4;
     if (side_cap < cap) cap = side_cap;
   }
-  const int taps = a.taps > 1 ? a.taps : 1;
   if (taps > 1 && cap > WGRAD_MAX_PARTS / taps) cap = WGRAD_MAX_PARTS / taps;   // the workspace holds MAX_PARTS slabs
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   const int tpw = (int)((tiles + blocks - 1) / blocks);
   blocks = (tiles + tpw - 1) / tpw;
-  const bool qd = a.row_mode == C3D_ROWS_DENSE && taps == 1;
-  const dim3 grid((unsigned)blocks, taps), blk(WG_THREADS);
-  if (a.p_coef || a.p_fin.sums) {
-    if (qd) pw_wgrad_kernel<T, true, true><<<grid, blk, lds, stream>>>(a, tpw, WN, WK, MT);
-    else pw_wgrad_kernel<T, true, false><<<grid, blk, lds, stream>>>(a, tpw, WN, WK, MT);
-  } else {
-    if (qd) pw_wgrad_kernel<T, false, true><<<grid, blk, lds, stream>>>(a, tpw, WN, WK, MT);
-    else pw_wgrad_kernel<T, false, false><<<grid, blk, lds, stream>>>(a, tpw, WN, WK, MT);
-  }
+  const dim3 grid((unsigned)blocks, taps);
+  const int rc = (a.p_coef || a.p_fin.sums) ? launch_wgrad_pick<T, true>(a, qd, inst, grid, lds, tpw, WN, WK, MT, stream)
+                                            : launch_wgrad_pick<T, false>(a, qd, inst, grid, lds, tpw, WN, WK, MT, stream);
+  if (rc != 0) return rc;
   C3D_CHECK_LAUNCH();
   const int nk = a.N * a.K;
   pw_wgrad_reduce_kernel<<<dim3((nk + 31) / 32, taps), dim3(256), 0, stream>>>(a.ws, a.dw, a.N, a.K, (int)blocks,

@@ -218,12 +218,16 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
 struct ProfRec { char name[64]; hipEvent_t e0, e1; double bytes; };
 std::vector<ProfRec> g_prof;
 int g_prof_flags = -1;   // < 0: off; bit 0: weight gradients inline on the main stream; bit 1: names carry shape / mode
+char g_prof_tag[32] = "";   // detail mode: geometry of the block being enqueued, appended to names without a shape of their own
 
 template <typename F>
 int prof_call(const char* name, double bytes, hipStream_t s, F&& fn) {
   if (g_prof_flags < 0) return fn();
   ProfRec r;
-  std::snprintf(r.name, sizeof(r.name), "%s", name);
+  if ((g_prof_flags & 2) && g_prof_tag[0] && !std::strchr(name, '['))
+    std::snprintf(r.name, sizeof(r.name), "%s[%s]", name, g_prof_tag);
+  else
+    std::snprintf(r.name, sizeof(r.name), "%s", name);
   r.bytes = bytes;
   HIPRC(hipEventCreate(&r.e0));
   HIPRC(hipEventCreate(&r.e1));
@@ -546,6 +550,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
   for (int i = 0; i < d->n_blocks; ++i) {
     const c3d_block_desc& k = d->blocks[i];
     const BlkGeom& G = P.g[i];
+    if (prof_detail()) std::snprintf(g_prof_tag, sizeof(g_prof_tag), "H=%d Ci=%d s=%d se=%d", G.H, G.Ci, G.s, (int)G.se);
     const BlkFwd& F = P.f[i];
     void* a = at(ws, F.a); void* b = at(ws, F.b); void* c = at(ws, F.c); void* sc = at(ws, F.sc);
     void* y = F.y == SIZE_MAX ? y_out : at(ws, F.y);
@@ -666,6 +671,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   for (int i = d->n_blocks - 1; i >= 0; --i) {
     const c3d_block_desc& k = d->blocks[i];
     const BlkGeom& G = P.g[i];
+    if (prof_detail()) std::snprintf(g_prof_tag, sizeof(g_prof_tag), "H=%d Ci=%d s=%d se=%d", G.H, G.Ci, G.s, (int)G.se);
     const BlkFwd& F = P.f[i];
     const BlkBwd& Bk = P.b[i];
     const void* xin = i == 0 ? x : (P.f[i - 1].y == SIZE_MAX ? y_out : at(ws, P.f[i - 1].y));
@@ -809,6 +815,7 @@ extern "C" int c3d_prof_begin(int32_t flags) {
   for (ProfRec& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_prof.clear();
   g_prof_flags = flags & 3;
+  g_prof_tag[0] = 0;
   return 0;
 }
 
