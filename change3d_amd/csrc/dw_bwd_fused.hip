@@ -394,16 +394,30 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     pin_acc<TT>(acc);                                                                                             \
     pin_dw(dwa[(S)], dwa[9 + (S)], dwa[18 + (S)]);                                                                \
   }
-    FB_LOAD(0, 0)
-    FB_LOAD(1, 1) FB_STEP(0, 0)
-    FB_LOAD(2, 0) FB_STEP(1, 1)
-    FB_LOAD(3, 1) FB_STEP(2, 0)
-    FB_LOAD(4, 0) FB_STEP(3, 1)
-    FB_LOAD(5, 1) FB_STEP(4, 0)
-    FB_LOAD(6, 0) FB_STEP(5, 1)
-    FB_LOAD(7, 1) FB_STEP(6, 0)
-    FB_LOAD(8, 0) FB_STEP(7, 1)
-    FB_STEP(8, 0)
+    if constexpr (TT <= 3) {
+      FB_LOAD(0, 0)
+      FB_LOAD(1, 1) FB_STEP(0, 0)
+      FB_LOAD(2, 0) FB_STEP(1, 1)
+      FB_LOAD(3, 1) FB_STEP(2, 0)
+      FB_LOAD(4, 0) FB_STEP(3, 1)
+      FB_LOAD(5, 1) FB_STEP(4, 0)
+      FB_LOAD(6, 0) FB_STEP(5, 1)
+      FB_LOAD(7, 1) FB_STEP(6, 0)
+      FB_LOAD(8, 0) FB_STEP(7, 1)
+      FB_STEP(8, 0)
+    } else {
+      // five frames (SCD): the second fragment slot (32 registers) does not fit beside 20 + 20 + 108 accumulators --
+      // the pipelined walk spilled 240 B per lane and ran at 1.1 TB/s; one slot, reads and FMAs in turn
+      FB_LOAD(0, 0) FB_STEP(0, 0)
+      FB_LOAD(1, 0) FB_STEP(1, 0)
+      FB_LOAD(2, 0) FB_STEP(2, 0)
+      FB_LOAD(3, 0) FB_STEP(3, 0)
+      FB_LOAD(4, 0) FB_STEP(4, 0)
+      FB_LOAD(5, 0) FB_STEP(5, 0)
+      FB_LOAD(6, 0) FB_STEP(6, 0)
+      FB_LOAD(7, 0) FB_STEP(7, 0)
+      FB_LOAD(8, 0) FB_STEP(8, 0)
+    }
 #undef FB_LOAD
 #undef FB_STEP
     FB_EPI(0, 0)

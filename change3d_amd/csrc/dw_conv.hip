@@ -1572,6 +1572,218 @@ int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, doubl
   return 0;
 }
 
+// ----------------------------------------------------------------------------------------------
+// Forward v2, stride 2 (the first block of every stage).  Same roles as v2 -- wave = one 8-channel vector with
+// wave-uniform weights, lane = an output pixel, walking workgroup with the next tile's raw rows prefetched -- over a
+// POLYPHASE tile: the 9 x 33 input pixels a 4 x 16 output tile reads are staged as four parity planes
+// [t][iy & 1][ix & 1][iy >> 1][ix >> 1], so tap (ky, kx) of output (oy, ox) is plane (ky & 1, kx & 1) at
+// (oy + (ky == 2), ox + (kx == 2)): the lanes of a wave (consecutive ox) read consecutive 16-byte pixels, as in the
+// stride-1 kernel (reading every second pixel of a dense tile is a two-way bank conflict on every ds_read_b128).
+// The v1 kernel this replaces (thread = pixel x channel vector, 4 x 8 tiles, no prefetch) ran the three stride-2 blocks
+// of the BCD step at 0.42 TB/s.
+// Empty asm that "uses" the 24 accumulators: keeps the scheduler from hoisting the LDS reads of all nine (ky, kx) steps
+// above the first FMA (432 live registers, 836 B of scratch per lane without it).
+__device__ __forceinline__ void pin_acc3(float (&a)[3][8]) {
+  asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[0][4]), "+v"(a[0][5]), "+v"(a[0][6]),
+                    "+v"(a[0][7]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(a[1][4]), "+v"(a[1][5]),
+                    "+v"(a[1][6]), "+v"(a[1][7]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[2][2]), "+v"(a[2][3]), "+v"(a[2][4]),
+                    "+v"(a[2][5]), "+v"(a[2][6]), "+v"(a[2][7]));
+}
+template <int TT> __device__ __forceinline__ void pin_acc_tt(float (&a)[TT][8]) {
+  if constexpr (TT == 3) pin_acc3(a);
+}
+constexpr int S2_TH = 4, S2_TW = 16, S2_IH = 2 * S2_TH + 1, S2_IW = 2 * S2_TW + 1, S2_HY = S2_TH + 1, S2_HX = S2_TW + 1;
+template <int TT> struct V2S2Geo {
+  static constexpr int PAR = S2_HY * S2_HX;                     // float4 units per (frame, parity) plane
+  static constexpr int PLANE = TT * 4 * PAR + 1;                // per (channel vector, half vector)
+  static constexpr int NI = TT * S2_IH * S2_IW * DW_CV;         // staged 8-channel vectors per tile
+  static constexpr int SL = (NI + 255) / 256;
+};
+
+template <typename T, int TT>
+__global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ x, const float* __restrict__ ss,
+                                                          const float* __restrict__ w, T* __restrict__ y,
+                                                          double* __restrict__ nc, const DwGeom g,
+                                                          const int tiles_per_wg, const c3d_bn_fin fin) {
+  typedef RawD<T> RW;
+  typedef V2S2Geo<TT> G;
+  constexpr int NI = G::NI, SL = G::SL, PLANE = G::PLANE, PAR = G::PAR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);                  // [27][32]
+  float* fss = wl + 27 * 32;                                   // [2][32] scale | shift of this chunk (fin.sums mode)
+  float4* tile = reinterpret_cast<float4*>(fss + 64);          // [4 cv][2 halves][PLANE]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wcv = __builtin_amdgcn_readfirstlane(tid >> 6);    // this wave's channel vector
+  const int lx = lane & 15, ly = lane >> 4;                    // lane = output pixel (ly, lx) of the tile
+  const int tiles_x = (g.Wo + S2_TW - 1) / S2_TW, tiles_y = (g.Ho + S2_TH - 1) / S2_TH;
+  const int ntiles = tiles_x * tiles_y;
+  const int gx = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
+  const ChunkOrder co = chunk_order((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), gx * g.B);
+  if (co.group < 0) return;
+  const int chunk = co.chunk, b = co.group / gx, tg = co.group % gx;
+  const int c0 = chunk * DW_CV * 8;
+  const int scv = tid & 3;              // staging role: item i = tid + 256*slot -> (cv = i & 3, pixel = i >> 2)
+  const int sbase = c0 + scv * 8;
+  const bool s_ok = sbase < g.Cp;
+  const int cbase = c0 + wcv * 8;       // compute role
+  const bool c_ok = cbase < g.Cp;
+
+  for (int i = tid; i < 27 * 32; i += 256) {
+    const int tap = i / 32, c = c0 + (i & 31);
+    wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+
+  // per-slot constants of the staging role: offset inside the input tile (global) and inside the parity planes (LDS)
+  typename RW::type raw[SL];
+  unsigned vmask = 0;
+#define S2_ISSUE(TL)                                                                            \
+  {                                                                                             \
+    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                       \
+    vmask = 0;                                                                                  \
+    _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                         \
+      const int i_ = tid + sl * 256;                                                            \
+      const int p_ = i_ >> 2;                                                                   \
+      const int ix_ = p_ % S2_IW, q_ = p_ / S2_IW;                                              \
+      const int iy_ = q_ % S2_IH, t_ = q_ / S2_IH;                                              \
+      const int gy_ = ty_ * (2 * S2_TH) - 1 + iy_, gx_ = tx_ * (2 * S2_TW) - 1 + ix_;           \
+      if (i_ < NI && s_ok && t_ < g.T && gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W) {     \
+        raw[sl] = RW::load(x + ((((size_t)b * g.T + t_) * g.H + gy_) * g.W + gx_) * g.Cp + sbase); \
+        vmask |= 1u << sl;                                                                      \
+      }                                                                                         \
+    }                                                                                           \
+  }
+
+  const int tl0 = tg * tiles_per_wg;
+  int tl1 = tl0 + tiles_per_wg;
+  if (tl1 > ntiles) tl1 = ntiles;
+  if (tl0 < tl1) S2_ISSUE(tl0)
+  float sc[8], sh[8];
+  if (fin.sums) {   // BatchNorm_a scale / shift rebuilt from conv_a's completed sums (csrc/bn_fin.h), as in the stride-1 kernel
+    if (tid == 0 && co.chunk == 0 && co.group == 0 && fin.training && fin.nbt) *fin.nbt += 1;
+    c3dfin::bn_consume(fin, g.C, g.Cp, c0, 32, co.group == 0, fss, fss + 32, tid, 256);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = s_ok ? fss[scv * 8 + j] : 0.f; sh[j] = s_ok ? fss[32 + scv * 8 + j] : 0.f; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = s_ok ? ss[sbase + j] : 0.f; sh[j] = s_ok ? ss[g.Cp + sbase + j] : 0.f; }
+  }
+  for (int tl = tl0; tl < tl1; ++tl) {
+    const int tx = tl % tiles_x, ty = tl / tiles_x;
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int i = tid + sl * 256;
+      if (i < NI) {
+        float f[8];
+        if ((vmask >> sl) & 1u) {
+          RW::cvt(raw[sl], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = 0.f;
+        }
+        const int p = i >> 2;
+        const int ix = p % S2_IW, q = p / S2_IW;
+        const int iy = q % S2_IH, t = q / S2_IH;
+        const int d = ((t * 2 + (iy & 1)) * 2 + (ix & 1)) * PAR + (iy >> 1) * S2_HX + (ix >> 1);
+        tile[(scv * 2 + 0) * PLANE + d] = make_float4(f[0], f[1], f[2], f[3]);
+        tile[(scv * 2 + 1) * PLANE + d] = make_float4(f[4], f[5], f[6], f[7]);
+      }
+    }
+    if (tl + 1 < tl1) S2_ISSUE(tl + 1)
+    __syncthreads();
+
+    float acc[TT][8];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    const float4* pl0 = tile + (wcv * 2 + 0) * PLANE + ly * S2_HX + lx;
+    const float4* pl1 = tile + (wcv * 2 + 1) * PLANE + ly * S2_HX + lx;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float wk[3][8];  // wave-uniform: broadcast LDS reads
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) lds_ld8v2(wl + (kt * 9 + ky * 3 + kx) * 32 + wcv * 8, wk[kt]);
+        const int off = ((ky & 1) * 2 + (kx & 1)) * PAR + (ky >> 1) * S2_HX + (kx >> 1);   // compile-time immediate
+#pragma unroll
+        for (int ti = 0; ti < TT; ++ti) {
+          const float4 h0 = pl0[ti * 4 * PAR + off], h1 = pl1[ti * 4 * PAR + off];
+          const float in[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+          for (int kt = 0; kt < 3; ++kt) {
+            const int to = ti - kt + 1;  // out[to] += in[to + kt - 1] * w[kt]
+            if (to >= 0 && to < TT) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[to][j] = fmaf(in[j], wk[kt][j], acc[to][j]);
+            }
+          }
+        }
+        pin_acc_tt<TT>(acc);
+      }
+    }
+    const int ox = tx * S2_TW + lx, oy = ty * S2_TH + ly;
+    if (c_ok && oy < g.Ho && ox < g.Wo) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (t < g.T) {
+          T* dst = y + ((((size_t)b * g.T + t) * g.Ho + oy) * g.Wo + ox) * g.Cp + cbase;
+          Vec8<T>::store(dst, acc[t]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float r = round_as<T>(acc[t][j]);
+            s1[j] += r; s2[j] = fmaf(r, r, s2[j]);
+          }
+        }
+      }
+    }
+  }
+#undef S2_ISSUE
+  if (nc == nullptr) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float r1 = wave_sum(s1[j]), r2 = wave_sum(s2[j]);
+    const int c = cbase + j;
+    if (lane == 0 && c < g.C) {
+      atomicAdd(nc + ((size_t)b * g.Cp + c) * 2, (double)r1);
+      atomicAdd(nc + ((size_t)b * g.Cp + c) * 2 + 1, (double)r2);
+    }
+  }
+}
+
+template <typename T, int TT>
+int launch_fwd_v2s2(const void* x, const float* ss, const float* w, void* y, double* nc, const DwGeom& g,
+                    hipStream_t stream, const c3d_bn_fin* fin = nullptr) {
+  const size_t lds = (27 * 32 + 64) * sizeof(float) + (size_t)DW_CV * 2 * V2S2Geo<TT>::PLANE * sizeof(float4);
+  if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;   // (five frames: 218 KB -- the v1 kernel)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2s2_kernel<T, TT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int ntiles = ((g.Wo + S2_TW - 1) / S2_TW) * ((g.Ho + S2_TH - 1) / S2_TH);
+  const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
+  int tpw = c3d_knob("C3D_DWF2_TPW", 16);   // one workgroup per CU (LDS): ~2 rounds of workgroups, >= 4 tiles for the prefetch
+  while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 2L * device_cus()) tpw >>= 1;
+  if (tpw > ntiles) tpw = ntiles;
+  dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
+  c3d_bn_fin f0;
+  std::memset(&f0, 0, sizeof(f0));
+  dw_fwd_v2s2_kernel<T, TT><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
+                                                              reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T, int S> struct DwTile;  // forward / wgrad output tile per workgroup
 template <typename T> struct DwTile<T, 1> { static constexpr int TH = 8, TW = 8; };
 template <typename T> struct DwTile<T, 2> { static constexpr int TH = 4, TW = 8; };
@@ -1786,6 +1998,13 @@ extern "C" int c3d_dw333_fwd(const void* x, const float* ss, const float* w, voi
     else return C3D_E_BADARG;
     if (rc != C3D_E_UNSUPPORTED) return rc;
   }
+  if (stride == 2 && T <= 3 && c3d_knob("C3D_DWF2_V2", 1)) {   // polyphase v2 (three frames: the tile fits LDS)
+    int rc = C3D_E_UNSUPPORTED;
+    if (dtype == C3D_DT_F32) rc = launch_fwd_v2s2<float, 3>(x, ss, w, y, nc_sums, g, s);
+    else if (dtype == C3D_DT_BF16) rc = launch_fwd_v2s2<bf16_t, 3>(x, ss, w, y, nc_sums, g, s);
+    else return C3D_E_BADARG;
+    if (rc != C3D_E_UNSUPPORTED) return rc;
+  }
   if (dtype == C3D_DT_F32) return stride == 1 ? launch_fwd<float, 1>(x, ss, w, y, nc_sums, g, s)
                                               : launch_fwd<float, 2>(x, ss, w, y, nc_sums, g, s);
   if (dtype == C3D_DT_BF16) return stride == 1 ? launch_fwd<bf16_t, 1>(x, ss, w, y, nc_sums, g, s)
@@ -1811,6 +2030,11 @@ extern "C" int c3d_dw333_fwd_fin(const void* x, const c3d_bn_fin* fin, const flo
                                          : launch_fwd_v2<float, 5>(x, fin->ss, w, y, nc_sums, g, s, fin);
     else rc = T <= 3 ? launch_fwd_v2<bf16_t, 3>(x, fin->ss, w, y, nc_sums, g, s, fin)
                      : launch_fwd_v2<bf16_t, 5>(x, fin->ss, w, y, nc_sums, g, s, fin);
+    if (rc != C3D_E_UNSUPPORTED) return rc;
+  }
+  if (stride == 2 && T <= 3 && (dtype == C3D_DT_F32 || dtype == C3D_DT_BF16) && c3d_knob("C3D_DWF2_V2", 1)) {
+    const int rc = dtype == C3D_DT_F32 ? launch_fwd_v2s2<float, 3>(x, fin->ss, w, y, nc_sums, g, s, fin)
+                                       : launch_fwd_v2s2<bf16_t, 3>(x, fin->ss, w, y, nc_sums, g, s, fin);
     if (rc != C3D_E_UNSUPPORTED) return rc;
   }
   // no folded kernel for this shape: the separate launch, then the plain kernel

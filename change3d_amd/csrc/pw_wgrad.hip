@@ -431,22 +431,24 @@ int launch_wgrad_inst(const c3d_pw_wgrad_args& a, dim3 grid, size_t lds, int tpw
 }
 
 // Instantiated per-wave tile grids (TN x TK): a launch takes the smallest that covers its ceil(NT / WN) x ceil(KT / WK).
-// Dense rows (all layers of the residual stages): every grid; shifted / strided rows (shortcut convolutions, the
-// transposed-convolution taps): the 4 x 4 one only.
 struct WgInst { int tn, tk; };
 constexpr WgInst WG_INSTS[] = {{1, 1}, {2, 2}, {3, 4}, {4, 3}, {4, 4}};
 
+template <typename T, bool HASP2, bool QD>
+int launch_wgrad_pick2(const c3d_pw_wgrad_args& a, int inst, dim3 grid, size_t lds, int tpw, int WN, int WK, int MT, hipStream_t s) {
+  switch (inst) {
+    case 0: return launch_wgrad_inst<T, HASP2, QD, 1, 1>(a, grid, lds, tpw, WN, WK, MT, s);
+    case 1: return launch_wgrad_inst<T, HASP2, QD, 2, 2>(a, grid, lds, tpw, WN, WK, MT, s);
+    case 2: return launch_wgrad_inst<T, HASP2, QD, 3, 4>(a, grid, lds, tpw, WN, WK, MT, s);
+    case 3: return launch_wgrad_inst<T, HASP2, QD, 4, 3>(a, grid, lds, tpw, WN, WK, MT, s);
+    default: return launch_wgrad_inst<T, HASP2, QD, 4, 4>(a, grid, lds, tpw, WN, WK, MT, s);
+  }
+}
 template <typename T, bool HASP2>
 int launch_wgrad_pick(const c3d_pw_wgrad_args& a, bool qd, int inst, dim3 grid, size_t lds, int tpw, int WN, int WK, int MT,
                       hipStream_t s) {
-  if (!qd) return launch_wgrad_inst<T, HASP2, false, 4, 4>(a, grid, lds, tpw, WN, WK, MT, s);
-  switch (inst) {
-    case 0: return launch_wgrad_inst<T, HASP2, true, 1, 1>(a, grid, lds, tpw, WN, WK, MT, s);
-    case 1: return launch_wgrad_inst<T, HASP2, true, 2, 2>(a, grid, lds, tpw, WN, WK, MT, s);
-    case 2: return launch_wgrad_inst<T, HASP2, true, 3, 4>(a, grid, lds, tpw, WN, WK, MT, s);
-    case 3: return launch_wgrad_inst<T, HASP2, true, 4, 3>(a, grid, lds, tpw, WN, WK, MT, s);
-    default: return launch_wgrad_inst<T, HASP2, true, 4, 4>(a, grid, lds, tpw, WN, WK, MT, s);
-  }
+  return qd ? launch_wgrad_pick2<T, HASP2, true>(a, inst, grid, lds, tpw, WN, WK, MT, s)
+            : launch_wgrad_pick2<T, HASP2, false>(a, inst, grid, lds, tpw, WN, WK, MT, s);
 }
 
 template <typename T>
@@ -462,16 +464,18 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   for (int c = 0; c < 4; ++c) {
     const int tn = (NT + cand[c][0] - 1) / cand[c][0], tk = (KT + cand[c][1] - 1) / cand[c][1];
     if (tn > 4 || tk > 4) continue;
-    const int cost = tn * tk * 4 + tn + tk;  // MFMAs dominate, then fragment loads
+    // the instantiated grid that will run (zero-padded) is what costs: MFMAs dominate, then fragment loads
+    int ti = 4, tj = 4;
+    for (int i = 0; i < 5; ++i)
+      if (WG_INSTS[i].tn >= tn && WG_INSTS[i].tk >= tk) { ti = WG_INSTS[i].tn; tj = WG_INSTS[i].tk; break; }
+    const int cost = ti * tj * 4 + ti + tj;
     if (cost < best) { best = cost; WN = cand[c][0]; WK = cand[c][1]; tn_need = tn; tk_need = tk; }
   }
   if (WN == 0) return C3D_E_UNSUPPORTED;
   int inst = 4;
-  if (qd) {
-    for (int i = 0; i < 5; ++i)
-      if (WG_INSTS[i].tn >= tn_need && WG_INSTS[i].tk >= tk_need) { inst = i; break; }
-  }
-  const int TNi = qd ? WG_INSTS[inst].tn : 4, TKi = qd ? WG_INSTS[inst].tk : 4;
+  for (int i = 0; i < 5; ++i)
+    if (WG_INSTS[i].tn >= tn_need && WG_INSTS[i].tk >= tk_need) { inst = i; break; }
+  const int TNi = WG_INSTS[inst].tn, TKi = WG_INSTS[inst].tk;
   // rows per tile: as tall as 256 staging threads per operand allow (WG_RPT rows x 8 channels each)
   const int maxG = (a.Np > a.Kp ? a.Np : a.Kp) >> 3;
   int MT = (256 / maxG) * WG_RPT / 32 * 32;

@@ -580,11 +580,11 @@ def test_scd_losses_vs_torch():
 # --------------------------------------------------------------- consumer-side BatchNorm finalisation
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C,T,stride,shape", [(54, 3, 1, (2, 16, 24)), (216, 3, 1, (3, 16, 16)), (108, 5, 1, (2, 16, 24)),
-                                              (54, 3, 2, (2, 16, 24))])
+                                              (54, 3, 2, (2, 16, 24)), (432, 3, 2, (2, 8, 8)), (108, 3, 2, (2, 40, 72))])
 def test_dw_fwd_with_folded_bn_finalize_is_bit_identical(dtype, C, T, stride, shape):
     """c3d_dw333_fwd_fin (scale/shift rebuilt from the producer's sums in the kernel's prologue, csrc/bn_fin.h) against
     c3d_bn_finalize + c3d_dw333_fwd: output, per-sample statistics, saved scale/shift and mean/rstd, running
-    statistics and num_batches_tracked are bit-identical (stride 2 runs the two launches internally)."""
+    statistics and num_batches_tracked are bit-identical (stride 2, three frames: the polyphase kernel's prologue)."""
     _need_gpu()
     from change3d_amd import ops
     B, H, W = shape
