@@ -21,6 +21,20 @@
 #include "bn_fin.h"
 #include "../../include/change3d_hip.h"
 #include <cstdlib>
+#include <type_traits>
+
+#ifdef C3D_PW_CLOCK
+// Debug build only (tools/pw_phase_clock.py --fb): per-phase shader-clock sums, one slot per (workgroup, wave).
+constexpr int FCLK_WAVES = 16384;
+__device__ unsigned long long c3d_fb_clk[FCLK_WAVES][10];
+#define FCLK_DECL unsigned long long fclk_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long fclk_last_ = __builtin_amdgcn_s_memtime();
+#define FCLK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); fclk_[i] += t_ - fclk_last_; fclk_last_ = t_; }
+#define FCLK_FLUSH if ((threadIdx.x & 63) == 0) { const int w_ = (blockIdx.x * 8 + (threadIdx.x >> 6)) % FCLK_WAVES; for (int i_ = 0; i_ < 9; ++i_) c3d_fb_clk[w_][i_] += fclk_[i_]; c3d_fb_clk[w_][9] += 1ull; }
+#else
+#define FCLK_DECL
+#define FCLK(i)
+#define FCLK_FLUSH
+#endif
 
 namespace {
 
@@ -154,6 +168,7 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
   float4* tile = reinterpret_cast<float4*>(cf + 7 * 32);  // [2 buffers][2 half-vector planes][NI]
 
   const int tid = threadIdx.x;
+  FCLK_DECL
   const int h = tid >> 8;                                 // channel half of the vector (wave-uniform)
   const int cv = tid & (DW_CV - 1);
   const int pix = (tid & 255) >> 2;
@@ -255,6 +270,7 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
   if (tl1 > ntiles) tl1 = ntiles;
   if (tl0 < tl1) FB_ISSUE(tl0)
   __syncthreads();   // wl / cf staged
+  FCLK(0)
 
   for (int tl = tl0; tl < tl1; ++tl) {
     const int tx = tl % tiles_x, ty = tl / tiles_x;
@@ -286,6 +302,7 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
         }
       }
     }
+    FCLK(1)
     // ---- one pixel of this thread (class (CY, CX) of its quad; stride 1: the only one): a_in = relu(bn_a(a)) for the
     // weight gradient and the mask
     typename R4::type arc[TT];
@@ -356,8 +373,13 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
       FB_EPI(1, 1)
       continue;
     }
+    // (Issuing the next tile's loads one per tap step instead of in a bunch here was measured in round 3: the stalled
+    // issue time just moves into the tap walk, +8 % per launch -- the stall is the memory system's back-pressure at
+    // ~10 B/clk/CU, not a queue that drains while the address path idles; profiles/r03_dw_bwd_fused_phase_clock.txt.)
     if (tl + 1 < tl1) FB_ISSUE(tl + 1)
+    FCLK(2)
     __syncthreads();
+    FCLK(3)
 
     // ---- 27 taps: one LDS read feeds the data gradient (x weight) and the weight gradient (x a_in)
     // lowest-address tap (ky = kx = 2) as base: every other tap is a non-negative immediate offset of the ds_read
@@ -420,7 +442,9 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     }
 #undef FB_LOAD
 #undef FB_STEP
+    FCLK(4)
     FB_EPI(0, 0)
+    FCLK(5)
   }
 #undef FB_PRE
 #undef FB_EPI
@@ -458,6 +482,7 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     const int c = c0 + v * 8 + hh * 4 + j;
     if (c < g.C) atomicAdd(dsums + (size_t)which * g.C + c, sacc);
   }
+  FCLK(6)
   // ---- weight gradient: dump [tap][thread] per channel-of-four, 64-pixel sums in fixed order, f32 atomics
   if (dw == nullptr) return;
   float* dump = reinterpret_cast<float*>(tile);      // 27 * 512 floats = 55 KB <= 2 * 2 * NI * 16 B
@@ -479,6 +504,8 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
       if (part == 0 && c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, s);
     }
   }
+  FCLK(7)
+  FCLK_FLUSH
 }
 
 template <typename T, int TT, int S>
@@ -562,3 +589,16 @@ extern "C" int c3d_dw333_bwd_fused_fin(const void* t1, const void* b, const c3d_
   return dispatch_fused(t1, b, nullptr, nullptr, nullptr, w, a, ss_a, mr_a, t2, dsums, dw, g, dtype,
                         reinterpret_cast<hipStream_t>(stream), *fin_b);
 }
+
+#ifdef C3D_PW_CLOCK
+extern "C" int c3d_debug_fb_clock(unsigned long long* out, int reset) {   // out[FCLK_WAVES][10]
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(c3d_fb_clk), sizeof(unsigned long long) * FCLK_WAVES * 10);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(c3d_fb_clk));
+    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * FCLK_WAVES * 10);
+  }
+  return (int)e;
+}
+#endif
