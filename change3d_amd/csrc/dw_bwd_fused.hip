@@ -152,6 +152,43 @@ __device__ __forceinline__ void fb_taps_s2(const float4* tp, const float* wlp, f
   }
 }
 
+// Stride-1 tap walk in plain (compiler-scheduled) form: one fragment slot, nine (ky, kx) steps.  Five frames (SCD) run
+// this: the hand-pipelined walk below needs a second fragment slot that does not fit beside 20 + 20 + 108 accumulators.
+template <int TT>
+__device__ __forceinline__ void fb_taps_s1(const float4* tp, const float* wlp, f32x2_t (&acc)[TT][2], f32x2_t (&dwa)[27][2],
+                                           const f32x2_t (&ain)[TT][2]) {
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      f32x2_t wk[3][2];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const float4 wv = *reinterpret_cast<const float4*>(wlp + (kt * 9 + ky * 3 + kx) * 32);
+        wk[kt][0] = f32x2_t{wv.x, wv.y}; wk[kt][1] = f32x2_t{wv.z, wv.w};
+      }
+#pragma unroll
+      for (int to = 0; to < TT; ++to) {
+        const float4 hv = tp[((to * FB_DH + (2 - ky)) * FB_DW + (2 - kx)) * DW_CV];
+        const f32x2_t v0 = {hv.x, hv.y}, v1 = {hv.z, hv.w};
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+          const int ti = to + kt - 1;
+          if (ti >= 0 && ti < TT) {
+            const int k = kt * 9 + ky * 3 + kx;
+            acc[ti][0] = __builtin_elementwise_fma(v0, wk[kt][0], acc[ti][0]);
+            acc[ti][1] = __builtin_elementwise_fma(v1, wk[kt][1], acc[ti][1]);
+            dwa[k][0] = __builtin_elementwise_fma(v0, ain[ti][0], dwa[k][0]);
+            dwa[k][1] = __builtin_elementwise_fma(v1, ain[ti][1], dwa[k][1]);
+          }
+        }
+      }
+      pin_acc<TT>(acc);
+      pin_dw(dwa[ky * 3 + kx], dwa[9 + ky * 3 + kx], dwa[18 + ky * 3 + kx]);
+    }
+  }
+}
+
 template <typename T, int TT, int S>
 __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
@@ -428,17 +465,7 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
       FB_LOAD(8, 0) FB_STEP(7, 1)
       FB_STEP(8, 0)
     } else {
-      // five frames (SCD): the second fragment slot (32 registers) does not fit beside 20 + 20 + 108 accumulators --
-      // the pipelined walk spilled 240 B per lane and ran at 1.1 TB/s; one slot, reads and FMAs in turn
-      FB_LOAD(0, 0) FB_STEP(0, 0)
-      FB_LOAD(1, 0) FB_STEP(1, 0)
-      FB_LOAD(2, 0) FB_STEP(2, 0)
-      FB_LOAD(3, 0) FB_STEP(3, 0)
-      FB_LOAD(4, 0) FB_STEP(4, 0)
-      FB_LOAD(5, 0) FB_STEP(5, 0)
-      FB_LOAD(6, 0) FB_STEP(6, 0)
-      FB_LOAD(7, 0) FB_STEP(7, 0)
-      FB_LOAD(8, 0) FB_STEP(8, 0)
+      fb_taps_s1<TT>(tp, wl + cv * 8 + h * 4, acc, dwa, ain);   // five frames (SCD)
     }
 #undef FB_LOAD
 #undef FB_STEP

@@ -1355,7 +1355,9 @@ __global__ __launch_bounds__(WgDot2<TT>::NCOMP + D2_LOADERS) void dw_wgrad_dot2_
 //     kx / kt taps and all T frames (about 11 FMA per LDS read);
 //   * workgroup = 8x16 output pixels x 32 channels, walks `tiles_per_wg` tiles of one sample keeping
 //     the per-(sample,channel) statistics in registers, with the next tile's raw rows prefetched.
-constexpr int V2_TH = 8, V2_TW = 16, V2_IH = V2_TH + 2, V2_IW = V2_TW + 2;
+// PYR = rows per lane: 2 (8 x 16 tiles) for three frames; 1 (4 x 16 tiles) for five frames, whose 8 x 16 tile is 115 KB of
+// LDS = one workgroup per CU (1.3 TB/s); the 4 x 16 tile is 69 KB = two.
+constexpr int V2_TW = 16, V2_IW = V2_TW + 2;
 
 __device__ __forceinline__ void lds_ld8v2(const float* p, float (&f)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p);
@@ -1367,8 +1369,10 @@ __device__ __forceinline__ void lds_ld8v2(const float* p, float (&f)[8]) {
 // per pixel, [t][iy][ix]; the plane stride is padded by one float4 so the 8 planes of a pixel fall on
 // distinct bank groups (conflict-free staging writes), and lanes walk x so stencil reads are dense.
 template <int TT> struct V2Geo {
-  static constexpr int PLANE = TT * V2_IH * V2_IW + 1;          // float4 units
-  static constexpr int NI = TT * V2_IH * V2_IW * DW_CV;         // staged 8-channel vectors per tile
+  static constexpr int PYR = TT <= 3 ? 2 : 1;
+  static constexpr int TH = 4 * PYR, IH = TH + 2;
+  static constexpr int PLANE = TT * IH * V2_IW + 1;             // float4 units
+  static constexpr int NI = TT * IH * V2_IW * DW_CV;            // staged 8-channel vectors per tile
   static constexpr int SL = (NI + 255) / 256;
 };
 
@@ -1379,7 +1383,7 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
                                                         const int tiles_per_wg, const c3d_bn_fin fin) {
   typedef RawD<T> RW;
   typedef V2Geo<TT> G;
-  constexpr int NI = G::NI, SL = G::SL, PLANE = G::PLANE;
+  constexpr int NI = G::NI, SL = G::SL, PLANE = G::PLANE, PYR = G::PYR, V2_TH = G::TH, V2_IH = G::IH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wl = reinterpret_cast<float*>(smem);                  // [27][32]
   float* fss = wl + 27 * 32;                                   // [2][32] scale | shift of this chunk (fin.sums mode)
@@ -1387,7 +1391,7 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wcv = __builtin_amdgcn_readfirstlane(tid >> 6);    // this wave's channel vector
-  const int lx = lane & 15, yp = lane >> 4;                    // lane = column x, row pair (2yp, 2yp+1)
+  const int lx = lane & 15, yp = lane >> 4;                    // lane = column x, rows PYR*yp .. PYR*yp + PYR-1
   const int tiles_x = (g.W + V2_TW - 1) / V2_TW, tiles_y = (g.H + V2_TH - 1) / V2_TH;
   const int ntiles = tiles_x * tiles_y;
   const int gx = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
@@ -1469,11 +1473,11 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
     if (tl + 1 < tl1) V2_ISSUE(tl + 1)
     __syncthreads();
 
-    float acc[TT][2][8];
+    float acc[TT][PYR][8];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
 #pragma unroll
-      for (int py = 0; py < 2; ++py)
+      for (int py = 0; py < PYR; ++py)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][py][j] = 0.f;
     const float4* pl0 = tile + (wcv * 2 + 0) * PLANE;
@@ -1487,10 +1491,10 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
         for (int kt = 0; kt < 3; ++kt) lds_ld8v2(wl + (kt * 9 + ky * 3 + kx) * 32 + wcv * 8, wk[kt]);
 #pragma unroll
         for (int ti = 0; ti < TT; ++ti) {
-          float in[2][8];
+          float in[PYR][8];
 #pragma unroll
-          for (int py = 0; py < 2; ++py) {
-            const int p = (ti * V2_IH + 2 * yp + py + ky) * V2_IW + lx + kx;
+          for (int py = 0; py < PYR; ++py) {
+            const int p = (ti * V2_IH + PYR * yp + py + ky) * V2_IW + lx + kx;
             const float4 h0 = pl0[p], h1 = pl1[p];
             in[py][0] = h0.x; in[py][1] = h0.y; in[py][2] = h0.z; in[py][3] = h0.w;
             in[py][4] = h1.x; in[py][5] = h1.y; in[py][6] = h1.z; in[py][7] = h1.w;
@@ -1500,7 +1504,7 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
             const int to = ti - kt + 1;  // out[to] += in[to + kt - 1] * w[kt]
             if (to >= 0 && to < TT) {
 #pragma unroll
-              for (int py = 0; py < 2; ++py)
+              for (int py = 0; py < PYR; ++py)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[to][py][j] = fmaf(in[py][j], wk[kt][j], acc[to][py][j]);
             }
@@ -1510,8 +1514,8 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
     }
     const int ox = tx * V2_TW + lx;
 #pragma unroll
-    for (int py = 0; py < 2; ++py) {
-      const int oy = ty * V2_TH + 2 * yp + py;
+    for (int py = 0; py < PYR; ++py) {
+      const int oy = ty * V2_TH + PYR * yp + py;
       if (c_ok && oy < g.H && ox < g.W) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -1553,8 +1557,9 @@ int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, doubl
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  constexpr int V2_TH = V2Geo<TT>::TH;
   const int ntiles = ((g.W + V2_TW - 1) / V2_TW) * ((g.H + V2_TH - 1) / V2_TH);
-  int tpw = 16;  // swept on MI355X: 1:427us 4:255 8:240 16:233 32:250 (stage-1 shape)
+  int tpw = 16 * 2 / V2Geo<TT>::PYR;  // swept on MI355X: 1:427us 4:255 8:240 16:233 32:250 (stage-1 shape)
   // ...but a walk is a serial chain (~5.5 us per tile): keep ~2 workgroups per CU in the grid
   // (the 64x64 / 32x32 stages launched 256 / 224 workgroups of 16 / 8 tiles: one per CU, 98 / 52 us)
   const int chunks_ = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
