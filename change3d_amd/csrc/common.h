@@ -39,6 +39,14 @@ template <> struct Vec8<float> {
     *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
   }
+  // raw form: the load is issued now, converted where it is consumed (register prefetch across a loop iteration)
+  struct raw_t { float4 a, b; };
+  static __device__ __forceinline__ raw_t load_raw(const float* p) {
+    raw_t r; r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4); return r;
+  }
+  static __device__ __forceinline__ void cvt_raw(const raw_t& r, float (&f)[8]) {
+    f[0] = r.a.x; f[1] = r.a.y; f[2] = r.a.z; f[3] = r.a.w; f[4] = r.b.x; f[5] = r.b.y; f[6] = r.b.z; f[7] = r.b.w;
+  }
 };
 template <> struct Vec8<bf16_t> {
   static __device__ __forceinline__ void load(const bf16_t* p, float (&f)[8]) {
@@ -53,6 +61,14 @@ template <> struct Vec8<bf16_t> {
     v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
     v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
     *reinterpret_cast<uint4*>(p) = v;
+  }
+  typedef uint4 raw_t;
+  static __device__ __forceinline__ raw_t load_raw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ void cvt_raw(const raw_t& v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
   }
 };
 

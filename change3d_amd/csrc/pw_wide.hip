@@ -66,22 +66,66 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
   const bool w_vec4 = ((uintptr_t)a.w & 15) == 0 && (kc_contig ? ((a.w_sn & 3) == 0 && (a.K & 3) == 0)
                                                                : (a.w_sn == 1 && (a.w_sk & 3) == 0 && (a.N & 3) == 0));
 
-  for (int kc = 0; kc < Kp; kc += KC) {
-    __syncthreads();
-    // ---- X chunk: 8-element vectors (row, kv), prologue applied, converted to the MFMA operand type
-    for (int i = tid; i < WB_M * (KC / 8); i += 256) {
+  // Software pipeline over the K chunks: the global loads of chunk c+1 (raw X vectors, SE gates, weights) are issued into
+  // registers before the MFMAs of chunk c and converted / written to LDS after them -- the loop used to load, convert,
+  // barrier and multiply in turn, paying a full global round trip per 64-channel chunk (7 per launch on the 432-channel
+  // res5 layers: 40-66 us for 15 MB of operands).
+  constexpr int NXI = (WB_M * (KC / 8) + 255) / 256;       // X vectors per thread and chunk
+  constexpr int NWI = (WB_N * KC / 4 + 255) / 256;         // weight float4s per thread and chunk (w_vec4 layouts)
+  typedef typename Vec8<T>::raw_t xraw_t;
+  xraw_t rx[NXI], rx2[PRO == C3D_PRO_AFFINE2 ? NXI : 1];
+  float4 rgate[PRO == C3D_PRO_BN_SE_SWISH ? NXI : 1][2];
+  float4 rw[NWI];
+  unsigned xmask = 0;
+  auto fetch = [&](const int kc) {
+    xmask = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < NXI; ++s_) {
+      const int i = tid + s_ * 256;
       const int kv = i % (KC / 8), r = i / (KC / 8);
       const int64_t m = m0 + r;
+      const int k0 = kc + kv * 8;
+      if (i < WB_M * (KC / 8) && m < a.M && k0 < Kp) {
+        const int64_t off = wide_row_offset(a, m) + k0;
+        rx[s_] = Vec8<T>::load_raw(X + off);
+        if (PRO == C3D_PRO_AFFINE2) rx2[PRO == C3D_PRO_AFFINE2 ? s_ : 0] = Vec8<T>::load_raw(X2 + off);
+        if (PRO == C3D_PRO_BN_SE_SWISH && a.pro_gate) {
+          const float* gp = a.pro_gate + (m / rps) * Kp + k0;
+          rgate[PRO == C3D_PRO_BN_SE_SWISH ? s_ : 0][0] = *reinterpret_cast<const float4*>(gp);
+          rgate[PRO == C3D_PRO_BN_SE_SWISH ? s_ : 0][1] = *reinterpret_cast<const float4*>(gp + 4);
+        }
+        xmask |= 1u << s_;
+      }
+    }
+    if (w_vec4) {
+#pragma unroll
+      for (int s_ = 0; s_ < NWI; ++s_) {
+        const int i = tid + s_ * 256;
+        int n, k;
+        if (kc_contig) { k = (i % (KC / 4)) * 4; n = i / (KC / 4); } else { n = (i % (WB_N / 4)) * 4; k = i / (WB_N / 4); }
+        const int gn = n0 + n, gk = kc + k;
+        rw[s_] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < WB_N * KC / 4 && gn < a.N && gk < a.K)
+          rw[s_] = *reinterpret_cast<const float4*>(a.w + (size_t)gn * a.w_sn + (size_t)gk * a.w_sk);
+      }
+    }
+  };
+  auto commit = [&](const int kc) {
+    // ---- X chunk: 8-element vectors (row, kv), prologue applied, converted to the MFMA operand type
+#pragma unroll
+    for (int s_ = 0; s_ < NXI; ++s_) {
+      const int i = tid + s_ * 256;
+      if (i >= WB_M * (KC / 8)) continue;
+      const int kv = i % (KC / 8), r = i / (KC / 8);
       const int k0 = kc + kv * 8;
       float f[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = 0.f;
-      if (m < a.M && k0 < Kp) {
-        const int64_t off = wide_row_offset(a, m) + k0;
-        Vec8<T>::load(X + off, f);
+      if ((xmask >> s_) & 1u) {
+        Vec8<T>::cvt_raw(rx[s_], f);
         if (PRO == C3D_PRO_BN_SE_SWISH) {
-          float g[8];
-          if (a.pro_gate) Vec8<float>::load(a.pro_gate + (m / rps) * Kp + k0, g);
+          const float4 g0 = rgate[PRO == C3D_PRO_BN_SE_SWISH ? s_ : 0][0], g1 = rgate[PRO == C3D_PRO_BN_SE_SWISH ? s_ : 0][1];
+          const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float q = (a.pro_gate ? g[j] : 1.f) * fmaf(f[j], Pp[k0 + j], Pp[Kp + k0 + j]);
@@ -89,7 +133,7 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
           }
         } else if (PRO == C3D_PRO_AFFINE2) {
           float f2[8];
-          Vec8<T>::load(X2 + off, f2);
+          Vec8<T>::cvt_raw(rx2[PRO == C3D_PRO_AFFINE2 ? s_ : 0], f2);
 #pragma unroll
           for (int j = 0; j < 8; ++j) f[j] = fmaf(Pp[k0 + j], f[j], fmaf(Pp[2 * Kp + k0 + j], f2[j], Pp[Kp + k0 + j]));
         }
@@ -98,12 +142,13 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
     }
     // ---- W chunk: Ws[n][k] = w[(n0+n)*w_sn + (kc+k)*w_sk]; threads run along the contiguous dimension of w
     if (w_vec4) {
-      for (int i = tid; i < WB_N * KC / 4; i += 256) {
+#pragma unroll
+      for (int s_ = 0; s_ < NWI; ++s_) {
+        const int i = tid + s_ * 256;
+        if (i >= WB_N * KC / 4) continue;
         int n, k;
         if (kc_contig) { k = (i % (KC / 4)) * 4; n = i / (KC / 4); } else { n = (i % (WB_N / 4)) * 4; k = i / (WB_N / 4); }
-        const int gn = n0 + n, gk = kc + k;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gn < a.N && gk < a.K) v = *reinterpret_cast<const float4*>(a.w + (size_t)gn * a.w_sn + (size_t)gk * a.w_sk);
+        const float4 v = rw[s_];
         if (kc_contig) {
           Ws[n * KL + k] = MM::cvt(v.x); Ws[n * KL + k + 1] = MM::cvt(v.y); Ws[n * KL + k + 2] = MM::cvt(v.z); Ws[n * KL + k + 3] = MM::cvt(v.w);
         } else {
@@ -119,7 +164,13 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
         Ws[n * KL + k] = MM::cvt(v);
       }
     }
+  };
+  fetch(0);
+  for (int kc = 0; kc < Kp; kc += KC) {
+    __syncthreads();   // (first pass: prologue parameters staged; later: the previous chunk's MFMAs have read Xs / Ws)
+    commit(kc);
     __syncthreads();
+    if (kc + KC < Kp) fetch(kc + KC);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const typename MM::frag_t xb = MM::load(Xs, wave * 16 + (lane & 15), ks, KL, lane);
@@ -306,39 +357,68 @@ __global__ __launch_bounds__(256) void pw_wide_wgrad_kernel(const c3d_pw_wgrad_a
   f32x4_t acc[4];   // wave = n tile, 4 k tiles
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // 32 rows x 8 column vectors for each operand = 256 vectors: one of each per thread, written transposed.  The raw
+  // vectors (and SE gates) of chunk c+1 are loaded into registers before the MFMAs of chunk c (software pipeline, as
+  // in pw_wide_kernel).
+  const int cv = tid & 7, r = tid >> 3;
+  const int cn = n0 + cv * 8, ck = k0 + cv * 8;
+  typedef typename Vec8<T>::raw_t raw_t;
+  raw_t rp, rp2, rq;
+  float4 rgt[2];
+  bool p_ok = false, q_ok = false;
+  int64_t q_n = 0;
+  auto fetch = [&](const int64_t mb) {
+    const int64_t m = mb + r;
+    p_ok = m < mhi && cn < a.Np;
+    q_ok = m < mhi && ck < a.Kp;
+    if (p_ok) {
+      rp = Vec8<T>::load_raw(P + m * a.Np + cn);
+      if (a.p_coef) rp2 = Vec8<T>::load_raw(P2 + m * a.Np + cn);
+    }
+    if (q_ok) {
+      rq = Vec8<T>::load_raw(Q + m * a.Kp + ck);
+      if (a.q_mode == C3D_PRO_BN_SE_SWISH && a.q_gate) {
+        q_n = m / rps;
+        rgt[0] = *reinterpret_cast<const float4*>(a.q_gate + q_n * a.Kp + ck);
+        rgt[1] = *reinterpret_cast<const float4*>(a.q_gate + q_n * a.Kp + ck + 4);
+      }
+    }
+  };
+  float pcA[8], pcB[8], pcC[8], qs[8], qh[8];   // per-channel coefficients of this thread's column vectors
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool pc = a.p_coef && cn < a.Np;
+    pcA[j] = pc ? a.p_coef[cn + j] : 1.f; pcB[j] = pc ? a.p_coef[a.Np + cn + j] : 0.f; pcC[j] = pc ? a.p_coef[2 * a.Np + cn + j] : 0.f;
+    const bool qc = a.q_mode == C3D_PRO_BN_SE_SWISH && ck < a.Kp;
+    qs[j] = qc ? a.q_ss[ck + j] : 1.f; qh[j] = qc ? a.q_ss[a.Kp + ck + j] : 0.f;
+  }
+  fetch(mlo);
   for (int64_t mb = mlo; mb < mhi; mb += WG_R) {
     __syncthreads();
-    // 32 rows x 8 column vectors for each operand = 256 vectors: one of each per thread, written transposed
     {
-      const int cv = tid & 7, r = tid >> 3;
-      const int64_t m = mb + r;
       float f[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = 0.f;
-      const int cn = n0 + cv * 8;
-      if (m < mhi && cn < a.Np) {
-        Vec8<T>::load(P + m * a.Np + cn, f);
+      if (p_ok) {
+        Vec8<T>::cvt_raw(rp, f);
         if (a.p_coef) {
           float f2[8];
-          Vec8<T>::load(P2 + m * a.Np + cn, f2);
+          Vec8<T>::cvt_raw(rp2, f2);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            f[j] = fmaf(a.p_coef[cn + j], f[j], fmaf(a.p_coef[2 * a.Np + cn + j], f2[j], a.p_coef[a.Np + cn + j]));
+          for (int j = 0; j < 8; ++j) f[j] = fmaf(pcA[j], f[j], fmaf(pcC[j], f2[j], pcB[j]));
         }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) Pt[(cv * 8 + j) * RL + r] = MM::cvt(f[j]);
-      const int ck = k0 + cv * 8;
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = 0.f;
-      if (m < mhi && ck < a.Kp) {
-        Vec8<T>::load(Q + m * a.Kp + ck, f);
+      if (q_ok) {
+        Vec8<T>::cvt_raw(rq, f);
         if (a.q_mode == C3D_PRO_BN_SE_SWISH) {
-          const int64_t n = m / rps;
+          const float g[8] = {rgt[0].x, rgt[0].y, rgt[0].z, rgt[0].w, rgt[1].x, rgt[1].y, rgt[1].z, rgt[1].w};
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float g = a.q_gate ? a.q_gate[n * a.Kp + ck + j] : 1.f;
-            const float qq = g * fmaf(f[j], a.q_ss[ck + j], a.q_ss[a.Kp + ck + j]);
+            const float qq = (a.q_gate ? g[j] : 1.f) * fmaf(f[j], qs[j], qh[j]);
             f[j] = qq * sigmoid_t<T>(qq);
           }
         }
@@ -347,6 +427,7 @@ __global__ __launch_bounds__(256) void pw_wide_wgrad_kernel(const c3d_pw_wgrad_a
       for (int j = 0; j < 8; ++j) Qt[(cv * 8 + j) * RL + r] = MM::cvt(f[j]);
     }
     __syncthreads();
+    if (mb + WG_R < mhi) fetch(mb + WG_R);
 #pragma unroll
     for (int rs = 0; rs < RS; ++rs) {
       const typename MM::frag_t pa = MM::load(Pt, wave * 16 + (lane & 15), rs, RL, lane);   // A[i = n][k = row]
