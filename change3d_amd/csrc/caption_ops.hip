@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qb,
 }
 
 // ---- cross-entropy over the decoded steps.  logits row (l, b) = l*B + b, Vp columns; target = caps[b][l+1];
-// valid iff l < declen[b] and target != ignore.  acc f64 [3] = (sum nll, count, top-1 hits), zeroed by the entry point.
+// valid iff l < declen[b] and target != ignore (a counted target outside [0, V) poisons the loss with NaN).
+// acc f64 [3] = (sum nll, count, top-1 hits), zeroed by the entry point.
 template <typename T>
 __global__ __launch_bounds__(256) void cap_ce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ caps,
                                                          const int64_t* __restrict__ declen, double* __restrict__ acc,
@@ -283,7 +284,15 @@ __global__ __launch_bounds__(256) void cap_ce_fwd_kernel(const T* __restrict__ l
   const int b = (int)(row % B), l = (int)(row / B);
   const int64_t tgt = l + 1 < L ? caps[(int64_t)b * L + l + 1] : ignore;
   const bool valid = l < declen[b] && tgt != ignore && tgt >= 0 && tgt < V;
-  if (!valid) { if (lane == 0) lse[row] = 0.f; return; }
+  if (!valid) {
+    if (lane == 0) {
+      lse[row] = 0.f;
+      // a counted position whose target is outside [0, V) (wrong --vocab_size, corrupt word map): nn.CrossEntropyLoss
+      // in the reference trips a device assert; here the loss turns NaN -- loud in every log, no host read-back
+      if (l < declen[b] && tgt != ignore) atomicAdd(acc, (double)NAN);
+    }
+    return;
+  }
   float mx = -INFINITY;
   int am = 0;
   for (int j = lane; j < V; j += 64) { const float x = ld1<T>(logits + row * Vp + j); if (x > mx) { mx = x; am = j; } }

@@ -67,6 +67,11 @@ def _ndhwc_storage(t):
     return p if p.is_contiguous() else None
 
 
+# False: _TapFrames never writes into the gradient it receives (set it when hooks / retain_grad observe stage outputs:
+# a kept reference to that gradient would otherwise see the tapped-frame terms added later).  Costs one copy per stage.
+TAP_INPLACE = True
+
+
 class _TapFrames(torch.autograd.Function):
     """x -> (x, x[:, :, k0], ..., x[:, :, k0+n-1]) with the frame gradients accumulated by ONE strided
     HIP pass per tapped frame (`c3d_frame_scatter`, accumulate=1) into the gradient that arrives for x.
@@ -93,7 +98,11 @@ class _TapFrames(torch.autograd.Function):
         dev = (gx if gx is not None else live[0][1]).device
         dt = ops.dt_code(act)
         fresh = gx is None
-        buf = None if fresh else (_ndhwc_storage(gx) if gx.dtype == act else None)
+        # in-place accumulation only into a gradient nobody else can observe: the buffer the next stage's backward just
+        # produced for this edge (no autograd history, not a leaf's .grad).  A gradient that went through a tensor hook /
+        # retain_grad (requires_grad or grad_fn set under create_graph) or any foreign layout is copied first.
+        own = TAP_INPLACE and (not fresh) and gx.dtype == act and not gx.requires_grad and gx.grad_fn is None
+        buf = _ndhwc_storage(gx) if own else None
         if buf is None:
             buf = torch.empty((B, T, H, W, C), dtype=act, device=dev)
             if fresh:   # frames nobody tapped carry no gradient

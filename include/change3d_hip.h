@@ -533,7 +533,8 @@ int c3d_cap_attn_bwd(const void* q, const void* k, const void* v, int32_t ldq, i
  * gather): logits rows (l*B+b) of round_up(V,8) columns; target = caps[b][l+1] (caps int64 [B][L], sorted by length);
  * a step counts iff l < declen[b] (int64 [B]) and target != ignore_index; loss = mean; lse f32 [L*B];
  * acc2 f64 [3] = (sum of the negative log-likelihoods, counted steps, top-1 hits = caption_accuracy(scores, targets, 1)
- * of reference model/utils.py:493-507 before its percentage scaling).                                             */
+ * of reference model/utils.py:493-507 before its percentage scaling).  A counted step whose target lies outside [0, V)
+ * makes the loss NaN (torch.nn.CrossEntropyLoss trips a device assert there): never silently ignored.              */
 int c3d_cap_ce_fwd(const void* logits, const int64_t* caps, const int64_t* declen, double* acc2, float* lse, float* loss,
                    int32_t B, int32_t L, int32_t V, int64_t ignore_index, int32_t dtype, void* stream);
 int c3d_cap_ce_bwd(const void* logits, const int64_t* caps, const int64_t* declen, const double* acc2, const float* lse,

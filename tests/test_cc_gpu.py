@@ -299,3 +299,26 @@ def test_beam_search_bf16_runs_and_terminates():
     for s in seqs:
         assert s[0] == V - 2 and s[-1] == end_id and end_id not in s[1:-1] and len(s) <= 53
     assert best is None or best in seqs
+
+
+def test_packed_cross_entropy_rejects_out_of_range_targets():
+    """A counted target outside [0, vocab) (wrong --vocab_size, corrupt word map) must not be dropped quietly:
+    torch.nn.CrossEntropyLoss (reference scripts/train_CC.py:131-132) trips a device assert; the fused kernel turns the
+    loss NaN.  ignore_index and the steps beyond a caption's length are still ignored."""
+    _need_gpu()
+    from change3d_amd.model.caption_decoder import packed_cross_entropy
+    B, L, V = 3, 7, 11
+    g = torch.Generator().manual_seed(5)
+    Vp = (V + 7) // 8 * 8
+    logits = torch.randn(L, B, Vp, generator=g).to(DEV)
+    caps = torch.randint(1, V, (B, L), generator=g)
+    caplens = torch.tensor([[7], [5], [4]])
+    ok = packed_cross_entropy(logits, caps.to(DEV), caplens.to(DEV), V)
+    assert torch.isfinite(ok).item()
+    bad = caps.clone(); bad[1, 2] = V          # a decoded step of caption 1
+    assert torch.isnan(packed_cross_entropy(logits, bad.to(DEV), caplens.to(DEV), V)).item()
+    bad = caps.clone(); bad[2, 3] = -4
+    assert torch.isnan(packed_cross_entropy(logits, bad.to(DEV), caplens.to(DEV), V)).item()
+    pad = caps.clone(); pad[2, 5] = V + 3      # beyond caption 2's length: not counted, not an error
+    same = packed_cross_entropy(logits, pad.to(DEV), caplens.to(DEV), V)
+    assert torch.equal(same, ok)

@@ -57,6 +57,34 @@ def test_tap_frames_backward_matches_plain_indexing(last):
     assert torch.allclose(xd.grad, xr.grad, rtol=1e-6, atol=1e-6)
 
 
+def test_tap_frames_copy_mode_leaves_the_incoming_gradient_untouched():
+    """`trainer.TAP_INPLACE = False` (for hooks / retain_grad on stage outputs): the gradient that arrives for x is
+    not written -- a reference kept by a tensor hook still holds the next stage's gradient alone -- and x.grad is the
+    same as in the default in-place mode."""
+    _need_gpu()
+    from change3d_amd import synthetic as synth
+    from change3d_amd.model import trainer as tr
+    B, C, T, H, W = 2, 24, 5, 8, 8
+    base = synth.synth_tensor((B, T, H, W, C), 3).to(DEV).permute(0, 4, 1, 2, 3)
+    gy = synth.synth_tensor((B, T, H, W, C), 4).to(DEV).permute(0, 4, 1, 2, 3)
+    gfs = [synth.synth_tensor((B, H, W, C), 5 + i).to(DEV).permute(0, 3, 1, 2) for i in range(3)]
+    grads, seen = [], []
+    try:
+        for inplace in (True, False):
+            tr.TAP_INPLACE = inplace
+            xd = base.clone().requires_grad_(True)
+            y, fd = tr.tap_frames(xd * 1.0, 1, 3)
+            kept = []
+            y.register_hook(lambda g, kept=kept: kept.append((g, g.clone())))
+            (sum((f * g).sum() for f, g in zip(fd, gfs)) + (y * 2.0 * gy).sum()).backward()
+            grads.append(xd.grad.clone())
+            seen.append(torch.equal(kept[0][0], kept[0][1]))
+    finally:
+        tr.TAP_INPLACE = True
+    assert torch.equal(grads[0], grads[1])
+    assert seen[1], "copy mode wrote into the gradient it received"
+
+
 def test_checkpoint_round_trip_mirror_oracle_mirror(tmp_path):
     """reference scripts/train_BCD.py:333-349 (checkpoint layout) / model/utils.py:205-232 (resume): a checkpoint
     written from the HIP mirror after a train step strict-loads into the oracle (= the reference module tree) and

@@ -69,7 +69,7 @@ def main():
         nc3 = torch.zeros(B * Cip * 3, dtype=torch.float64, device=DEV)
         rps = T * H * H
         ia = iat = ic = ict = None
-        if ops.PW_IMG:   # packed weight images (the product path); C3D_PW_IMG=0: every workgroup converts the f32 weights
+        if os.environ.get("C3D_PW_IMG", "1") != "0":   # packed weight images (the product path); 0: every workgroup converts the f32 weights
             mk = lambda N, K: torch.empty(ops.pw_weight_image_bytes(N, K, dt), dtype=torch.uint8, device=DEV)  # noqa: E731
             ia, iat, ic, ict = mk(Ci, Cin), mk(Cin, Ci), mk(Co, Ci), mk(Ci, Co)
             ops.pw_pack_weights([(wa, ia, Ci, Cin, Cin, 1), (wa, iat, Cin, Ci, 1, Cin), (wc, ic, Co, Ci, Ci, 1),
