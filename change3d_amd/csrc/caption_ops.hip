@@ -143,6 +143,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   for (int d = lane; d < D; d += 64, ++nv) { atomicAdd(dgamma + d, dg[nv]); atomicAdd(dbeta + d, db[nv]); }
 }
 
+// o[d] = sum_j w[j] * m[j * hs + d] for d = lane % hd, with the 64 lanes split into 64 / hd groups over j and four
+// independent partial sums per lane: the serial form (lanes < hd, one fma chain of Lk dependent LDS reads) cost ~18 k clocks
+// per query row at Lk = 256.  Result valid in lanes < hd.
+__device__ __forceinline__ float attn_row_times_matrix(const float* w, const float* m, int Lk, int hs, int hd, int lane) {
+  const int np = 64 / hd;                       // groups (2 for hd = 24)
+  const int part = lane / hd, d = lane - part * hd;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+  if (part < np) {
+    int j = part;
+    for (; j + 3 * np < Lk; j += 4 * np) {
+      o0 = fmaf(w[j], m[(size_t)j * hs + d], o0);
+      o1 = fmaf(w[j + np], m[(size_t)(j + np) * hs + d], o1);
+      o2 = fmaf(w[j + 2 * np], m[(size_t)(j + 2 * np) * hs + d], o2);
+      o3 = fmaf(w[j + 3 * np], m[(size_t)(j + 3 * np) * hs + d], o3);
+    }
+    for (; j < Lk; j += np) o0 = fmaf(w[j], m[(size_t)j * hs + d], o0);
+  }
+  float o = (o0 + o1) + (o2 + o3);
+  float tot = o;
+  for (int g = 1; g < np; ++g) tot += __shfl(o, d + g * hd, 64);   // (all lanes execute the shuffle; lanes < hd keep the sum)
+  return tot;
+}
+
 // ---- multi-head attention, one workgroup per (sample b, head h); rows are sequence-first (row = l*B + b)
 //   S[i][j] = scale * q_i . k_j (+ -inf for j > i when causal);  P = softmax_j(S);  Pd = drop(P);  o_i = sum_j Pd[i][j] v_j
 // q at qb + row*ldq + h*hd (ld in elements), likewise k, v; P (pre-dropout) saved f32 [B*H][Lq][Lk].
@@ -152,31 +175,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qb,
                                                        int B, int H, int Lq, int Lk, int hd, float scale, int causal, float p,
                                                        uint64_t seed) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* ks = sm;                         // [Lk][hd]
-  float* vs = ks + (size_t)Lk * hd;       // [Lk][hd]
-  float* qs = vs + (size_t)Lk * hd;       // [Lq][hd]
-  float* ps = qs + (size_t)Lq * hd;       // [4 waves][Lk]
+  // rows are padded to an ODD stride: the score loop reads k_j . q_i with the lanes over j, and a stride of hd = 24
+  // floats put 64 lanes on 8 banks (8-way conflict on every read)
+  const int hs = hd | 1;
+  float* ks = sm;                         // [Lk][hs]
+  float* vs = ks + (size_t)Lk * hs;       // [Lk][hs]
+  float* qs = vs + (size_t)Lk * hs;       // [Lq][hs]
+  float* ps = qs + (size_t)Lq * hs;       // [4 waves][Lk]
   const int b = blockIdx.x % B, h = blockIdx.x / B;
+  // gridDim.y workgroups share the query rows of one (sample, head): [i_lo, i_hi) each (K / V are staged by all of them --
+  // 128 workgroups of 13 serial rows per wave left half of the 256 CUs idle)
+  const int rows_y = (Lq + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int i_lo = (int)blockIdx.y * rows_y, i_hi = i_lo + rows_y < Lq ? i_lo + rows_y : Lq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < Lk * hd; i += 256) {
     const int j = i / hd, d = i - j * hd;
-    ks[i] = ld1<T>(kb + ((int64_t)j * B + b) * ldk + h * hd + d);
-    vs[i] = ld1<T>(vb + ((int64_t)j * B + b) * ldv + h * hd + d);
+    ks[j * hs + d] = ld1<T>(kb + ((int64_t)j * B + b) * ldk + h * hd + d);
+    vs[j * hs + d] = ld1<T>(vb + ((int64_t)j * B + b) * ldv + h * hd + d);
   }
-  for (int i = tid; i < Lq * hd; i += 256) {
+  for (int i = i_lo * hd + tid; i < i_hi * hd; i += 256) {
     const int l = i / hd, d = i - l * hd;
-    qs[i] = ld1<T>(qb + ((int64_t)l * B + b) * ldq + h * hd + d) * scale;
+    qs[l * hs + d] = ld1<T>(qb + ((int64_t)l * B + b) * ldq + h * hd + d) * scale;
   }
   __syncthreads();
   float* pw = ps + (size_t)wave * Lk;
   float* Pout = P + (size_t)blockIdx.x * Lq * Lk;   // [(h*B + b)][Lq][Lk]
-  for (int i = wave; i < Lq; i += 4) {
+  for (int i = i_lo + wave; i < i_hi; i += 4) {
     float mx = -INFINITY;
     for (int j = lane; j < Lk; j += 64) {
       float s = -INFINITY;
       if (!causal || j <= i) {
         s = 0.f;
-        for (int d = 0; d < hd; ++d) s = fmaf(qs[i * hd + d], ks[j * hd + d], s);
+        for (int d = 0; d < hd; ++d) s = fmaf(qs[i * hs + d], ks[j * hs + d], s);
       }
       pw[j] = s;
       mx = fmaxf(mx, s);
@@ -193,10 +223,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qb,
       pw[j] = pr * keep_scale(p, seed, ((uint64_t)blockIdx.x * Lq + i) * Lk + j);
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane < hd) {
-      float o = 0.f;
-      for (int j = 0; j < Lk; ++j) o = fmaf(pw[j], vs[j * hd + lane], o);
-      st1<T>(ob + ((int64_t)i * B + b) * ldo + h * hd + lane, o);
+    {
+      const float o = attn_row_times_matrix(pw, vs, Lk, hs, hd, lane);
+      if (lane < hd) st1<T>(ob + ((int64_t)i * B + b) * ldo + h * hd + lane, o);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -213,50 +242,73 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qb,
                                                        T* __restrict__ dvb, int lddq, int lddk, int lddv, int B, int H, int Lq,
                                                        int Lk, int hd, float scale, float p, uint64_t seed) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* ks = sm;                          // [Lk][hd]
-  float* vs = ks + (size_t)Lk * hd;        // [Lk][hd]
-  float* qs = vs + (size_t)Lk * hd;        // [Lq][hd]
-  float* dos = qs + (size_t)Lq * hd;       // [Lq][hd]
-  float* DS = dos + (size_t)Lq * hd;       // [Lq][Lk]: dS, then dropped P
+  const int hs = hd | 1;                   // odd row stride: see attn_fwd_kernel
+  float* ks = sm;                          // [Lk][hs]
+  float* vs = ks + (size_t)Lk * hs;        // [Lk][hs]
+  float* qs = vs + (size_t)Lk * hs;        // [Lq][hs]
+  float* dos = qs + (size_t)Lq * hs;       // [Lq][hs]
+  float* DS = dos + (size_t)Lq * hs;       // [Lq][Lk]: dS, then dropped P
   const int b = blockIdx.x % B, h = blockIdx.x / B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < Lk * hd; i += 256) {
     const int j = i / hd, d = i - j * hd;
-    ks[i] = ld1<T>(kb + ((int64_t)j * B + b) * ldk + h * hd + d);
-    vs[i] = ld1<T>(vb + ((int64_t)j * B + b) * ldv + h * hd + d);
+    ks[j * hs + d] = ld1<T>(kb + ((int64_t)j * B + b) * ldk + h * hd + d);
+    vs[j * hs + d] = ld1<T>(vb + ((int64_t)j * B + b) * ldv + h * hd + d);
   }
   for (int i = tid; i < Lq * hd; i += 256) {
     const int l = i / hd, d = i - l * hd;
-    qs[i] = ld1<T>(qb + ((int64_t)l * B + b) * ldq + h * hd + d);
-    dos[i] = ld1<T>(dob + ((int64_t)l * B + b) * ldo + h * hd + d);
+    qs[l * hs + d] = ld1<T>(qb + ((int64_t)l * B + b) * ldq + h * hd + d);
+    dos[l * hs + d] = ld1<T>(dob + ((int64_t)l * B + b) * ldo + h * hd + d);
   }
-  __syncthreads();
+  // the saved probabilities of this (sample, head) go to LDS with the operands, in one coalesced pass: read inside the
+  // row loops below they were a serial global round trip per 64 keys (13 rows x 4-8 trips per wave: most of the launch)
   const float* Pin = P + (size_t)blockIdx.x * Lq * Lk;
+  for (int e = tid; e < Lq * Lk; e += 256) DS[e] = Pin[e];
+  __syncthreads();
   for (int i = wave; i < Lq; i += 4) {
     float* ds = DS + (size_t)i * Lk;
     float dot = 0.f;
-    for (int j = lane; j < Lk; j += 64) {
-      const float pr = Pin[(size_t)i * Lk + j];
+    float prr[8];   // this lane's probabilities of the row (Lk <= 512; beyond that they are read again from memory)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = lane + 64 * u;
+      prr[u] = 0.f;
+      if (j < Lk) {
+        const float pr = ds[j];
+        prr[u] = pr;
+        float dpd = 0.f;
+        for (int d = 0; d < hd; ++d) dpd = fmaf(dos[i * hs + d], vs[j * hs + d], dpd);
+        const float dp = dpd * keep_scale(p, seed, ((uint64_t)blockIdx.x * Lq + i) * Lk + j);
+        ds[j] = dp;
+        dot += dp * pr;
+      }
+    }
+    for (int j = lane + 512; j < Lk; j += 64) {
+      const float pr = ds[j];
       float dpd = 0.f;
-      for (int d = 0; d < hd; ++d) dpd = fmaf(dos[i * hd + d], vs[j * hd + d], dpd);
+      for (int d = 0; d < hd; ++d) dpd = fmaf(dos[i * hs + d], vs[j * hs + d], dpd);
       const float dp = dpd * keep_scale(p, seed, ((uint64_t)blockIdx.x * Lq + i) * Lk + j);
       ds[j] = dp;
       dot += dp * pr;
     }
     dot = wave_sum(dot);
-    for (int j = lane; j < Lk; j += 64) ds[j] = Pin[(size_t)i * Lk + j] * (ds[j] - dot) * scale;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = lane + 64 * u;
+      if (j < Lk) ds[j] = prr[u] * (ds[j] - dot) * scale;
+    }
+    for (int j = lane + 512; j < Lk; j += 64) ds[j] = Pin[(size_t)i * Lk + j] * (ds[j] - dot) * scale;
     __builtin_amdgcn_wave_barrier();
-    if (lane < hd) {   // dQ_i = sum_j dS[i][j] K_j
-      float o = 0.f;
-      for (int j = 0; j < Lk; ++j) o = fmaf(ds[j], ks[j * hd + lane], o);
-      st1<T>(dqb + ((int64_t)i * B + b) * lddq + h * hd + lane, o);
+    {   // dQ_i = sum_j dS[i][j] K_j
+      const float o = attn_row_times_matrix(ds, ks, Lk, hs, hd, lane);
+      if (lane < hd) st1<T>(dqb + ((int64_t)i * B + b) * lddq + h * hd + lane, o);
     }
   }
   __syncthreads();
   for (int e = tid; e < Lk * hd; e += 256) {   // dK_j = sum_i dS[i][j] Q_i
     const int j = e / hd, d = e - j * hd;
     float o = 0.f;
-    for (int i = 0; i < Lq; ++i) o = fmaf(DS[(size_t)i * Lk + j], qs[i * hd + d], o);
+    for (int i = 0; i < Lq; ++i) o = fmaf(DS[(size_t)i * Lk + j], qs[i * hs + d], o);
     st1<T>(dkb + ((int64_t)j * B + b) * lddk + h * hd + d, o);
   }
   __syncthreads();
@@ -266,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qb,
   for (int e = tid; e < Lk * hd; e += 256) {   // dV_j = sum_i Pd[i][j] dO_i
     const int j = e / hd, d = e - j * hd;
     float o = 0.f;
-    for (int i = 0; i < Lq; ++i) o = fmaf(DS[(size_t)i * Lk + j], dos[i * hd + d], o);
+    for (int i = 0; i < Lq; ++i) o = fmaf(DS[(size_t)i * Lk + j], dos[i * hs + d], o);
     st1<T>(dvb + ((int64_t)j * B + b) * lddv + h * hd + d, o);
   }
 }
@@ -419,17 +471,19 @@ extern "C" int c3d_cap_attn_fwd(const void* q, const void* k, const void* v, int
                                 float* P, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale, int32_t causal,
                                 float p, uint64_t seed, int32_t dtype, void* stream) {
   if (!q || !k || !v || !o || !P || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || hd <= 0 || hd > 64 || p < 0.f || p >= 1.f) return C3D_E_BADARG;
-  const size_t lds = ((size_t)2 * Lk * hd + (size_t)Lq * hd + (size_t)4 * Lk) * sizeof(float);
+  const int hs = hd | 1;
+  const size_t lds = ((size_t)2 * Lk * hs + (size_t)Lq * hs + (size_t)4 * Lk) * sizeof(float);
+  const int qsplit = Lq >= 16 ? 4 : 1;   // query rows of a (sample, head) over 4 workgroups
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  CAP_DISPATCH(dtype, (attn_fwd_kernel<float><<<B * H, 256, lds, s>>>((const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, (float*)o, ldo, P, B, H, Lq, Lk, hd, scale, causal, p, seed)),
-               (attn_fwd_kernel<bf16_t><<<B * H, 256, lds, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, (bf16_t*)o, ldo, P, B, H, Lq, Lk, hd, scale, causal, p, seed)));
+  CAP_DISPATCH(dtype, (attn_fwd_kernel<float><<<dim3(B * H, qsplit), 256, lds, s>>>((const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, (float*)o, ldo, P, B, H, Lq, Lk, hd, scale, causal, p, seed)),
+               (attn_fwd_kernel<bf16_t><<<dim3(B * H, qsplit), 256, lds, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, (bf16_t*)o, ldo, P, B, H, Lq, Lk, hd, scale, causal, p, seed)));
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -439,13 +493,14 @@ extern "C" int c3d_cap_attn_bwd(const void* q, const void* k, const void* v, int
                                 int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale, float p, uint64_t seed,
                                 int32_t dtype, void* stream) {
   if (!q || !k || !v || !dout || !P || !dq || !dk || !dv || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || hd <= 0 || hd > 64) return C3D_E_BADARG;
-  const size_t lds = ((size_t)2 * Lk * hd + (size_t)2 * Lq * hd + (size_t)Lq * Lk) * sizeof(float);
+  const int hs = hd | 1;
+  const size_t lds = ((size_t)2 * Lk * hs + (size_t)2 * Lq * hs + (size_t)Lq * Lk) * sizeof(float);
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   CAP_DISPATCH(dtype, (attn_bwd_kernel<float><<<B * H, 256, lds, s>>>((const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, (const float*)dout, ldo, P, (float*)dq, (float*)dk, (float*)dv, lddq, lddk, lddv, B, H, Lq, Lk, hd, scale, p, seed)),
