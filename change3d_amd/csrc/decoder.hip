@@ -246,15 +246,17 @@ __global__ __launch_bounds__(HD_TH * HD_TW) void head_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ prob, const T* __restrict__ x,
     const float* __restrict__ w, T* __restrict__ dx, float* __restrict__ dw, int B, int H, int W, int NC,
     int has_sigmoid, int tiles_per_wg) {
-  __shared__ float wl[9 * HD_C * HD_MAXNC];
+  __shared__ __attribute__((aligned(16))) float wl[9 * HD_C * HD_MAXNC];
   __shared__ float dl[HD_MAXNC][HD_TH + 2][HD_TW + 2];
   __shared__ float xt[HD_TH + 2][HD_TW + 2][HD_C + 1];
   const int tid = threadIdx.x;
   constexpr int NTHR = HD_TH * HD_TW;
+  // [n][tap][c]: the data-gradient loop below reads the 24 channel weights of a (class, tap) as six 16-byte vectors
+  // (the [tap][c][n] layout of the forward kernel made them 24 scalar LDS reads per tap and pixel)
   for (int i = tid; i < 9 * HD_C * HD_MAXNC; i += NTHR) {
-    const int n = i % HD_MAXNC;
-    int q = i / HD_MAXNC;
-    const int c = q % HD_C, tap = q / HD_C;
+    const int c = i % HD_C;
+    int q = i / HD_C;
+    const int tap = q % 9, n = q / 9;
     wl[i] = (n < NC) ? w[((size_t)n * HD_C + c) * 9 + tap] : 0.f;
   }
   const int tiles_x = (W + HD_TW - 1) / HD_TW, tiles_y = (H + HD_TH - 1) / HD_TH;
@@ -320,7 +322,11 @@ __global__ __launch_bounds__(HD_TH * HD_TW) void head_bwd_kernel(
           for (int kx = 0; kx < 3; ++kx) {
             const float d = dl[n][py + 2 - ky][px + 2 - kx];  // output pixel (y-ky+1, x-kx+1)
 #pragma unroll
-            for (int c = 0; c < HD_C; ++c) acc[c] = fmaf(d, wl[((ky * 3 + kx) * HD_C + c) * HD_MAXNC + n], acc[c]);
+            for (int c4 = 0; c4 < HD_C / 4; ++c4) {
+              const float4 wv = *reinterpret_cast<const float4*>(wl + (n * 9 + ky * 3 + kx) * HD_C + c4 * 4);
+              acc[c4 * 4 + 0] = fmaf(d, wv.x, acc[c4 * 4 + 0]); acc[c4 * 4 + 1] = fmaf(d, wv.y, acc[c4 * 4 + 1]);
+              acc[c4 * 4 + 2] = fmaf(d, wv.z, acc[c4 * 4 + 2]); acc[c4 * 4 + 3] = fmaf(d, wv.w, acc[c4 * 4 + 3]);
+            }
           }
         }
       }
