@@ -492,8 +492,24 @@ def caption_accuracy(scores, targets, k):
 
 
 def eval_caption_score(references, hypotheses):
-    """reference model/utils.py:509-536: BLEU / METEOR / ROUGE-L / CIDEr through pycocoevalcap (java METEOR scorer).  Host-side
-    string scoring, outside the hot path (out of scope); the name exists so that
-    `from model.utils import ... eval_caption_score` (reference scripts/train_CC.py:22-23) resolves through the drop-in."""
-    raise NotImplementedError("caption text metrics (pycocoevalcap: BLEU/METEOR/ROUGE/CIDEr) are not part of the MI355X hot path; "
-                              "score the decoded captions with the reference's own eval_caption_score")
+    """reference model/utils.py:509-536: BLEU-1..4 / METEOR / ROUGE-L / CIDEr of decoded captions through pycocoevalcap (its METEOR
+    scorer drives a java process).  Host-side string scoring, outside the MI355X hot path (out of scope):
+    where pycocoevalcap is installed this delegates to it with the reference's argument handling and return value (so a ported
+    `scripts/train_CC.py` validation pass completes); where it is not, it raises -- no silent substitute score."""
+    try:
+        from pycocoevalcap.bleu.bleu import Bleu
+        from pycocoevalcap.cider.cider import Cider
+        from pycocoevalcap.meteor.meteor import Meteor
+        from pycocoevalcap.rouge.rouge import Rouge
+    except ImportError as e:
+        raise NotImplementedError("caption text metrics need pycocoevalcap (BLEU / METEOR / ROUGE-L / CIDEr; host-side string scoring, "
+                                  "not part of the MI355X hot path) and it is not importable here: " + str(e)) from e
+    scorers = [(Bleu(4), ["Bleu_1", "Bleu_2", "Bleu_3", "Bleu_4"]), (Meteor(), "METEOR"), (Rouge(), "ROUGE_L"), (Cider(), "CIDEr")]
+    hypo = [[" ".join(str(t) for t in h)] for h in hypotheses]
+    ref = [[" ".join(str(t) for t in r) for r in rs] for rs in references]
+    out = {}
+    for scorer, name in scorers:
+        value, _ = scorer.compute_score(ref, hypo)
+        print("{} {}".format(name, value))
+        out.update(zip(name, value) if isinstance(name, list) else [(name, value)])
+    return out

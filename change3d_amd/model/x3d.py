@@ -229,11 +229,12 @@ class _StageFn(torch.autograd.Function):
         # needs_input_grad reports requires_grad of the inputs even under torch.no_grad(); the caller's grad mode
         # (grad mode is always off inside Function.forward) is passed in explicitly
         keep = grad_mode and any(ctx.needs_input_grad)
+        ctx.eval_graph = False
         if keep and not stage.training:
-            # eval-mode BatchNorm under autograd (frozen-BN fine-tuning): its backward is dx = gamma*rstd*g, not the
-            # batch-statistics form the backward kernels implement -- refuse instead of returning wrong gradients
-            raise NotImplementedError("gradients through an eval()-mode residual stage are not implemented (the backward "
-                                      "kernels implement train-mode BatchNorm); call .train() or run under torch.no_grad()")
+            # eval()-mode stage called with grad mode on (`model.eval(); model(x)` without torch.no_grad(), as the reference
+            # allows): the forward runs -- on the inference path, nothing saved -- and only backward() through it refuses:
+            # eval-mode BatchNorm's backward is dx = gamma*rstd*g, not the batch-statistics form the backward kernels implement
+            keep, ctx.eval_graph = False, True
         bn0 = stage.res_blocks[0].branch2.norm_a
         bind.desc.flags = int(stage.driver_flags)
         bind.refresh(B, T, H, W, ops.dt_code(act), stage.training, float(bn0.momentum), float(bn0.eps), with_grads=False)
@@ -258,10 +259,15 @@ class _StageFn(torch.autograd.Function):
         ops.stage_fwd(bind, xin, ws, y)
         if keep:
             ctx.stage, ctx.saved_ws, ctx.xin, ctx.y, ctx.x_dtype, ctx.dims = stage, ws, xin, y, x.dtype, (B, T, H, W)
+        else:
+            ctx.saved_ws = None
         return to_logical(y)
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.eval_graph:
+            raise NotImplementedError("gradients through an eval()-mode residual stage are not implemented (the backward "
+                                      "kernels implement train-mode BatchNorm); call .train() before the forward pass")
         stage, ws, xin, y = ctx.stage, ctx.saved_ws, ctx.xin, ctx.y
         if ws is None:
             raise RuntimeError("Trying to backward through a residual stage a second time: its saved activations were "
@@ -301,7 +307,7 @@ class X3DResStage(nn.Module):
         self._binding = None
         # eval / no-grad forward with BatchNorm folded into the conv weights.  The folded copy is rebuilt lazily
         # after every train()/eval() switch, load_state_dict(), .to(), and whenever the library's own in-place
-        # writers ran since it was made (FusedAdam / broadcast_module_state / ParamArena bump ops.weights_version());
+        # writers ran since it was made (FusedAdam.launch and broadcast_module_state bump ops.weights_version());
         # code that edits parameters or running statistics by hand while the module stays in eval mode must call
         # invalidate_folded_bn().
         self.fold_bn_eval = os.environ.get("C3D_FOLD_BN", "1") != "0"

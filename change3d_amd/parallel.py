@@ -74,6 +74,23 @@ class GradSync:
         self._tail_launched = False
 
 
+_HOST_GROUP = None
+
+
+def host_barrier(timeout_hours=12.0):
+    """Every rank waits here for the slowest one, on the HOST (a gloo group with a long timeout, created on first use).
+    Used where one rank does long rank-local work between exchanges -- rank 0 validating and writing a checkpoint after an
+    epoch: the other ranks must neither sit in an RCCL collective for longer than its watchdog allows (10 min by default)
+    nor tear the process group down while rank 0 still works."""
+    global _HOST_GROUP
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    if _HOST_GROUP is None:
+        import datetime
+        _HOST_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=timeout_hours))
+    dist.barrier(group=_HOST_GROUP)
+
+
 def broadcast_module_state(module, src=0, group=None):
     """Rank-`src` parameters and buffers to everyone (once, at start)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

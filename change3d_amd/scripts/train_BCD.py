@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 from change3d_amd.data.transforms import DeviceBatchTransform, draw_augmentation_flags  # noqa: E402
 from change3d_amd.model.trainer import Trainer  # noqa: E402
 from change3d_amd.model.utils import BCEDiceLoss, FusedAdam, adjust_learning_rate  # noqa: E402
-from change3d_amd.parallel import broadcast_module_state, setup_data_parallel  # noqa: E402
+from change3d_amd.parallel import broadcast_module_state, host_barrier, setup_data_parallel  # noqa: E402
 from change3d_amd.utils.metric_tool import ConfuseMatrixMeter  # noqa: E402
 
 
@@ -145,8 +145,11 @@ def trainValidate(args):
         if epoch == 0:
             continue
         # rank 0 validates (BatchNorm running statistics are per rank by design; the checkpoint holds rank 0's, so
-        # its score is the one that describes the saved model); the other ranks go on and meet it at the next exchange
+        # its score is the one that describes the saved model); the other ranks wait for it on the host (gloo barrier
+        # with a long timeout): neither an RCCL collective left pending across a long validation pass nor a process
+        # group torn down while rank 0 still writes its checkpoint
         if args.rank != 0:
+            host_barrier()
             continue
         loss_val, score_val = val(args, test_loader, model, epoch)
         logger.write("\n%d\t\t%.4f\t\t%.4f\t\t%.4f\t\t%.4f\t\t%.4f" % (
@@ -160,6 +163,7 @@ def trainValidate(args):
             torch.save(model.state_dict(), model_file_name)
         print(f"\nEpoch No. {epoch}:\tTrain Loss = {loss_train:.4f}\tVal Loss = {loss_val:.4f}\t"
               f"F1(tr) = {score_tr['F1']:.4f}\tF1(val) = {score_val['F1']:.4f}")
+        host_barrier()
     if logger:
         logger.close()
     if world > 1:

@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 from change3d_amd.model.trainer import Trainer  # noqa: E402
 from change3d_amd.model.utils import (AverageMeter, BCEDiceLoss, ChangeSimilarity, CrossEntropyLoss2d, FusedAdam,  # noqa: E402
                                       SCDHistogram, adjust_learning_rate)
-from change3d_amd.parallel import broadcast_module_state, setup_data_parallel  # noqa: E402
+from change3d_amd.parallel import broadcast_module_state, host_barrier, setup_data_parallel  # noqa: E402
 
 
 class SyntheticSCDLoader:
@@ -158,6 +158,7 @@ def trainValidate(args):
             if args.val_pairs > 0:   # rank 0 validates on its own BatchNorm statistics (the ones a checkpoint would hold)
                 vl = SyntheticSCDLoader(args.val_pairs, min(args.batch_size, args.val_pairs), args.in_height, args.num_class, seed=5)
                 val(args, vl, model)
+        host_barrier()   # the other ranks wait (on the host) for rank 0's validation pass before the next exchange / teardown
     if world > 1:
         dist.destroy_process_group()
 
