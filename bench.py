@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--windows", type=int, default=1,
                     help="split the K timed steps into this many equal windows (a device sync between them) and report each "
                          "window's ms/step as config.ms_per_step_windows (min / median of a short run); `value` stays K steps / total time")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="c3d_set_option before the run (A/B of the library's run-time options, e.g. FUSE_WGRAD=1)")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel HIP-event table (JSON) here")
     return ap.parse_args()
 
@@ -233,6 +235,9 @@ def main():
     from change3d_amd.parallel import broadcast_module_state, setup_data_parallel
     from change3d_amd.utils.metric_tool import ConfuseMatrixMeter
 
+    for ov in a.option:
+        name, val = ov.split("=")
+        ops.set_option(getattr(ops, "OPT_" + name.upper()), int(val))
     act = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     scd, cc = a.task == "scd", a.task == "cc"
     if a.batch <= 0:

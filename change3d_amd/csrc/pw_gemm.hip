@@ -22,6 +22,7 @@ extern "C" int c3d_debug_pw_clock(unsigned long long* out, int reset) {   // out
 #endif
 
 int c3d_detail_pw_gemm_wide(const c3d_pw_args* args, void* stream);   // pw_wide.hip
+__attribute__((visibility("hidden"))) int c3d_detail_pw_gemm_wg(const c3d_pw_args* args, void* stream);   // pw_gemm_wg.hip
 
 // ------------------------------------------------------------------------------------------ weight images
 namespace {
@@ -99,6 +100,8 @@ extern "C" int c3d_pw_pack_weights(const c3d_pw_pack_desc* descs, int32_t n, int
   return 0;
 }
 
+extern "C" int64_t c3d_pw_gemm_wg_ws_floats(int32_t K, int32_t N) { return (int64_t)PW_WG_MAX_PARTS * K * N; }
+
 extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   if (!args || !args->x || !args->y || !args->w) return C3D_E_BADARG;
   const c3d_pw_args& a = *args;
@@ -119,13 +122,19 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   if (a.pro_mode == C3D_PRO_BN_SE_SWISH && a.pro_gate && !wide && (a.rows_per_sample & 15)) return C3D_E_BADARG;
   if (a.M >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
   if (a.w_img && ((uintptr_t)a.w_img & 15)) return C3D_E_BADARG;
+  if (a.wg_mode != C3D_WG_NONE) {
+    if (a.wg_mode != C3D_WG_SWISH && a.wg_mode != C3D_WG_ROWS) return C3D_E_BADARG;
+    if (!a.wg_dw || !a.wg_ws || (a.wg_mode == C3D_WG_ROWS && !a.wg_x3)) return C3D_E_BADARG;
+    if (wide || a.dtype != C3D_DT_BF16) return C3D_E_UNSUPPORTED;
+  }
   if (wide) return c3d_detail_pw_gemm_wide(args, stream);
+  if (a.wg_mode != C3D_WG_NONE) return c3d_detail_pw_gemm_wg(args, stream);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = C3D_E_BADARG;
   if (a.dtype == C3D_DT_F32) rc = c3d_detail_pw_gemm_f32(args, stream);
   else if (a.dtype == C3D_DT_BF16) rc = dispatch_mode<bf16_t>(a, s);
   // shapes the wave-private-tile kernel cannot hold in LDS (f32 storage with K*N near 224 x 224): block-tiled kernel
-  if (rc == C3D_E_UNSUPPORTED && !a.fin.ticket && !a.fin.sums) rc = c3d_detail_pw_gemm_wide(args, stream);
+  if (rc == C3D_E_UNSUPPORTED && !a.fin.ticket && !a.fin.sums && a.wg_mode == C3D_WG_NONE) rc = c3d_detail_pw_gemm_wide(args, stream);
   return rc;
 }
 

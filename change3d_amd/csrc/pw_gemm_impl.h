@@ -41,6 +41,8 @@ __device__ unsigned long long c3d_pw_clk[CLK_WAVES][16];   // per-wave slots (at
 #define CLK_FLUSH
 #endif
 
+int c3d_detail_pw_wgrad_reduce(const float* ws, float* dw, int N, int K, int parts, int sn, int sk, hipStream_t stream);   // pw_wgrad.hip
+
 namespace {
 
 // ---- hand-scheduled weight-fragment pipeline (bf16) ------------------------------------------------------
@@ -309,13 +311,34 @@ struct PwLaunch {
   int xs_rows;         // rows of the wave's X region (= tpi*16)
   int w_off, p_off, wave_off, wave_bytes, os_off, gs_off;  // byte offsets in dynamic LDS
   int flush_shuffle_max;  // row-lanes per channel vector up to which the final sums are shuffled instead of dumped
+  int dw_off, ldw;        // fused weight gradient (WG != 0): byte offset and row stride (floats) of the workgroup's dW accumulators
 };
+
+// ---- weight gradient fused into the data-gradient launch (c3d_pw_args.wg_mode) -------------------------------------
+// dW[k][n] = sum_rows P[row][k] * Q[row][n]: both operands of a 16-row tile sit in this wave's LDS regions in
+// [row][channel] layout (P = the prologue'd rows staged for the GEMM, Q = written over the result tile by the epilogue
+// passes); gfx950's transposing LDS read (ds_read_b64_tr_b16: lane l, element j <- img[4*(l/16) + j][c0 + l%16] when
+// lane l addresses the 8-byte chunk (row 4*(l/16) + (l%16)/4, columns c0 + 4*(l%4) ..)) delivers them as the A / B
+// fragments of v_mfma_f32_16x16x16_bf16 with the ROWS as the contraction index.  The products are added to a
+// workgroup-shared F64 accumulator image in LDS (ds_add_f64): the data-gradient variants sit at 230-256 VGPRs, per-wave
+// register accumulators (32 / 84 per lane on res2 / res3) do not fit beside them, 12 transient registers do.
+// (tools/micro/lds_atomic_rate.hip on MI355X: ds_add_f32 takes ~190 clocks per wave-instruction -- 48x ds_add_u32, the first
+// version of this kernel ran 10x slower than the pair it replaces -- ds_add_f64 takes ~8, ds_add_u32 ~4.  With f64 sums the
+// order in which the waves' contributions land no longer shows in the f32 result.)
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr_t;
+constexpr int WG_NTP_MAX = 7;   // K tiles (P channels) held as fragments: Kp <= 112 (C3D_WG_ROWS: conv_a, K = inner channels)
+constexpr int WG_NTP_MAX_SWISH = 3;   // C3D_WG_SWISH: conv_c, K = the block's output channels (<= 48 on res2 / res3)
+
 
 // DENSE = rows are consecutive in memory (row_mode C3D_ROWS_DENSE): a 16-row tile is one contiguous span, so
 // every lane's load address is (wave-uniform tile base) + lane*16 B + constant -- no per-slot index arithmetic,
 // no 64-bit vector multiplies (the generic path's row_offset() code cost ~50 VGPRs and spilled).
-template <typename T, int NT, int PRO, int EPI, int WAVES, bool DENSE>
+template <typename T, int NT, int PRO, int EPI, int WAVES, bool DENSE, int WG = 0>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES == 8 ? 2 : 1, 2))) void pw_gemm_kernel(const c3d_pw_args a, const PwLaunch L) {
+  static_assert(WG == 0 || (sizeof(T) == 2 && PRO == C3D_PRO_AFFINE2 && DENSE &&
+                            ((WG == C3D_WG_SWISH && EPI == C3D_EPI_SWISH_SE_BWD) || (WG == C3D_WG_ROWS && EPI == C3D_EPI_ADD))),
+                "fused weight gradient: bf16 data-gradient variants only");
   typedef Mma<T> MM;
   typedef typename MM::lds_t lds_t;
   typedef Raw<T> RW;
@@ -339,6 +362,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   lds_t* Xs = reinterpret_cast<lds_t*>(wreg);
   os_t* Os = reinterpret_cast<os_t*>(wreg + L.os_off);
   float* Gs = reinterpret_cast<float*>(wreg + L.gs_off);  // gate of the current sample [Kp]
+  double* dWs = reinterpret_cast<double*>(smem + L.dw_off);  // WG: f64 dW accumulators [ceil(Kp/16)*16][L.ldw], shared by the waves
+  const int wg_ntp = (Kp + 15) >> 4, wg_ntq = (Np + 15) >> 4;
 
   // The first tile's rows (and the per-lane epilogue parameters) are requested BEFORE the weights are
   // staged: a launch is a chain of dependent global round trips (parameters, weights, first tile,
@@ -506,6 +531,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         else stage_weights<T, 1, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
       }
     }
+    if constexpr (WG != 0) {
+      for (int i = tid; i < wg_ntp * 16 * L.ldw; i += WAVES * 64) dWs[i] = 0.0;
+    }
     CLK(12)
     __syncthreads();
     CLK(13)
@@ -525,12 +553,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   const int npass = (16 + RPo - 1) / RPo;
   const int v_oc = act_o ? v_o : 0;             // clamped: inactive lanes load a valid address (result unused)
   typename RW::type e1n = RW::zero();
+  typename RW::type x3n = RW::zero();   // WG == C3D_WG_ROWS: this lane's row vector of wg_x3 (Y's row layout), one pass ahead like e1n
+  const T* X3 = reinterpret_cast<const T*>(a.wg_x3);
   // this lane's E1 vector for pass P of the tile starting at ROW0: wave-uniform row base (scalar registers) + a
   // loop-invariant 32-bit lane offset; lanes without a row in this pass read the pass's first row (result unused)
   const int e1_lane = rr_o * Np + v_oc * 8;
 #define PW_E1_PTR(ROW0, P)                                                                                          \
   (E1 + (int64_t)((ROW0) + (P) * RPo < M32 ? (ROW0) + (P) * RPo : M32 - 1) * Np +                                   \
    (((P) * RPo + rr_o < 16 && (ROW0) + (P) * RPo + rr_o < M32) ? e1_lane : v_oc * 8))
+#define PW_X3_PTR(ROW0, P) (X3 + (PW_E1_PTR(ROW0, P) - E1))
 
   // Weight fragments: narrow outputs (NT <= 4) with K <= 64 keep ALL of them in registers (the per-tile MFMA phase
   // was LDS-read latency: X fragment, then each weight fragment, serially); wide outputs run two sub-tiles per
@@ -611,12 +642,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     }
     CLK(2)
     if (e1_rows) e1n = RW::load(PW_E1_PTR(it0 << 4, 0));
+    if constexpr (WG == C3D_WG_ROWS) x3n = RW::load(PW_X3_PTR(it0 << 4, 0));
     // ---------------- prefetch the next iteration's rows -------------------------------------
     if (it0 + L.tpi < t1) { PW_ISSUE(it0 + L.tpi) }
     CLK(3)
 
     // stage one 16-row result tile to Os, run the fused epilogue over it, store
-    auto finish_tile = [&](const f32x4_t (&acc)[NT], const int row0, const bool has_next) {
+    auto finish_tile = [&](const f32x4_t (&acc)[NT], const int row0, const bool has_next, const lds_t* xt) {
       // ---------------- stage result tile: Os[row = lane&15][channel] -------------------------
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -662,6 +694,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
           if (p + 1 < npass) e1n = RW::load(PW_E1_PTR(row0, p + 1));
           else if (has_next) e1n = RW::load(PW_E1_PTR(row0 + 16, 0));   // first pass of the next tile of this iteration
         }
+        typename RW::type x3c = x3n;
+        if constexpr (WG == C3D_WG_ROWS) {
+          if (p + 1 < npass) x3n = RW::load(PW_X3_PTR(row0, p + 1));
+          else if (has_next) x3n = RW::load(PW_X3_PTR(row0 + 16, 0));
+        }
         if constexpr (sizeof(T) == 2 && (EPI == C3D_EPI_STORE || EPI == C3D_EPI_STATS)) {
           // bf16 plain-store / statistics epilogue: the staged tile already holds the stored bits -- copy the 16 bytes
           // as they are (the f32 round trip cost 8 unpack + 8 re-round + 4 pack VALU per vector for an identity)
@@ -688,7 +725,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
               s0[j] += r; s1[j] += r * r;
             }
           } else if (EPI == C3D_EPI_SWISH_SE_BWD) {
-            float bv[8];
+            float bv[8], qs[8];
             RW::cvt(e1c, bv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -701,7 +738,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
               s1[j] += t;                              // sum t1
               s2[j] += t * ((bv[j] - eM[j]) * eR[j]);  // sum t1*bhat (centred)
               f[j] = t;
+              qs[j] = q * sg;                          // the forward operand of this convolution (WG: Q of the weight gradient)
             }
+            if constexpr (WG == C3D_WG_SWISH) Vec8<os_t>::store(Os + row * NL + v_o * 8, qs);   // over the staged result vector this lane just read
           } else if (EPI == C3D_EPI_ADD) {
             if (a.res_mode == 0) {
               float rv[8];
@@ -724,6 +763,39 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             }
           }
           Vec8<T>::store(Y + yoff, f);
+          if constexpr (WG == C3D_WG_ROWS) *reinterpret_cast<typename RW::type*>(Os + row * NL + v_o * 8) = x3c;
+        }
+      }
+      if constexpr (WG != 0) {
+        // ---------------- fused weight gradient of this 16-row tile ---------------------------------
+        // Os now holds Q (rows past M and the padding columns kept the zero accumulators of zero operand rows / zero weight
+        // rows); a wave's LDS writes are ordered before its later LDS reads: no barrier
+        const int g4 = lane >> 4, li = lane & 15;
+        const lds_s16x4_ptr_t pp = (lds_s16x4_ptr_t)(xt + (4 * g4 + (li >> 2)) * KL + 4 * (li & 3));
+        const lds_s16x4_ptr_t qp = (lds_s16x4_ptr_t)(Os + (4 * g4 + (li >> 2)) * NL + 4 * (li & 3));
+        constexpr int NTPM = WG == C3D_WG_SWISH ? WG_NTP_MAX_SWISH : WG_NTP_MAX;
+        s16x4_t pf[NTPM];
+#pragma unroll
+        for (int i = 0; i < NTPM; ++i)
+          if (i < wg_ntp) pf[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pp + i * 4);   // 16 channels = 4 chunks of 8 bytes on
+        // one Q fragment at a time (a real loop: fully unrolled, the compiler keeps all NT x 7 zero-initialised MFMA results
+        // in flight -- 200 registers, 800 B of scratch)
+        const int ldw = L.ldw;
+        double* dwl = dWs + (4 * g4) * ldw + li;
+#pragma unroll 1
+        for (int j = 0; j < wg_ntq; ++j) {
+          const s16x4_t qf = __builtin_amdgcn_ds_read_tr16_b64_v4i16(qp + j * 4);
+#pragma unroll
+          for (int i = 0; i < NTPM; ++i) {
+            if (i < wg_ntp) {
+              const f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf[i], qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+              double* dst = dwl + (i * 16) * ldw + j * 16;
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                __hip_atomic_fetch_add(dst + r * ldw, (double)d[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __builtin_amdgcn_sched_barrier(0);   // one product in flight: 7 hoisted MFMAs + their f64 conversions spilled 160 B
+            }
+          }
         }
       }
     };
@@ -789,17 +861,28 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         }
       }
       CLK(4)
-      finish_tile(acc, row0, MT == 2 ? two : (sub + 1 < L.tpi && tile + 1 < t1));
-      if (MT == 2 && two) finish_tile(acc2, row0 + 16, sub + 2 < L.tpi && tile + 2 < t1);
+      finish_tile(acc, row0, MT == 2 ? two : (sub + 1 < L.tpi && tile + 1 < t1), Xt);
+      if (MT == 2 && two) finish_tile(acc2, row0 + 16, sub + 2 < L.tpi && tile + 2 < t1, Xt + 16 * KL);
       CLK(6)
     }
   }
+#undef PW_X3_PTR
 #undef PW_E1_PTR
 #undef PW_ISSUE
 #undef PW_ISSUE_DENSE
 #undef PW_ISSUE_GENERIC
 #undef PW_LIM
   CLK(7)
+  if constexpr (WG != 0) {
+    // this workgroup's dW partial -> wg_ws[blockIdx.x][K][N] (the reducer launched behind this kernel adds the partials in
+    // fixed order into wg_dw)
+    __syncthreads();
+    float* wsb = a.wg_ws + (size_t)blockIdx.x * a.K * a.N;
+    for (int i = tid; i < a.K * a.N; i += WAVES * 64) {
+      const int k = i / a.N, n = i - k * a.N;
+      wsb[i] = (float)dWs[k * L.ldw + n];
+    }
+  }
 
   // ---- final flush of per-lane partial sums -------------------------------------------------
   // lanes -> LDS ([value][lane] per wave, the X regions are dead now) -> one thread per output sums the
@@ -894,7 +977,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
 
 inline size_t al16(size_t v) { return (v + 15) / 16 * 16; }
 
-template <typename T, int NT, int PRO, int EPI, int WAVES>
+template <typename T, int NT, int PRO, int EPI, int WAVES, int WG = 0>
 bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   typedef Mma<T> MM;
   typedef typename OutStage<T, EPI>::type os_t;
@@ -907,14 +990,19 @@ bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   const size_t p_bytes = al16((size_t)3 * a.Kp * sizeof(float));
   const size_t os_bytes = al16((size_t)16 * NL * sizeof(os_t));
   const size_t gs_bytes = al16((size_t)a.Kp * sizeof(float));
+  // fused weight gradient: workgroup-shared f64 accumulators [ceil(Kp/16)*16][ceil(Np/16)*16 + 4] (row stride = 4 mod 8
+  // doubles: the four 16-lane groups of a ds_add_f64 -- rows 4g + r -- fall on the two halves of the 64 banks alternately)
+  const int ldw = ((a.Np + 15) / 16) * 16 + 4;
+  const size_t dw_bytes = WG != 0 ? al16((size_t)((a.Kp + 15) / 16) * 16 * ldw * sizeof(double)) : 0;
   for (int tpi = PW_SLOTS / Q; tpi >= 1; --tpi) {
     const size_t xs_bytes = al16((size_t)tpi * 16 * KL * sizeof(typename MM::lds_t));
     const size_t wave_bytes = xs_bytes + os_bytes + gs_bytes;
-    const size_t total = w_bytes + p_bytes + WAVES * wave_bytes;
+    const size_t total = w_bytes + p_bytes + WAVES * wave_bytes + dw_bytes;
     if (total <= 160 * 1024) {
       L.tpi = tpi; L.xs_rows = tpi * 16;
       L.w_off = 0; L.p_off = (int)w_bytes; L.wave_off = (int)(w_bytes + p_bytes);
       L.wave_bytes = (int)wave_bytes; L.os_off = (int)xs_bytes; L.gs_off = (int)(xs_bytes + os_bytes);
+      L.dw_off = (int)(w_bytes + p_bytes + WAVES * wave_bytes); L.ldw = ldw;
       lds = total;
       return true;
     }
@@ -922,14 +1010,16 @@ bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   return false;
 }
 
-template <typename T, int NT, int PRO, int EPI, int WAVES, bool DENSE>
+constexpr int PW_WG_MAX_PARTS = 512;   // workgroups (= dW partials) of a launch with the fused weight gradient
+
+template <typename T, int NT, int PRO, int EPI, int WAVES, bool DENSE, int WG = 0>
 int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
   PwLaunch L;
   size_t lds = 0;
-  if (!plan_pw<T, NT, PRO, EPI, WAVES>(a, L, lds)) return C3D_E_UNSUPPORTED;
+  if (!plan_pw<T, NT, PRO, EPI, WAVES, WG>(a, L, lds)) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE, WG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -938,7 +1028,8 @@ int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
   int occ = (int)((160 * 1024) / lds);
   if (occ > 32 / WAVES) occ = 32 / WAVES;
   if (occ < 1) occ = 1;
-  const int64_t max_blocks = (int64_t)device_cus() * occ;
+  int64_t max_blocks = (int64_t)device_cus() * occ;
+  if (WG != 0 && max_blocks > PW_WG_MAX_PARTS) max_blocks = PW_WG_MAX_PARTS;
   int64_t blocks = (tiles + (int64_t)WAVES * L.tpi - 1) / ((int64_t)WAVES * L.tpi);  // >= one iteration per wave
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks < 1) blocks = 1;
@@ -953,8 +1044,10 @@ int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
   L.tiles_per_wave = (int)tpw;
   static const int fsm = c3d_env("C3D_PW_FLUSH_SHFL") ? atoi(c3d_env("C3D_PW_FLUSH_SHFL")) : 0;   // tuning knob (measured: no gain)
   L.flush_shuffle_max = fsm;
-  pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE><<<dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream>>>(a, L);
+  pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE, WG><<<dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream>>>(a, L);
   C3D_CHECK_LAUNCH();
+  if (WG != 0)   // partials [blocks][K][N] -> dw[n*w_sn + k*w_sk] (+=), fixed order
+    return c3d_detail_pw_wgrad_reduce(a.wg_ws, a.wg_dw, a.K, a.N, (int)blocks, a.w_sk, a.w_sn, stream);
   return 0;
 }
 
@@ -993,6 +1086,7 @@ int dispatch_nt(const c3d_pw_args& a, hipStream_t stream) {
 template <typename T>
 int dispatch_mode(const c3d_pw_args& a, hipStream_t s) {
   const int pro = a.pro_mode, epi = a.epi_mode;
+  if (a.wg_mode != C3D_WG_NONE) return C3D_E_UNSUPPORTED;   // routed to pw_gemm_wg.hip by the entry point
   if (pro == C3D_PRO_NONE && epi == C3D_EPI_STORE) return dispatch_nt<T, C3D_PRO_NONE, C3D_EPI_STORE>(a, s);
   if (pro == C3D_PRO_NONE && epi == C3D_EPI_STATS) return dispatch_nt<T, C3D_PRO_NONE, C3D_EPI_STATS>(a, s);
   if (pro == C3D_PRO_BN_SE_SWISH && epi == C3D_EPI_STORE) return dispatch_nt<T, C3D_PRO_BN_SE_SWISH, C3D_EPI_STORE>(a, s);

@@ -1,0 +1,28 @@
+// Pointwise-convolution data gradient WITH the weight gradient fused in (c3d_pw_args.wg_mode): the bf16 8-wave dense-row
+// instantiations of pw_gemm_impl.h's kernel, in their own translation unit (they compile beside pw_gemm.hip).
+// Replaces the (c3d_pw_gemm, c3d_pw_wgrad) launch pair for conv_a / conv_c of the res2 / res3 blocks (reference
+// model/x3d.py:173-175,214-216: one convolution_backward produces both gradients).
+#include "pw_gemm_impl.h"
+
+namespace {
+
+template <int EPI, int WG>
+int dispatch_wg(const c3d_pw_args& a, hipStream_t s) {
+  const int nt = (a.Np + 15) / 16;
+  if (nt <= 2) return launch_pw_d<bf16_t, 2, C3D_PRO_AFFINE2, EPI, 8, true, WG>(a, s);
+  if (nt <= 4) return launch_pw_d<bf16_t, 4, C3D_PRO_AFFINE2, EPI, 8, true, WG>(a, s);
+  return launch_pw_d<bf16_t, 7, C3D_PRO_AFFINE2, EPI, 8, true, WG>(a, s);
+}
+
+}  // namespace
+
+__attribute__((visibility("hidden"))) int c3d_detail_pw_gemm_wg(const c3d_pw_args* args, void* stream) {
+  const c3d_pw_args& a = *args;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (a.dtype != C3D_DT_BF16 || a.pro_mode != C3D_PRO_AFFINE2 || a.row_mode != C3D_ROWS_DENSE || a.Kp > 16 * WG_NTP_MAX || a.Np > 112)
+    return C3D_E_UNSUPPORTED;
+  if (a.wg_mode == C3D_WG_SWISH && a.Kp > 16 * WG_NTP_MAX_SWISH) return C3D_E_UNSUPPORTED;
+  if (a.wg_mode == C3D_WG_SWISH && a.epi_mode == C3D_EPI_SWISH_SE_BWD) return dispatch_wg<C3D_EPI_SWISH_SE_BWD, C3D_WG_SWISH>(a, s);
+  if (a.wg_mode == C3D_WG_ROWS && a.epi_mode == C3D_EPI_ADD) return dispatch_wg<C3D_EPI_ADD, C3D_WG_ROWS>(a, s);
+  return C3D_E_UNSUPPORTED;
+}

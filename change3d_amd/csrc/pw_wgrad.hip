@@ -521,6 +521,15 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
 
 }  // namespace
 
+// the reducer alone: c3d_pw_gemm's fused weight gradient (pw_gemm_impl.h) writes per-workgroup partials [parts][N][K]
+__attribute__((visibility("hidden"))) int c3d_detail_pw_wgrad_reduce(const float* ws, float* dw, int N, int K, int parts, int sn,
+                                                                     int sk, hipStream_t stream) {
+  const int nk = N * K;
+  pw_wgrad_reduce_kernel<<<dim3((nk + 31) / 32, 1), dim3(256), 0, stream>>>(ws, dw, N, K, parts, sn, sk, 0);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int64_t c3d_pw_wgrad_ws_floats(int32_t N, int32_t K) { return (int64_t)WGRAD_MAX_PARTS * N * K; }
 
 int c3d_detail_pw_wgrad_wide(const c3d_pw_wgrad_args* args, void* stream);   // pw_wide.hip

@@ -82,7 +82,7 @@ struct Plan {
   std::vector<BlkFwd> f;
   std::vector<BlkBwd> b;
   size_t fwd_acc_off = 0, fwd_acc_bytes = 0, fwd_total = 0;
-  size_t bwd_acc_off = 0, bwd_acc_bytes = 0, bwd_total = 0, wgrad_ws = 0;
+  size_t bwd_acc_off = 0, bwd_acc_bytes = 0, bwd_total = 0, wgrad_ws = 0, wgrad_ws_fused = 0;
   size_t y_bytes = 0, dx_bytes = 0;
 };
 
@@ -90,6 +90,14 @@ struct Carver {
   size_t off = 0;
   size_t take(size_t bytes) { const size_t o = off; off += al(bytes); return o; }
 };
+
+// pointwise weight gradient inside the data-gradient launch (c3d_pw_args.wg_mode; csrc/pw_gemm_impl.h): bf16 layers whose
+// accumulator image fits in LDS beside the tiles -- the res2 / res3 shapes (K, N <= 112 padded)
+inline bool fuse_wgrad(const c3d_stage_desc* d, int Kp, int Np) {
+  return !(d->flags & C3D_STAGE_SEPARATE_WGRAD) && d->dtype == C3D_DT_BF16 && Kp <= 112 && Np <= 112 && c3d_knob("C3D_PW_WG", 1);
+}
+
+int g_fuse_wgrad = 3;      // c3d_set_option(C3D_OPT_FUSE_WGRAD, ...): bit 0 conv_a, bit 1 conv_c
 
 int make_plan(const c3d_stage_desc* d, Plan& P) {
   if (!d || d->n_blocks <= 0 || !d->blocks || d->B <= 0 || d->T <= 0 || d->H <= 0 || d->W <= 0) return C3D_E_BADARG;
@@ -163,9 +171,11 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
   //      by ring-1 blocks), per-block f32 coefficient vectors, one f64 accumulator region, the split-K scratch of
   //      the pointwise weight gradient
   size_t mx_g = 0, mx_t1 = 0, mx_t2 = 0, mx_dxs = 0, mx_dx = 0;
-  int64_t wsf = 0;
+  int64_t wsf = 0, wsf_fused = 0;
   for (int i = 0; i < n; ++i) {
     const BlkGeom& G = P.g[i];
+    if (fuse_wgrad(d, G.Cop, G.Cip)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Co, G.Ci));
+    if (fuse_wgrad(d, G.Cip, G.Cinp)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Ci, G.Cin));
     mx_g = std::max(mx_g, (size_t)G.Mo * G.Cop * e);
     mx_t1 = std::max(mx_t1, (size_t)G.Mo * G.Cip * e);
     mx_t2 = std::max(mx_t2, (size_t)G.M * G.Cip * e);
@@ -183,6 +193,7 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
     ring[r][3] = mx_dxs ? cb.take(mx_dxs) : SIZE_MAX; ring[r][4] = mx_dx ? cb.take(mx_dx) : SIZE_MAX;
   }
   P.wgrad_ws = cb.take((size_t)wsf * 4);
+  P.wgrad_ws_fused = wsf_fused ? cb.take((size_t)wsf_fused * 4) : SIZE_MAX;   // main stream: kernel, then its reducer
   for (int i = 0; i < n; ++i) {
     const BlkGeom& G = P.g[i];
     BlkBwd& Bk = P.b[i];
@@ -488,12 +499,12 @@ extern "C" int c3d_side_join(void* stream) { return side_join(reinterpret_cast<h
 namespace {
 
 int pw_launch(const c3d_pw_args& a, hipStream_t st) {
-  const double bytes = (double)a.M * ((double)a.Kp * (a.x2 ? 2 : 1) + (double)a.Np * (a.e1 ? 2 : 1) + (a.pro_out ? a.Kp : 0)) *
-                       (double)es(a.dtype);
+  const double bytes = (double)a.M * ((double)a.Kp * (a.x2 ? 2 : 1) + (double)a.Np * (a.e1 ? 2 : 1) + (a.pro_out ? a.Kp : 0) +
+                                     (a.wg_mode == C3D_WG_ROWS ? a.Np : 0)) * (double)es(a.dtype);
   char nm[64];
   if (prof_detail())
-    std::snprintf(nm, sizeof(nm), "c3d_pw_gemm[M=%lld K=%d N=%d pro=%d epi=%d rows=%d]", (long long)a.M, a.K, a.N, a.pro_mode,
-                  a.epi_mode, a.row_mode);
+    std::snprintf(nm, sizeof(nm), "c3d_pw_gemm[M=%lld K=%d N=%d pro=%d epi=%d rows=%d%s]", (long long)a.M, a.K, a.N, a.pro_mode,
+                  a.epi_mode, a.row_mode, a.wg_mode ? " +dW" : "");
   else
     std::snprintf(nm, sizeof(nm), "c3d_pw_gemm");
   return prof_call(nm, bytes, st, [&] { return c3d_pw_gemm(&a, st); });
@@ -664,6 +675,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   const double e = (double)es(dt);
   HIPRC(hipMemsetAsync(at(wb, P.bwd_acc_off), 0, P.bwd_acc_bytes, st));
   float* wgws = atT<float>(wb, P.wgrad_ws);
+  float* wgws_fused = atT<float>(wb, P.wgrad_ws_fused);
   const bool wimg = use_pw_img(d);   // transposed weight images written by this step's c3d_stage_fwd (training mode)
   auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
   const void* cur_dy = dy;
@@ -705,6 +717,8 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     if (!consb) RC(coef(dsums_c, (double)G.Mo, k.bn_c, mr_c, G.Co, G.Cop, coef_c));
     // ---- conv_c data gradient, Swish / SE backward in the epilogue; weight gradient on the side stream (it needs
     //      coef_c, not the data gradient: it is forked BEFORE the data-gradient launch)
+    const bool fuse_wc = (g_fuse_wgrad & 2) && fuse_wgrad(d, G.Cop, G.Cip) && G.Cop <= 48;
+    if (!fuse_wc)
     RC(side_run(st, [&](hipStream_t s2) {
       WgCall w(g, b, k.dw_c, wgws, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
       w.a.p2 = c; w.a.p_coef = coef_c; w.a.q_mode = C3D_PRO_BN_SE_SWISH; w.a.q_ss = ss_b; w.a.q_gate = gate;
@@ -714,6 +728,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     }));
     {
       PwCall p(g, k.w_c, t1, G.Mo, G.Co, G.Ci, 1, G.Ci, dt);
+      if (fuse_wc) { p.a.wg_mode = C3D_WG_SWISH; p.a.wg_dw = k.dw_c; p.a.wg_ws = wgws_fused; }
       p.a.x2 = c; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_c;
       if (consb) p.a.fin = fin_coef_consume(dsums_c, k.bn_c, (double)G.Mo, mr_c, true);
       p.a.epi_mode = C3D_EPI_SWISH_SE_BWD; p.a.e1 = b; p.a.epi_p = ss_b; p.a.epi_gate = gate; p.a.epi_q = mr_b;
@@ -777,6 +792,8 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     }
     // ---- conv_a data gradient (+ shortcut gradient in the epilogue) and weight gradient (forked first: it needs the
     //      coefficients, not the data gradient)
+    const bool fuse_wa = (g_fuse_wgrad & 1) && fuse_wgrad(d, G.Cip, G.Cinp);
+    if (!fuse_wa)
     RC(side_run(st, [&](hipStream_t s2) {
       WgCall w(t2, xin, k.dw_a, wgws, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
       w.a.p2 = a; w.a.p_coef = coef_a;
@@ -785,6 +802,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     }));
     {
       PwCall p(t2, k.w_a, dx, G.M, G.Ci, G.Cin, 1, G.Cin, dt);
+      if (fuse_wa) { p.a.wg_mode = C3D_WG_ROWS; p.a.wg_x3 = xin; p.a.wg_dw = k.dw_a; p.a.wg_ws = wgws_fused; }
       p.a.x2 = a; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_a;
       if (consb) p.a.fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, true);
       p.a.epi_mode = C3D_EPI_ADD; p.a.e1 = res; p.a.res_mode = res_mode; p.a.H = G.H; p.a.W = G.W;
@@ -807,6 +825,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_SIDE_STREAM: g_side_on = value ? 1 : 0; return 0;
     case C3D_OPT_STEM_MFMA: c3d_option_stem_mfma = value ? 1 : 0; return 0;
     case C3D_OPT_CONVT_MFMA: c3d_option_convt_mfma = value ? 1 : 0; return 0;
+    case C3D_OPT_FUSE_WGRAD: g_fuse_wgrad = value & 3; return 0;
     default: return C3D_E_BADARG;
   }
 }

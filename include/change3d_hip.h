@@ -121,7 +121,26 @@ typedef struct c3d_pw_args {
                          /* dtype).  The narrow kernel then copies it into LDS (one 16-byte DMA per lane) instead of     */
                          /* converting and scattering the f32 weights in every workgroup; same results bit for bit.     */
                          /* `w` must still be given (the block-tiled kernel reads it).                                  */
+  /* ---- weight gradient fused into the DATA-gradient launch (round 4; reference model/x3d.py:173-175,214-216: autograd's
+   * convolution_backward produces both gradients of a 1x1x1 convolution from one read of its operands).  For a data-gradient
+   * call (x = dY-side tensor with the C3D_PRO_AFFINE2 prologue, w addressed transposed) the kernel ALSO accumulates
+   *     dW[k][n] += sum_m P(m, k) * Q(m, n),   P = prologue(x, x2) (the rows already staged for the GEMM),
+   *     wg_mode C3D_WG_SWISH : Q = swish(bn(e1) * gate), the forward operand the C3D_EPI_SWISH_SE_BWD epilogue rebuilds anyway
+   *     wg_mode C3D_WG_ROWS  : Q = rows of wg_x3 ([M][Np] dense, storage dtype: the layer's forward input)
+   * into dw[n*w_sn + k*w_sk] (the strides of `w`): per-workgroup partial sums go to wg_ws (f32, at least
+   * c3d_pw_gemm_wg_ws_floats(K, N) elements) and a fixed-order reducer launched behind the kernel on the same stream adds them
+   * to wg_dw.  Narrow bf16 kernel, dense rows, Kp <= 112 and Np <= 112 only (C3D_E_UNSUPPORTED otherwise: callers keep
+   * c3d_pw_wgrad for those).  wg_mode 0 (the zero-initialised default): no weight gradient.                            */
+  const void* wg_x3;
+  float* wg_dw;
+  float* wg_ws;
+  int32_t wg_mode;
+  int32_t wg_reserved;
 } c3d_pw_args;
+#define C3D_WG_NONE 0
+#define C3D_WG_SWISH 1
+#define C3D_WG_ROWS 2
+int64_t c3d_pw_gemm_wg_ws_floats(int32_t K, int32_t N);
 
 /* K, N <= 224 run the wave-private-tile kernel (pw_gemm_impl.h); wider layers (X3D res5: 432 inner channels; the
  * caption decoder's 192 -> 576 / vocabulary projections) or a non-NULL bias run the block-tiled kernel of
@@ -438,7 +457,9 @@ typedef struct c3d_block_desc {
 enum {
   C3D_STAGE_SEPARATE_FINALIZE = 1,   /* c3d_bn_finalize / c3d_bn_bwd_coef launches instead of the consumers' prologues     */
   C3D_STAGE_NO_WEIGHT_IMAGES = 2,    /* every GEMM workgroup converts the f32 weights itself (no c3d_pw_pack_weights)      */
-  C3D_STAGE_SEPARATE_RESIDUAL = 4    /* c3d_block_out_fwd launches instead of the next block's conv_a prologue             */
+  C3D_STAGE_SEPARATE_RESIDUAL = 4,   /* c3d_block_out_fwd launches instead of the next block's conv_a prologue             */
+  C3D_STAGE_SEPARATE_WGRAD = 8       /* every pointwise weight gradient through c3d_pw_wgrad on the side stream (round 3's   */
+                                     /* sequence) instead of fused into the data-gradient launch where the shape allows it  */
 };
 
 typedef struct c3d_stage_desc {
@@ -470,8 +491,10 @@ int c3d_side_join(void* stream);
  *                         graph, and for one-kernel-at-a-time traces)
  *   C3D_OPT_STEM_MFMA   : 0 = scalar-FMA stem kernels (csrc/stem.hip) instead of the matrix-core ones (bit-identical
  *                         u / dv / dx: tests/test_model_gpu.py::test_stem_mfma_kernels_equal_the_scalar_kernels)
- *   C3D_OPT_CONVT_MFMA  : 0 = scalar ConvTranspose2d kernels on the bf16 path too                                  */
-enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2 };
+ *   C3D_OPT_CONVT_MFMA  : 0 = scalar ConvTranspose2d kernels on the bf16 path too
+ *   C3D_OPT_FUSE_WGRAD  : which pointwise weight gradients the stage driver fuses into their data-gradient launch where the
+ *                         shape allows it (c3d_pw_args.wg_mode): bit 0 = conv_a, bit 1 = conv_c; default = measured best   */
+enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3 };
 int c3d_set_option(int32_t option, int32_t value);
 /* Per-launch profile of the stage driver: between c3d_prof_begin and c3d_prof_end every kernel c3d_stage_fwd /
  * c3d_stage_bwd enqueue is bracketed by a HIP event pair on its launch stream and billed its algorithmic bytes

@@ -657,7 +657,7 @@ def test_e2e_bf16_tracks_f32():
             assert torch.isfinite(p.grad).all(), n
 
 
-@pytest.mark.parametrize("flag", ["STAGE_SEPARATE_FINALIZE", "STAGE_NO_WEIGHT_IMAGES", "STAGE_SEPARATE_RESIDUAL"])
+@pytest.mark.parametrize("flag", ["STAGE_SEPARATE_FINALIZE", "STAGE_NO_WEIGHT_IMAGES", "STAGE_SEPARATE_RESIDUAL", "STAGE_SEPARATE_WGRAD"])
 def test_folded_batchnorm_launches_are_bit_identical_end_to_end(flag):
     """Default launch sequence (BatchNorm finalisation / backward coefficients rebuilt by their consumers, csrc/bn_fin.h;
     pointwise weights read as packed LDS images, c3d_pw_pack_weights; residual add in the next block's conv_a) vs the
@@ -692,12 +692,20 @@ def test_folded_batchnorm_launches_are_bit_identical_end_to_end(flag):
     assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 400
     bad = [(n, (a["grads"][n] - b["grads"][n]).abs().max().item()) for n in a["grads"] if not torch.equal(a["grads"][n], b["grads"][n])]
     bad += [(n, -1.0) for n in a["bufs"] if not torch.equal(a["bufs"][n], b["bufs"][n])]
-    # weight gradients that end in f32 atomics (stem, depthwise conv_b, SE, perception frames, decoder heads) differ in
-    # the last bits between ANY two runs; everything the folded launches compute -- BatchNorm parameter gradients, the
-    # pointwise weight gradients that read the coefficients, running statistics -- must be identical
-    exact = lambda n: (".norm" in n or "branch1_norm" in n or n.endswith(("conv_a.weight", "conv_c.weight", "branch1_conv.weight"))) and ".norm_b.1." not in n  # noqa: E731
+    # weight gradients that end in f32 atomics (stem, depthwise conv_b, SE, perception frames, decoder heads; since round 4
+    # conv_a / conv_c of res2 and res3, whose weight gradient is accumulated with LDS atomics inside the data-gradient launch)
+    # differ in the last bits between ANY two runs; everything the folded launches compute -- BatchNorm parameter gradients,
+    # the res4 pointwise weight gradients that read the coefficients, shortcut convolutions, running statistics -- must be identical
+    fused_dw = lambda n: n.endswith(("conv_a.weight", "conv_c.weight")) and (".blocks.1." in n or ".blocks.2." in n)  # noqa: E731
+    exact = lambda n: ((".norm" in n or "branch1_norm" in n or n.endswith(("conv_a.weight", "conv_c.weight", "branch1_conv.weight")))  # noqa: E731
+                       and ".norm_b.1." not in n and not fused_dw(n))
     wrong = [(n, e) for n, e in bad if e < 0 or exact(n)]
     assert not wrong, (len(wrong), wrong[:8])
+    # the fused weight gradients: same bf16 operands, f32 sums in another order (and vs the separate c3d_pw_wgrad kernel)
+    for n in a["grads"]:
+        if fused_dw(n):
+            rel = ((a["grads"][n] - b["grads"][n]).abs().max() / a["grads"][n].abs().max().clamp_min(1e-30)).item()
+            assert rel < 2e-5, (n, rel)
     for n, e in bad:
         assert e <= 1e-5 * b["grads"][n].abs().max().item(), (n, e)
-    assert sum(1 for n in a["grads"] if exact(n)) > 300
+    assert sum(1 for n in a["grads"] if exact(n)) > 270

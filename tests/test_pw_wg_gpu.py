@@ -1,0 +1,125 @@
+"""GPU op tests of the pointwise data gradient WITH the weight gradient fused in (`c3d_pw_args.wg_mode`, round 4;
+reference model/x3d.py:173-175,214-216: autograd's convolution_backward yields both gradients of a 1x1x1 convolution).
+
+The fused launch must (a) leave the data gradient and its statistics BIT-identical to the unfused launch, (b) reproduce the
+weight gradient of the separate `c3d_pw_wgrad` kernel (same bf16 operands, f32 accumulation in another order) and of a
+torch-CPU f64 computation of the same contraction.
+"""
+import pytest
+import torch
+
+from test_ops_gpu import DEV, _need_gpu, padc, q, rnd
+
+pytestmark = pytest.mark.gpu
+DT = torch.bfloat16
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max()).item()
+
+
+# conv_c of a res2 / res3 block: data gradient rows [M][Co] -> [M][Ci], Swish / SE backward in the epilogue
+@pytest.mark.parametrize("Co,Ci,rows", [(24, 54, 16 * 13), (48, 108, 16 * 9), (24, 54, 16 * 120), (48, 108, 16 * 64)])
+@pytest.mark.parametrize("ragged", [0, 5])
+def test_conv_c_data_gradient_with_fused_weight_gradient(Co, Ci, rows, ragged):
+    _need_gpu()
+    from change3d_amd import ops
+    B = 3
+    M = B * rows - ragged
+    dt = ops.dt_code(DT)
+    Cop, Cip = ops.cpad(Co), ops.cpad(Ci)
+    g, c = q(rnd((M, Co), 1), DT), q(rnd((M, Co), 2), DT)
+    A, Bc, Cc = rnd((Co,), 3), rnd((Co,), 4, 0.1), rnd((Co,), 5, 0.1)
+    w = rnd((Co, Ci), 6, 0.2)                                   # conv_c weight [out][in]; the data gradient reads it transposed
+    b = q(rnd((M, Ci), 7), DT)
+    scale, shift = rnd((Ci,), 8).abs() + 0.5, rnd((Ci,), 9, 0.3)
+    gate = torch.sigmoid(rnd((B, Ci), 10))
+    mean, rstd = rnd((Ci,), 11, 0.5), rnd((Ci,), 12).abs() + 0.5
+    gd, cd = (padc(t, Cop).to(DEV, DT).contiguous() for t in (g, c))
+    bd = padc(b, Cip).to(DEV, DT).contiguous()
+    coef = torch.cat([padc(A, Cop), padc(Bc, Cop), padc(Cc, Cop)]).to(DEV)
+    ss = torch.cat([padc(scale, Cip), padc(shift, Cip)]).to(DEV)
+    mr = torch.cat([padc(mean, Cip), padc(rstd, Cip)]).to(DEV)
+    gt = padc(gate, Cip).to(DEV).contiguous()
+    wd = w.to(DEV)
+
+    def run(fused):
+        t1 = torch.full((M, Cip), float("nan"), dtype=DT, device=DEV)
+        nc3 = torch.zeros(B * Cip * 3, dtype=torch.float64, device=DEV)
+        dw = torch.ones((Co, Ci), dtype=torch.float32, device=DEV)        # accumulate semantics: += onto ones
+        kw = dict(wg_mode=ops.WG_SWISH, wg_dw=dw) if fused else {}
+        ops.pw_gemm(gd, wd, t1, M=M, K=Co, N=Ci, w_sn=1, w_sk=Ci, dtype=dt, x2=cd, pro_mode=ops.PRO_AFFINE2, pro_p=coef,
+                    epi_mode=ops.EPI_SWISH_SE_BWD, e1=bd, epi_p=ss, epi_gate=gt, epi_q=mr, stats=nc3, rows_per_sample=rows, **kw)
+        torch.cuda.synchronize()
+        return t1, nc3, dw
+
+    t1_a, nc_a, _ = run(False)
+    t1_b, nc_b, dw = run(True)
+    assert torch.equal(t1_a.view(torch.int16), t1_b.view(torch.int16)), "the data gradient must not change"
+    assert torch.allclose(nc_a, nc_b, rtol=1e-9, atol=1e-9)
+    dw_sep = torch.ones((Co, Ci), dtype=torch.float32, device=DEV)
+    ops.pw_wgrad(gd, bd, dw_sep, M=M, K=Ci, N=Co, dw_sn=Ci, dw_sk=1, dtype=dt, p2=cd, p_coef=coef, q_mode=ops.PRO_BN_SE_SWISH,
+                 q_ss=ss, q_gate=gt, rows_per_sample=rows)
+    torch.cuda.synchronize()
+    assert _rel(dw, dw_sep) < 2e-5, _rel(dw, dw_sep)            # same bf16 operands, f32 sums in another order
+    P = q(A * g + Bc + Cc * c, DT).double()
+    v = (b * scale + shift) * gate.repeat_interleave(rows, 0)[:M]
+    Q = q(v * torch.sigmoid(v), DT).double()
+    ref = (P.t() @ Q + 1.0).float()
+    assert _rel(dw, ref) < 3e-3, _rel(dw, ref)                  # (the device rounds P, Q once more than this reference does)
+
+
+# conv_a of a res2 / res3 block: data gradient rows [M][Ci] -> [M][Cin] + residual gradient, Q = the layer's forward input
+@pytest.mark.parametrize("Ci,Cin,M", [(54, 24, 16 * 37), (108, 48, 16 * 29), (54, 24, 16 * 400 - 3), (108, 48, 16 * 300 - 9)])
+@pytest.mark.parametrize("res_mode", [0, 1])
+def test_conv_a_data_gradient_with_fused_weight_gradient(Ci, Cin, M, res_mode):
+    _need_gpu()
+    from change3d_amd import ops
+    dt = ops.dt_code(DT)
+    H = W = 0
+    if res_mode == 1:      # first block of a stage: the shortcut's gradient lives at half resolution
+        BT, H, W = 2, 8, 12
+        M = BT * H * W
+    Cip, Cinp = ops.cpad(Ci), ops.cpad(Cin)
+    t2, a_ = q(rnd((M, Ci), 21), DT), q(rnd((M, Ci), 22), DT)
+    A, Bc, Cc = rnd((Ci,), 23), rnd((Ci,), 24, 0.1), rnd((Ci,), 25, 0.1)
+    w = rnd((Ci, Cin), 26, 0.2)                                 # conv_a weight [out][in]
+    xin = q(rnd((M, Cin), 27), DT)
+    res = q(rnd((M if res_mode == 0 else M // 4, Cin), 28), DT)
+    t2d, ad = (padc(t, Cip).to(DEV, DT).contiguous() for t in (t2, a_))
+    xd, rd = (padc(t, Cinp).to(DEV, DT).contiguous() for t in (xin, res))
+    coef = torch.cat([padc(A, Cip), padc(Bc, Cip), padc(Cc, Cip)]).to(DEV)
+    wd = w.to(DEV)
+
+    def run(fused):
+        dx = torch.full((M, Cinp), float("nan"), dtype=DT, device=DEV)
+        dw = torch.ones((Ci, Cin), dtype=torch.float32, device=DEV)
+        kw = dict(wg_mode=ops.WG_ROWS, wg_dw=dw, wg_x3=xd) if fused else {}
+        ops.pw_gemm(t2d, wd, dx, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=ad, pro_mode=ops.PRO_AFFINE2, pro_p=coef,
+                    epi_mode=ops.EPI_ADD, e1=rd, res_mode=res_mode, H=H, W=W, **kw)
+        torch.cuda.synchronize()
+        return dx, dw
+
+    dx_a, _ = run(False)
+    dx_b, dw = run(True)
+    assert torch.equal(dx_a.view(torch.int16), dx_b.view(torch.int16)), "the data gradient must not change"
+    dw_sep = torch.ones((Ci, Cin), dtype=torch.float32, device=DEV)
+    ops.pw_wgrad(t2d, xd, dw_sep, M=M, K=Cin, N=Ci, dw_sn=Cin, dw_sk=1, dtype=dt, p2=ad, p_coef=coef)
+    torch.cuda.synchronize()
+    assert _rel(dw, dw_sep) < 2e-5, _rel(dw, dw_sep)
+    P = q(A * t2 + Bc + Cc * a_, DT).double()
+    ref = (P.t() @ xin.double() + 1.0).float()
+    assert _rel(dw, ref) < 2e-5, _rel(dw, ref)
+
+
+def test_fused_weight_gradient_refuses_shapes_it_does_not_take():
+    _need_gpu()
+    from change3d_amd import ops
+    M, Ci, Cin = 64, 216, 96                                     # res4: the accumulator image does not fit beside the tiles
+    z = lambda *s: torch.zeros(*s, dtype=DT, device=DEV)  # noqa: E731
+    from change3d_amd._lib import Change3DHipError
+    with pytest.raises(Change3DHipError):
+        ops.pw_gemm(z(M, Ci), torch.zeros(Ci, Cin, device=DEV), z(M, Cin), M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin,
+                    dtype=ops.dt_code(DT), x2=z(M, Ci), pro_mode=ops.PRO_AFFINE2, pro_p=torch.zeros(3 * Ci, device=DEV),
+                    epi_mode=ops.EPI_ADD, e1=z(M, Cin), wg_mode=ops.WG_ROWS, wg_x3=z(M, Cin),
+                    wg_dw=torch.zeros(Ci, Cin, device=DEV))
