@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--windows", type=int, default=1,
                     help="split the K timed steps into this many equal windows (a device sync between them) and report each "
                          "window's ms/step as config.ms_per_step_windows (min / median of a short run); `value` stays K steps / total time")
+    ap.add_argument("--dry-run-ranks", type=int, default=0, metavar="N",
+                    help="no GPU needed: launch N ranks on the HOST (gloo) through the same self-launch / process-group / GradSync "
+                         "code the N-GPU run uses, exchange one synthetic gradient buffer per step, verify the result, and print "
+                         "the JSON line with the job geometry (n_gpus, dist_world_size, global_batch) and value = null -- a "
+                         "launch-readiness check of the multi-GPU path, never a measurement")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="c3d_set_option before the run (A/B of the library's run-time options, e.g. FUSE_WGRAD=1)")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel HIP-event table (JSON) here")
@@ -204,8 +209,60 @@ def self_launch(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def dry_run_ranks(a):
+    """`--dry-run-ranks N` (CPU, gloo): everything of an N-rank job except the model step -- launcher, rendezvous on
+    127.0.0.1, the world-size check, the BCD parameter arena in all-reduce order, the overlapped tail bucket + head
+    all-reduce + 1/world of `GradSync` on rank-dependent synthetic gradients (checked against the closed form), the
+    max-over-ranks timing reduction and the JSON line."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--dry-run-ranks {a.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    from change3d_amd.synthetic import make_args
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.parallel import setup_data_parallel
+    with contextlib.redirect_stdout(sys.stderr):
+        net = Trainer(make_args(size=a.size))
+    arena, sync = setup_data_parallel(net, torch.device("cpu"), overlap=True)
+    if dist.get_world_size() != a.gpus or sync.world != a.gpus:
+        raise SystemExit(f"process group has {dist.get_world_size()} ranks (GradSync {sync.world}) but --dry-run-ranks {a.gpus}")
+    ok = True
+    base = torch.linspace(-1.0, 1.0, arena.numel)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for it in range(a.steps):
+        arena.flat_grad.copy_(base * (rank + 1 + it))          # rank r contributes (r + 1 + it) * base
+        sync.launch_tail()                                     # what the res4 stage hook does from inside backward
+        sync.finish()
+        want = base * (sum(r + 1 + it for r in range(world)) / world)
+        ok = ok and bool(torch.allclose(arena.flat_grad, want, rtol=1e-5, atol=1e-6))
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0, 0.0 if ok else 1.0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        batch = a.batch if a.batch > 0 else 32
+        print(json.dumps({"metric": "train images/sec (256x256 pairs, X3D-L BCD)", "value": None, "unit": "images/s", "dry_run": True,
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                          "config": {"workload": "DRY RUN on host cores (gloo): launcher + process group + gradient exchange only",
+                                     "global_batch": batch * world, "parallelism": f"dp{world}", "dist_world_size": dist.get_world_size(),
+                                     "dist_backend": dist.get_backend(), "exchange_floats": arena.numel,
+                                     "exchange_verified": tt[1].item() == 0.0,
+                                     "exchange_ms_per_step_host": round(tt[0].item() / max(a.steps, 1) * 1e3, 3)}}), flush=True)
+    dist.destroy_process_group()
+    if tt[1].item() != 0.0:
+        raise SystemExit("dry run: the reduced gradient buffer is wrong")
+
+
 def main():
     a = parse()
+    if a.dry_run_ranks > 0:
+        a.gpus = a.dry_run_ranks
+        if "WORLD_SIZE" not in os.environ:
+            self_launch(a)
+        return dry_run_ranks(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))

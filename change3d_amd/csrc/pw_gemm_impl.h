@@ -296,8 +296,10 @@ template <typename T, int NT, int PRO, int EPI> struct PwPair {
 template <int NT, int PRO, int EPI> struct PwFragBatch {
   static constexpr int value = (NT == 14 && PRO == C3D_PRO_AFFINE2 && EPI == C3D_EPI_SWISH_SE_BWD) ? 0 : (NT < 7 ? NT : 7);
 };
-template <int NT, int PRO, int EPI, int WAVES> struct PwSlots {
-  static constexpr int value = (PRO == C3D_PRO_AFFINE2 && WAVES == 8 && (NT == 14 || EPI == C3D_EPI_SWISH_SE_BWD)) ? 6 : 8;
+template <int NT, int PRO, int EPI, int WAVES, int WG = 0> struct PwSlots {
+  // (the fused weight gradient of the Swish/SE-backward variant needs ~16 more registers: 4 slots keep it out of scratch)
+  static constexpr int value = (WG == C3D_WG_SWISH) ? 4 :
+                               (PRO == C3D_PRO_AFFINE2 && WAVES == 8 && (NT == 14 || EPI == C3D_EPI_SWISH_SE_BWD)) ? 6 : 8;
 };
 
 // Output staging type: plain-store / statistics epilogues round once to the storage type anyway,
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   typedef typename MM::lds_t lds_t;
   typedef Raw<T> RW;
   typedef typename OutStage<T, EPI>::type os_t;
-  constexpr int PW_SLOTS = PwSlots<NT, PRO, EPI, WAVES>::value;
+  constexpr int PW_SLOTS = PwSlots<NT, PRO, EPI, WAVES, WG>::value;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -981,7 +983,7 @@ template <typename T, int NT, int PRO, int EPI, int WAVES, int WG = 0>
 bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   typedef Mma<T> MM;
   typedef typename OutStage<T, EPI>::type os_t;
-  constexpr int PW_SLOTS = PwSlots<NT, PRO, EPI, WAVES>::value;
+  constexpr int PW_SLOTS = PwSlots<NT, PRO, EPI, WAVES, WG>::value;
   const int Kpad = (a.Kp + MM::KSTEP - 1) / MM::KSTEP * MM::KSTEP;
   const int KL = Kpad + MM::KPAD;
   const int NL = NT * 16 + (sizeof(os_t) == 4 ? 4 : 8);

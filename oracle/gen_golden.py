@@ -7,7 +7,7 @@ weights/inputs from `oracle/synth.py`, first asserting that the repo's restateme
 (`oracle/model.py`) reproduces it bit-for-bit, then writes small fixtures:
 
     tests/golden/bcd_s{S}_b{B}.npz      (BCD: update_bcd, BCE+Dice, 3 Adam steps, eval mode)
-    tests/golden/scd_s64_b{B}.npz       (SCD, SURVEY.md 8(f).1: update_scd + the train_SCD.py loss)
+    tests/golden/scd_s{64,256}_b{B}.npz (SCD, SURVEY.md 8(f).1: update_scd + the train_SCD.py loss)
     tests/golden/cc_s{S}_b{B}.npz       (CC, SURVEY.md 8(f).2: encoder blocks 0-4 + CaptionDecoder + packed CE,
                                          two Adam steps with gradient clipping as scripts/train_CC.py:118-147)
 
@@ -450,7 +450,9 @@ def main():
         for s in a.sizes:
             run(s, a.batch)
     if not a.cc_only:
-        run_scd(64, a.batch)
+        for s in (64, 256):      # the benchmarked SCD resolution has a reference-generated fixture too
+            if s in a.sizes or a.scd_only:
+                run_scd(s, a.batch)
     if not a.scd_only:
         for s in (64, 256):
             run_cc(s, a.batch)

@@ -63,11 +63,12 @@ def test_oracle_matches_reference_golden_s64(golden_dir):
     assert abs(sc["IoU"] - G["scores"][1]) < 1e-12 and abs(sc["F1"] - G["scores"][2]) < 1e-12
 
 
-def test_oracle_scd_matches_reference_golden_s64(golden_dir):
-    """the oracle's SCD restatement (update_scd + the train_SCD.py loss) against the fixture
-    the real reference produced."""
+@pytest.mark.parametrize("gsize", [64, 256])
+def test_oracle_scd_matches_reference_golden(gsize, golden_dir):
+    """the oracle's SCD restatement (update_scd + the train_SCD.py loss) against the fixtures
+    the real reference produced, at 64 and at the benchmarked 256 resolution."""
     from oracle import model as om, synth
-    G = np.load(os.path.join(golden_dir, "scd_s64_b2.npz"))
+    G = np.load(os.path.join(golden_dir, f"scd_s{gsize}_b2.npz"))
     size, batch = int(G["meta"][0]), int(G["meta"][1])
     net = om.Trainer(om.make_args(num_perception_frame=int(G["meta"][4]), size=size, dataset="SECOND",
                                   num_class=int(G["meta"][5])))
@@ -670,3 +671,23 @@ def test_two_rank_gloo_cc_two_arena_allreduce_is_mean_of_local_grads():
     for k in range(2):
         assert np.array_equal(f0[k], f1[k])
         assert np.allclose(f0[k], 0.5 * (l0[k] + l1[k]), rtol=1e-6, atol=1e-7)
+
+
+def test_bench_dry_run_launches_eight_ranks_and_reports_the_job_geometry():
+    """`python bench.py --dry-run-ranks 8` (no GPU): the launcher, the 127.0.0.1 rendezvous, the world-size check, the BCD
+    gradient arena in all-reduce order and GradSync's overlapped tail / head all-reduce / 1/world run with EIGHT host ranks
+    over gloo; the printed line must describe the 8-GPU job (n_gpus, dist_world_size, global batch 8 x 32) and carry no value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run-ranks", "8", "--steps", "2"], capture_output=True,
+                       text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == 8
+    c = d["config"]
+    assert c["dist_world_size"] == 8 and c["global_batch"] == 256 and c["parallelism"] == "dp8" and c["dist_backend"] == "gloo"
+    assert c["exchange_verified"] is True and c["exchange_floats"] > 1_700_000

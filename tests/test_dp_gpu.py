@@ -123,7 +123,40 @@ def _rccl_worker(port, q):
         sync.finish()
         torch.cuda.synchronize()
         out.append((fired, arena.flat_grad.cpu().numpy().copy()))
-    q.put((dist.get_backend(), out))
+    # ---- the end of a data-parallel step, as bench.py / scripts/train_BCD.py issue it: GradSync.finish() (head all-reduce on
+    # the compute stream, fence on the communication stream, mul_(1 / world)) and FusedAdam.launch() are ENQUEUED back to back
+    # on one stream -- no host synchronisation in between (torch's sync debug mode turns any into an error; an explicit
+    # torch.cuda.synchronize() is patched to raise), and the Adam kernel sees the AVERAGED gradients (eps = 1 makes the update
+    # proportional to the gradient, so an update computed from the unscaled buffer would be twice as large)
+    from change3d_amd.model.utils import FusedAdam
+    opt = FusedAdam(arena, lr=1e-2, betas=(0.9, 0.99), eps=1.0, weight_decay=0.0)
+    arena.zero_grad()
+    BCEDiceLoss(net.update_bcd(pre, post), tgt).backward()
+    hp = opt.prepare_step()
+    torch.cuda.synchronize()
+    p_before = arena.flat_param.clone()
+    stream_before = torch.cuda.current_stream().cuda_stream
+    real_sync = torch.cuda.synchronize
+
+    def no_sync(*a, **k):
+        raise AssertionError("host synchronisation between GradSync.finish() and FusedAdam.launch()")
+    torch.cuda.synchronize = no_sync
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        sync.finish()
+        opt.launch(*hp)
+        same_stream = torch.cuda.current_stream().cuda_stream == stream_before
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize = real_sync
+    torch.cuda.synchronize()
+    g = arena.flat_grad.double()                       # averaged gradients (Adam does not modify them)
+    lr, bc1, bc2s = hp
+    m, v = 0.1 * g, 0.01 * g * g
+    want = p_before.double() - lr * (m / bc1) / (v.sqrt() / bc2s + 1.0)
+    upd = (arena.flat_param.double() - p_before.double())
+    adam_err = ((arena.flat_param.double() - want).norm() / (want - p_before.double()).norm()).item()
+    q.put((dist.get_backend(), out, dict(same_stream=bool(same_stream), adam_err=adam_err, upd_norm=upd.norm().item())))
     dist.destroy_process_group()
 
 
@@ -142,9 +175,12 @@ def test_overlapped_allreduce_through_rccl_single_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(29700 + (os.getpid() % 2000), q))
     p.start()
-    backend, out = q.get(timeout=900)
+    backend, out, tail = q.get(timeout=900)
     p.join(timeout=120)
     assert p.exitcode == 0 and backend == "nccl"
+    # finish() + launch(): one stream, no host sync, Adam on the averaged buffer (an update from the unscaled gradients
+    # would be off by a factor of two: relative error 1.0)
+    assert tail["same_stream"] and tail["upd_norm"] > 0 and tail["adam_err"] < 1e-3, tail
     for fired, flat in out:
         assert fired, "the stage hook did not launch the tail bucket"
         err = np.linalg.norm(flat.astype(np.float64) - 0.5 * ref) / np.linalg.norm(0.5 * ref)

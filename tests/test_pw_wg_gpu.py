@@ -56,7 +56,9 @@ def test_conv_c_data_gradient_with_fused_weight_gradient(Co, Ci, rows, ragged):
     t1_a, nc_a, _ = run(False)
     t1_b, nc_b, dw = run(True)
     assert torch.equal(t1_a.view(torch.int16), t1_b.view(torch.int16)), "the data gradient must not change"
-    assert torch.allclose(nc_a, nc_b, rtol=1e-9, atol=1e-9)
+    # (the fused variant prefetches fewer tiles per iteration: another tile -> wave partition, i.e. another grouping of the
+    # per-wave f32 partial sums behind the f64 per-sample statistics)
+    assert torch.allclose(nc_a, nc_b, rtol=2e-5, atol=1e-5 * nc_a.abs().max().item())
     dw_sep = torch.ones((Co, Ci), dtype=torch.float32, device=DEV)
     ops.pw_wgrad(gd, bd, dw_sep, M=M, K=Ci, N=Co, dw_sn=Ci, dw_sk=1, dtype=dt, p2=cd, p_coef=coef, q_mode=ops.PRO_BN_SE_SWISH,
                  q_ss=ss, q_gate=gt, rows_per_sample=rows)
