@@ -357,16 +357,21 @@ __global__ __launch_bounds__(HD_TH * HD_TW) void head_bwd_kernel(
       }
     }
   }
-  // slices -> LDS (the weight copy is dead now and has exactly 27 x 8 x 8 floats) -> one global atomic per value
+  // slices -> LDS (the weight copy is dead now and has exactly 27 x 8 x 8 floats) -> one global atomic per value.  The nine
+  // pixel slices add their partial sums one after the other with plain LDS read-modify-writes (the 27 owners of a slice hold
+  // distinct addresses): fixed order, and no LDS float atomics -- ds_add_f32 costs ~190 clocks per wave-instruction on
+  // gfx950 (tools/micro/lds_atomic_rate.hip), the 56 of them per thread were a third of this kernel on the 7-class heads
   __syncthreads();
   for (int i = tid; i < 27 * HD_MAXNC * 8; i += NTHR) wl[i] = 0.f;
-  __syncthreads();
-  if (tid < 27 * HD_NSL) {
+  for (int sl = 0; sl < HD_NSL; ++sl) {
+    __syncthreads();
+    if (tid < 27 * HD_NSL && wsl == sl) {
 #pragma unroll
-    for (int n = 0; n < HD_MAXNC; ++n) {
-      if (n < NC) {
+      for (int n = 0; n < HD_MAXNC; ++n) {
+        if (n < NC) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(&wl[(wown * HD_MAXNC + n) * 8 + j], dwacc[n][j]);
+          for (int j = 0; j < 8; ++j) wl[(wown * HD_MAXNC + n) * 8 + j] += dwacc[n][j];
+        }
       }
     }
   }
