@@ -218,6 +218,49 @@ __device__ __forceinline__ void bn_consume_nc(const c3d_bn_fin& f, int C, int Cp
   __syncthreads();
 }
 
+// SqueezeExcitation gate of the samples [n_lo, n_lo + ns) by the consuming workgroup (after bn_consume_nc: scale / shift in
+// lds_sc / lds_sh): the three steps of bn_se_finalize_kernel with its arithmetic and summation order -- z = fma(sc,
+// (float)(sum / cnt), sh); FC1 over 8 adjacent lanes (c = q, q + 8, ...) combined with xor 1, 2, 4, + bias, ReLU; FC2 as one
+// sequential fma chain over the hidden units, accurate expf -- so gate and hid are bit-identical to the separate launch.
+// zg: LDS [ns][Cp] (z, then overwritten by the gate), hl: LDS [ns][Cr].  own_lo / own_hi: samples whose first row lies in
+// this workgroup's rows (it writes their gate / hid to global memory for the backward pass).  Ends with __syncthreads().
+__device__ __forceinline__ void se_gate_consume(const double* nc, double cnt_per_sample, int C, int Cp, const float* w1,
+                                                const float* b1, const float* w2, const float* b2, int Cr, int n_lo, int ns,
+                                                int own_lo, int own_hi, const float* lds_sc, const float* lds_sh, float* zg,
+                                                float* hl, float* gate, float* hid, int tid, int nthreads) {
+  for (int idx = tid; idx < ns * Cp; idx += nthreads) {
+    const int n = idx / Cp, c = idx - n * Cp;
+    zg[idx] = c < C ? fmaf(lds_sc[c], (float)(nc[((size_t)(n_lo + n) * Cp + c) * 2] / cnt_per_sample), lds_sh[c]) : 0.f;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < ns * Cr * 8; idx += nthreads) {   // 8 lanes per (sample, hidden unit)
+    const int i = idx >> 3, q = idx & 7;
+    const int n = i / Cr, r = i - n * Cr;
+    float a = 0.f;
+    for (int c = q; c < C; c += 8) a = fmaf(w1[(size_t)r * C + c], zg[n * Cp + c], a);
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+    a += b1[r];
+    a = a > 0.f ? a : 0.f;
+    if (q == 0) {
+      hl[i] = a;
+      if (n_lo + n >= own_lo && n_lo + n <= own_hi) hid[(size_t)(n_lo + n) * Cr + r] = a;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < ns * Cp; idx += nthreads) {
+    const int n = idx / Cp, c = idx - n * Cp;
+    float g = 0.f;
+    if (c < C) {
+      float a = b2[c];
+      for (int r = 0; r < Cr; ++r) a = fmaf(w2[(size_t)c * Cr + r], hl[n * Cr + r], a);
+      g = 1.0f / (1.0f + expf(-a));
+    }
+    zg[idx] = g;
+    if (n_lo + n >= own_lo && n_lo + n <= own_hi) gate[(size_t)(n_lo + n) * Cp + c] = g;
+  }
+  __syncthreads();
+}
+
 // Backward.  nc3 f64 [B][Cp][3] (Swish/SE-backward epilogue: d gate, sum t1, sum t1*bhat) -> db = A*t1 + Bc + C*b for the
 // channel `c` (no SE: Bc is the same for every sample), same arithmetic and summation tree as se_bn_bwd_coef_kernel's
 // no-SE branch.  Called by the four lanes q = 0..3 of a channel (adjacent lanes); the result is valid in all four.

@@ -127,12 +127,31 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
     if (!a.wg_dw || !a.wg_ws || (a.wg_mode == C3D_WG_ROWS && !a.wg_x3)) return C3D_E_BADARG;
     if (wide || a.dtype != C3D_DT_BF16) return C3D_E_UNSUPPORTED;
   }
+  if (a.se_w1) {
+    if (a.pro_mode != C3D_PRO_BN_SE_SWISH || !a.fin.sums || a.fin.batch <= 0 || !a.pro_gate || !a.se_b1 || !a.se_w2 || !a.se_b2 ||
+        !a.se_hid || a.se_cr <= 0 || a.rows_per_sample <= 0 || !a.fin.ss)
+      return C3D_E_BADARG;
+    if (wide) return C3D_E_UNSUPPORTED;
+  }
   if (wide) return c3d_detail_pw_gemm_wide(args, stream);
   if (a.wg_mode != C3D_WG_NONE) return c3d_detail_pw_gemm_wg(args, stream);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = C3D_E_BADARG;
   if (a.dtype == C3D_DT_F32) rc = c3d_detail_pw_gemm_f32(args, stream);
   else if (a.dtype == C3D_DT_BF16) rc = dispatch_mode<bf16_t>(a, s);
+  if (rc == PW_E_SE_FALLBACK) {
+    // a workgroup would span more samples than the in-kernel SE gate holds (tiny inputs): the separate finalize launch, then
+    // the same GEMM reading scale / shift / gate from memory
+    rc = c3d_bn_se_finalize(a.fin.sums, a.fin.batch, (double)a.rows_per_sample, a.fin.gamma, a.fin.beta, a.fin.running_mean,
+                            a.fin.running_var, a.fin.nbt, a.fin.momentum, a.fin.eps, a.K, a.Kp, 1, a.se_w1, a.se_b1, a.se_w2,
+                            a.se_b2, a.se_cr, a.fin.ss, a.fin.mr, const_cast<float*>(a.pro_gate), a.se_hid, stream);
+    if (rc != 0) return rc;
+    c3d_pw_args b = a;
+    std::memset(&b.fin, 0, sizeof(b.fin));
+    b.se_w1 = nullptr;
+    b.pro_p = a.fin.ss;
+    return c3d_pw_gemm(&b, stream);
+  }
   // shapes the wave-private-tile kernel cannot hold in LDS (f32 storage with K*N near 224 x 224): block-tiled kernel
   if (rc == C3D_E_UNSUPPORTED && !a.fin.ticket && !a.fin.sums && a.wg_mode == C3D_WG_NONE) rc = c3d_detail_pw_gemm_wide(args, stream);
   return rc;

@@ -313,6 +313,7 @@ struct PwLaunch {
   int xs_rows;         // rows of the wave's X region (= tpi*16)
   int w_off, p_off, wave_off, wave_bytes, os_off, gs_off;  // byte offsets in dynamic LDS
   int flush_shuffle_max;  // row-lanes per channel vector up to which the final sums are shuffled instead of dumped
+  int se_off;             // consumer-side SqueezeExcitation gate (a.se_w1): byte offset of the [PW_SE_NS][Kp] gates + [PW_SE_NS][32] hidden units
   int dw_off, ldw;        // fused weight gradient (WG != 0): byte offset and row stride (floats) of the workgroup's dW accumulators
 };
 
@@ -329,6 +330,9 @@ struct PwLaunch {
 // order in which the waves' contributions land no longer shows in the f32 result.)
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr_t;
+constexpr int PW_SE_NS = 4;     // samples a workgroup may span with the consumer-side SE gate (else: separate c3d_bn_se_finalize)
+constexpr int PW_SE_CR = 32;    // hidden units (se_cr) at most
+constexpr int PW_E_SE_FALLBACK = -1000;   // internal: launch_pw_d -> c3d_pw_gemm
 constexpr int WG_NTP_MAX = 7;   // K tiles (P channels) held as fragments: Kp <= 112 (C3D_WG_ROWS: conv_a, K = inner channels)
 constexpr int WG_NTP_MAX_SWISH = 3;   // C3D_WG_SWISH: conv_c, K = the block's output channels (<= 48 on res2 / res3)
 
@@ -407,6 +411,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   if (t1 > tiles) t1 = tiles;
   const uint32_t rps32 = a.rows_per_sample > 0 ? (uint32_t)a.rows_per_sample : 1u;
   const int64_t nmax = (int64_t)(((uint32_t)a.M - 1u) / rps32);
+  // first sample of this workgroup's rows (consumer-side SE gates are indexed from it)
+  const int se_n_lo = (int)((uint32_t)(((int)blockIdx.x * WAVES * L.tiles_per_wave < tiles ? (int)blockIdx.x * WAVES * L.tiles_per_wave : tiles) << 4) / rps32);
   int cur_n = -1;       // sample whose partial sums are accumulated (SWISH_SE_BWD epilogue)
   int gate_n = -1;      // sample whose gate is cached in Gs (BN_SE_SWISH prologue)
 
@@ -509,6 +515,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       // c3d_bn_se_finalize launch between conv_b and conv_c); workgroup 0 owns ss / mr / the running statistics
       if (blockIdx.x == 0 && tid == 0 && a.fin.nbt) *a.fin.nbt += 1;
       c3dfin::bn_consume_nc(a.fin, a.K, Kp, blockIdx.x == 0, Pp, Pp + Kp, tid, WAVES * 64);
+      if (a.se_w1) {
+        // SE gate of the samples this workgroup's rows belong to (at most PW_SE_NS: the launcher checked), while the first
+        // tile's rows are in flight; the workgroup holding a sample's first row writes gate / hid for the backward pass
+        const int tiles_ = ((int)a.M + 15) >> 4;
+        int wt0 = (int)blockIdx.x * WAVES * L.tiles_per_wave, wt1 = wt0 + WAVES * L.tiles_per_wave;
+        if (wt0 > tiles_) wt0 = tiles_;
+        if (wt1 > tiles_) wt1 = tiles_;
+        if (wt0 < wt1) {
+          const uint32_t rps_ = (uint32_t)a.rows_per_sample;
+          const int r0 = wt0 << 4, r1 = ((wt1 << 4) < (int)a.M ? (wt1 << 4) : (int)a.M) - 1;
+          const int n_lo = (int)((uint32_t)r0 / rps_), n_hi = (int)((uint32_t)r1 / rps_);
+          const int own_lo = (int)(((uint32_t)r0 + rps_ - 1) / rps_);   // first sample whose row 0 is >= r0
+          float* zg = reinterpret_cast<float*>(smem + L.se_off);
+          c3dfin::se_gate_consume(a.fin.sums, (double)a.rows_per_sample, a.K, Kp, a.se_w1, a.se_b1, a.se_w2, a.se_b2, a.se_cr, n_lo,
+                                  n_hi - n_lo + 1, own_lo, n_hi, Pp, Pp + Kp, zg, zg + PW_SE_NS * Kp,
+                                  const_cast<float*>(a.pro_gate), a.se_hid, tid, WAVES * 64);
+        }
+      }
     } else if (PRO != C3D_PRO_NONE) {
       const int np = (PRO == C3D_PRO_AFFINE2 ? 3 : 2) * Kp;
       for (int i = tid; i < np; i += WAVES * 64) Pp[i] = a.pro_p[i];
@@ -603,7 +627,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             float sc[8], sh[8], g[8];
             lds_ld8(Pp + v_ * 8, sc);
             lds_ld8(Pp + Kp + v_ * 8, sh);
-            if (a.pro_gate) {
+            if (a.se_w1 && a.fin.sums) {   // gates of this workgroup's samples were computed in the prologue (LDS)
+              int n_ = (int)((uint32_t)(tl_ << 4) / rps32);
+              if (n_ > (int)nmax) n_ = (int)nmax;
+              lds_ld8(reinterpret_cast<const float*>(smem + L.se_off) + (n_ - se_n_lo) * Kp + v_ * 8, g);
+            } else if (a.pro_gate) {
               int n_ = (int)((uint32_t)(tl_ << 4) / rps32);
               if (n_ > (int)nmax) n_ = (int)nmax;
               if (n_ != gate_n) {  // wave-uniform: a sub-tile never straddles two samples
@@ -996,15 +1024,17 @@ bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   // doubles: the four 16-lane groups of a ds_add_f64 -- rows 4g + r -- fall on the two halves of the 64 banks alternately)
   const int ldw = ((a.Np + 15) / 16) * 16 + 4;
   const size_t dw_bytes = WG != 0 ? al16((size_t)((a.Kp + 15) / 16) * 16 * ldw * sizeof(double)) : 0;
+  const size_t se_bytes = (PRO == C3D_PRO_BN_SE_SWISH && a.se_w1) ? al16((size_t)PW_SE_NS * (a.Kp + PW_SE_CR) * sizeof(float)) : 0;
   for (int tpi = PW_SLOTS / Q; tpi >= 1; --tpi) {
     const size_t xs_bytes = al16((size_t)tpi * 16 * KL * sizeof(typename MM::lds_t));
     const size_t wave_bytes = xs_bytes + os_bytes + gs_bytes;
-    const size_t total = w_bytes + p_bytes + WAVES * wave_bytes + dw_bytes;
+    const size_t total = w_bytes + p_bytes + WAVES * wave_bytes + dw_bytes + se_bytes;
     if (total <= 160 * 1024) {
       L.tpi = tpi; L.xs_rows = tpi * 16;
       L.w_off = 0; L.p_off = (int)w_bytes; L.wave_off = (int)(w_bytes + p_bytes);
       L.wave_bytes = (int)wave_bytes; L.os_off = (int)xs_bytes; L.gs_off = (int)(xs_bytes + os_bytes);
       L.dw_off = (int)(w_bytes + p_bytes + WAVES * wave_bytes); L.ldw = ldw;
+      L.se_off = (int)(w_bytes + p_bytes + WAVES * wave_bytes + dw_bytes);
       lds = total;
       return true;
     }
@@ -1044,6 +1074,11 @@ int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
   if (round_iters || blocks_r * 16 >= blocks * 15) tpw = tpw_r;
   blocks = (tiles + tpw * WAVES - 1) / (tpw * WAVES);
   L.tiles_per_wave = (int)tpw;
+  if (PRO == C3D_PRO_BN_SE_SWISH && a.se_w1) {   // consumer-side SE gate: a workgroup's rows may span at most PW_SE_NS samples
+    const int64_t rows_wg = tpw * WAVES * 16;
+    if (a.rows_per_sample <= 0 || (rows_wg + a.rows_per_sample - 2) / a.rows_per_sample + 1 > PW_SE_NS || a.se_cr > PW_SE_CR)
+      return PW_E_SE_FALLBACK;
+  }
   static const int fsm = c3d_env("C3D_PW_FLUSH_SHFL") ? atoi(c3d_env("C3D_PW_FLUSH_SHFL")) : 0;   // tuning knob (measured: no gain)
   L.flush_shuffle_max = fsm;
   pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE, WG><<<dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream>>>(a, L);

@@ -97,6 +97,7 @@ inline bool fuse_wgrad(const c3d_stage_desc* d, int Kp, int Np) {
   return !(d->flags & C3D_STAGE_SEPARATE_WGRAD) && d->dtype == C3D_DT_BF16 && Kp <= 112 && Np <= 112 && c3d_knob("C3D_PW_WG", 1);
 }
 
+int g_fold_se = 1;         // c3d_set_option(C3D_OPT_FOLD_SE, ...): SE gate computed by conv_c's workgroups (forward)
 int g_fuse_wgrad = 3;      // c3d_set_option(C3D_OPT_FUSE_WGRAD, ...): bit 0 conv_a, bit 1 conv_c
 
 int make_plan(const c3d_stage_desc* d, Plan& P) {
@@ -386,6 +387,23 @@ inline char* at(void* base, size_t off) { return off == SIZE_MAX ? nullptr : rei
 template <typename T> inline T* atT(void* base, size_t off) { return reinterpret_cast<T*>(at(base, off)); }
 
 
+// Zero fill of the accumulator regions with an ordinary kernel launch: hipMemsetAsync goes through the runtime's blit path,
+// and the kernel trace shows a ~32 us hole in the main queue in front of every one of them (7 per BCD step = 0.22 ms;
+// tools/trace_step.sh).  The regions are carved in 256-byte units, 16-byte aligned.
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+int zero_fill(void* p, size_t bytes, hipStream_t st) {
+  if (!bytes) return 0;
+  if (((uintptr_t)p & 15) || (bytes & 15)) { HIPRC(hipMemsetAsync(p, 0, bytes, st)); return 0; }
+  const size_t n16 = bytes >> 4;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  zero_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(reinterpret_cast<uint4*>(p), n16);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 // ------------------------------------------------------------------------------------------ eval: folded BatchNorm
 // Eval-mode BatchNorm is the per-channel affine map y = x*scale + shift with scale = gamma / sqrt(running_var + eps),
 // shift = beta - running_mean*scale (reference scripts/train_BCD.py:92-154 runs the model under model.eval()).
@@ -529,7 +547,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int dt = d->dtype, tr = d->training ? 1 : 0, B = d->B, T = d->T;
   const double e = (double)es(dt);
-  HIPRC(hipMemsetAsync(at(ws, P.fwd_acc_off), 0, P.fwd_acc_bytes, st));
+  RC(zero_fill(at(ws, P.fwd_acc_off), P.fwd_acc_bytes, st));
   // Weight images of the whole stage in one launch per 64 images: the f32 master weights change once per optimizer
   // step, the four (six with a shortcut convolution) GEMMs of a block read them in ~256 workgroups each.  The backward
   // pass of this forward reads the transposed images from the same workspace.
@@ -603,7 +621,8 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
     // BatchNorm_b (+ the SqueezeExcitation gate).  Blocks WITHOUT SE (every odd block) need only the batch statistics:
     // conv_c's prologue rebuilds scale / shift from the per-sample sums itself (csrc/bn_fin.h bn_consume_nc; narrow
     // kernel) -- one single-workgroup launch less on the forward critical path per such block
-    const bool fold_b = cons && !G.se && G.Cip <= 224 && G.Cop <= 224;
+    // (blocks WITH SE since round 4: every conv_c workgroup also computes the gate of its samples, c3d_pw_args.se_w1)
+    const bool fold_b = cons && G.Cip <= 224 && G.Cop <= 224 && (!G.se || (g_fold_se && G.Cr <= 32));
     if (!fold_b)
     RC(prof_call("c3d_bn_se_finalize", 0.0, st, [&] {
       return c3d_bn_se_finalize(nc_b, B, (double)rps, k.bn_b.gamma, k.bn_b.beta, k.bn_b.running_mean, k.bn_b.running_var,
@@ -616,6 +635,7 @@ extern "C" int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws, v
       if (fold_b) {
         p.a.fin = fin_consume(nc_b, k.bn_b, (double)rps * B, d->momentum, d->eps, ss_b, mr_b);
         p.a.fin.batch = B;
+        if (G.se) { p.a.se_w1 = k.se_w1; p.a.se_b1 = k.se_b1; p.a.se_w2 = k.se_w2; p.a.se_b2 = k.se_b2; p.a.se_hid = hid; p.a.se_cr = G.Cr; }
       }
       p.a.epi_mode = epi; p.a.stats = sums_c; p.a.w_img = imgp(F.img_c);
       RC(pw_launch(p.a, st));
@@ -673,7 +693,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int dt = d->dtype, B = d->B, T = d->T;
   const double e = (double)es(dt);
-  HIPRC(hipMemsetAsync(at(wb, P.bwd_acc_off), 0, P.bwd_acc_bytes, st));
+  RC(zero_fill(at(wb, P.bwd_acc_off), P.bwd_acc_bytes, st));
   float* wgws = atT<float>(wb, P.wgrad_ws);
   float* wgws_fused = atT<float>(wb, P.wgrad_ws_fused);
   const bool wimg = use_pw_img(d);   // transposed weight images written by this step's c3d_stage_fwd (training mode)
@@ -826,6 +846,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_STEM_MFMA: c3d_option_stem_mfma = value ? 1 : 0; return 0;
     case C3D_OPT_CONVT_MFMA: c3d_option_convt_mfma = value ? 1 : 0; return 0;
     case C3D_OPT_FUSE_WGRAD: g_fuse_wgrad = value & 3; return 0;
+    case C3D_OPT_FOLD_SE: g_fold_se = value ? 1 : 0; return 0;
     default: return C3D_E_BADARG;
   }
 }
@@ -911,7 +932,7 @@ extern "C" int c3d_stage_fwd_folded(const c3d_stage_desc* d, const void* fold_c,
   void* fold = const_cast<void*>(fold_c);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int dt = d->dtype, B = d->B, T = d->T;
-  if (Q.acc_bytes) HIPRC(hipMemsetAsync(at(ws, Q.acc_off), 0, Q.acc_bytes, st));
+  RC(zero_fill(at(ws, Q.acc_off), Q.acc_bytes, st));
   const void* cur = x;
   for (int i = 0; i < d->n_blocks; ++i) {
     const c3d_block_desc& k = d->blocks[i];

@@ -136,6 +136,17 @@ typedef struct c3d_pw_args {
   float* wg_ws;
   int32_t wg_mode;
   int32_t wg_reserved;
+  /* ---- SqueezeExcitation gate computed by the CONSUMER (round 4): with C3D_PRO_BN_SE_SWISH, fin.sums (per-sample sums of
+   * c3d_dw333_fwd, fin.batch > 0) and se_w1 != NULL, every workgroup of the narrow kernel rebuilds BatchNorm_b's scale / shift
+   * AND the SE gate of the samples its rows belong to (z = bn(mean_n), FC1 + ReLU, FC2 + sigmoid: the arithmetic and summation
+   * order of c3d_bn_se_finalize, bit-identical) in its prologue -- no c3d_bn_se_finalize launch between conv_b and conv_c.  The
+   * workgroup that holds a sample's first row writes gate[n][Kp] (-> pro_gate, which must be given: the backward pass reads it)
+   * and se_hid[n][Cr].  When a workgroup would span more than 4 samples (tiny inputs) the entry point launches
+   * c3d_bn_se_finalize itself and runs the unfused form.  Reference: fvcore SqueezeExcitation at model/x3d.py:194-202.      */
+  const float* se_w1; const float* se_b1; const float* se_w2; const float* se_b2;
+  float* se_hid;
+  int32_t se_cr;
+  int32_t se_reserved;
 } c3d_pw_args;
 #define C3D_WG_NONE 0
 #define C3D_WG_SWISH 1
@@ -493,8 +504,10 @@ int c3d_side_join(void* stream);
  *                         u / dv / dx: tests/test_model_gpu.py::test_stem_mfma_kernels_equal_the_scalar_kernels)
  *   C3D_OPT_CONVT_MFMA  : 0 = scalar ConvTranspose2d kernels on the bf16 path too
  *   C3D_OPT_FUSE_WGRAD  : which pointwise weight gradients the stage driver fuses into their data-gradient launch where the
- *                         shape allows it (c3d_pw_args.wg_mode): bit 0 = conv_a, bit 1 = conv_c; default = measured best   */
-enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3 };
+ *                         shape allows it (c3d_pw_args.wg_mode): bit 0 = conv_a, bit 1 = conv_c; default = measured best
+ *   C3D_OPT_FOLD_SE     : 0 = c3d_bn_se_finalize launches for the blocks with SqueezeExcitation (default 1: conv_c's workgroups
+ *                         compute the gate of their samples, c3d_pw_args.se_w1)                                          */
+enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3, C3D_OPT_FOLD_SE = 4 };
 int c3d_set_option(int32_t option, int32_t value);
 /* Per-launch profile of the stage driver: between c3d_prof_begin and c3d_prof_end every kernel c3d_stage_fwd /
  * c3d_stage_bwd enqueue is bracketed by a HIP event pair on its launch stream and billed its algorithmic bytes
