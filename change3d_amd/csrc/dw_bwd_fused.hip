@@ -597,8 +597,8 @@ extern "C" int c3d_dw333_bwd_fused(const void* t1, const void* b, const float* c
                                    const float* coefC, const float* w, const void* a, const float* ss_a,
                                    const float* mr_a, void* t2, double* dsums, float* dw, int32_t B, int32_t T,
                                    int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype, void* stream) {
-  if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1))) return C3D_E_UNSUPPORTED;
-  DwGeom g{B, T, H, W, H / stride, W / stride, C, Cp, stride};
+  if (stride != 1 && stride != 2) return C3D_E_UNSUPPORTED;
+  DwGeom g{B, T, H, W, (H - 1) / stride + 1, (W - 1) / stride + 1, C, Cp, stride};
   if (!t1 || !b || !coefA || !coefB || !coefC || !w || !a || !ss_a || !mr_a || !t2 || !dsums || !dw || !geom_ok(g))
     return C3D_E_BADARG;
   return dispatch_fused(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, dtype,
@@ -609,8 +609,8 @@ extern "C" int c3d_dw333_bwd_fused_fin(const void* t1, const void* b, const c3d_
                                        const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw, int32_t B,
                                        int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
                                        void* stream) {
-  if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1))) return C3D_E_UNSUPPORTED;
-  DwGeom g{B, T, H, W, H / stride, W / stride, C, Cp, stride};
+  if (stride != 1 && stride != 2) return C3D_E_UNSUPPORTED;
+  DwGeom g{B, T, H, W, (H - 1) / stride + 1, (W - 1) / stride + 1, C, Cp, stride};
   if (!t1 || !b || !w || !a || !ss_a || !mr_a || !t2 || !dsums || !dw || !geom_ok(g)) return C3D_E_BADARG;
   if (!fin_b || !fin_b->sums || fin_b->batch != B || !fin_b->gamma || !fin_b->mr || !(fin_b->count > 0)) return C3D_E_BADARG;
   return dispatch_fused(t1, b, nullptr, nullptr, nullptr, w, a, ss_a, mr_a, t2, dsums, dw, g, dtype,

@@ -28,7 +28,7 @@ done
 rm -rf gpurun_out/pmc_mfma
 C3D_WGRAD_SIDE=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
     -d gpurun_out/pmc_mfma -- python bench.py --no-cpu-baseline --no-also --no-graph --no-kernel-profile --steps 1 --warmup 1 > gpurun_out/pmc_mfma.log 2>&1
-python tools/summarize_rocprof.py gpurun_out ${C3D_ROUND_TAG:-r03}
+python tools/summarize_rocprof.py gpurun_out ${C3D_ROUND_TAG:-r04}
 # host-side profile of the step loop (where the enqueue time goes)
 timeout 600 python -m cProfile -o gpurun_out/host.prof bench.py --no-cpu-baseline --no-also --no-kernel-profile --steps 30 --warmup 5 > /dev/null 2> gpurun_out/host_prof.err
 python -c "
