@@ -96,11 +96,6 @@ SIGNATURES = {
                                  vp, vp, vp, vp, vp, vp]),
     "c3d_dw333_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_dw333_fwd_fin": (i32, [vp, C.POINTER(BnFin), vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "c3d_dw333_bwd_data": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
-                                 i32, vp]),
-    "c3d_dw333_bwd_data_fin": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
-                                     i32, C.POINTER(BnFin), vp]),
-    "c3d_dw333_wgrad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_dw333_bwd_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_dw333_bwd_fused_fin": (i32, [vp, vp, C.POINTER(BnFin), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_block_out_fwd": (i32, [vp, vp, vp, vp, i32, vp, i64, i32, i32, vp]),

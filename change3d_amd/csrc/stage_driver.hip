@@ -763,9 +763,8 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       return c3d_se_bn_bwd_coef(nc3, nc_b, B, (double)rps, k.bn_b.gamma, mr_b, ss_b, G.Ci, G.Cip, G.se ? k.se_w1 : nullptr,
                                 k.se_w2, gate, hid, G.Cr, cA, cC, cB, k.bn_b.dgamma, k.bn_b.dbeta, k.dse_w1, k.dse_b1,
                                 k.dse_w2, k.dse_b2, st); }));
-    // ---- depthwise conv_b: data gradient and weight gradient in ONE pass over t1, b, a (csrc/dw_bwd_fused.hip; the
-    //      stride-2 first block of a stage too when H and W are even -- odd extents keep the pair, the weight gradient
-    //      forked first on the side stream).
+    // ---- depthwise conv_b: data gradient and weight gradient in ONE pass over t1, b, a (csrc/dw_bwd_fused.hip; stride 1
+    //      and the stride-2 first block of a stage, any extents)
     if (fold_b) {
       c3d_bn_fin fb;
       std::memset(&fb, 0, sizeof(fb));
@@ -773,16 +772,9 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       fb.running_mean = k.bn_b.dgamma; fb.running_var = k.bn_b.dbeta;
       RC(prof_call("c3d_dw333_bwd_fused", ((double)G.Mo * 2 + (double)G.M * 2) * G.Cip * e, st, [&] {
         return c3d_dw333_bwd_fused_fin(t1, b, &fb, k.w_b, a, ss_a, mr_a, t2, dsums_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, 1, dt, st); }));
-    } else if (G.s == 1 || (((G.H | G.W) & 1) == 0 && c3d_knob("C3D_DWBF_S2", 1))) {
+    } else {
       RC(prof_call("c3d_dw333_bwd_fused", ((double)G.Mo * 2 + (double)G.M * 2) * G.Cip * e, st, [&] {
         return c3d_dw333_bwd_fused(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st); }));
-    } else {
-      RC(side_run(st, [&](hipStream_t s2) {
-        return prof_call("c3d_dw333_wgrad", ((double)G.Mo * 2 + (double)G.M) * G.Cip * e, s2, [&] {
-          return c3d_dw333_wgrad(t1, b, cA, cB, cC, a, ss_a, k.dw_b, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, s2); });
-      }));
-      RC(prof_call("c3d_dw333_bwd_data", ((double)G.Mo * 2 + (double)G.M * 2) * G.Cip * e, st, [&] {
-        return c3d_dw333_bwd_data(t1, b, cA, cB, cC, k.w_b, a, ss_a, mr_a, t2, dsums_a, B, T, G.H, G.W, G.Ci, G.Cip, G.s, dt, st); }));
     }
     if (!consb) RC(coef(dsums_a, (double)G.M, k.bn_a, mr_a, G.Ci, G.Cip, coef_a));
     // ---- shortcut branch

@@ -381,21 +381,6 @@ def dw_fwd_fin(x, fin, w, y, nc, B, T, H, W, C_, stride, dtype):
                                   dtype, _stream())
 
 
-def dw_bwd_data(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, B, T, H, W, C_, stride, dtype):
-    _launch("c3d_dw333_bwd_data", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_data, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2),
-                                       _p(dsums), B, T, H, W, C_, cpad(C_), stride, dtype, _stream())
-
-
-def dw_bwd_data_fin(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, B, T, H, W, C_, stride, dtype, fin):
-    _launch("c3d_dw333_bwd_data", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_data_fin, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(w), _p(a), _p(ss_a), _p(mr_a), _p(t2),
-            _p(dsums), B, T, H, W, C_, cpad(C_), stride, dtype, C.byref(fin), _stream())
-
-
-def dw_wgrad(t1, b, cA, cB, cC, a, ss_a, dw, B, T, H, W, C_, stride, dtype):
-    _launch("c3d_dw333_wgrad", (t1.numel() + b.numel() + a.numel()) * _es(dtype), L.lib().c3d_dw333_wgrad, _p(t1), _p(b), _p(cA), _p(cB), _p(cC), _p(a), _p(ss_a), _p(dw), B, T, H, W,
-                                    C_, cpad(C_), stride, dtype, _stream())
-
-
 def dw_bwd_fused(t1, b, cA, cB, cC, w, a, ss_a, mr_a, t2, dsums, dw, B, T, H, W, C_, dtype, stride=1):
     """Depthwise backward: data gradient, BatchNorm_a-backward sums and weight gradient in one pass."""
     _launch("c3d_dw333_bwd_fused", (t1.numel() + b.numel() + a.numel() + t2.numel()) * _es(dtype), L.lib().c3d_dw333_bwd_fused,

@@ -63,7 +63,7 @@ int c3d_device_cus(void);
  * is non-NULL the producing kernel itself turns the completed sums into scale/shift (+ running statistics), or into
  * the BatchNorm-backward coefficients, instead of a separate c3d_bn_finalize / c3d_bn_bwd_coef launch.
  *   forward  (c3d_pw_gemm C3D_EPI_STATS)          : ss = scale|shift [2][Cp], mr = mean|rstd [2][Cp] (may be NULL)
- *   backward (c3d_block_out_bwd, c3d_dw333_bwd_data): ss = coefficients A|B|C [3][Cp], mr = saved mean|rstd (input),
+ *   backward (c3d_block_out_bwd): ss = coefficients A|B|C [3][Cp], mr = saved mean|rstd (input),
  *              running_mean / running_var carry dgamma / dbeta (accumulated), beta / nbt unused
  * `ticket` is a zeroed uint32 (re-zeroed by the caller before every launch that uses it).                        */
 typedef struct c3d_bn_fin {
@@ -253,22 +253,9 @@ int c3d_dw333_fwd(const void* x, const float* ss, const float* w, void* y, doubl
 int c3d_dw333_fwd_fin(const void* x, const c3d_bn_fin* fin, const float* w, void* y, double* nc_sums, int32_t B,
                       int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
                       void* stream);
-int c3d_dw333_bwd_data(const void* t1, const void* b, const float* coefA, const float* coefB,
-                       const float* coefC, const float* w, const void* a, const float* ss_a,
-                       const float* mr_a, void* t2, double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
-                       int32_t stride, int32_t dtype, void* stream);
-/* as c3d_dw333_bwd_data; with fin->ticket != NULL the last workgroup also writes BatchNorm_a's backward coefficients */
-int c3d_dw333_bwd_data_fin(const void* t1, const void* b, const float* coefA, const float* coefB,
-                           const float* coefC, const float* w, const void* a, const float* ss_a,
-                           const float* mr_a, void* t2, double* dsums, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t Cp,
-                           int32_t stride, int32_t dtype, const c3d_bn_fin* fin, void* stream);
-int c3d_dw333_wgrad(const void* t1, const void* b, const float* coefA, const float* coefB,
-                    const float* coefC, const void* a, const float* ss_a, float* dw, int32_t B, int32_t T,
-                    int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t stride, int32_t dtype,
-                    void* stream);
 /* bwd_data AND wgrad from one staged tile of db (csrc/dw_bwd_fused.hip) -- what autograd's convolution_backward returns
- * for conv_b (reference model/x3d.py:184-193) in one pass over t1, b and a: t2 and dsums exactly as c3d_dw333_bwd_data
- * writes them, dw += as c3d_dw333_wgrad (f32 atomics).  stride 1 or 2 (stride 2: H and W even).                      */
+ * for conv_b (reference model/x3d.py:184-193) in one pass over t1, b and a: t2 = d conv * (bn_a(a) > 0), dsums f64 [2][C] =
+ * (sum t2, sum t2 * ahat), dw += (f32 atomics).  stride 1 or 2, any extents.                      */
 int c3d_dw333_bwd_fused(const void* t1, const void* b, const float* coefA, const float* coefB,
                         const float* coefC, const float* w, const void* a, const float* ss_a,
                         const float* mr_a, void* t2, double* dsums, float* dw, int32_t B, int32_t T,
@@ -489,7 +476,7 @@ int c3d_stage_ws_bytes(const c3d_stage_desc* d, int64_t* ws_fwd_bytes, int64_t* 
 /* x: [B][T][H][W][cpad(cin)] channels-last, storage dtype.  y: stage output (also re-read by backward).      */
 int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws_fwd, void* y, void* stream);
 /* dy: gradient of y (same layout); dx: gradient of x (written).  x / y / ws_fwd as given to c3d_stage_fwd.
- * The weight gradients (c3d_pw_wgrad, c3d_dw333_wgrad) are launched on the library's side stream, each forked ahead
+ * The weight gradients that are not fused into their data-gradient launch (c3d_pw_wgrad) are launched on the library's side stream, each forked ahead
  * of the data-gradient kernel that reads the same operands, with their grids capped at 3/4 and 1/2 of the CUs so
  * that the data-gradient chain always finds free CUs (csrc/launch_hints.h); ws_bwd holds a ring of three blocks'
  * temporaries, so the side stream may lag the chain by two blocks.                                              */

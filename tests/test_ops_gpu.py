@@ -416,32 +416,28 @@ def test_dw333_fwd_bwd(dtype, stride, C, T):
     t1d = padc(t1, Cp).to(DEV, dtype).contiguous()
     mean_a, rstd_a = rnd((C,), 58, 0.5), rnd((C,), 59).abs() + 0.5
     mr = torch.cat([padc(mean_a, Cp), padc(rstd_a, Cp)]).to(DEV)
-    ops.dw_bwd_data(t1d, b, padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV),
-                    w.to(DEV).contiguous(), ad, ss, mr, t2, dsums, B, T, H, W, C, stride, ops.dt_code(dtype))
-    close(t2[..., :C], t2_ref, dtype, "dw bwd data", scale=t2_ref.abs().max().item())
-    t2q = t2[..., :C].float().cpu().double()
-    sd = dsums.cpu()
-    assert torch.allclose(sd[:C], t2q.sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(sd[C:], (t2q * ((a - mean_a) * rstd_a).double()).sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3)
     dw = torch.zeros((C, 27), dtype=torch.float32, device=DEV)
-    ops.dw_wgrad(t1d, b, padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV), ad, ss, dw,
-                 B, T, H, W, C, stride, ops.dt_code(dtype))
-    close(dw, w_r.grad.view(C, 27), dtype, "dw wgrad", scale=w_r.grad.abs().max().item())
-    # one-pass kernel: same t2 / sums as the data-gradient kernel (bit for bit), same dw
+    # one pass: data gradient (with the ReLU mask), BatchNorm_a-backward sums and weight gradient against torch autograd
     _check_fused_dw(ops, t1d, b, padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV),
-                    w.to(DEV).contiguous(), ad, ss, mr, t2, dsums, dw, w_r.grad.view(C, 27), B, T, H, W, C, dtype, stride)
+                    w.to(DEV).contiguous(), ad, ss, mr, t2_ref, a, mean_a, rstd_a, w_r.grad.view(C, 27), B, T, H, W, C, dtype, stride)
 
 
-def _check_fused_dw(ops, t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, dsums, dw, dw_ref, B, T, H, W, C, dtype, stride=1):
+def _check_fused_dw(ops, t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2_ref, a, mean_a, rstd_a, dw_ref, B, T, H, W, C, dtype, stride=1):
+    """c3d_dw333_bwd_fused against torch-CPU autograd of relu(bn(a)) -> conv3d (the separate data-gradient / weight-gradient
+    kernels it was once compared with bit for bit were deleted in round 4)."""
     t2f = torch.full_like(ad, float("nan"))
-    dsf = torch.zeros_like(dsums)
-    dwf = torch.zeros_like(dw)
+    dsf = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    dwf = torch.zeros((C, 27), dtype=torch.float32, device=DEV)
     ops.dw_bwd_fused(t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2f, dsf, dwf, B, T, H, W, C, ops.dt_code(dtype), stride)
     torch.cuda.synchronize()
-    assert torch.equal(t2f, t2), f"fused t2 differs: max {(t2f.float() - t2.float()).abs().max().item():.3e}"
-    sc = dsums.abs().max().item() + 1e-30
-    assert (dsf - dsums).abs().max().item() <= 1e-6 * sc + 1e-9, (dsf - dsums).abs().max().item()
-    close(dwf, dw_ref, dtype, "fused dw wgrad", scale=dw_ref.abs().max().item())
+    close(t2f[..., :C], t2_ref, dtype, "dw bwd data", scale=t2_ref.abs().max().item())
+    if t2f.shape[-1] > C:
+        assert (t2f[..., C:].float() == 0).all()
+    t2q = t2f[..., :C].float().cpu().double()
+    sd = dsf.cpu()
+    assert torch.allclose(sd[:C], t2q.sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3 * max(1.0, B / 8))
+    assert torch.allclose(sd[C:], (t2q * ((a - mean_a) * rstd_a).double()).sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3 * max(1.0, B / 8))
+    close(dwf, dw_ref, dtype, "dw wgrad", scale=dw_ref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -451,11 +447,11 @@ def _check_fused_dw(ops, t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, dsums, dw, 
     (3, 17, 19, 54, 2),     # odd extents under stride 2 (the last 2x2 quad of a row / column is partial)
     (2, 15, 9, 108, 2),
     (40, 24, 24, 54, 1),    # workgroup walks cross sample boundaries (per-sample coefB rows)
-    (1100, 8, 8, 54, 1),    # one tile per sample: a walk touches > 8 samples (LDS-DMA kernel declines)
+    (1100, 8, 8, 54, 1),    # one tile per sample: a walk touches > 8 samples
 ])
 def test_dw333_backward_walks(dtype, B, H, W, C, stride):
-    """Backward depthwise kernels on shapes that exercise the tile walks: the LDS-DMA weight-gradient
-    producer (bf16, T=3), its register-staged fallback, and the walking data-gradient kernel."""
+    """The fused depthwise backward kernel on shapes that exercise the tile walks (ragged tiles, walks across sample
+    boundaries, one tile per sample, odd extents under stride 2)."""
     _need_gpu()
     from change3d_amd import ops
     T = 3
@@ -482,21 +478,7 @@ def test_dw333_backward_walks(dtype, B, H, W, C, stride):
     t1d = padc(t1, Cp).to(DEV, dtype).contiguous()
     cAd, cBd, cCd = padc(cA, Cp).to(DEV), padc(cB, Cp).to(DEV).contiguous(), padc(cC, Cp).to(DEV)
     wd = w.to(DEV).contiguous()
-    t2 = torch.full_like(ad, float("nan"))
-    dsums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
-    ops.dw_bwd_data(t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, dsums, B, T, H, W, C, stride, ops.dt_code(dtype))
-    close(t2[..., :C], t2_ref, dtype, "dw bwd data", scale=t2_ref.abs().max().item())
-    t2q = t2[..., :C].float().cpu().double()
-    sd = dsums.cpu()
-    assert torch.allclose(sd[:C], t2q.sum((0, 1, 2, 3)), rtol=1e-5, atol=1e-3 * max(1.0, B / 8))
-    assert torch.allclose(sd[C:], (t2q * ((a - mean_a) * rstd_a).double()).sum((0, 1, 2, 3)), rtol=1e-5,
-                          atol=1e-3 * max(1.0, B / 8))
-    dw = torch.zeros((C, 27), dtype=torch.float32, device=DEV)
-    ops.dw_wgrad(t1d, bd, cAd, cBd, cCd, ad, ss, dw, B, T, H, W, C, stride, ops.dt_code(dtype))
-    # the reduction runs over B*T*Ho*Wo products: scale the absolute tolerance with its length
-    close(dw, w_r.grad.view(C, 27), dtype, "dw wgrad", scale=w_r.grad.abs().max().item())
-    if True:
-        _check_fused_dw(ops, t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, dsums, dw, w_r.grad.view(C, 27), B, T, H, W, C, dtype, stride)
+    _check_fused_dw(ops, t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2_ref, a, mean_a, rstd_a, w_r.grad.view(C, 27), B, T, H, W, C, dtype, stride)
 
 
 # --------------------------------------------------------------------------- loss / optimizer

@@ -85,10 +85,8 @@ def dw_family():
         n = a_.numel() * 2
         us = timeit(lambda: ops.dw_fwd(a_, ss, w, b_, nc, B, T, H, H, Ci, 1, dt))
         report(f"s{st} dw fwd C={Ci} {H}x{H}", us, 2 * n)
-        us = timeit(lambda: ops.dw_bwd_data(t1, b_, cA, cB, cC, w, a_, ss, ss, t2, dsums, B, T, H, H, Ci, 1, dt))
-        report(f"s{st} dw bwd-data", us, 4 * n)
-        us = timeit(lambda: ops.dw_wgrad(t1, b_, cA, cB, cC, a_, ss, dw, B, T, H, H, Ci, 1, dt))
-        report(f"s{st} dw wgrad", us, 3 * n)
+        us = timeit(lambda: ops.dw_bwd_fused(t1, b_, cA, cB, cC, w, a_, ss, ss, t2, dsums, dw, B, T, H, H, Ci, dt, 1))
+        report(f"s{st} dw bwd fused (data + weight gradient)", us, 4 * n)
 
 
 if __name__ == "__main__":

@@ -22,6 +22,7 @@ for Ci in (32, 64, 96, 128, 24, 56, 112):
     dsums = torch.zeros(2 * Ci, dtype=torch.float64, device=DEV)
     cA, cC, cB = torch.rand(Cip, device=DEV), torch.rand(Cip, device=DEV), torch.rand(B * Cip, device=DEV)
     n = a_.numel() * 2
-    us = timeit(lambda: ops.dw_bwd_data(t1, b_, cA, cB, cC, w, a_, ss, ss, t2, dsums, B, T, H, H, Ci, 1, dt))
+    dw = torch.zeros(Ci, 27, device=DEV)
+    us = timeit(lambda: ops.dw_bwd_fused(t1, b_, cA, cB, cC, w, a_, ss, ss, t2, dsums, dw, B, T, H, H, Ci, dt, 1))
     usf = timeit(lambda: ops.dw_fwd(a_, ss, w, b_, nc, B, T, H, H, Ci, 1, dt))
     print(f"C={Ci:4d} Cp={Cip:4d}: bwd-data {us:8.1f} us {4*n/us/1e3:8.1f} GB/s ({us/Cip:6.3f} us/ch)   fwd {usf:8.1f} us {2*n/usf/1e3:8.1f} GB/s ({usf/Cip:6.3f} us/ch)")

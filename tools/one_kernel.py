@@ -17,8 +17,7 @@ x = rt(M, Cin); wa = torch.randn(Ci, Cin, device=DEV) * 0.1; wc = torch.randn(Co
 stats = torch.zeros(16 * 2 * 256, dtype=torch.float64, device=DEV); gate = torch.rand(B * Cip, device=DEV)
 for _ in range(3):
     if which == "dwfwd": ops.dw_fwd(a_, ss, w, b_, nc, B, T, H, H, Ci, 1, dt)
-    elif which == "dwbwd": ops.dw_bwd_data(t1, b_, cA, cB, cC, w, a_, ss, ss, t2, ds, B, T, H, H, Ci, 1, dt)
-    elif which == "dwwgrad": ops.dw_wgrad(t1, b_, cA, cB, cC, a_, ss, dw, B, T, H, H, Ci, 1, dt)
+    elif which == "dwbwd": ops.dw_bwd_fused(t1, b_, cA, cB, cC, w, a_, ss, ss, t2, ds, dw, B, T, H, H, Ci, dt, 1)
     elif which == "pwa": ops.pw_gemm(x, wa, a_.view(M, Cip), M=M, K=Cin, N=Ci, w_sn=Cin, w_sk=1, dtype=dt, epi_mode=ops.EPI_STATS, stats=stats)
     elif which == "pwc": ops.pw_gemm(b_.view(M, Cip), wc, x, M=M, K=Ci, N=Co, w_sn=Ci, w_sk=1, dtype=dt, pro_mode=ops.PRO_BN_SE_SWISH, pro_p=ss, pro_gate=gate, rows_per_sample=T * H * H, epi_mode=ops.EPI_STATS, stats=stats)
 torch.cuda.synchronize()

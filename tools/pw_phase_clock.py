@@ -23,7 +23,7 @@ def build():
     import __graft_entry__ as g
     g.build(verbose=False)
     objdir = os.path.join(g.LIBDIR, "obj")
-    clk = ["pw_gemm.hip", "pw_wgrad.hip", "dw_conv.hip", "dw_bwd_fused.hip"]
+    clk = ["pw_gemm.hip", "pw_wgrad.hip", "dw_bwd_fused.hip"]
     procs = []
     for src in clk:
         o = os.path.join(objdir, src.replace(".hip", "_clk.o"))
@@ -171,55 +171,6 @@ DW_PHASES = ["setup (weights, coefficients)", "barrier A (previous taps done)", 
              "issue a rows + next tile", "barrier B", "27 taps", "epilogue + store", "final sums flush"]
 
 
-def main_dw():
-    os.environ["C3D_LIB"] = CLK_LIB
-    import numpy as np
-    import torch
-    from change3d_amd import _lib, ops
-    h = _lib.lib()
-    h.c3d_debug_dw_clock.restype = C.c_int
-    h.c3d_debug_dw_clock.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-    buf = (C.c_ulonglong * (16384 * 10))()
-
-    def read():
-        torch.cuda.synchronize()
-        assert h.c3d_debug_dw_clock(buf, 1) == 0
-        return np.frombuffer(buf, dtype=np.uint64).reshape(16384, 10).astype(np.float64)
-
-    DEV, DT, B, T = "cuda:0", torch.bfloat16, 32, 3
-    dt = ops.dt_code(DT)
-    rt = lambda *s: torch.randn(*s, device=DEV).to(DT)  # noqa: E731
-    for st, H, Ci in [(1, 128, 54), (2, 64, 108), (3, 32, 216)]:
-        Cip = ops.cpad(Ci)
-        a_, b_, t1, t2 = (rt(B, T, H, H, Cip) for _ in range(4))
-        w = torch.randn(Ci, 27, device=DEV) * 0.1
-        ss = torch.rand(2 * Cip, device=DEV)
-        dsums = torch.zeros(2 * Ci, dtype=torch.float64, device=DEV)
-        cA, cC, cB = torch.rand(Cip, device=DEV), torch.rand(Cip, device=DEV), torch.rand(B * Cip, device=DEV)
-        fn = lambda: ops.dw_bwd_data(t1, b_, cA, cB, cC, w, a_, ss, ss, t2, dsums, B, T, H, H, Ci, 1, dt)  # noqa: E731
-        for _ in range(3):
-            fn()
-        read()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 10
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        a = read()
-        us = e0.elapsed_time(e1) / iters * 1e3
-        a = a[a[:, 9] > 0]
-        per = a[:, :9].sum(1) / a[:, 9]
-        print(f"s{st} dw bwd-data C={Ci} {H}x{H}: {us:.1f} us/launch, {len(a)} wave slots ({a[:, 9].sum() / iters:.0f} waves/launch), "
-              f"clk per wave mean {per.mean():.0f} min {per.min():.0f} max {per.max():.0f}")
-        for i, ph in enumerate(DW_PHASES):
-            print(f"    {ph:34s} {a[:, i].sum() / a[:, 9].sum():10.0f} clk  {100.0 * a[:, i].sum() / a[:, :9].sum():5.1f} %")
-
-
-FB_PHASES = ["setup (weights, coefficients, first loads)", "convert -> f32 LDS planes", "a_in + issue next tile", "barrier",
-             "27 taps (data + weight gradient)", "epilogue + store", "BN_a sums flush", "dW flush"]
-
-
 def main_fb():
     """csrc/dw_bwd_fused.hip (stride 1 and 2) at the three BCD stage shapes."""
     os.environ["C3D_LIB"] = CLK_LIB
@@ -274,8 +225,6 @@ if __name__ == "__main__":
         build()
     elif "--fb" in sys.argv:
         main_fb()
-    elif "--dw" in sys.argv:
-        main_dw()
     elif "--wgrad" in sys.argv:
         main_wgrad()
     else:

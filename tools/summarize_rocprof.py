@@ -18,8 +18,7 @@ from collections import defaultdict
 
 ENTRY = [  # kernel-name prefix -> C-ABI entry point (bench.py's kernel table key)
     ("pw_gemm_kernel", "c3d_pw_gemm"), ("pw_wgrad_kernel", "c3d_pw_wgrad"), ("pw_wgrad_reduce", "c3d_pw_wgrad"),
-    ("dw_fwd", "c3d_dw333_fwd"), ("dw_bwd_fused", "c3d_dw333_bwd_fused"), ("dw_bwd_data", "c3d_dw333_bwd_data"),
-    ("dw_wgrad", "c3d_dw333_wgrad"),
+    ("dw_fwd", "c3d_dw333_fwd"), ("dw_bwd_fused", "c3d_dw333_bwd_fused"),
     ("block_out_fwd", "c3d_block_out_fwd"), ("block_out_bwd", "c3d_block_out_bwd"),
     ("se_bn_bwd_coef", "c3d_se_bn_bwd_coef"), ("bn_se_finalize", "c3d_bn_se_finalize"),
     ("bn_finalize", "c3d_bn_finalize"), ("bn_bwd_coef", "c3d_bn_bwd_coef"), ("stem_", "c3d_stem_*"),
