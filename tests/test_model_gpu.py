@@ -350,22 +350,28 @@ def test_e2e_vs_oracle_conditioned_weights_every_gradient_bcd():
 
 def test_e2e_vs_oracle_conditioned_weights_every_gradient_scd():
     """SCD (T=5, three decoders): the same STRICT bound -- every one of the 490 gradient tensors within 1e-4 of the fp32
-    oracle.  There are ~120 ReLU layers over 5/3 as many elements as BCD; when ONE pre-activation lands on the other side
-    of the kink (a last-bit difference in an early BatchNorm scale is enough, on either side) ~100 upstream tensors move
-    by 1e-4 .. 1e-3 (tools/dbg_flip.py; tools/scan_scd_seed.py: 21 of 24 weight seeds hit one).  The bound is therefore
-    asserted on the three kink-free seeds 23, 26, 27 (worst tensor 1.4e-5 / 1.7e-5 / 1.4e-5 on MI355X) and must hold on at
-    least TWO of them, so that a future last-bit change that flips one ReLU in one case does not hide -- or fake -- a
-    regression; every case (and the kinked default seed 16) must also satisfy the distribution bound: median < 2e-5,
-    70 % of the tensors < 1e-4, none above 5e-3."""
+    oracle -- on ALL THREE kink-free weight seeds 23, 26, 27 (worst tensor 1.1e-5 .. 1.4e-5 on MI355X), nothing waived.
+    There are ~120 ReLU layers over 5/3 as many elements as BCD; when ONE pre-activation lands on the other side of the
+    kink (a last-bit difference in an early BatchNorm scale is enough, on either side) ~100 upstream tensors move by
+    1e-4 .. 1e-3 (tools/dbg_flip.py; tools/scan_scd_seed.py: 47 of 54 scanned weight seeds hit one), which is why the strict
+    cases are seeds found kink-free -- under two different roundings of the oracle (1 and 4 threads).  Should a future
+    last-bit change push one of the three across a kink, the failure message says which, and how the spare kink-free seeds
+    64 and 66 (1.6e-5 / 2.1e-5 at round 4; also 61) do: a regression moves all of them, a flip moves one -- which is then to be
+    replaced by a spare here, with the flip recorded.  Every case (and the kinked default seed 16) must also satisfy the
+    distribution bound: median < 2e-5, 70 % of the tensors < 1e-4, none above 5e-3."""
     _need_gpu()
-    strict_ok = 0
+    worst_of = {}
     for wseed in (23, 26, 27, 16):
         errs = _conditioned_case("scd", wseed)
         worst, med, n_over = _summ("scd", wseed, errs)
         assert med < 2e-5 and n_over <= 0.3 * len(errs) and worst < 5e-3, (wseed, med, n_over, worst)
-        if wseed != 16 and worst < 1e-4:
-            strict_ok += 1
-    assert strict_ok >= 2, f"strict 1e-4 bound holds on {strict_ok} of the 3 kink-free seeds"
+        worst_of[wseed] = worst
+    failed = [w for w in (23, 26, 27) if worst_of[w] >= 1e-4]
+    if failed:
+        spare = {w: _summ("scd", w, _conditioned_case("scd", w))[0] for w in (64, 66)}
+        raise AssertionError(f"strict 1e-4 bound broken on weight seed(s) {failed}: worst tensor per seed {worst_of}; spare kink-free "
+                             f"seeds 64 / 66 now give {spare} -- all high = a regression, one seed high = a ReLU flip on that seed "
+                             f"(replace it by a spare and record the flip in this docstring)")
 
 
 @pytest.mark.parametrize("T,dtype,shape", [(3, torch.float32, (2, 64, 64)), (5, torch.float32, (2, 40, 72)),

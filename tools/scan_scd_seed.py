@@ -13,7 +13,8 @@ torch.set_num_threads(1)   # the oracle's own f32 rounding depends on the thread
 size, batch = 64, 2
 mk = lambda: om.make_args(num_perception_frame=3, size=size, dataset="SECOND", num_class=7)
 rel = lambda a, b: ((a.detach().double().cpu() - b.detach().double().cpu()).norm() / (b.detach().double().cpu().norm() + 1e-30)).item()
-for wseed, dseed in [(s, 0) for s in range(16, 40)]:
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (16, 40)
+for wseed, dseed in [(s, 0) for s in range(lo, hi)]:
     with contextlib.redirect_stdout(io.StringIO()):
         ref, mine = om.Trainer(mk()), Trainer(mk())
     sd = synth.synth_state_dict(ref, seed=wseed, mask_margin=0.25, branch_gain=0.1)
