@@ -117,7 +117,8 @@ SIGNATURES = {
     "c3d_convT4s2_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "c3d_col_sum": (i32, [vp, vp, i64, i32, i32, i32, vp]),
     "c3d_head3x3_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "c3d_head3x3_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "c3d_head3x3_bwd_ws_floats": (i64, [i32, i32, i32, i32]),
+    "c3d_head3x3_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "c3d_bce_dice_fwd": (i32, [vp, vp, i64, vp, vp, vp]),
     "c3d_bce_dice_bwd": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "c3d_ce2d_fwd": (i32, [vp, vp, i64, i32, i64, i64, i64, i64, vp, vp, vp]),

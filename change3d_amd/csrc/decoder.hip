@@ -389,6 +389,11 @@ int c3d_detail_convt_fwd_bf16(const void* in, const float* w, const float* bias,
                               int B, int h, int wd, int C, hipStream_t st);
 int c3d_detail_convt_bwd_data_bf16(const void* dout, const float* w, void* din, int B, int h, int wd, int C, hipStream_t st);
 static bool convt_mfma_on() { return c3d_option_convt_mfma != 0; }
+// head 3x3 on the matrix cores (head_mfma.hip; same option: the scalar kernels stay the parity reference)
+int c3d_detail_head_fwd_bf16(const void* x, const float* w, float* out, int B, int H, int W, int NC, int has_sigmoid, hipStream_t s);
+int c3d_detail_head_bwd_bf16(const float* dout, const float* prob, const void* x, const float* w, void* dx, float* dw, float* ws,
+                             int B, int H, int W, int NC, int has_sigmoid, hipStream_t s);
+int64_t c3d_detail_head_ws_floats(int B, int H, int W, int NC);
 
 extern "C" int c3d_convT4s2_fwd(const void* in, const float* w, const float* bias, const void* skip,
                                 int64_t skip_bstride, void* out, int32_t B, int32_t h, int32_t wd, int32_t C,
@@ -473,6 +478,7 @@ extern "C" int c3d_head3x3_fwd(const void* x, const float* w, float* out, int32_
   if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || C != HD_C || NC <= 0 || NC > HD_MAXNC) return C3D_E_BADARG;
   dim3 grid(((W + HD_TW - 1) / HD_TW) * ((H + HD_TH - 1) / HD_TH), B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == C3D_DT_BF16 && convt_mfma_on()) return c3d_detail_head_fwd_bf16(x, w, out, B, H, W, NC, has_sigmoid, s);   // head_mfma.hip
   if (dtype == C3D_DT_F32)
     head_fwd_kernel<float><<<grid, HD_TH * HD_TW, 0, s>>>((const float*)x, w, out, B, H, W, NC, has_sigmoid);
   else if (dtype == C3D_DT_BF16)
@@ -482,11 +488,17 @@ extern "C" int c3d_head3x3_fwd(const void* x, const float* w, float* out, int32_
   return 0;
 }
 
+extern "C" int64_t c3d_head3x3_bwd_ws_floats(int32_t B, int32_t H, int32_t W, int32_t NC) {
+  return (B > 0 && H > 0 && W > 0 && NC > 0) ? c3d_detail_head_ws_floats(B, H, W, NC) : 0;
+}
+
 extern "C" int c3d_head3x3_bwd(const float* dout, const float* prob, const void* x, const float* w, void* dx,
-                               float* dw, int32_t B, int32_t H, int32_t W, int32_t C, int32_t NC,
+                               float* dw, float* ws, int32_t B, int32_t H, int32_t W, int32_t C, int32_t NC,
                                int32_t has_sigmoid, int32_t dtype, void* stream) {
   if (!dout || !x || !w || !dx || !dw || B <= 0 || C != HD_C || NC <= 0 || NC > HD_MAXNC) return C3D_E_BADARG;
   if (has_sigmoid && !prob) return C3D_E_BADARG;
+  if (dtype == C3D_DT_BF16 && convt_mfma_on())
+    return c3d_detail_head_bwd_bf16(dout, prob, x, w, dx, dw, ws, B, H, W, NC, has_sigmoid, reinterpret_cast<hipStream_t>(stream));
   const int ntiles = ((W + HD_TW - 1) / HD_TW) * ((H + HD_TH - 1) / HD_TH);
   static const int env_tpw = c3d_env("C3D_HEAD_TPW") ? atoi(c3d_env("C3D_HEAD_TPW")) : 0;   // tuning knob
   int tpw = env_tpw > 0 ? env_tpw : 16;    // long walks: every workgroup ends with 216*NC same-address global atomics

@@ -492,7 +492,8 @@ def head_fwd(x, w, out, B, H, W, C_, NC, has_sigmoid, dtype):
 
 
 def head_bwd(dout, prob, x, w, dx, dw, B, H, W, C_, NC, has_sigmoid, dtype):
-    _launch("c3d_head3x3_bwd", 2 * x.numel() * _es(dtype) + 2 * dout.numel() * 4, L.lib().c3d_head3x3_bwd, _p(dout), _p(prob), _p(x), _p(w), _p(dx), _p(dw), B, H, W, C_, NC,
+    ws = _ws(x.device, max(1, L.lib().c3d_head3x3_bwd_ws_floats(B, H, W, NC)))
+    _launch("c3d_head3x3_bwd", 2 * x.numel() * _es(dtype) + 2 * dout.numel() * 4, L.lib().c3d_head3x3_bwd, _p(dout), _p(prob), _p(x), _p(w), _p(dx), _p(dw), ws.data_ptr(), B, H, W, C_, NC,
                                     1 if has_sigmoid else 0, dtype, _stream())
 
 

@@ -342,8 +342,12 @@ int c3d_convT4s2_wgrad(const void* t, const void* dout, float* dw, float* ws, in
 int c3d_col_sum(const void* x, float* out, int64_t M, int32_t C, int32_t Cp, int32_t dtype, void* stream);
 int c3d_head3x3_fwd(const void* x, const float* w, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
                     int32_t NC, int32_t has_sigmoid, int32_t dtype, void* stream);
+/* ws: optional f32 scratch of c3d_head3x3_bwd_ws_floats elements for the bf16 matrix-core kernel (per-workgroup partials of dw +
+ * fixed-order reducer); NULL: every workgroup adds its partial with global atomics (~1000 of them queue on the same 216 NC
+ * addresses: 3-4 x slower on the full-size heads).                                                                          */
+int64_t c3d_head3x3_bwd_ws_floats(int32_t B, int32_t H, int32_t W, int32_t NC);
 int c3d_head3x3_bwd(const float* dout, const float* prob, const void* x, const float* w, void* dx,
-                    float* dw, int32_t B, int32_t H, int32_t W, int32_t C, int32_t NC, int32_t has_sigmoid,
+                    float* dw, float* ws, int32_t B, int32_t H, int32_t W, int32_t C, int32_t NC, int32_t has_sigmoid,
                     int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -61,3 +61,52 @@ def test_convT4s2_fwd_bwd_data_wgrad(dtype, C, B, h, w):
         ops.convT_wgrad(xd, dd, gw, B, h, w, C, dt)
         torch.cuda.synchronize()
         assert (gw.cpu() - 2 * wr.grad).norm().item() / wr.grad.norm().item() < 6e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("NC,sig", [(1, True), (7, False), (2, True)])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (3, 13, 37), (1, 40, 100)])
+def test_head3x3_fwd_bwd(dtype, NC, sig, B, H, W):
+    """Final 3x3 convolution 24 -> NC (+ sigmoid for the change head; reference model/change_decoder.py:46-55,78-81) against
+    torch-CPU `conv2d` and its autograd.  bf16 storage runs the matrix-core kernels (csrc/head_mfma.hip: weights and the
+    logit gradient are rounded to bf16 there), f32 storage the scalar kernels (csrc/decoder.hip); ragged tiles included."""
+    _need_gpu()
+    from change3d_amd import ops
+    dt = ops.dt_code(dtype)
+    bf = dtype == torch.bfloat16
+    C = 24
+    x = q(rnd((B, H, W, C), 11), dtype)
+    wt = rnd((NC, C, 3, 3), 12, 0.2)
+    wq = wt.to(torch.bfloat16).float() if bf else wt
+    dout = rnd((B, NC, H, W), 13)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    logit = F.conv2d(xr, wr, padding=1)
+    yr = torch.sigmoid(logit) if sig else logit
+    yr.backward(dout)
+    xd, wd_, dd = x.to(DEV).to(dtype), wt.to(DEV), dout.to(DEV)
+    out = torch.full((B, NC, H, W), float("nan"), device=DEV)
+    ops.head_fwd(xd, wd_, out, B, H, W, C, NC, sig, dt)
+    dx = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=DEV)
+    dw = torch.ones((NC, C, 3, 3), device=DEV)                      # accumulate semantics
+    ops.head_bwd(dd, out if sig else None, xd, wd_, dx, dw, B, H, W, C, NC, sig, dt)
+    torch.cuda.synchronize()
+    tol_out = 2e-5 if not bf else 2e-3
+    assert (out.cpu() - yr.detach()).abs().max().item() < tol_out * max(1.0, float(yr.detach().abs().max()))
+    close(dx.permute(0, 3, 1, 2), xr.grad, dtype, "head data gradient", scale=float(xr.grad.abs().max()))
+    rel = ((dw.cpu() - 1.0) - wr.grad).norm().item() / wr.grad.norm().item()
+    assert rel < (2e-5 if not bf else 4e-3), ("head weight gradient rel-L2", rel)
+    if bf:   # the scalar kernels of the same storage type (C3D_OPT_CONVT_MFMA = 0) agree with the matrix-core ones
+        ops.set_option(ops.OPT_CONVT_MFMA, 0)
+        try:
+            out2 = torch.empty_like(out)
+            ops.head_fwd(xd, wd_, out2, B, H, W, C, NC, sig, dt)
+            dx2 = torch.empty_like(dx)
+            dw2 = torch.zeros_like(dw)
+            ops.head_bwd(dd, out2 if sig else None, xd, wd_, dx2, dw2, B, H, W, C, NC, sig, dt)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_option(ops.OPT_CONVT_MFMA, 1)
+        assert (out - out2).abs().max().item() < 1.5e-2 * max(1.0, float(out2.abs().max()))   # (f32 vs bf16-rounded weights)
+        assert ((dx.float() - dx2.float()).norm() / dx2.float().norm()).item() < 1e-2
+        assert (((dw - 1.0) - dw2).norm() / dw2.norm()).item() < 1e-2
