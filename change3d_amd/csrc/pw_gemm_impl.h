@@ -29,7 +29,7 @@
 #ifdef C3D_PW_CLOCK
 // Debug build only (tools/pw_phase_clock.py): per-phase shader-clock sums over all waves.
 constexpr int CLK_WAVES = 8192;
-__device__ unsigned long long c3d_pw_clk[CLK_WAVES][16];   // per-wave slots (atomics on shared slots stall the launch)
+static __device__ unsigned long long c3d_pw_clk[CLK_WAVES][16];   // per-wave slots (atomics on shared slots stall the launch); one per translation unit
 #define CLK_DECL unsigned long long clk_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long clk_last_ = __builtin_amdgcn_s_memtime();
 #define CLK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); clk_[i] += t_ - clk_last_; clk_last_ = t_; }
 #define CLK_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -797,6 +797,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         }
       }
       if constexpr (WG != 0) {
+        CLK(6)
         // ---------------- fused weight gradient of this 16-row tile ---------------------------------
         // Os now holds Q (rows past M and the padding columns kept the zero accumulators of zero operand rows / zero weight
         // rows); a wave's LDS writes are ordered before its later LDS reads: no barrier
@@ -827,6 +828,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             }
           }
         }
+        CLK(14)
       }
     };
 

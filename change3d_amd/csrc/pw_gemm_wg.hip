@@ -26,3 +26,16 @@ __attribute__((visibility("hidden"))) int c3d_detail_pw_gemm_wg(const c3d_pw_arg
   if (a.wg_mode == C3D_WG_ROWS && a.epi_mode == C3D_EPI_ADD) return dispatch_wg<C3D_EPI_ADD, C3D_WG_ROWS>(a, s);
   return C3D_E_UNSUPPORTED;
 }
+
+#ifdef C3D_PW_CLOCK
+extern "C" int c3d_debug_pw_wg_clock(unsigned long long* out, int reset) {   // out[CLK_WAVES][16]: the fused variants' phase clocks
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(c3d_pw_clk), sizeof(unsigned long long) * CLK_WAVES * 16);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(c3d_pw_clk));
+    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * CLK_WAVES * 16);
+  }
+  return (int)e;
+}
+#endif

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CLK_LIB = os.path.join(ROOT, "change3d_amd", "lib", "libchange3d_hip_clk.so")
 PHASES = ["zero X region", "wait loads", "convert+prologue", "issue prefetch", "mfma", "stage Os", "epilogue+store",
-          "loop exit", "stats flush", "params+first issue", "zero W, Pp", "barrier 1", "W load+scatter", "barrier 2"]
+          "loop exit", "stats flush", "params+first issue", "zero W, Pp", "barrier 1", "W load+scatter", "barrier 2",
+          "fused weight gradient"]
 NP = len(PHASES)
 
 
@@ -23,7 +24,7 @@ def build():
     import __graft_entry__ as g
     g.build(verbose=False)
     objdir = os.path.join(g.LIBDIR, "obj")
-    clk = ["pw_gemm.hip", "pw_wgrad.hip", "dw_bwd_fused.hip"]
+    clk = ["pw_gemm.hip", "pw_gemm_wg.hip", "pw_wgrad.hip", "dw_bwd_fused.hip"]
     procs = []
     for src in clk:
         o = os.path.join(objdir, src.replace(".hip", "_clk.o"))
@@ -40,13 +41,17 @@ def main():
     import torch
     from change3d_amd import _lib, ops
     h = _lib.lib()
-    h.c3d_debug_pw_clock.restype = C.c_int
-    h.c3d_debug_pw_clock.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    readers = {}
+    for nm in ("c3d_debug_pw_clock", "c3d_debug_pw_wg_clock"):   # one clock array per translation unit (plain / fused variants)
+        f = getattr(h, nm)
+        f.restype, f.argtypes = C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]
+        readers[nm] = f
     buf = (C.c_ulonglong * (8192 * 16))()
+    state = {"reader": "c3d_debug_pw_clock"}
 
     def read(reset=True):
         torch.cuda.synchronize()
-        assert h.c3d_debug_pw_clock(buf, 1 if reset else 0) == 0
+        assert readers[state["reader"]](buf, 1 if reset else 0) == 0
         import numpy as np
         a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 16).astype(np.float64)
         a = a[a[:, 15] > 0]
@@ -88,9 +93,20 @@ def main():
                                                             pro_mode=ops.PRO_AFFINE2, pro_p=coef3, epi_mode=ops.EPI_ADD,
                                                             e1=c_, res_mode=0, w_img=iat),
         }
+        if Ci <= 112:   # the fused data + weight gradient variants (res2 / res3; csrc/pw_gemm_wg.hip)
+            dwa_, dwc_ = torch.zeros(Ci, Cin, device=DEV), torch.zeros(Co, Ci, device=DEV)
+            x3 = rt(M, Cin)
+            cases["conv_c bwd-d AFFINE2+SWISH_SE_BWD +dW"] = lambda: ops.pw_gemm(
+                c_, wc, a_, M=M, K=Co, N=Ci, w_sn=1, w_sk=Ci, dtype=dt, x2=c_, pro_mode=ops.PRO_AFFINE2, pro_p=coefo,
+                epi_mode=ops.EPI_SWISH_SE_BWD, e1=b_, epi_p=ss, epi_gate=gate, epi_q=ss, stats=nc3, rows_per_sample=rps,
+                w_img=ict, wg_mode=ops.WG_SWISH, wg_dw=dwc_)
+            cases["conv_a bwd-d AFFINE2+ADD +dW"] = lambda: ops.pw_gemm(
+                a_, wa, x, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=b_, pro_mode=ops.PRO_AFFINE2, pro_p=coef3,
+                epi_mode=ops.EPI_ADD, e1=c_, res_mode=0, w_img=iat, wg_mode=ops.WG_ROWS, wg_dw=dwa_, wg_x3=x3)
         for name, fn in cases.items():
             if only and not any(o in f"s{st} {name}" for o in only):
                 continue
+            state["reader"] = "c3d_debug_pw_wg_clock" if name.endswith("+dW") else "c3d_debug_pw_clock"
             for _ in range(3):
                 fn()
             read()
