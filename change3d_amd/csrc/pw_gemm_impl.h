@@ -314,6 +314,8 @@ struct PwLaunch {
   int w_off, p_off, wave_off, wave_bytes, os_off, gs_off;  // byte offsets in dynamic LDS
   int flush_shuffle_max;  // row-lanes per channel vector up to which the final sums are shuffled instead of dumped
   int se_off;             // consumer-side SqueezeExcitation gate (a.se_w1): byte offset of the [PW_SE_NS][Kp] gates + [PW_SE_NS][32] hidden units
+  int wg_pair;            // fused weight gradient: 1 = a second result-tile buffer per wave (os_off2), tiles are taken in pairs
+  int os_off2;
   int dw_off, ldw;        // fused weight gradient (WG != 0): byte offset and row stride (floats) of the workgroup's dW accumulators
 };
 
@@ -366,7 +368,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   float* Pp = reinterpret_cast<float*>(smem + L.p_off);  // prologue parameters [3][Kp]
   unsigned char* wreg = smem + L.wave_off + (size_t)wave * L.wave_bytes;
   lds_t* Xs = reinterpret_cast<lds_t*>(wreg);
-  os_t* Os = reinterpret_cast<os_t*>(wreg + L.os_off);
+  os_t* const OsA = reinterpret_cast<os_t*>(wreg + L.os_off);
+  os_t* const OsB = (WG != 0 && L.wg_pair) ? reinterpret_cast<os_t*>(wreg + L.os_off2) : OsA;   // odd tiles of an iteration (pairs)
   float* Gs = reinterpret_cast<float*>(wreg + L.gs_off);  // gate of the current sample [Kp]
   double* dWs = reinterpret_cast<double*>(smem + L.dw_off);  // WG: f64 dW accumulators [ceil(Kp/16)*16][L.ldw], shared by the waves
   const int wg_ntp = (Kp + 15) >> 4, wg_ntq = (Np + 15) >> 4;
@@ -678,7 +681,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     CLK(3)
 
     // stage one 16-row result tile to Os, run the fused epilogue over it, store
-    auto finish_tile = [&](const f32x4_t (&acc)[NT], const int row0, const bool has_next, const lds_t* xt) {
+    // wg_prev: the first tile of a weight-gradient PAIR (its P rows and its Q tile in the other result buffer), or nullptr;
+    // wg_defer: this tile's weight-gradient step is left to the next tile of the iteration (which passes it as wg_prev)
+    auto finish_tile = [&](const f32x4_t (&acc)[NT], const int row0, const bool has_next, const lds_t* xt, os_t* const Os,
+                           const lds_t* const wg_prev_x, const os_t* const wg_prev_q, const bool wg_defer) {
       // ---------------- stage result tile: Os[row = lane&15][channel] -------------------------
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -798,33 +804,75 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       }
       if constexpr (WG != 0) {
         CLK(6)
-        // ---------------- fused weight gradient of this 16-row tile ---------------------------------
+        // ---------------- fused weight gradient ------------------------------------------------------
         // Os now holds Q (rows past M and the padding columns kept the zero accumulators of zero operand rows / zero weight
-        // rows); a wave's LDS writes are ordered before its later LDS reads: no barrier
-        const int g4 = lane >> 4, li = lane & 15;
-        const lds_s16x4_ptr_t pp = (lds_s16x4_ptr_t)(xt + (4 * g4 + (li >> 2)) * KL + 4 * (li & 3));
-        const lds_s16x4_ptr_t qp = (lds_s16x4_ptr_t)(Os + (4 * g4 + (li >> 2)) * NL + 4 * (li & 3));
-        constexpr int NTPM = WG == C3D_WG_SWISH ? WG_NTP_MAX_SWISH : WG_NTP_MAX;
-        s16x4_t pf[NTPM];
+        // rows); a wave's LDS writes are ordered before its later LDS reads: no barrier.  With a second result buffer the
+        // tiles of an iteration are taken in PAIRS (32 rows = one k-step of v_mfma_f32_16x16x32_bf16): half the ds_add_f64 per
+        // row -- the LDS atomic rate (8 clocks per wave-instruction per CU) is what this step runs at.
+        if (!wg_defer) {
+          const int g4 = lane >> 4, li = lane & 15;
+          const int poff = (4 * g4 + (li >> 2)) * KL + 4 * (li & 3), qoff = (4 * g4 + (li >> 2)) * NL + 4 * (li & 3);
+          const lds_s16x4_ptr_t pp = (lds_s16x4_ptr_t)(xt + poff);
+          const lds_s16x4_ptr_t qp = (lds_s16x4_ptr_t)(Os + qoff);
+          const int ldw = L.ldw;
+          double* dwl = dWs + (4 * g4) * ldw + li;
+          // the smaller operand side is held as fragments, the other is walked by a real loop (fully unrolled, the compiler
+          // keeps every zero-initialised MFMA result in flight: 200 registers, 800 B of scratch): conv_c (C3D_WG_SWISH) holds
+          // its <= 3 P tiles (K = block output channels), conv_a (C3D_WG_ROWS) its <= NT Q tiles (N = block input channels)
+          constexpr bool HOLD_P = WG == C3D_WG_SWISH;
+          constexpr int NH = HOLD_P ? WG_NTP_MAX_SWISH : NT;
+          const int n_hold = HOLD_P ? wg_ntp : wg_ntq, n_walk = HOLD_P ? wg_ntq : wg_ntp;
+          const lds_s16x4_ptr_t hp = HOLD_P ? pp : qp, wp = HOLD_P ? qp : pp;
+          // dW[p-channel tile][q-channel tile]: element (4 g4 + r, li) of tile (ip, iq) at dwl + ip*16*ldw + iq*16 + r*ldw
+          const int hstep = HOLD_P ? 16 * ldw : 16, wstep = HOLD_P ? 16 : 16 * ldw;
+          if (wg_prev_x) {          // pair: k = 8 rows per lane, 4 of the previous tile then 4 of this one (same map for P and Q)
+            const lds_s16x4_ptr_t pp0 = (lds_s16x4_ptr_t)(wg_prev_x + poff);
+            const lds_s16x4_ptr_t qp0 = (lds_s16x4_ptr_t)(wg_prev_q + qoff);
+            const lds_s16x4_ptr_t hp0 = HOLD_P ? pp0 : qp0, wp0 = HOLD_P ? qp0 : pp0;
+            typedef short s16x8_t __attribute__((ext_vector_type(8)));
+            s16x8_t hf[NH];
 #pragma unroll
-        for (int i = 0; i < NTPM; ++i)
-          if (i < wg_ntp) pf[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pp + i * 4);   // 16 channels = 4 chunks of 8 bytes on
-        // one Q fragment at a time (a real loop: fully unrolled, the compiler keeps all NT x 7 zero-initialised MFMA results
-        // in flight -- 200 registers, 800 B of scratch)
-        const int ldw = L.ldw;
-        double* dwl = dWs + (4 * g4) * ldw + li;
+            for (int i = 0; i < NH; ++i)
+              if (i < n_hold) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(hp0 + i * 4), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(hp + i * 4);
+                hf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              }
 #pragma unroll 1
-        for (int j = 0; j < wg_ntq; ++j) {
-          const s16x4_t qf = __builtin_amdgcn_ds_read_tr16_b64_v4i16(qp + j * 4);
+            for (int j = 0; j < n_walk; ++j) {
+              const s16x4_t wlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(wp0 + j * 4), whi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(wp + j * 4);
+              const s16x8_t wf = __builtin_shufflevector(wlo, whi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-          for (int i = 0; i < NTPM; ++i) {
-            if (i < wg_ntp) {
-              const f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf[i], qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-              double* dst = dwl + (i * 16) * ldw + j * 16;
+              for (int i = 0; i < NH; ++i) {
+                if (i < n_hold) {
+                  const bf16x8_t pa = __builtin_bit_cast(bf16x8_t, HOLD_P ? hf[i] : wf), qb = __builtin_bit_cast(bf16x8_t, HOLD_P ? wf : hf[i]);
+                  const f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, qb, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                  double* dst = dwl + i * hstep + j * wstep;
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                __hip_atomic_fetch_add(dst + r * ldw, (double)d[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __builtin_amdgcn_sched_barrier(0);   // one product in flight: 7 hoisted MFMAs + their f64 conversions spilled 160 B
+                  for (int r = 0; r < 4; ++r)
+                    __hip_atomic_fetch_add(dst + r * ldw, (double)d[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            }
+          } else {                  // single tile (k = 16 rows)
+            s16x4_t hf[NH];
+#pragma unroll
+            for (int i = 0; i < NH; ++i)
+              if (i < n_hold) hf[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(hp + i * 4);   // 16 channels = 4 chunks of 8 bytes on
+#pragma unroll 1
+            for (int j = 0; j < n_walk; ++j) {
+              const s16x4_t wf = __builtin_amdgcn_ds_read_tr16_b64_v4i16(wp + j * 4);
+#pragma unroll
+              for (int i = 0; i < NH; ++i) {
+                if (i < n_hold) {
+                  const f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(HOLD_P ? hf[i] : wf, HOLD_P ? wf : hf[i], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                  double* dst = dwl + i * hstep + j * wstep;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    __hip_atomic_fetch_add(dst + r * ldw, (double)d[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __builtin_amdgcn_sched_barrier(0);   // one product in flight: 7 hoisted MFMAs + their f64 conversions spilled 160 B
+                }
+              }
             }
           }
         }
@@ -893,8 +941,17 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         }
       }
       CLK(4)
-      finish_tile(acc, row0, MT == 2 ? two : (sub + 1 < L.tpi && tile + 1 < t1), Xt);
-      if (MT == 2 && two) finish_tile(acc2, row0 + 16, sub + 2 < L.tpi && tile + 2 < t1, Xt + 16 * KL);
+      if constexpr (WG != 0 && MT == 1) {
+        // weight-gradient pairs: the even tile of an iteration defers its step when the odd one follows in the same iteration
+        const bool nxt = sub + 1 < L.tpi && tile + 1 < t1;
+        const bool odd = (sub & 1) != 0;
+        const bool pair = L.wg_pair != 0;
+        finish_tile(acc, row0, nxt, Xt, odd ? OsB : OsA, (pair && odd) ? Xt - 16 * KL : nullptr, (pair && odd) ? OsA : nullptr,
+                    pair && !odd && nxt);
+      } else {
+        finish_tile(acc, row0, MT == 2 ? two : (sub + 1 < L.tpi && tile + 1 < t1), Xt, OsA, nullptr, nullptr, false);
+        if (MT == 2 && two) finish_tile(acc2, row0 + 16, sub + 2 < L.tpi && tile + 2 < t1, Xt + 16 * KL, OsA, nullptr, nullptr, false);
+      }
       CLK(6)
     }
   }
@@ -1029,7 +1086,12 @@ bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   const size_t se_bytes = (PRO == C3D_PRO_BN_SE_SWISH && a.se_w1) ? al16((size_t)PW_SE_NS * (a.Kp + PW_SE_CR) * sizeof(float)) : 0;
   for (int tpi = PW_SLOTS / Q; tpi >= 1; --tpi) {
     const size_t xs_bytes = al16((size_t)tpi * 16 * KL * sizeof(typename MM::lds_t));
-    const size_t wave_bytes = xs_bytes + os_bytes + gs_bytes;
+    size_t wave_bytes = xs_bytes + os_bytes + gs_bytes;
+    // fused weight gradient: a second result-tile buffer per wave (tile pairs) when the iteration has >= 2 tiles and it fits
+    const bool pair = WG != 0 && tpi >= 2 && w_bytes + p_bytes + WAVES * (wave_bytes + os_bytes) + dw_bytes + se_bytes <= 160 * 1024;
+    L.wg_pair = pair ? 1 : 0;
+    L.os_off2 = (int)(xs_bytes + os_bytes + gs_bytes);
+    if (pair) wave_bytes += os_bytes;
     const size_t total = w_bytes + p_bytes + WAVES * wave_bytes + dw_bytes + se_bytes;
     if (total <= 160 * 1024) {
       L.tpi = tpi; L.xs_rows = tpi * 16;
