@@ -15,7 +15,7 @@ EPI_STORE, EPI_STATS, EPI_SWISH_SE_BWD, EPI_ADD = 0, 1, 2, 3
 ROWS_DENSE, ROWS_FRAME, ROWS_STRIDE2, ROWS_S2SHIFT = 0, 1, 2, 3
 SC_NONE, SC_IDENTITY, SC_BN, SC_RAW = 0, 1, 2, 3
 STAT_STRIPES = 16
-OPT_SIDE_STREAM, OPT_STEM_MFMA, OPT_CONVT_MFMA, OPT_FUSE_WGRAD, OPT_FOLD_SE = 0, 1, 2, 3, 4
+OPT_SIDE_STREAM, OPT_STEM_MFMA, OPT_CONVT_MFMA, OPT_FUSE_WGRAD, OPT_FOLD_SE, OPT_MASK_IN_DGRAD = 0, 1, 2, 3, 4, 5
 STAGE_SEPARATE_FINALIZE, STAGE_NO_WEIGHT_IMAGES, STAGE_SEPARATE_RESIDUAL, STAGE_SEPARATE_WGRAD = 1, 2, 4, 8
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
@@ -34,7 +34,7 @@ class PwArgs(C.Structure):
                 ("K", i32), ("Kp", i32), ("N", i32), ("Np", i32), ("w_sn", i32), ("w_sk", i32),
                 ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32),
                 ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32), ("fin", BnFin), ("bias", vp), ("pro_out", vp), ("w_img", vp),
-                ("wg_x3", vp), ("wg_dw", vp), ("wg_ws", vp), ("wg_mode", i32), ("wg_reserved", i32),
+                ("wg_x3", vp), ("wg_dw", vp), ("wg_ws", vp), ("wg_mode", i32), ("wg_mask_out", i32),
                 ("se_w1", vp), ("se_b1", vp), ("se_w2", vp), ("se_b2", vp), ("se_hid", vp), ("se_cr", i32), ("se_reserved", i32)]
 
 

@@ -798,6 +798,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
               }
             }
           }
+          if constexpr (WG == C3D_WG_ROWS) {
+            if (a.wg_mask_out) {   // g = dx * (y > 0) of the previous block's output y = wg_x3 (relu output: > 0 <=> nonzero bits)
+              const uint32_t xw[4] = {x3c.x, x3c.y, x3c.z, x3c.w};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) f[j] = ((xw[j >> 1] >> ((j & 1) * 16)) & 0x7fffu) != 0u && !((xw[j >> 1] >> ((j & 1) * 16)) & 0x8000u) ? f[j] : 0.f;
+            }
+          }
           Vec8<T>::store(Y + yoff, f);
           if constexpr (WG == C3D_WG_ROWS) *reinterpret_cast<typename RW::type*>(Os + row * NL + v_o * 8) = x3c;
         }

@@ -97,6 +97,7 @@ inline bool fuse_wgrad(const c3d_stage_desc* d, int Kp, int Np) {
   return !(d->flags & C3D_STAGE_SEPARATE_WGRAD) && d->dtype == C3D_DT_BF16 && Kp <= 112 && Np <= 112 && c3d_knob("C3D_PW_WG", 1);
 }
 
+int g_mask_in_dgrad = 1;   // c3d_set_option(C3D_OPT_MASK_IN_DGRAD, ...)
 int g_fold_se = 1;         // c3d_set_option(C3D_OPT_FOLD_SE, ...): SE gate computed by conv_c's workgroups (forward)
 int g_fuse_wgrad = 3;      // c3d_set_option(C3D_OPT_FUSE_WGRAD, ...): bit 0 conv_a, bit 1 conv_c
 
@@ -699,6 +700,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   const bool wimg = use_pw_img(d);   // transposed weight images written by this step's c3d_stage_fwd (training mode)
   auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
   const void* cur_dy = dy;
+  bool premasked = false;   // cur_dy is already dy * (y > 0): the conv_a data gradient of the block above stored it that way
   std::deque<uint64_t> lag;   // side-stream marks of the blocks whose ring slots are still in flight
   for (int i = d->n_blocks - 1; i >= 0; --i) {
     const c3d_block_desc& k = d->blocks[i];
@@ -731,6 +733,12 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
         return c3d_bn_bwd_coef(dsums, 1, count, bn.gamma, mr, C, Cp, out, bn.dgamma, bn.dbeta, st); });
     };
     // ---- y = relu(bn_c(c) + shortcut)
+    if (premasked) {   // the mask was applied where dy was produced (c3d_pw_args.wg_mask_out): statistics only, g IS dy
+      g = const_cast<void*>(cur_dy);
+      RC(prof_call("c3d_block_out_bwd", (double)G.Mo * G.Cop * (scbn ? 3 : 2) * e, st, [&] {
+        return c3d_block_out_bwd(cur_dy, nullptr, c, scbn ? sc : nullptr, nullptr, mr_c, scbn ? mr_1 : nullptr, dsums_c,
+                                 scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, st); }));
+    } else
     RC(prof_call("c3d_block_out_bwd", (double)G.Mo * G.Cop * (scbn ? 5 : 4) * e, st, [&] {
       return c3d_block_out_bwd(cur_dy, y, c, scbn ? sc : nullptr, g, mr_c, scbn ? mr_1 : nullptr, dsums_c,
                                scbn ? dsums_1 : nullptr, G.Mo, G.Co, G.Cop, dt, st); }));
@@ -805,6 +813,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     // ---- conv_a data gradient (+ shortcut gradient in the epilogue) and weight gradient (forked first: it needs the
     //      coefficients, not the data gradient)
     const bool fuse_wa = (g_fuse_wgrad & 1) && fuse_wgrad(d, G.Cip, G.Cinp);
+    bool mask_next = false;
     if (!fuse_wa)
     RC(side_run(st, [&](hipStream_t s2) {
       WgCall w(t2, xin, k.dw_a, wgws, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
@@ -815,6 +824,9 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     {
       PwCall p(t2, k.w_a, dx, G.M, G.Ci, G.Cin, 1, G.Cin, dt);
       if (fuse_wa) { p.a.wg_mode = C3D_WG_ROWS; p.a.wg_x3 = xin; p.a.wg_dw = k.dw_a; p.a.wg_ws = wgws_fused; }
+      // xin is the previous block's output y: its ReLU mask goes onto dx here, c3d_block_out_bwd of that block only sums
+      mask_next = fuse_wa && i > 0 && g_mask_in_dgrad;
+      p.a.wg_mask_out = mask_next ? 1 : 0;
       p.a.x2 = a; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_a;
       if (consb) p.a.fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, true);
       p.a.epi_mode = C3D_EPI_ADD; p.a.e1 = res; p.a.res_mode = res_mode; p.a.H = G.H; p.a.W = G.W;
@@ -825,6 +837,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     lag.push_back(side_mark());
     if ((int)lag.size() >= bwd_ring()) { RC(side_join(st, lag.front())); lag.pop_front(); }
     cur_dy = dx;
+    premasked = mask_next;
   }
   return 0;
 }
@@ -839,6 +852,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_CONVT_MFMA: c3d_option_convt_mfma = value ? 1 : 0; return 0;
     case C3D_OPT_FUSE_WGRAD: g_fuse_wgrad = value & 3; return 0;
     case C3D_OPT_FOLD_SE: g_fold_se = value ? 1 : 0; return 0;
+    case C3D_OPT_MASK_IN_DGRAD: g_mask_in_dgrad = value ? 1 : 0; return 0;
     default: return C3D_E_BADARG;
   }
 }

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib as L
-from ._lib import (OPT_CONVT_MFMA, OPT_FOLD_SE, OPT_FUSE_WGRAD, OPT_SIDE_STREAM, OPT_STEM_MFMA, STAGE_NO_WEIGHT_IMAGES, STAGE_SEPARATE_FINALIZE,  # noqa: F401
+from ._lib import (OPT_CONVT_MFMA, OPT_FOLD_SE, OPT_FUSE_WGRAD, OPT_MASK_IN_DGRAD, OPT_SIDE_STREAM, OPT_STEM_MFMA, STAGE_NO_WEIGHT_IMAGES, STAGE_SEPARATE_FINALIZE,  # noqa: F401
                    STAGE_SEPARATE_RESIDUAL, STAGE_SEPARATE_WGRAD)
 from ._lib import (DT_BF16, DT_F32, EPI_ADD, EPI_STATS, EPI_STORE, EPI_SWISH_SE_BWD, PRO_AFFINE2,  # noqa: F401
                    PRO_BN_SE_SWISH, PRO_NONE, ROWS_DENSE, ROWS_FRAME, ROWS_S2SHIFT, ROWS_STRIDE2, SC_BN,
@@ -261,11 +261,11 @@ WG_NONE, WG_SWISH, WG_ROWS = 0, 1, 2
 def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, pro_p=None,
             pro_gate=None, epi_mode=EPI_STORE, e1=None, epi_p=None, epi_gate=None, epi_q=None, stats=None,
             rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, res_mode=0,
-            x_ptr=None, e1_ptr=None, fin=None, bias=None, pro_out=None, w_img=None, wg_mode=WG_NONE, wg_x3=None, wg_dw=None):
+            x_ptr=None, e1_ptr=None, fin=None, bias=None, pro_out=None, w_img=None, wg_mode=WG_NONE, wg_x3=None, wg_dw=None, wg_mask_out=0):
     a = L.PwArgs()
     a.w_img = _p(w_img)
     if wg_mode != WG_NONE:   # weight gradient fused into this data-gradient launch (include/change3d_hip.h c3d_pw_args.wg_mode)
-        a.wg_mode, a.wg_x3, a.wg_dw = wg_mode, _p(wg_x3), _p(wg_dw)
+        a.wg_mode, a.wg_x3, a.wg_dw, a.wg_mask_out = wg_mode, _p(wg_x3), _p(wg_dw), int(wg_mask_out)
         a.wg_ws = _ws(wg_dw.device, L.lib().c3d_pw_gemm_wg_ws_floats(K, N)).data_ptr()
     if fin is not None:
         a.fin = fin

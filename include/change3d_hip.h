@@ -135,7 +135,9 @@ typedef struct c3d_pw_args {
   float* wg_dw;
   float* wg_ws;
   int32_t wg_mode;
-  int32_t wg_reserved;
+  int32_t wg_mask_out;   /* C3D_WG_ROWS with C3D_EPI_ADD: 1 = the stored output is dx * (wg_x3 > 0) -- the ReLU mask of the PREVIOUS   */
+                         /* block's output (wg_x3 is that output), i.e. the g = dy * (y > 0) of c3d_block_out_bwd, which then */
+                         /* only has to produce the BatchNorm-backward sums (its y = g = NULL form)                          */
   /* ---- SqueezeExcitation gate computed by the CONSUMER (round 4): with C3D_PRO_BN_SE_SWISH, fin.sums (per-sample sums of
    * c3d_dw333_fwd, fin.batch > 0) and se_w1 != NULL, every workgroup of the narrow kernel rebuilds BatchNorm_b's scale / shift
    * AND the SE gate of the samples its rows belong to (z = bn(mean_n), FC1 + ReLU, FC2 + sigmoid: the arithmetic and summation
@@ -280,6 +282,7 @@ int c3d_block_out_fwd(const void* c, const float* ss_c, const void* shortcut, co
  * C = real channel count.  fin_1 is NULL unless sc_mode is BN.                                                     */
 int c3d_block_out_fwd_fin(const void* c, const c3d_bn_fin* fin_c, const void* shortcut, const c3d_bn_fin* fin_1,
                           int32_t sc_mode, void* y, int64_t M, int32_t C, int32_t Cp, int32_t dtype, void* stream);
+/* y == NULL and g == NULL: `dy` already IS dy * (y > 0) (masked by its producer, c3d_pw_args.wg_mask_out): only the sums. */
 int c3d_block_out_bwd(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
                       const float* mr_c, const float* mr_1, double* dsums_c, double* dsums_1, int64_t M,
                       int32_t C, int32_t Cp, int32_t dtype, void* stream);
@@ -497,8 +500,11 @@ int c3d_side_join(void* stream);
  *   C3D_OPT_FUSE_WGRAD  : which pointwise weight gradients the stage driver fuses into their data-gradient launch where the
  *                         shape allows it (c3d_pw_args.wg_mode): bit 0 = conv_a, bit 1 = conv_c; default = measured best
  *   C3D_OPT_FOLD_SE     : 0 = c3d_bn_se_finalize launches for the blocks with SqueezeExcitation (default 1: conv_c's workgroups
- *                         compute the gate of their samples, c3d_pw_args.se_w1)                                          */
-enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3, C3D_OPT_FOLD_SE = 4 };
+ *                         compute the gate of their samples, c3d_pw_args.se_w1)
+ *   C3D_OPT_MASK_IN_DGRAD : 0 = c3d_block_out_bwd applies the ReLU mask itself everywhere (default 1: conv_a's fused data-gradient
+ *                         launch of the NEXT block stores dx * (y > 0), c3d_block_out_bwd only sums)                       */
+enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3, C3D_OPT_FOLD_SE = 4,
+       C3D_OPT_MASK_IN_DGRAD = 5 };
 int c3d_set_option(int32_t option, int32_t value);
 /* Per-launch profile of the stage driver: between c3d_prof_begin and c3d_prof_end every kernel c3d_stage_fwd /
  * c3d_stage_bwd enqueue is bracketed by a HIP event pair on its launch stream and billed its algorithmic bytes

@@ -112,6 +112,28 @@ def test_conv_a_data_gradient_with_fused_weight_gradient(Ci, Cin, M, res_mode):
     P = q(A * t2 + Bc + Cc * a_, DT).double()
     ref = (P.t() @ xin.double() + 1.0).float()
     assert _rel(dw, ref) < 2e-5, _rel(dw, ref)
+    # wg_mask_out: the stored data gradient carries the ReLU mask of the previous block's output (= wg_x3), i.e. it IS the
+    # g = dy * (y > 0) of c3d_block_out_bwd, whose statistics-only form (y = g = NULL) then gives the same sums
+    xin_relu = torch.relu(xin)
+    xrd = padc(xin_relu, Cinp).to(DEV, DT).contiguous()
+    dx_m = torch.full((M, Cinp), float("nan"), dtype=DT, device=DEV)
+    dw_m = torch.zeros((Ci, Cin), dtype=torch.float32, device=DEV)
+    ops.pw_gemm(t2d, wd, dx_m, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=ad, pro_mode=ops.PRO_AFFINE2, pro_p=coef,
+                epi_mode=ops.EPI_ADD, e1=rd, res_mode=res_mode, H=H, W=W, wg_mode=ops.WG_ROWS, wg_dw=dw_m, wg_x3=xrd, wg_mask_out=1)
+    torch.cuda.synchronize()
+    want = torch.where(xrd > 0, dx_a, torch.zeros_like(dx_a))
+    assert torch.equal(dx_m.view(torch.int16), want.view(torch.int16))
+    cten = q(rnd((M, Cin), 29), DT)
+    cd_ = padc(cten, Cinp).to(DEV, DT).contiguous()
+    mr = torch.cat([padc(rnd((Cin,), 30, 0.5), Cinp), padc(rnd((Cin,), 31).abs() + 0.5, Cinp)]).to(DEV)
+    s_full = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+    g_full = torch.empty_like(dx_a)
+    ops.block_out_bwd(dx_a, xrd, cd_, None, g_full, mr, None, s_full, None, M, Cin, dt)
+    s_pre = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+    ops.block_out_bwd(dx_m, None, cd_, None, None, mr, None, s_pre, None, M, Cin, dt)
+    torch.cuda.synchronize()
+    assert torch.equal(g_full.view(torch.int16), dx_m.view(torch.int16))
+    assert torch.allclose(s_full, s_pre, rtol=1e-12, atol=0)
 
 
 def test_fused_weight_gradient_refuses_shapes_it_does_not_take():
