@@ -1085,7 +1085,7 @@ bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   const size_t w_bytes = al16((size_t)NT * 16 * KL * sizeof(typename MM::lds_t));
   const size_t p_bytes = al16((size_t)3 * a.Kp * sizeof(float));
   const size_t os_bytes = al16((size_t)16 * NL * sizeof(os_t));
-  const size_t gs_bytes = al16((size_t)a.Kp * sizeof(float));
+  const size_t gs_bytes = PRO == C3D_PRO_BN_SE_SWISH ? al16((size_t)a.Kp * sizeof(float)) : 0;   // per-wave gate copy
   // fused weight gradient: workgroup-shared f64 accumulators [ceil(Kp/16)*16][ceil(Np/16)*16 + 4] (row stride = 4 mod 8
   // doubles: the four 16-lane groups of a ds_add_f64 -- rows 4g + r -- fall on the two halves of the 64 banks alternately)
   const int ldw = ((a.Np + 15) / 16) * 16 + 4;

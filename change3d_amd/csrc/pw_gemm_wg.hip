@@ -10,6 +10,9 @@ template <int EPI, int WG>
 int dispatch_wg(const c3d_pw_args& a, hipStream_t s) {
   const int nt = (a.Np + 15) / 16;
   if (nt <= 2) return launch_pw_d<bf16_t, 2, C3D_PRO_AFFINE2, EPI, 8, true, WG>(a, s);
+  // N = 48 (conv_a of res3) on THREE output tiles: the first 48 rows of the NT = 4 weight image; 8 KB less LDS (weights,
+  // result tile) is what lets this variant hold the second result-tile buffer of the weight-gradient pairs
+  if (nt == 3 && WG == C3D_WG_ROWS) return launch_pw_d<bf16_t, 3, C3D_PRO_AFFINE2, EPI, 8, true, WG>(a, s);
   if (nt <= 4) return launch_pw_d<bf16_t, 4, C3D_PRO_AFFINE2, EPI, 8, true, WG>(a, s);
   return launch_pw_d<bf16_t, 7, C3D_PRO_AFFINE2, EPI, 8, true, WG>(a, s);
 }
