@@ -107,7 +107,10 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   const c3d_pw_args& a = *args;
   if (a.M <= 0 || (a.Kp & 7) || (a.Np & 7) || a.K > a.Kp || a.N > a.Np) return C3D_E_BADARG;
   const bool wide = a.Kp > 224 || a.Np > 224 || a.bias != nullptr;
-  if (wide && (a.Kp > 1024 || a.Np > 1024 || a.fin.ticket || a.fin.sums || a.pro_out)) return C3D_E_UNSUPPORTED;
+  // (the block-tiled kernel consumes BatchNorm-BACKWARD sums only: forward statistics tickets stay with the narrow kernel)
+  if (wide && (a.Kp > 1024 || a.Np > 1024 || a.fin.ticket || a.pro_out ||
+               (a.fin.sums && (a.pro_mode != C3D_PRO_AFFINE2 || a.fin.training))))
+    return C3D_E_UNSUPPORTED;
   if (a.pro_out && (a.pro_mode != C3D_PRO_AFFINE2 || a.row_mode != C3D_ROWS_DENSE)) return C3D_E_BADARG;
   if (a.pro_mode == C3D_PRO_AFFINE2 && !a.x2) return C3D_E_BADARG;
   if (a.pro_mode != C3D_PRO_NONE && !a.pro_p && !(a.pro_mode == C3D_PRO_AFFINE2 && a.fin.sums)) return C3D_E_BADARG;
@@ -153,7 +156,9 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
     return c3d_pw_gemm(&b, stream);
   }
   // shapes the wave-private-tile kernel cannot hold in LDS (f32 storage with K*N near 224 x 224): block-tiled kernel
-  if (rc == C3D_E_UNSUPPORTED && !a.fin.ticket && !a.fin.sums && a.wg_mode == C3D_WG_NONE) rc = c3d_detail_pw_gemm_wide(args, stream);
+  if (rc == C3D_E_UNSUPPORTED && !a.fin.ticket && a.wg_mode == C3D_WG_NONE &&
+      (!a.fin.sums || (a.pro_mode == C3D_PRO_AFFINE2 && !a.fin.training)))
+    rc = c3d_detail_pw_gemm_wide(args, stream);
   return rc;
 }
 

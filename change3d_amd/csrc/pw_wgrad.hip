@@ -539,7 +539,7 @@ extern "C" int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream) {
   const c3d_pw_wgrad_args& a = *args;
   if (a.M <= 0 || (a.Kp & 7) || (a.Np & 7) || a.K > a.Kp || a.N > a.Np) return C3D_E_BADARG;
   if (a.Kp > 224 || a.Np > 224) {   // wide layers (res5, caption-decoder linears): block-tiled kernel, f32 atomics
-    if (a.Kp > 1024 || a.Np > 1024 || a.p_fin.sums) return C3D_E_UNSUPPORTED;
+    if (a.Kp > 1024 || a.Np > 1024) return C3D_E_UNSUPPORTED;
     if ((a.p_coef || a.p_fin.sums) && !a.p2) return C3D_E_BADARG;
     if (a.q_mode == C3D_PRO_BN_SE_SWISH && (!a.q_ss || (a.q_gate && a.rows_per_sample <= 0))) return C3D_E_BADARG;
     return c3d_detail_pw_wgrad_wide(args, stream);
@@ -551,7 +551,7 @@ extern "C" int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream) {
   int rc = C3D_E_BADARG;
   if (a.dtype == C3D_DT_F32) rc = launch_wgrad<float>(a, s);
   else if (a.dtype == C3D_DT_BF16) rc = launch_wgrad<bf16_t>(a, s);
-  if (rc == C3D_E_UNSUPPORTED && !a.p_fin.sums) rc = c3d_detail_pw_wgrad_wide(args, stream);   // shapes that do not fit its LDS plan
+  if (rc == C3D_E_UNSUPPORTED) rc = c3d_detail_pw_wgrad_wide(args, stream);   // shapes that do not fit its LDS plan
   return rc;
 }
 

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "../../include/change3d_hip.h"
 #include "pw_common.h"
+#include "bn_fin.h"
 
 namespace {
 
@@ -57,7 +58,15 @@ __global__ __launch_bounds__(256) void pw_wide_kernel(const c3d_pw_args a) {
   f32x4_t acc[WB_NT];
 #pragma unroll
   for (int nt = 0; nt < WB_NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  if (PRO != C3D_PRO_NONE) {
+  if (PRO == C3D_PRO_AFFINE2 && a.fin.sums) {
+    // BatchNorm-backward coefficients rebuilt from the producer's completed sums (csrc/bn_fin.h; no c3d_bn_bwd_coef launch
+    // in front of this kernel); workgroup (0, 0) also accumulates dgamma / dbeta
+    for (int c = tid; c < Kp; c += 256) {
+      float cA, cB, cC;
+      c3dfin::bn_bwd_coef_consume(a.fin, a.K, Kp, c, blockIdx.x == 0 && blockIdx.y == 0, cA, cB, cC);
+      Pp[c] = cA; Pp[Kp + c] = cB; Pp[2 * Kp + c] = cC;
+    }
+  } else if (PRO != C3D_PRO_NONE) {
     const int np = (PRO == C3D_PRO_AFFINE2 ? 3 : 2) * Kp;
     for (int i = tid; i < np; i += 256) Pp[i] = a.pro_p[i];
   }
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(256) void pw_wide_wgrad_kernel(const c3d_pw_wgrad_a
     q_ok = m < mhi && ck < a.Kp;
     if (p_ok) {
       rp = Vec8<T>::load_raw(P + m * a.Np + cn);
-      if (a.p_coef) rp2 = Vec8<T>::load_raw(P2 + m * a.Np + cn);
+      if (a.p_coef || a.p_fin.sums) rp2 = Vec8<T>::load_raw(P2 + m * a.Np + cn);
     }
     if (q_ok) {
       rq = Vec8<T>::load_raw(Q + m * a.Kp + ck);
@@ -389,6 +398,8 @@ __global__ __launch_bounds__(256) void pw_wide_wgrad_kernel(const c3d_pw_wgrad_a
   for (int j = 0; j < 8; ++j) {
     const bool pc = a.p_coef && cn < a.Np;
     pcA[j] = pc ? a.p_coef[cn + j] : 1.f; pcB[j] = pc ? a.p_coef[a.Np + cn + j] : 0.f; pcC[j] = pc ? a.p_coef[2 * a.Np + cn + j] : 0.f;
+    // coefficients rebuilt from the producer's sums (csrc/bn_fin.h); nothing is accumulated here
+    if (a.p_fin.sums && cn < a.Np) c3dfin::bn_bwd_coef_consume(a.p_fin, a.N, a.Np, cn + j, false, pcA[j], pcB[j], pcC[j]);
     const bool qc = a.q_mode == C3D_PRO_BN_SE_SWISH && ck < a.Kp;
     qs[j] = qc ? a.q_ss[ck + j] : 1.f; qh[j] = qc ? a.q_ss[a.Kp + ck + j] : 0.f;
   }
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(256) void pw_wide_wgrad_kernel(const c3d_pw_wgrad_a
       for (int j = 0; j < 8; ++j) f[j] = 0.f;
       if (p_ok) {
         Vec8<T>::cvt_raw(rp, f);
-        if (a.p_coef) {
+        if (a.p_coef || a.p_fin.sums) {
           float f2[8];
           Vec8<T>::cvt_raw(rp2, f2);
 #pragma unroll

@@ -725,9 +725,9 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     double* nc3 = atT<double>(wb, Bk.nc3); double* dsums_a = atT<double>(wb, Bk.dsums_a);
     const int64_t rps = (int64_t)T * G.Ho * G.Wo;
     const bool scbn = G.sc_bn;
-    // BatchNorm-backward coefficients rebuilt by their consumers (narrow bf16 kernels; csrc/bn_fin.h) instead of
+    // BatchNorm-backward coefficients rebuilt by their consumers (bf16 kernels, narrow and wide; csrc/bn_fin.h) instead of
     // c3d_bn_bwd_coef launches
-    const bool consb = fin_consumer(d) && dt == C3D_DT_BF16 && G.Cip <= 224 && G.Cop <= 224 && G.Cinp <= 224;
+    const bool consb = fin_consumer(d) && dt == C3D_DT_BF16;
     auto coef = [&](const double* dsums, double count, const c3d_bn_ptrs& bn, const float* mr, int C, int Cp, float* out) {
       return prof_call("c3d_bn_bwd_coef", 0.0, st, [&] {
         return c3d_bn_bwd_coef(dsums, 1, count, bn.gamma, mr, C, Cp, out, bn.dgamma, bn.dbeta, st); });
