@@ -11,5 +11,6 @@
 extern thread_local int c3d_side_launch;
 
 // c3d_set_option (stage_driver.hip): kernel-family selectors with a parity test between the two implementations
-extern int c3d_option_stem_mfma;    // 1: stem on the matrix cores (stem_mfma.hip), 0: scalar-FMA kernels (stem.hip)
+extern int c3d_option_stem_mfma;    // 2: + c3d_stem_bwd_wx of bf16 storage on the bf16 matrix cores, 1: stem on the f32 matrix cores
+                                    // (stem_mfma.hip), 0: scalar-FMA kernels (stem.hip)
 extern int c3d_option_convt_mfma;   // 1: bf16 ConvTranspose2d on the matrix cores (convt_mfma.hip), 0: decoder.hip's

@@ -843,12 +843,12 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
 }
 
 // ---- profile / runtime switches --------------------------------------------------------------------------------
-int c3d_option_stem_mfma = 1, c3d_option_convt_mfma = 1;   // read by stem.hip / decoder.hip (launch_hints.h)
+int c3d_option_stem_mfma = 2, c3d_option_convt_mfma = 1;   // read by stem.hip / decoder.hip (launch_hints.h)
 
 extern "C" int c3d_set_option(int32_t option, int32_t value) {
   switch (option) {
     case C3D_OPT_SIDE_STREAM: g_side_on = value ? 1 : 0; return 0;
-    case C3D_OPT_STEM_MFMA: c3d_option_stem_mfma = value ? 1 : 0; return 0;
+    case C3D_OPT_STEM_MFMA: c3d_option_stem_mfma = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case C3D_OPT_CONVT_MFMA: c3d_option_convt_mfma = value ? 1 : 0; return 0;
     case C3D_OPT_FUSE_WGRAD: g_fuse_wgrad = value & 3; return 0;
     case C3D_OPT_FOLD_SE: g_fold_se = value ? 1 : 0; return 0;

@@ -522,6 +522,208 @@ __global__ __launch_bounds__(NTHR) void stem_bwd_wx_mfma_kernel(
   }
 }
 
+
+// ---- stem_bwd_wx on the bf16 matrix cores (bf16 storage only; round 4).  Same tile, same walk over the samples as the f32
+// kernel above; what changes is the arithmetic:
+//   d w_t   D[ch][(tap, ci)] += sum_px dv[px][ch] * x[px + tap][ci]: PIXELS are the contraction index, both operands come out of
+//           [pixel][channel] LDS tiles through ds_read_b64_tr_b16 -- dv as it is staged (24 channels per pixel), x as a bf16
+//           [pixel][3 ci + 1 zero] tile whose 8-byte pixel IS one transposed-read chunk: a lane addresses the chunk of tap
+//           4 nt + lane % 4, so the 16 columns of an n-tile are 4 taps x 4 ci without an im2col image.  6 x v_mfma_f32_16x16x16_bf16
+//           and 5 LDS reads per 16 pixels (the f32 kernel: 16 x v_mfma_f32_16x16x4_f32, 32 scalar LDS reads).
+//   d input of the perception frames: dx[ci][px] = sum_tap W[ci][tap][0..31] . dv[px - tap][0..31] -- one k-step of 32 per tap
+//           (24 channels + a zero vector), the B fragment is ONE ds_read_b128 of a neighbour pixel, the nine weight fragments
+//           live in registers (the layout of head_fwd_mfma_kernel); 9 MFMA per 16 pixels against 648 FMA per pixel on the VALU.
+// x (the normalised input image) and w_t are rounded to bf16 for the products; sums stay f32.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr_t;
+
+__device__ __forceinline__ f32x4_t mfma32b(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+template <int TT>
+__global__ __launch_bounds__(NTHR, TT == 3 ? 2 : 1) void stem_bwd_wx_bf16_kernel(
+    const float* __restrict__ x, const float* __restrict__ w_t, const bf16_t* __restrict__ dv, float* __restrict__ dw_t,
+    float* __restrict__ dP, const Geom g, const int t_first, const int n_frames, const int per_sample) {
+  constexpr int NF = TT - 2 > 0 ? TT - 2 : 1;        // perception frames a launch may carry (the host checks n_frames <= NF)
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  bf16_t* dt_ = reinterpret_cast<bf16_t*>(sm);       // [T][IH][IW][24] raw dv with halo
+  bf16_t* xb = dt_ + (size_t)TT * IHW * SC + 8;      // [T][IH][IW][4]: ci 0..2 + a zero  (the 16 bytes in front: m-tile 1 of the
+                                                     // last pixel reads "channels 24..31" there -- rows of D nobody uses)
+  bf16_t* zs = xb + (size_t)TT * IHW * 4;            // 16 bytes of zeros: k-group 3 of the input-gradient B fragment
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g4 = lane >> 4, li = lane & 15;
+  const int tiles_x = (g.W + TW - 1) / TW;
+  for (int i = tid; i < TT * IHW + 2 + 2; i += NTHR)   // xb (its zero column is never written again), the 8 elements in front, zs
+    *reinterpret_cast<uint2*>(xb - 8 + (size_t)i * 4) = make_uint2(0, 0);
+  // input gradient: A[m = ci][k = channel] of tap sp (rows ci >= 3 and channels >= 24 are zero)
+  uint4 wA[9];
+#pragma unroll
+  for (int sp = 0; sp < 9; ++sp) {
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 8 * g4 + j;
+      f[j] = (li < SCI && c < SC) ? w_t[c * 27 + li * 9 + sp] : 0.f;
+    }
+    wA[sp] = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+  }
+  // weight gradient: D[mt][nt], m = channel 16 mt + .., n = 4 (tap - 4 nt) + ci.  Lane offsets of the transposed reads:
+  //   A chunk (pixel 4 g4 + li / 4, channels c0 + 4 (li % 4)) of dv;  B chunk = the pixel of tap 4 nt + li % 4 in xb
+  const int pxl = 4 * g4 + (li >> 2);
+  int boff[3];
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+    int tap = 4 * nt + (li & 3);
+    if (tap > 8) tap = 8;                             // columns nobody reads: any valid address
+    boff[nt] = ((tap / 3) * IW + pxl + tap % 3) * 4;
+  }
+  const int aoff = (IW + 1 + pxl) * SC + 4 * (li & 3);
+  f32x4_t dwacc[2][3];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) dwacc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t dxa[NF][4];
+#pragma unroll
+  for (int k = 0; k < NF; ++k)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dxa[k][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int tl = blockIdx.x;
+  const int tx = tl % tiles_x, ty = tl / tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  for (int b = blockIdx.y; b < g.B; b += gridDim.y) {
+    // the staging addresses do not depend on the sample: left alone, the compiler keeps all ~50 of them (offsets, masks, LDS
+    // addresses) in registers across the walk -- 396 registers, one workgroup per CU.  An opaque copy of the thread index per
+    // iteration makes it recompute them (a few dozen integer operations per tile).
+    int tidv = tid;
+    asm volatile("" : "+v"(tidv));
+    XTile<TT> xq;
+    xq.issue(x, g, b, y0, x0, tidv);
+    constexpr int DITEMS = TT * IHW * 3, DNL = (DITEMS + NTHR - 1) / NTHR;
+    uint4 dr[DNL];
+#pragma unroll
+    for (int j = 0; j < DNL; ++j) {
+      const int i = tidv + j * NTHR;
+      const int cvv = i % 3;
+      int q = i / 3;
+      const int ix = q % IW;
+      q /= IW;
+      const int iy = q % IH, t = q / IH;
+      const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+      dr[j] = make_uint4(0, 0, 0, 0);
+      if (i < DITEMS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
+        dr[j] = *reinterpret_cast<const uint4*>(dv + ((((size_t)b * TT + t) * g.H + gy) * g.W + gx) * SC + cvv * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < XTile<TT>::NL; ++j) {
+      const int i = tidv + j * NTHR;
+      if (i < XTile<TT>::ITEMS) {
+        const int ix = i % IW;
+        int q = i / IW;
+        const int iy = q % IH;
+        q /= IH;                                      // ci * T + t
+        const int ci = q / TT, t = q - ci * TT;
+        xb[((size_t)(t * IH + iy) * IW + ix) * 4 + ci] = f32_to_bf16(xq.r[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DNL; ++j) {
+      const int i = tidv + j * NTHR;
+      if (i < DITEMS) *reinterpret_cast<uint4*>(dt_ + (size_t)i * 8) = dr[j];
+    }
+    __syncthreads();
+    // ---- d input for the perception frames: wave w owns tile rows {2w, 2w+1} x the two 16-pixel segments
+    if (dP) {
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        if (k < n_frames) {
+          const int t = t_first + k;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = 2 * wave + (q >> 1), xs = (q & 1) * 16;
+            f32x4_t acc = per_sample ? f32x4_t{0.f, 0.f, 0.f, 0.f} : dxa[k][q];
+#pragma unroll
+            for (int sp = 0; sp < 9; ++sp) {
+              const int ky = sp / 3, kx = sp - ky * 3;
+              const bf16_t* bp = g4 < 3 ? dt_ + ((size_t)(t * IH + r + 2 - ky) * IW + xs + li + 2 - kx) * SC + 8 * g4 : zs;
+              acc = mfma32b(wA[sp], *reinterpret_cast<const uint4*>(bp), acc);
+            }
+            if (per_sample) {   // dP is a full NCDHW gradient [B][3][T][H][W]; lanes 0..15 hold ci = 0..2 of pixel xs + li
+              const int gy = y0 + r, gx = x0 + xs + li;
+              if (g4 == 0 && gy < g.H && gx < g.W) {
+#pragma unroll
+                for (int ci = 0; ci < SCI; ++ci) dP[((((size_t)b * SCI + ci) * TT + t) * g.H + gy) * g.W + gx] = acc[ci];
+              }
+            } else {
+              dxa[k][q] = acc;
+            }
+          }
+        }
+      }
+    }
+    // ---- d w_t
+#pragma unroll 1
+    for (int t = 0; t < TT; ++t) {
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        const int r = 2 * wave + (q >> 1), xs = (q & 1) * 16;
+        const bf16_t* ap = dt_ + (size_t)((t * IH + r) * IW + xs) * SC + aoff;
+        const bf16_t* bp = xb + (size_t)((t * IH + r) * IW + xs) * 4;
+        const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)ap);
+        const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ap + 16));
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          const s16x4_t bf = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(bp + boff[nt]));
+          dwacc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, bf, dwacc[0][nt], 0, 0, 0);
+          dwacc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, bf, dwacc[1][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (dP && !per_sample) {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      if (k < n_frames) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gy = y0 + 2 * wave + (q >> 1), gx = x0 + (q & 1) * 16 + li;
+          if (g4 == 0 && gy < g.H && gx < g.W) {
+#pragma unroll
+            for (int ci = 0; ci < SCI; ++ci) {
+              float* dst = dP + (((size_t)ci * n_frames + k) * g.H + gy) * g.W + gx;
+              if (gridDim.y == 1) *dst += dxa[k][q][ci];     // sole owner of this pixel
+              else atomicAdd(dst, dxa[k][q][ci]);
+            }
+          }
+        }
+      }
+    }
+  }
+  // d w_t: the four waves' partial tiles through LDS (fixed order), then one atomic per weight and workgroup
+  __syncthreads();
+  float* wred = reinterpret_cast<float*>(dt_);      // [4 waves][32 ch][32 k]
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      const int tap = 4 * nt + (li >> 2), ci = li & 3;
+      if (tap < 9 && ci < SCI) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wred[(wave * 32 + mt * 16 + 4 * g4 + i) * 32 + ci * 9 + tap] = dwacc[mt][nt][i];
+      }
+    }
+  __syncthreads();
+  for (int i = tid; i < SC * 27; i += NTHR) {
+    const int c = i / 27, k = i - c * 27;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) a += wred[(w * 32 + c) * 32 + k];
+    atomicAdd(dw_t + (size_t)c * 27 + k, a);
+  }
+}
+
 template <typename T, int TT>
 int fwd_t(const float* x, const float* w_t, const float* w_xy, void* u, double* sums, const Geom& g, hipStream_t s) {
   const size_t lds = (2 * 4 * 2 * 32 + (size_t)SCI * TT * IHW) * sizeof(float);
@@ -563,6 +765,21 @@ int wx_t(const float* x, const float* w_t, const void* dv, float* dw_t, float* d
   int bsplit = (2 * 256 + ntiles - 1) / ntiles;   // split the batch only when there are too few tiles
   if (bsplit > g.B) bsplit = g.B;
   if (bsplit < 1) bsplit = 1;
+  if (sizeof(T) == 2 && c3d_option_stem_mfma >= 2 && (!dP || n_frames <= (TT - 2 > 0 ? TT - 2 : 1))) {
+    // bf16 storage: both gradients on the bf16 matrix cores (c3d_set_option(C3D_OPT_STEM_MFMA, 1) keeps the f32-MFMA kernel)
+    size_t lb = ((size_t)TT * IHW * SC + 8 + (size_t)TT * IHW * 4 + 8) * sizeof(bf16_t);
+    if (lb < 4 * 32 * 32 * sizeof(float)) lb = 4 * 32 * 32 * sizeof(float);
+    static bool attr_b = false;
+    if (!attr_b) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_bwd_wx_bf16_kernel<TT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_b = true;
+    }
+    stem_bwd_wx_bf16_kernel<TT><<<dim3(ntiles, bsplit), NTHR, lb, s>>>(x, w_t, reinterpret_cast<const bf16_t*>(dv), dw_t, dP, g,
+                                                                      t_first, n_frames, per_sample);
+    return 0;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_bwd_wx_mfma_kernel<T, TT>),

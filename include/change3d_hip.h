@@ -495,7 +495,9 @@ int c3d_side_join(void* stream);
  *   C3D_OPT_SIDE_STREAM : 0 = weight gradients inline on the caller's stream (needed when the step is captured in a HIP
  *                         graph, and for one-kernel-at-a-time traces)
  *   C3D_OPT_STEM_MFMA   : 0 = scalar-FMA stem kernels (csrc/stem.hip) instead of the matrix-core ones (bit-identical
- *                         u / dv / dx: tests/test_model_gpu.py::test_stem_mfma_kernels_equal_the_scalar_kernels)
+ *                         u / dv / dx: tests/test_model_gpu.py::test_stem_mfma_kernels_equal_the_scalar_kernels);
+ *                         1 = f32 matrix-core kernels everywhere; 2 (default) = c3d_stem_bwd_wx of bf16 storage multiplies on
+ *                         the bf16 matrix cores (x and w_t rounded to bf16 for the products, f32 sums)
  *   C3D_OPT_CONVT_MFMA  : 0 = scalar ConvTranspose2d kernels on the bf16 path too
  *   C3D_OPT_FUSE_WGRAD  : which pointwise weight gradients the stage driver fuses into their data-gradient launch where the
  *                         shape allows it (c3d_pw_args.wg_mode): bit 0 = conv_a, bit 1 = conv_c; default = measured best

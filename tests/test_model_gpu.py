@@ -412,12 +412,61 @@ def test_stem_mfma_kernels_equal_the_scalar_kernels(T, dtype, shape):
     try:
         (ea, sa), (eb, sb) = run(True), run(False)
     finally:
-        ops.set_option(ops.OPT_STEM_MFMA, 1)
+        ops.set_option(ops.OPT_STEM_MFMA, 2)
     for k in ea:
         assert torch.equal(ea[k], eb[k]), k
     for k in sa:
         assert (sa[k] - sb[k]).abs().max().item() <= 2e-6 * sb[k].abs().max().item(), k
     assert eb["u"].float().abs().max().item() > 0.1 and eb["dP"].abs().max().item() > 0.1
+
+
+@pytest.mark.parametrize("T,shape", [(3, (2, 40, 72)), (3, (3, 17, 70)), (3, (5, 64, 64)), (4, (2, 16, 48)), (5, (2, 24, 40)), (3, (40, 16, 32))])
+def test_stem_bwd_wx_on_the_bf16_matrix_cores(T, shape):
+    """C3D_OPT_STEM_MFMA = 2 (default): c3d_stem_bwd_wx of bf16 storage multiplies on the bf16 matrix cores (x and w_t rounded to
+    bf16 for the products; reference model/x3d.py:84-95 conv_xy backward).  Against the f32 matrix-core kernel on the same
+    bf16 dv: the rounding of one operand of every product, relative to the largest entry."""
+    _need_gpu()
+    from change3d_amd import ops
+    B, H, W = shape
+    dt = ops.dt_code(torch.bfloat16)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 3, T, H, W, generator=g).to(DEV)
+    w_t = (torch.randn(24, 3, 1, 3, 3, generator=g) * 0.3).to(DEV)
+    dv = torch.randn(B, T, H, W, 24, generator=g).to(DEV).to(torch.bfloat16)
+
+    def run(opt):
+        ops.set_option(ops.OPT_STEM_MFMA, opt)
+        dw_t = torch.ones(24, 27, device=DEV)                   # accumulate semantics
+        dPs = torch.ones(3, T - 2, H, W, device=DEV)
+        ops.stem_bwd_wx(x, w_t, dv, dw_t, dPs, B, T, H, W, 1, T - 2, False, dt)
+        dw_t2 = torch.zeros(24, 27, device=DEV)
+        dP = torch.zeros(B, 3, T, H, W, device=DEV)
+        ops.stem_bwd_wx(x, w_t, dv, dw_t2, dP, B, T, H, W, 1, T - 2, True, dt)
+        dw_t3 = torch.zeros(24, 27, device=DEV)
+        ops.stem_bwd_wx(x, w_t, dv, dw_t3, None, B, T, H, W, 0, 0, False, dt)
+        torch.cuda.synchronize()
+        return dict(dw_t=dw_t, dPs=dPs, dw_t2=dw_t2, dP=dP, dw_t3=dw_t3)
+
+    try:
+        a, b = run(2), run(1)
+    finally:
+        ops.set_option(ops.OPT_STEM_MFMA, 2)
+    for k in a:
+        err = (a[k] - b[k]).abs().max().item() / b[k].abs().max().item()
+        assert err < 6e-3, (k, err)
+    assert torch.equal(a["dP"][:, :, 0], torch.zeros_like(a["dP"][:, :, 0]))   # only the perception frames are written
+    assert (a["dw_t2"] - a["dw_t3"]).abs().max().item() <= 2e-6 * a["dw_t3"].abs().max().item()
+    # and against an f64 convolution of the same tensors
+    xd, wd = x.double().cpu(), w_t.double().cpu()
+    dvd = dv.double().cpu().permute(0, 4, 1, 2, 3)             # [B][24][T][H][W]
+    xd.requires_grad_(True); wd.requires_grad_(True)
+    v = torch.nn.functional.conv3d(xd, wd, padding=(0, 1, 1))
+    (v * dvd).sum().backward()
+    ref_dw = wd.grad.reshape(24, 27).float()
+    ref_dx = xd.grad[:, :, 1:T - 1].sum(0).float()              # [3][T-2][H][W]
+    e_dw = (a["dw_t3"].cpu() - ref_dw).abs().max().item() / ref_dw.abs().max().item()
+    e_dx = (a["dPs"].cpu() - 1.0 - ref_dx).abs().max().item() / ref_dx.abs().max().item()
+    assert e_dw < 6e-3 and e_dx < 6e-3, (e_dw, e_dx)
 
 
 @pytest.mark.parametrize("size", [64, 256])
