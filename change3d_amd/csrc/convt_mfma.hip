@@ -82,12 +82,30 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(const bf16_t* __res
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const int co = nt * 16 + g * 4 + r; bv[nt][r] = co < C ? bias[co] : 0.f; }
+  // Output staging (round 4): the four parity classes of a wave's 16 input pixels are the two output rows 2qy, 2qy+1 x 32
+  // pixels = 2 x 1536 contiguous bytes.  Stored class by class they were 8-byte pieces at a 96-byte stride (and the skip rows
+  // were read the same way, after the MFMAs); now the f32 results go through a per-wave LDS tile [2 rows][32 px][C], the skip
+  // rows are requested as 16-byte vectors BEFORE the MFMAs and the tile leaves as 16-byte vectors of whole rows.
+  constexpr int CH16 = C / 8;                         // 16-byte chunks per output pixel
+  constexpr int NCH = 2 * 32 * CH16;                  // chunks of a wave tile
+  constexpr int NJ = (NCH + 63) / 64;
+  float* Ot = reinterpret_cast<float*>(Wl + 4 * NT * KS * 64) + (size_t)wave * 2 * 32 * C;
   for (int64_t t = ((int64_t)blockIdx.x * 4 + wave); t < ntile; t += (int64_t)gridDim.x * 4) {
     const int tx = (int)(t % tiles_x);
     const int64_t r_ = t / tiles_x;
     const int qy = (int)(r_ % h), b = (int)(r_ / h);
     const int qx = tx * 16 + p;
     const bf16_t* inb = in + (size_t)b * h * wd * C;
+    u32x4 sk[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      const int row = c / (32 * CH16), cc = c - row * (32 * CH16);
+      const int opx = cc / CH16;
+      sk[j] = u32x4{0u, 0u, 0u, 0u};
+      if (skip && c < NCH && tx * 32 + opx < W)
+        sk[j] = ld16(skip + (size_t)b * skip_bstride + ((size_t)(2 * qy + row) * W + tx * 32) * C + (size_t)cc * 8);
+    }
 #pragma unroll
     for (int par = 0; par < 4; ++par) {
       const int py = par >> 1, px = par & 1;
@@ -108,24 +126,32 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(const bf16_t* __res
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(Wl[((par * NT + nt) * KS + ks) * 64 + lane], xf[ks], acc[nt]);
-      if (qx < wd) {
-        const int oy = 2 * qy + py, ox = 2 * qx + px;
-        const size_t o = ((size_t)oy * W + ox) * C;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int co = nt * 16 + g * 4;
-          if (co < C) {
-            float v0 = acc[nt][0], v1 = acc[nt][1], v2 = acc[nt][2], v3 = acc[nt][3];
-            if (skip) {
-              const uint2 s = *reinterpret_cast<const uint2*>(skip + (size_t)b * skip_bstride + o + co);
-              v0 += __uint_as_float(s.x << 16); v1 += __uint_as_float(s.x & 0xffff0000u);
-              v2 += __uint_as_float(s.y << 16); v3 += __uint_as_float(s.y & 0xffff0000u);
-            }
-            *reinterpret_cast<uint2*>(out + (size_t)b * H * W * C + o + co) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-          }
-        }
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 16 + g * 4;
+        if (co < C) *reinterpret_cast<float4*>(Ot + (size_t)(py * 32 + 2 * p + px) * C + co) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
       }
     }
+    __builtin_amdgcn_wave_barrier();                  // (LDS operations of one wave complete in order)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      const int row = c / (32 * CH16), cc = c - row * (32 * CH16);
+      const int opx = cc / CH16;
+      if (c < NCH && tx * 32 + opx < W) {
+        const float4 lo = *reinterpret_cast<const float4*>(Ot + (size_t)row * 32 * C + (size_t)cc * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(Ot + (size_t)row * 32 * C + (size_t)cc * 8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (skip) {
+          const uint32_t sw[4] = {sk[j][0], sk[j][1], sk[j][2], sk[j][3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(sw[e] << 16); v[2 * e + 1] += __uint_as_float(sw[e] & 0xffff0000u); }
+        }
+        *reinterpret_cast<u32x4*>(out + (size_t)b * H * W * C + ((size_t)(2 * qy + row) * W + tx * 32) * C + (size_t)cc * 8) =
+            u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -335,7 +361,7 @@ template <int C>
 int launch_fwd(const void* in, const float* w, const float* bias, const void* skip, int64_t skip_bstride, void* out, int B,
                int h, int wd, hipStream_t st) {
   constexpr int NT = (C + 15) / 16, KS = 4 * C / 32;
-  const size_t lds = (size_t)4 * NT * KS * 64 * 16;
+  const size_t lds = (size_t)4 * NT * KS * 64 * 16 + (size_t)4 * 2 * 32 * C * sizeof(float);
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_fwd_mfma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return C3D_E_UNSUPPORTED;
