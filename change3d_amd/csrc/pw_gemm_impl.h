@@ -468,6 +468,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     }                                                                                          \
   }
 #define PW_ISSUE(TILE0) if constexpr (DENSE) PW_ISSUE_DENSE(TILE0) else { PW_ISSUE_GENERIC(TILE0) }
+  // One slot of PW_ISSUE_DENSE (the Swish-prologue forward re-requests a slot as soon as its registers are free: see the
+  // convert loop)
+#define PW_ISSUE_DENSE_SLOT(TILE0, J, XB, LO)                                                  \
+  {                                                                                            \
+    const int i_ = lane + 64 * slot_q[J];                                                      \
+    const int o_ = slot_s[J] * 16 * Kp + 512 * slot_q[J] + (LO);                               \
+    if (i_ < PW_LIM((TILE0) + slot_s[J])) xr[J] = RW::load((XB) + o_);                         \
+    else xr[J] = RW::zero();                                                                   \
+  }
+  // conv_c forward (BatchNorm x SE x Swish on load: 13 VALU units per element, as long as the memory time of the tile): the
+  // next iteration's rows are requested slot by slot, each right after the prologue that consumed its registers, so the
+  // requests of the first slots are in flight under the activation arithmetic of the others
+  constexpr bool SLOT_REISSUE = DENSE && PRO == C3D_PRO_BN_SE_SWISH && WG == 0 && sizeof(T) == 2;
 
   if (t0 < t1) { PW_ISSUE(t0) }
   CLK(9)
@@ -611,6 +624,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   for (int it0 = t0; it0 < t1; it0 += L.tpi) {
     CLK_WAITVM
     CLK(1)
+    const bool reissue = SLOT_REISSUE && it0 + L.tpi < t1;
+    const T* xb_next = X + (int64_t)(it0 + L.tpi) * 16 * Kp;
+    int lo_next = lane * 8;
+    if constexpr (SLOT_REISSUE) asm volatile("" : "+v"(lo_next));
     // ---------------- convert + prologue -> LDS (all sub-tiles of this iteration) ------------
 #pragma unroll
     for (int j = 0; j < PW_SLOTS; ++j) {
@@ -671,13 +688,18 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
           }
           MM::store8(Xs + (slot_s[j] * 16 + row_) * KL + v_ * 8, f);
         }
+        if constexpr (SLOT_REISSUE) {
+          if (reissue) PW_ISSUE_DENSE_SLOT(it0 + L.tpi, j, xb_next, lo_next)
+        }
       }
     }
     CLK(2)
     if (e1_rows) e1n = RW::load(PW_E1_PTR(it0 << 4, 0));
     if constexpr (WG == C3D_WG_ROWS) x3n = RW::load(PW_X3_PTR(it0 << 4, 0));
     // ---------------- prefetch the next iteration's rows -------------------------------------
-    if (it0 + L.tpi < t1) { PW_ISSUE(it0 + L.tpi) }
+    if constexpr (!SLOT_REISSUE) {
+      if (it0 + L.tpi < t1) { PW_ISSUE(it0 + L.tpi) }
+    }
     CLK(3)
 
     // stage one 16-row result tile to Os, run the fused epilogue over it, store
@@ -966,6 +988,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
 #undef PW_E1_PTR
 #undef PW_ISSUE
 #undef PW_ISSUE_DENSE
+#undef PW_ISSUE_DENSE_SLOT
 #undef PW_ISSUE_GENERIC
 #undef PW_LIM
   CLK(7)

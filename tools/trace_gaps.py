@@ -55,6 +55,26 @@ def main():
             tot["main_kernel_time"] += e - s
             gap_by[n] += max(0, s - prev_end); dur_by[n] += e - s; cnt_by[n] += 1
             prev_end = max(prev_end, e)
+    # the largest individual main-queue gaps of the last step, with the kernels on either side and whether the other queue
+    # was busy meanwhile
+    a, b = steps[-1]
+    ks = rows[a + 1:b + 1]
+    qcount = defaultdict(int)
+    for s_, e_, q_, n_ in ks: qcount[q_] += 1
+    mainq = max(qcount, key=qcount.get)
+    side = [(s_, e_) for s_, e_, q_, n_ in ks if q_ != mainq]
+    gaps, prev = [], (rows[a][1], "adam(prev step)")
+    for s_, e_, q_, n_ in ks:
+        if q_ != mainq: continue
+        if s_ > prev[0]:
+            ov = sum(max(0, min(e2, s_) - max(s2, prev[0])) for s2, e2 in side)
+            gaps.append((s_ - prev[0], prev[1], n_, ov))
+        if e_ > prev[0]: prev = (e_, n_)
+    gaps.sort(reverse=True)
+    print("largest main-queue gaps of the last step: gap us | side queue busy us | after -> before")
+    for gp, pn, nn, ov in gaps[:14]:
+        print(f"  {gp/1e3:8.1f} {ov/1e3:8.1f}   {pn} -> {nn}")
+    print(f"  (sum of all {len(gaps)} gaps {sum(g_[0] for g_ in gaps)/1e6:.3f} ms, of which side queue busy {sum(g_[3] for g_ in gaps)/1e6:.3f} ms)")
     n = len(steps)
     print(f"{n} steps: wall {tot['wall']/n/1e6:.3f} ms  busy(any kernel) {tot['busy']/n/1e6:.3f}  idle {(tot['wall']-tot['busy'])/n/1e6:.3f}  "
           f"two queues at once {tot['both']/n/1e6:.3f}  main-queue kernel time {tot['main_kernel_time']/n/1e6:.3f}  "
