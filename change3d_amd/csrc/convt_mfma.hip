@@ -47,6 +47,13 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Wl = reinterpret_cast<u32x4*>(smem);   // [4 parities][NT][KS][64 lanes] weight fragments
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the f32 weights go to LDS in one coalesced pass (into the region the output staging uses later): the fragment image below
+  // was gathered element by element from global memory -- 37 k dependent-latency 4-byte loads per workgroup at C = 48, 45 us
+  // for a launch that moves 15 MB
+  constexpr int WRS = C * 16 + 2;                                     // ci rows padded by one dword (LDS banks)
+  bf16_t* wraw = reinterpret_cast<bf16_t*>(Wl + 4 * NT * KS * 64);   // (bf16: 72 KB at C = 48, beside the 72 KB image)
+  for (int i = tid; i < C * C * 16; i += 256) wraw[(i / (C * 16)) * WRS + i % (C * 16)] = f32_to_bf16(w[i]);
+  __syncthreads();
   // ---- weight fragment image: element (f, l, e): co = nt*16 + (l&15), k = ks*32 + (l>>4)*8 + e = tap*C + ci
   for (int i = tid; i < 4 * NT * KS * 64; i += 256) {
     const int l = i & 63, f = i >> 6;
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(const bf16_t* __res
     uint32_t pk[4];
 #pragma unroll
     for (int e2 = 0; e2 < 4; ++e2) {
-      float v[2];
+      uint32_t v[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int k = ks * 32 + (l >> 4) * 8 + e2 * 2 + hh;
@@ -63,9 +70,9 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(const bf16_t* __res
         int ky, kx, dd;
         par_tap(par >> 1, tap >> 1, ky, dd);
         par_tap(par & 1, tap & 1, kx, dd);
-        v[hh] = co < C ? w[(((size_t)ci * C + co) * 4 + ky) * 4 + kx] : 0.f;
+        v[hh] = co < C ? wraw[ci * WRS + (co * 4 + ky) * 4 + kx] : 0u;
       }
-      pk[e2] = pack_bf16x2(v[0], v[1]);
+      pk[e2] = v[0] | (v[1] << 16);
     }
     Wl[i] = u32x4{pk[0], pk[1], pk[2], pk[3]};
   }
@@ -164,6 +171,12 @@ __global__ __launch_bounds__(256) void convt_bwd_data_mfma_kernel(const bf16_t* 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Wl = reinterpret_cast<u32x4*>(smem);   // [NT][KS][64]: A[i = ci][k = tap16*C + co] = W[ci][co][ky][kx]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (see the forward kernel; aliases the patch staging.  Rows of ci padded by one dword: the 16 lanes of a fragment read 16
+  // different ci at the same (co, tap) -- 768 bytes apart, one bank)
+  constexpr int WRS = C * 16 + 2;
+  bf16_t* wraw = reinterpret_cast<bf16_t*>(Wl + NT * KS * 64);
+  for (int i = tid; i < C * C * 16; i += 256) wraw[(i / (C * 16)) * WRS + i % (C * 16)] = f32_to_bf16(w[i]);
+  __syncthreads();
   for (int i = tid; i < NT * KS * 64; i += 256) {
     const int l = i & 63, f = i >> 6;
     const int ks = f % KS, nt = f / KS;
@@ -171,14 +184,14 @@ __global__ __launch_bounds__(256) void convt_bwd_data_mfma_kernel(const bf16_t* 
     uint32_t pk[4];
 #pragma unroll
     for (int e2 = 0; e2 < 4; ++e2) {
-      float v[2];
+      uint32_t v[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int k = ks * 32 + (l >> 4) * 8 + e2 * 2 + hh;
         const int tap = k / C, co = k - tap * C;
-        v[hh] = ci < C ? w[((size_t)ci * C + co) * 16 + tap] : 0.f;
+        v[hh] = ci < C ? wraw[ci * WRS + co * 16 + tap] : 0u;
       }
-      pk[e2] = pack_bf16x2(v[0], v[1]);
+      pk[e2] = v[0] | (v[1] << 16);
     }
     Wl[i] = u32x4{pk[0], pk[1], pk[2], pk[3]};
   }
@@ -187,12 +200,41 @@ __global__ __launch_bounds__(256) void convt_bwd_data_mfma_kernel(const bf16_t* 
   const int tiles_x = (wd + 15) >> 4;
   const int64_t ntile = (int64_t)B * h * tiles_x;
   const int H = 2 * h, W = 2 * wd;
-  for (int64_t t = ((int64_t)blockIdx.x * 4 + wave); t < ntile; t += (int64_t)gridDim.x * 4) {
+  // dout patch of a wave's 16 input pixels: output rows 2iy-1 .. 2iy+2 x columns 2x0-1 .. 2x0+32 = 4 rows of 34 pixels,
+  // each row contiguous in memory.  Round 4: the patch is staged in LDS by 16-byte row vectors (next tile's vectors are in
+  // registers while this tile multiplies) and the 16 x C/8 operand vectors of a lane are ds_read_b128 -- the gathers used to be
+  // 16-byte global loads at a 2-pixel stride, every dout pixel fetched by four lanes through L1.
+  constexpr int CH16 = C / 8, PW_ = 34, PCH = 4 * PW_ * CH16, NJ = (PCH + 63) / 64;
+  bf16_t* Pl = reinterpret_cast<bf16_t*>(Wl + NT * KS * 64) + (size_t)wave * (4 * PW_ * C + 8);
+  auto issue = [&](const int64_t t, u32x4 (&r)[NJ]) {
+    const int tx = (int)(t % tiles_x);
+    const int64_t r_ = t / tiles_x;
+    const int iy = (int)(r_ % h), b = (int)(r_ / h);
+    const bf16_t* db = dout + (size_t)b * H * W * C;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      const int row = c / (PW_ * CH16), cc = c - row * (PW_ * CH16);
+      const int oy = 2 * iy - 1 + row, ox = 2 * tx * 16 - 1 + cc / CH16;
+      r[j] = u32x4{0u, 0u, 0u, 0u};
+      if (c < PCH && oy >= 0 && oy < H && ox >= 0 && ox < W) r[j] = ld16(db + ((size_t)oy * W + ox) * C + (cc % CH16) * 8);
+    }
+  };
+  u32x4 nx[NJ];
+  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  if (t < ntile) issue(t, nx);
+  for (; t < ntile; t += (int64_t)gridDim.x * 4) {
     const int tx = (int)(t % tiles_x);
     const int64_t r_ = t / tiles_x;
     const int iy = (int)(r_ % h), b = (int)(r_ / h);
     const int ix = tx * 16 + p;
-    const bf16_t* db = dout + (size_t)b * H * W * C;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < PCH) *reinterpret_cast<u32x4*>(Pl + (size_t)c * 8) = nx[j];
+    }
+    if (t + (int64_t)gridDim.x * 4 < ntile) issue(t + (int64_t)gridDim.x * 4, nx);
+    __builtin_amdgcn_wave_barrier();
     f32x4_t acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -200,12 +242,11 @@ __global__ __launch_bounds__(256) void convt_bwd_data_mfma_kernel(const bf16_t* 
     for (int ks = 0; ks < KS; ++ks) {
       const int k0 = ks * 32 + g * 8;
       const int tap = k0 / C, co0 = k0 - tap * C;
-      const int oy = 2 * iy - 1 + (tap >> 2), ox = 2 * ix - 1 + (tap & 3);
-      const bool ok = oy >= 0 && oy < H && ox >= 0 && ox < W && ix < wd;
-      const u32x4 xf = ok ? ld16(db + ((size_t)oy * W + ox) * C + co0) : u32x4{0u, 0u, 0u, 0u};
+      const u32x4 xf = *reinterpret_cast<const u32x4*>(Pl + (size_t)((tap >> 2) * PW_ + 2 * p + (tap & 3)) * C + co0);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(Wl[(nt * KS + ks) * 64 + lane], xf, acc[nt]);
     }
+    __builtin_amdgcn_wave_barrier();
     if (ix < wd) {
       bf16_t* o = din + (((size_t)b * h + iy) * wd + ix) * C;
 #pragma unroll
@@ -361,7 +402,9 @@ template <int C>
 int launch_fwd(const void* in, const float* w, const float* bias, const void* skip, int64_t skip_bstride, void* out, int B,
                int h, int wd, hipStream_t st) {
   constexpr int NT = (C + 15) / 16, KS = 4 * C / 32;
-  const size_t lds = (size_t)4 * NT * KS * 64 * 16 + (size_t)4 * 2 * 32 * C * sizeof(float);
+  size_t stage = (size_t)4 * 2 * 32 * C * sizeof(float);
+  if (stage < (size_t)C * (C * 16 + 2) * sizeof(bf16_t)) stage = (size_t)C * (C * 16 + 2) * sizeof(bf16_t);   // the raw weights, first
+  const size_t lds = (size_t)4 * NT * KS * 64 * 16 + stage;
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_fwd_mfma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return C3D_E_UNSUPPORTED;
@@ -377,7 +420,9 @@ int launch_fwd(const void* in, const float* w, const float* bias, const void* sk
 template <int C>
 int launch_bwd_data(const void* dout, const float* w, void* din, int B, int h, int wd, hipStream_t st) {
   constexpr int NT = (C + 15) / 16, KS = 16 * C / 32;
-  const size_t lds = (size_t)NT * KS * 64 * 16;
+  size_t stage = (size_t)4 * (4 * 34 * C + 8) * sizeof(bf16_t);
+  if (stage < (size_t)C * (C * 16 + 2) * sizeof(bf16_t)) stage = (size_t)C * (C * 16 + 2) * sizeof(bf16_t);
+  const size_t lds = (size_t)NT * KS * 64 * 16 + stage;
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_bwd_data_mfma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return C3D_E_UNSUPPORTED;

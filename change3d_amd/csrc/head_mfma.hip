@@ -243,14 +243,22 @@ __global__ __launch_bounds__(HM_NTHR) __attribute__((amdgpu_waves_per_eu(2, 3)))
   }
 }
 
-// dw[i] += sum over the workgroups' partials, 8 lanes per value (fixed order)
+// dw[i] += sum over the workgroups' partials, 32 lanes per value, four loads in flight per lane (fixed order).  (8 lanes with one
+// load -> add chain each: ~128 dependent memory round trips, 40 us for 432 values.)
 __global__ __launch_bounds__(256) void head_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nvals, int parts) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int i = gid >> 3, q = gid & 7;
-  float s = 0.f;
-  if (i < nvals)
-    for (int p = q; p < parts; p += 8) s += ws[(size_t)p * nvals + i];
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  const int i = gid >> 5, q = gid & 31;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < nvals) {
+    int p = q;
+    for (; p + 96 < parts; p += 128) {
+      s0 += ws[(size_t)p * nvals + i]; s1 += ws[(size_t)(p + 32) * nvals + i];
+      s2 += ws[(size_t)(p + 64) * nvals + i]; s3 += ws[(size_t)(p + 96) * nvals + i];
+    }
+    for (; p < parts; p += 32) s0 += ws[(size_t)p * nvals + i];
+  }
+  float s = (s0 + s1) + (s2 + s3);
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
   if (i < nvals && q == 0) dw[i] += s;
 }
 
@@ -285,7 +293,7 @@ int c3d_detail_head_bwd_bf16(const float* dout, const float* prob, const void* x
   C3D_CHECK_LAUNCH();
   if (ws) {
     const int nvals = NC * HM_C * 9;
-    head_dw_reduce_kernel<<<dim3((nvals * 8 + 255) / 256), 256, 0, s>>>(ws, dw, nvals, (int)(grid.x * grid.y));
+    head_dw_reduce_kernel<<<dim3((nvals * 32 + 255) / 256), 256, 0, s>>>(ws, dw, nvals, (int)(grid.x * grid.y));
     C3D_CHECK_LAUNCH();
   }
   return 0;
