@@ -185,6 +185,13 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ dsums, int stripes
   if (dbeta) dbeta[c] += (float)s1;
 }
 
+#ifdef C3D_SE_CLOCK   // tools/se_phase_clock.py: s_memtime stamps of workgroup 0 / thread 0 around the phases below
+__device__ unsigned long long c3d_se_clk[16];
+#define SECLK(i) { __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c3d_se_clk[i] += t_ - se_t_last; se_t_last = t_; } }
+#else
+#define SECLK(i)
+#endif
+
 // -------------------------------------------------------------------------------------------
 // SE backward + BN_b backward coefficients.
 //   nc3 [B][Cp][3] = per (n,c): sum dq*pb (d gate), sum t1, sum t1*bhat   (bhat = (b-mean)*rstd)
@@ -207,13 +214,32 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
                                        //          w1 for dz (both at once did not fit LDS for res5: C=432, Cr=32, B=16)
   float* hids = wst + (size_t)C * Cr;  // [B][Cr]
   const int tid = threadIdx.x;
+#ifdef C3D_SE_CLOCK
+  unsigned long long se_t_last = __builtin_amdgcn_s_memtime();
+#endif
   const double count = cnt_per_sample * B;
+  const double inv_cps = 1.0 / cnt_per_sample;   // (SE terms only: an f64 division per sample and lane was a third of the last phase)
   const bool se = w1 != nullptr;
   // channel-sliced over gridDim.x workgroups: d gate and the FC2-backward hidden gradient need every
   // channel and are recomputed by each workgroup; everything written is owned by slice [c_lo, c_hi)
   const int cs = (Cp + (int)gridDim.x - 1) / (int)gridDim.x;
   const int c_lo = (int)blockIdx.x * cs, c_hi = c_lo + cs < Cp ? c_lo + cs : Cp;
   const int cw = c_hi - c_lo;
+  // The BatchNorm coefficient phase at the end reads 3 f64 per (sample, channel) of this slice from global memory: requested here,
+  // consumed ~15 us later (4 lanes per channel, <= PF samples per lane; other shapes load in the loop)
+  constexpr int PF = 8;
+  double pf1[PF], pf2[PF], pff[PF];
+  const bool pre = se && cw * 4 <= (int)blockDim.x && B <= 4 * PF;
+  if (pre && tid < cw * 4 && c_lo + (tid >> 2) < C) {
+    const int c = c_lo + (tid >> 2), q = tid & 3;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int n = q + 4 * k;
+      if (n < B) {
+        pf1[k] = nc3[((size_t)n * Cp + c) * 3 + 1]; pf2[k] = nc3[((size_t)n * Cp + c) * 3 + 2]; pff[k] = ncf[((size_t)n * Cp + c) * 2];
+      }
+    }
+  }
   if (se) {
     for (int i = tid; i < Cr * C; i += blockDim.x) wst[i] = w2[i];   // [C][Cr]
     for (int i = tid; i < B * Cr; i += blockDim.x) hids[i] = hid[i];
@@ -224,18 +250,60 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
       du[i] = (float)nc3[((size_t)n * Cp + c) * 3] * g * (1.f - g);
       zz[i] = fmaf(ss[c], (float)(ncf[((size_t)n * Cp + c) * 2] / cnt_per_sample), ss[Cp + c]);
     }
+    SECLK(0)
     __syncthreads();
-    for (int idx = tid; idx < B * Cr * 8; idx += blockDim.x) {  // 8 lanes per (sample, hidden unit)
-      const int i = idx >> 3, q = idx & 7;
-      const int n = i / Cr, r = i - n * Cr;
-      float a = 0.f;
-      for (int c = q; c < C; c += 8) a = fmaf(wst[(size_t)c * Cr + r], du[(size_t)n * C + c], a);
-      a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
-      if (q == 0) dh[i] = hids[i] > 0.f ? a : 0.f;
+    SECLK(1)
+    // dh[n][r] = relu'(hid) sum_c w2[c][r] du[n][c]: eight partial sums per (n, r) over c = q, q + 8, ...  Lane index = r fastest:
+    // a wave reads 16 / 32 CONSECUTIVE w2 values and broadcasts du (the first mapping -- 8 adjacent lanes = the 8 partial sums --
+    // put 4 lanes on every LDS bank it touched: the phase was 40 % of the res4 launch, 60 % of res5's).  The partial sums go
+    // through LDS (the dz region, not written yet) and are combined in the association of the xor-shuffle tree they replace.
+    float* part = 8 * Cr <= C ? dz : hids + (size_t)B * Cr;   // [8][B * Cr]: inside dz where it fits, else its own region (launcher)
+    const int BR = B * Cr;
+    const int NB4 = (B + 3) >> 2;                     // a thread carries 4 samples: one w2 read serves 4 FMAs (the phase is LDS-bound)
+    for (int idx = tid; idx < 8 * NB4 * Cr; idx += blockDim.x) {
+      // idx = (nb * 8 + q) * Cr + r: a wave's lanes differ in r and q -- consecutive w2 addresses, du values of one sample row
+      // (with the sample group as the middle index the 4 rows of a wave were 4 x 216 floats apart: one bank)
+      const int r = idx % Cr, j = idx / Cr;
+      const int q = j & 7, nb = j >> 3;
+      const int n0 = 4 * nb;
+      // (samples beyond B read sample B-1 again; their sums are not stored)
+      const float* d0 = du + (size_t)(n0 < B ? n0 : B - 1) * C;
+      const float* d1 = du + (size_t)(n0 + 1 < B ? n0 + 1 : B - 1) * C;
+      const float* d2 = du + (size_t)(n0 + 2 < B ? n0 + 2 : B - 1) * C;
+      const float* d3 = du + (size_t)(n0 + 3 < B ? n0 + 3 : B - 1) * C;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int c = q;
+      for (; c + 24 < C; c += 32) {   // (four steps' reads in flight; every FMA chain keeps its order)
+        float wv[4], x0[4], x1[4], x2[4], x3[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          wv[u] = wst[(size_t)(c + 8 * u) * Cr + r];
+          x0[u] = d0[c + 8 * u]; x1[u] = d1[c + 8 * u]; x2[u] = d2[c + 8 * u]; x3[u] = d3[c + 8 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a0 = fmaf(wv[u], x0[u], a0); a1 = fmaf(wv[u], x1[u], a1); a2 = fmaf(wv[u], x2[u], a2); a3 = fmaf(wv[u], x3[u], a3); }
+      }
+      for (; c < C; c += 8) {
+        const float w_ = wst[(size_t)c * Cr + r];
+        a0 = fmaf(w_, d0[c], a0); a1 = fmaf(w_, d1[c], a1); a2 = fmaf(w_, d2[c], a2); a3 = fmaf(w_, d3[c], a3);
+      }
+      float* pq = part + (size_t)q * BR + r;
+      if (n0 < B) pq[(size_t)n0 * Cr] = a0;
+      if (n0 + 1 < B) pq[(size_t)(n0 + 1) * Cr] = a1;
+      if (n0 + 2 < B) pq[(size_t)(n0 + 2) * Cr] = a2;
+      if (n0 + 3 < B) pq[(size_t)(n0 + 3) * Cr] = a3;
     }
+    __syncthreads();
+    for (int i = tid; i < BR; i += blockDim.x) {
+      const float a = ((part[i] + part[BR + i]) + (part[2 * BR + i] + part[3 * BR + i])) +
+                      ((part[4 * BR + i] + part[5 * BR + i]) + (part[6 * BR + i] + part[7 * BR + i]));
+      dh[i] = hids[i] > 0.f ? a : 0.f;
+    }
+    SECLK(2)
     __syncthreads();
     for (int i = tid; i < Cr * C; i += blockDim.x) wst[i] = w1[i];   // [Cr][C]
     __syncthreads();
+    SECLK(3)
     for (int i = tid; i < B * cw; i += blockDim.x) {
       const int n = i / cw, c = c_lo + (i - n * cw);
       if (c >= C) continue;
@@ -243,31 +311,46 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
       for (int r = 0; r < Cr; ++r) a = fmaf(wst[(size_t)r * C + c], dh[(size_t)n * Cr + r], a);
       dz[(size_t)n * C + c] = a;
     }
+    SECLK(4)
     // parameter gradients of the two FCs
     for (int i = tid; i < cw * Cr; i += blockDim.x) {
       const int c = c_lo + i / Cr, r = i % Cr;  // w2[c][r]
       if (c >= C) continue;
       float a = 0.f, b = 0.f;
-      for (int n = 0; n < B; ++n) {
+      int n = 0;
+      for (; n + 4 <= B; n += 4) {   // (reads of four samples in flight; the two FMA chains keep their order)
+        float x0[4], x1[4], x2[4], x3[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          x0[u] = du[(size_t)(n + u) * C + c]; x1[u] = hids[(size_t)(n + u) * Cr + r];
+          x2[u] = dh[(size_t)(n + u) * Cr + r]; x3[u] = zz[(size_t)(n + u) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a = fmaf(x0[u], x1[u], a); b = fmaf(x2[u], x3[u], b); }
+      }
+      for (; n < B; ++n) {
         a = fmaf(du[(size_t)n * C + c], hids[(size_t)n * Cr + r], a);
         b = fmaf(dh[(size_t)n * Cr + r], zz[(size_t)n * C + c], b);
       }
-      dw2[(size_t)c * Cr + r] += a;
-      dw1[(size_t)r * C + c] += b;
+      // (one owner per address: a no-return atomic is the same sum without the load -> add -> store round trip)
+      atomicAdd(&dw2[(size_t)c * Cr + r], a);
+      atomicAdd(&dw1[(size_t)r * C + c], b);
     }
     for (int c = c_lo + tid; c < c_hi && c < C; c += blockDim.x) {
       float a = 0.f;
       for (int n = 0; n < B; ++n) a += du[(size_t)n * C + c];
-      db2[c] += a;
+      atomicAdd(&db2[c], a);
     }
     if (blockIdx.x == 0) {
       for (int r = tid; r < Cr; r += blockDim.x) {
         float a = 0.f;
         for (int n = 0; n < B; ++n) a += dh[(size_t)n * Cr + r];
-        db1[r] += a;
+        atomicAdd(&db1[r], a);
       }
     }
+    SECLK(5)
     __syncthreads();
+    SECLK(6)
   }
   for (int idx = tid; idx < cw * 4; idx += blockDim.x) {  // 4 lanes per channel split the batch loops
     const int c = c_lo + (idx >> 2), q = idx & 3;
@@ -278,13 +361,25 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
     }
     const double mean = mr[c], rstd = mr[Cp + c];
     double s1 = 0, s2 = 0;
+    if (pre) {   // (idx == tid here: one pass)
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int n = q + 4 * k;
+        if (n < B) {
+          const double dzn = (double)dz[(size_t)n * C + c];
+          s1 += pf1[k] + dzn;
+          s2 += pf2[k] + dzn * inv_cps * rstd * (pff[k] - cnt_per_sample * mean);
+        }
+      }
+    } else {
 #pragma unroll 4
     for (int n = q; n < B; n += 4) {
       const double dzn = se ? (double)dz[(size_t)n * C + c] : 0.0;
       s1 += nc3[((size_t)n * Cp + c) * 3 + 1] + dzn;
       // the uniform SE term dz/cnt multiplies sum_thw bhat = rstd * (sum b - cnt*mean)
       s2 += nc3[((size_t)n * Cp + c) * 3 + 2] +
-            dzn / cnt_per_sample * rstd * (ncf[((size_t)n * Cp + c) * 2] - cnt_per_sample * mean);
+            dzn * inv_cps * rstd * (ncf[((size_t)n * Cp + c) * 2] - cnt_per_sample * mean);
+    }
     }
     s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
     s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
@@ -293,13 +388,14 @@ __global__ __launch_bounds__(SE_THREADS) void se_bn_bwd_coef_kernel(
     if (q == 0) { coefA[c] = (float)A; coefC[c] = (float)Cc; }
     for (int n = q; n < B; n += 4) {
       const double dzn = se ? (double)dz[(size_t)n * C + c] : 0.0;
-      coefB[(size_t)n * Cp + c] = (float)(A * dzn / cnt_per_sample - A * s1 / count - Cc * mean);
+      coefB[(size_t)n * Cp + c] = (float)(A * dzn * inv_cps - A * s1 / count - Cc * mean);
     }
     if (q == 0) {
       if (dgamma) dgamma[c] += (float)s2;
       if (dbeta) dbeta[c] += (float)s1;
     }
   }
+  SECLK(7)
 }
 
 }  // namespace
@@ -361,7 +457,7 @@ extern "C" int c3d_se_bn_bwd_coef(const double* nc3, const double* ncf, int32_t 
   if (!nc3 || !ncf || !gamma || !mr || !ss || !coefA || !coefC || !coefB || C <= 0 || Cp < C || B <= 0)
     return C3D_E_BADARG;
   if (w1 && (!w2 || !gate || !hid || !dw1 || !db1 || !dw2 || !db2 || Cr <= 0)) return C3D_E_BADARG;
-  const size_t lds = w1 ? ((size_t)3 * B * C + (size_t)2 * B * Cr + (size_t)C * Cr) * sizeof(float) : 0;
+  const size_t lds = w1 ? ((size_t)3 * B * C + (size_t)2 * B * Cr + (size_t)C * Cr + (8 * Cr <= C ? 0 : (size_t)8 * B * Cr)) * sizeof(float) : 0;
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
@@ -378,3 +474,14 @@ extern "C" int c3d_se_bn_bwd_coef(const double* nc3, const double* ncf, int32_t 
   C3D_CHECK_LAUNCH();
   return 0;
 }
+
+#ifdef C3D_SE_CLOCK
+extern "C" int c3d_debug_se_clock(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(c3d_se_clk), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c3d_se_clk), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
