@@ -70,11 +70,12 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
   extern __shared__ float sm[];  // z[B][C] then h[B][Cr]
   float* z = sm;
   float* h = sm + (size_t)B * C;
-  float* w1s = h + (size_t)B * Cr;      // [Cr][C]  FC weights staged once, coalesced (the FC loops read them
-  float* w2s = w1s + (size_t)Cr * C;    // [C][Cr]   element by element from global memory before)
+  const int Cw = C + ((8 - (C & 31)) & 31);   // w1 row stride in LDS = 8 (mod 32 banks): rows r, r+1, .. start 8 banks apart
+  float* w1s = h + (size_t)B * Cr;      // [Cr][Cw] FC weights staged once, coalesced (the FC loops read them
+  float* w2s = w1s + (size_t)Cr * Cw;   // [C][Cr]   element by element from global memory before)
   const int tid = threadIdx.x;
   if (w1) {
-    for (int i = tid; i < Cr * C; i += blockDim.x) { w1s[i] = w1[i]; w2s[i] = w2[i]; }
+    for (int i = tid; i < Cr * C; i += blockDim.x) { w1s[(i / C) * Cw + i % C] = w1[i]; w2s[i] = w2[i]; }
   }
   const double count = cnt_per_sample * B;
   // gridDim.x workgroups each recompute the cheap whole-layer parts (statistics, FC1) and OWN a
@@ -133,15 +134,49 @@ __global__ __launch_bounds__(SE_THREADS) void bn_se_finalize_kernel(
   }
   if (!w1) return;  // no SE in this block: consumers take gate = 1 (NULL)
   __syncthreads();
-  for (int idx = tid; idx < B * Cr * 8; idx += blockDim.x) {  // 8 lanes per (sample, hidden unit)
-    const int i = idx >> 3, q = idx & 7;
-    const int n = i / Cr, r = i - n * Cr;
-    float a = 0.f;
-    for (int c = q; c < C; c += 8) a = fmaf(w1s[(size_t)r * C + c], z[(size_t)n * C + c], a);
-    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+  // FC1: eight partial sums per (sample, hidden unit) over c = q, q + 8, ...; a thread carries 4 samples, a wave's lanes differ in
+  // q (fastest) and r: consecutive z addresses, w1 rows of distinct r.  (With 8 adjacent lanes = the 8 partial sums of one
+  // (n, r) the w1 reads of a wave fell on a quarter of the banks -- see se_bn_bwd_coef_kernel.)  The partial sums are combined
+  // through LDS in the association of the xor-shuffle tree they replace: bit-identical to it and to se_gate_consume (bn_fin.h).
+  float* part = w2s + (size_t)Cr * C;   // [8][B * Cr]
+  const int BR = B * Cr, NB4 = (B + 3) >> 2;
+  for (int idx = tid; idx < 8 * NB4 * Cr; idx += blockDim.x) {
+    const int q = idx & 7, j = idx >> 3;
+    const int r = j % Cr, nb = j / Cr;
+    const int n0 = 4 * nb;
+    const float* z0 = z + (size_t)(n0 < B ? n0 : B - 1) * C;
+    const float* z1 = z + (size_t)(n0 + 1 < B ? n0 + 1 : B - 1) * C;
+    const float* z2 = z + (size_t)(n0 + 2 < B ? n0 + 2 : B - 1) * C;
+    const float* z3 = z + (size_t)(n0 + 3 < B ? n0 + 3 : B - 1) * C;
+    const float* wr = w1s + (size_t)r * Cw;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int c = q;
+    for (; c + 24 < C; c += 32) {   // (four steps' reads in flight; every FMA chain keeps its order)
+      float wv[4], x0[4], x1[4], x2[4], x3[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { wv[u] = wr[c + 8 * u]; x0[u] = z0[c + 8 * u]; x1[u] = z1[c + 8 * u]; x2[u] = z2[c + 8 * u]; x3[u] = z3[c + 8 * u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a0 = fmaf(wv[u], x0[u], a0); a1 = fmaf(wv[u], x1[u], a1); a2 = fmaf(wv[u], x2[u], a2); a3 = fmaf(wv[u], x3[u], a3); }
+    }
+    for (; c < C; c += 8) {
+      const float w_ = wr[c];
+      a0 = fmaf(w_, z0[c], a0); a1 = fmaf(w_, z1[c], a1); a2 = fmaf(w_, z2[c], a2); a3 = fmaf(w_, z3[c], a3);
+    }
+    float* pq = part + (size_t)q * BR + r;
+    if (n0 < B) pq[(size_t)n0 * Cr] = a0;
+    if (n0 + 1 < B) pq[(size_t)(n0 + 1) * Cr] = a1;
+    if (n0 + 2 < B) pq[(size_t)(n0 + 2) * Cr] = a2;
+    if (n0 + 3 < B) pq[(size_t)(n0 + 3) * Cr] = a3;
+  }
+  __syncthreads();
+  for (int i = tid; i < BR; i += blockDim.x) {
+    const int r = i % Cr;
+    float a = ((part[i] + part[BR + i]) + (part[2 * BR + i] + part[3 * BR + i])) +
+              ((part[4 * BR + i] + part[5 * BR + i]) + (part[6 * BR + i] + part[7 * BR + i]));
     a += b1[r];
     a = a > 0.f ? a : 0.f;
-    if (q == 0) { h[i] = a; if (hid && blockIdx.x == 0) hid[i] = a; }
+    h[i] = a;
+    if (hid && blockIdx.x == 0) hid[i] = a;
   }
   __syncthreads();
   const int cw = c_hi - c_lo;
@@ -422,7 +457,8 @@ extern "C" int c3d_bn_se_finalize(const double* nc, int32_t B, double cnt_per_sa
                                   void* stream) {
   if (!nc || !gamma || !beta || !ss || C <= 0 || Cp < C || B <= 0) return C3D_E_BADARG;
   if (w1 && (!b1 || !w2 || !b2 || !gate || Cr <= 0)) return C3D_E_BADARG;
-  const size_t lds = w1 ? ((size_t)B * C + (size_t)B * Cr + (size_t)2 * C * Cr) * sizeof(float) : 0;
+  const int Cw = C + ((8 - (C & 31)) & 31);
+  const size_t lds = w1 ? ((size_t)B * C + (size_t)9 * B * Cr + (size_t)Cr * Cw + (size_t)C * Cr) * sizeof(float) : 0;
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
