@@ -253,7 +253,13 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wcv = __builtin_amdgcn_readfirstlane(tid >> 6);    // this wave's channel vector
-  const int lx = lane & 15, yp = lane >> 4;                    // lane = column x, rows PYR*yp .. PYR*yp + PYR-1
+  // lane = column x, rows PYR*yp .. PYR*yp + PYR-1.  The columns of ODD row groups are rotated: a ds_read_b128 is served in
+  // four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- i.e. half a row group plus
+  // half of the next one, PYR * V2_IW float4 further on: with the plain x = lane & 15 those two halves overlap in 4 of
+  // 16 bank quads (2 * 18 = 4 mod 16) and every stencil read takes 8 LDS cycles instead of 4
+  // (/opt/skills/guides/MI355X_MICROARCH.md, LDS table; tools/lds_bank_model.py).
+  const int yp = lane >> 4;
+  const int lx = (lane + (yp & 1) * ((16 - (PYR * V2_IW) % 16) & 15)) & 15;
   const int tiles_x = (g.W + V2_TW - 1) / V2_TW, tiles_y = (g.H + V2_TH - 1) / V2_TH;
   const int ntiles = tiles_x * tiles_y;
   const int gx = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
@@ -482,7 +488,10 @@ __global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wcv = __builtin_amdgcn_readfirstlane(tid >> 6);    // this wave's channel vector
-  const int lx = lane & 15, ly = lane >> 4;                    // lane = output pixel (ly, lx) of the tile
+  // lane = output pixel (ly, lx) of the tile; the columns of odd rows are rotated by one so that the two half rows a
+  // ds_read_b128 lane group joins (rows S2_HX = 17 float4 apart) fall on 16 distinct bank quads (see dw_fwd_v2_kernel)
+  const int ly = lane >> 4;
+  const int lx = (lane + (ly & 1) * ((16 - S2_HX % 16) & 15)) & 15;
   const int tiles_x = (g.Wo + S2_TW - 1) / S2_TW, tiles_y = (g.Ho + S2_TH - 1) / S2_TH;
   const int ntiles = tiles_x * tiles_y;
   const int gx = (ntiles + tiles_per_wg - 1) / tiles_per_wg;

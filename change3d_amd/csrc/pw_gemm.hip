@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void pw_pack_kernel(const PackArgs P) {
       const int k = k0 + e;
       v[e] = (n < d.N && k < d.K) ? d.w[(size_t)n * d.sn + (size_t)k * d.sk] : 0.f;
     }
-    typename MM::lds_t* dst = reinterpret_cast<typename MM::lds_t*>(d.img) + (size_t)n * d.KL + k0;
+    typename MM::lds_t* dst = reinterpret_cast<typename MM::lds_t*>(d.img) + MM::widx(n, k0, d.KL, d.NT * 16);   // (k0 % 4 == 0: one chunk)
     if (sizeof(typename MM::lds_t) == 2)
       *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     else

@@ -237,7 +237,7 @@ typedef const __attribute__((address_space(1))) void* pw_glb_ptr_t;
 // 8-byte / 16-byte write).  All of a thread's loads are issued before the first LDS write: one round trip.
 template <typename T, int VW, bool KC, int WAVES>
 __device__ __forceinline__ void stage_weights(const float* __restrict__ w, typename Mma<T>::lds_t* Ws, int CL, int OLn,
-                                              int ostride, int KL, int tid) {
+                                              int ostride, int KL, int NR, int tid) {
   typedef Mma<T> MM;
   typedef typename MM::lds_t lds_t;
   constexpr int WB = 8;
@@ -264,7 +264,7 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ w, typen
     for (int u = 0; u < WB; ++u) {
       if (oo[u] >= 0) {
         if constexpr (KC && VW == 4) {
-          lds_t* dst = Ws + oo[u] * KL + ii[u];
+          lds_t* dst = Ws + MM::widx(oo[u], ii[u], KL, NR);
           if (sizeof(lds_t) == 2) {
             *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[u][0], v[u][1]), pack_bf16x2(v[u][2], v[u][3]));
           } else {
@@ -275,7 +275,7 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ w, typen
           for (int e = 0; e < VW; ++e) {
             const int n = KC ? oo[u] : ii[u] + e;
             const int k = KC ? ii[u] + e : oo[u];
-            Ws[n * KL + k] = MM::cvt(v[u][e]);
+            Ws[MM::widx(n, k, KL, NR)] = MM::cvt(v[u][e]);
           }
         }
       }
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       // zero fill, no f32 -> operand-type conversion, no scattered 2-byte LDS writes for the transposed (data-gradient)
       // orientation, half the bytes.  Every workgroup of the launch reads the same image at the same moment: the
       // chunk order is rotated by the workgroup index so that the requests spread over the L2 channels.
-      const int wbytes = wtot * (int)sizeof(lds_t);
+      const int wbytes = (sizeof(T) == 2 ? NT * 16 * Kpad : wtot) * (int)sizeof(lds_t);   // (chunk-major bf16 image: no padding chunk read)
       const int nchunk = (wbytes + 1023) >> 10;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(a.w_img);
       const int rot = (int)blockIdx.x % nchunk;
@@ -563,14 +563,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       const int CL = kc ? a.K : a.N, OLn = kc ? a.N : a.K;
       const int ostride = kc ? a.w_sn : a.w_sk;
       if ((CL & 3) == 0 && (ostride & 3) == 0 && ((uintptr_t)a.w & 15) == 0) {
-        if (kc) stage_weights<T, 4, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-        else stage_weights<T, 4, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+        if (kc) stage_weights<T, 4, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, NT * 16, tid);
+        else stage_weights<T, 4, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, NT * 16, tid);
       } else if ((CL & 1) == 0 && (ostride & 1) == 0 && ((uintptr_t)a.w & 7) == 0) {
-        if (kc) stage_weights<T, 2, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-        else stage_weights<T, 2, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+        if (kc) stage_weights<T, 2, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, NT * 16, tid);
+        else stage_weights<T, 2, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, NT * 16, tid);
       } else {
-        if (kc) stage_weights<T, 1, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
-        else stage_weights<T, 1, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, tid);
+        if (kc) stage_weights<T, 1, true, WAVES>(a.w, Ws, CL, OLn, ostride, KL, NT * 16, tid);
+        else stage_weights<T, 1, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, NT * 16, tid);
       }
     }
     if constexpr (WG != 0) {
@@ -615,8 +615,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   if (WREG && KS <= 2) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      wr[WREG ? nt : 0] = MM::load(Ws, nt * 16 + (lane & 15), 0, KL, lane);
-      wr[WREG ? NT + nt : 0] = MM::load(Ws, nt * 16 + (lane & 15), KS == 2 ? 1 : 0, KL, lane);
+      wr[WREG ? nt : 0] = MM::loadw(Ws, nt * 16 + (lane & 15), 0, KL, NT * 16, lane);
+      wr[WREG ? NT + nt : 0] = MM::loadw(Ws, nt * 16 + (lane & 15), KS == 2 ? 1 : 0, KL, NT * 16, lane);
     }
   }
 
@@ -934,8 +934,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
           for (int nt = 0; nt < NT; ++nt) acc[nt] = MM::mma(wr[WREG ? NT + nt : 0], xb1, acc[nt]);
         }
       } else {
-        const uint32_t wstr = (uint32_t)(16 * KL * sizeof(lds_t));                       // bytes between output tiles
-        const uint32_t wlane = (uint32_t)(uintptr_t)Ws + (uint32_t)(((lane & 15) * KL + (lane >> 4) * 8) * sizeof(lds_t));
+        // (bf16 only below: the chunk-major weight image, Mma<bf16_t>::widx)
+        constexpr uint32_t wstr = 16 * 8 * 2;                                            // bytes between output tiles
+        constexpr uint32_t wks = 4 * NT * 16 * 8 * 2;                                    // bytes between k steps of 32
+        const uint32_t wlane = (uint32_t)(uintptr_t)Ws + (uint32_t)((((lane >> 4) * NT * 16 + (lane & 15)) * 8) * sizeof(lds_t));
         constexpr int UB = PwFragBatch<NT, PRO, EPI>::value;
         if (MT == 2 && two) {
           for (int ks = 0; ks < KS; ++ks) {
@@ -943,11 +945,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             const typename MM::frag_t xb2 = MM::load(Xt + 16 * KL, lane & 15, ks, KL, lane);
             if constexpr (sizeof(T) == 2 && UB > 0) {
               const u32x4_t xv = __builtin_bit_cast(u32x4_t, xb), xv2 = __builtin_bit_cast(u32x4_t, xb2);
-              MfmaSeq<NT, (UB > 0 ? UB : 1), 0, true>::run(acc, acc2, wlane + ks * 64, wstr, xv, xv2);
+              MfmaSeq<NT, (UB > 0 ? UB : 1), 0, true>::run(acc, acc2, wlane + ks * wks, wstr, xv, xv2);
             } else {
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
-                const typename MM::frag_t wa = MM::load(Ws, nt * 16 + (lane & 15), ks, KL, lane);
+                const typename MM::frag_t wa = MM::loadw(Ws, nt * 16 + (lane & 15), ks, KL, NT * 16, lane);
                 acc[nt] = MM::mma(wa, xb, acc[nt]);
                 acc2[nt] = MM::mma(wa, xb2, acc2[nt]);
               }
@@ -958,11 +960,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             const typename MM::frag_t xb = MM::load(Xt, lane & 15, ks, KL, lane);
             if constexpr (sizeof(T) == 2 && UB > 0) {
               const u32x4_t xv = __builtin_bit_cast(u32x4_t, xb);
-              MfmaSeq<NT, (UB > 0 ? UB : 1), 0, false>::run(acc, acc, wlane + ks * 64, wstr, xv, xv);
+              MfmaSeq<NT, (UB > 0 ? UB : 1), 0, false>::run(acc, acc, wlane + ks * wks, wstr, xv, xv);
             } else {
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
-                const typename MM::frag_t wa = MM::load(Ws, nt * 16 + (lane & 15), ks, KL, lane);
+                const typename MM::frag_t wa = MM::loadw(Ws, nt * 16 + (lane & 15), ks, KL, NT * 16, lane);
                 acc[nt] = MM::mma(wa, xb, acc[nt]);
               }
             }

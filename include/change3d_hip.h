@@ -160,8 +160,8 @@ int64_t c3d_pw_gemm_wg_ws_floats(int32_t K, int32_t N);
  * pw_wide.hip with the same prologues / epilogues (row modes DENSE and STRIDE2; no in-kernel finalisation). */
 int c3d_pw_gemm(const c3d_pw_args* args, void* stream);
 
-/* Weight images for c3d_pw_args.w_img: the narrow kernel's LDS operand layout ([NT*16][Kpad+pad] in the MFMA operand
- * type, zero padded) written once per weight VERSION instead of rebuilt by each of the ~256 workgroups of each launch
+/* Weight images for c3d_pw_args.w_img: the narrow kernel's LDS operand layout (f32: [NT*16][Kpad+pad]; bf16: 8-element
+ * k-chunk major [Kpad/8 + 1][NT*16][8], the bank-conflict-free form for ds_read_b128 A fragments; zero padded; opaque to callers) written once per weight VERSION instead of rebuilt by each of the ~256 workgroups of each launch
  * (the f32 master weights change once per optimizer step; a block's four GEMMs per step read two weights, each in two
  * orientations).  c3d_pw_weight_image_bytes returns 0 for shapes the narrow kernel does not take (Kp or Np > 224).
  * One launch packs up to C3D_PW_PACK_MAX images (descriptors travel as kernel arguments). */
