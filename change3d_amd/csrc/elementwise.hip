@@ -72,7 +72,7 @@ __global__ void block_out_fwd_kernel(const T* __restrict__ c, const float* __res
 // pass only produces the BatchNorm-backward sums.  (A compile-time switch: the same test at run time cost the unmasked form
 // 12 % -- 1.57 -> 1.76 ms per step.)
 template <typename T, bool PRE>
-__global__ void block_out_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ c,
+__global__ __launch_bounds__(256) void block_out_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ c,
                                      const T* __restrict__ s, T* __restrict__ g, const float* __restrict__ mr_c,
                                      const float* __restrict__ mr_1, double* __restrict__ dsums_c,
                                      double* __restrict__ dsums_1, int64_t nvec, int G, int C, const c3d_bn_fin fin_c,
@@ -93,20 +93,42 @@ __global__ void block_out_bwd_kernel(const T* __restrict__ dy, const T* __restri
     m1[j] = s ? mr_1[v * 8 + j] : 0.f; r1[j] = s ? mr_1[Cp + v * 8 + j] : 0.f;
   }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    float d[8], yv[8], cv[8], sv[8];
-    Vec8<T>::load(dy + i * 8, d);
-    if (!PRE) Vec8<T>::load(y + i * 8, yv);
-    Vec8<T>::load(c + i * 8, cv);
-    if (s) Vec8<T>::load(s + i * 8, sv);
+  // The grid is capped (the closing same-address atomics): ~1.5 workgroups per CU, so the bytes in flight come from the
+  // loop itself -- BOB_U iterations' loads (raw vectors) are issued before the first is consumed; a thread's terms are
+  // added in the order of the plain loop (bit-identical sums).
+  constexpr int BOB_U = 4;
+  typedef typename Vec8<T>::raw_t raw_t;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < nvec; i0 += BOB_U * stride) {
+    raw_t rd[BOB_U], ry[BOB_U], rc_[BOB_U], rs[BOB_U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float gg = (PRE || yv[j] > 0.f) ? d[j] : 0.f;
-      d[j] = gg;
-      s1[j] += gg; s2[j] += gg * ((cv[j] - mc[j]) * rc[j]);
-      if (s) s3[j] += gg * ((sv[j] - m1[j]) * r1[j]);
+    for (int u = 0; u < BOB_U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < nvec) {
+        rd[u] = Vec8<T>::load_raw(dy + i * 8);
+        if (!PRE) ry[u] = Vec8<T>::load_raw(y + i * 8);
+        rc_[u] = Vec8<T>::load_raw(c + i * 8);
+        if (s) rs[u] = Vec8<T>::load_raw(s + i * 8);
+      }
     }
-    if (!PRE) Vec8<T>::store(g + i * 8, d);
+#pragma unroll
+    for (int u = 0; u < BOB_U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < nvec) {
+        float d[8], yv[8], cv[8], sv[8];
+        Vec8<T>::cvt_raw(rd[u], d);
+        if (!PRE) Vec8<T>::cvt_raw(ry[u], yv);
+        Vec8<T>::cvt_raw(rc_[u], cv);
+        if (s) Vec8<T>::cvt_raw(rs[u], sv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float gg = (PRE || yv[j] > 0.f) ? d[j] : 0.f;
+          d[j] = gg;
+          s1[j] += gg; s2[j] += gg * ((cv[j] - mc[j]) * rc[j]);
+          if (s) s3[j] += gg * ((sv[j] - m1[j]) * r1[j]);
+        }
+        if (!PRE) Vec8<T>::store(g + i * 8, d);
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {

@@ -502,8 +502,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         int r = c + rot;
         if (r >= nchunk) r -= nchunk;
         const int off = r * 1024 + lane * 16;
+        int goff = off;
+        if constexpr (sizeof(T) == 2) {
+          // the image was packed for c3d_pw_pack_weights' row bucket (2 / 4 / 7 / 14 tiles of 16 rows per k-chunk); a kernel on
+          // fewer output tiles (conv_a of res3: NT = 3 of the NT = 4 image) copies the first NT * 16 rows of every chunk
+          const int ntn = (Np + 15) >> 4;
+          const int img_rows = (ntn <= 2 ? 2 : ntn <= 4 ? 4 : ntn <= 7 ? 7 : 14) * 16;
+          if (img_rows != NT * 16) {
+            const int ch = off / (NT * 16 * 16);
+            goff = ch * img_rows * 16 + (off - ch * (NT * 16 * 16));
+          }
+        }
         if (off < wbytes)
-          __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)(src + off), (pw_lds_ptr_t)(smem + L.w_off + r * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)(src + goff), (pw_lds_ptr_t)(smem + L.w_off + r * 1024), 16, 0, 0);
       }
     } else {
       for (int i = tid * 8; i < wtot; i += WAVES * 64 * 8) {

@@ -105,6 +105,18 @@ def test_conv_a_data_gradient_with_fused_weight_gradient(Ci, Cin, M, res_mode):
     dx_a, _ = run(False)
     dx_b, dw = run(True)
     assert torch.equal(dx_a.view(torch.int16), dx_b.view(torch.int16)), "the data gradient must not change"
+    # the same launches reading the packed weight image (c3d_pw_pack_weights): N = 48 runs the fused kernel on THREE output
+    # tiles of an image packed for the four-tile bucket -- the kernel copies the first 48 rows of every k-chunk
+    img = torch.zeros(ops.pw_weight_image_bytes(Cin, Ci, dt), dtype=torch.uint8, device=DEV)
+    ops.pw_pack_weights([(wd, img, Cin, Ci, 1, Cin)], dt)
+    for fused in (False, True):
+        dx_i = torch.full((M, Cinp), float("nan"), dtype=DT, device=DEV)
+        dw_i = torch.ones((Ci, Cin), dtype=torch.float32, device=DEV)
+        kw = dict(wg_mode=ops.WG_ROWS, wg_dw=dw_i, wg_x3=xd) if fused else {}
+        ops.pw_gemm(t2d, wd, dx_i, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=ad, pro_mode=ops.PRO_AFFINE2, pro_p=coef,
+                    epi_mode=ops.EPI_ADD, e1=rd, res_mode=res_mode, H=H, W=W, w_img=img, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(dx_a.view(torch.int16), dx_i.view(torch.int16)), ("weight image", fused)
     dw_sep = torch.ones((Ci, Cin), dtype=torch.float32, device=DEV)
     ops.pw_wgrad(t2d, xd, dw_sep, M=M, K=Cin, N=Ci, dw_sn=Cin, dw_sk=1, dtype=dt, p2=ad, p_coef=coef)
     torch.cuda.synchronize()
