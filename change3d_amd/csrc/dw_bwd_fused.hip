@@ -391,23 +391,36 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
       // is needed three tap steps from now, the raw rows a whole tile from now
       FB_ISSUE_A(tl, 1, 0)
       if (tl + 1 < tl1) FB_ISSUE_RAW(tl + 1)
+      FCLK(2)
       __syncthreads();
+      FCLK(3)
       const float4* tp = tb + (size_t)h * NI + (py * FB_DW + px) * DW_CV + cv;
       const float* wlp = wl + cv * 8 + h * 4;
       fb_taps_s2<TT, 0, 0>(tp, wlp, acc, dwa, ain);
+      FCLK(4)
       FB_EPI(0, 0)
+      FCLK(5)
       FB_PRE(1, 0)
       FB_ISSUE_A(tl, 0, 1)
+      FCLK(2)
       fb_taps_s2<TT, 1, 0>(tp, wlp, acc, dwa, ain);
+      FCLK(4)
       FB_EPI(1, 0)
+      FCLK(5)
       FB_PRE(0, 1)
       FB_ISSUE_A(tl, 1, 1)
+      FCLK(2)
       fb_taps_s2<TT, 0, 1>(tp, wlp, acc, dwa, ain);
+      FCLK(4)
       FB_EPI(0, 1)
+      FCLK(5)
       FB_PRE(1, 1)
       if (tl + 1 < tl1) FB_ISSUE_A(tl + 1, 0, 0)
+      FCLK(2)
       fb_taps_s2<TT, 1, 1>(tp, wlp, acc, dwa, ain);
+      FCLK(4)
       FB_EPI(1, 1)
+      FCLK(5)
       continue;
     }
     // (Issuing the next tile's loads one per tap step instead of in a bunch here was measured in round 3: the stalled
@@ -512,17 +525,24 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
   FCLK(6)
   // ---- weight gradient: dump [tap][thread] per channel-of-four, 64-pixel sums in fixed order, f32 atomics
   if (dw == nullptr) return;
-  float* dump = reinterpret_cast<float*>(tile);      // 27 * 512 floats = 55 KB <= 2 * 2 * NI * 16 B
+  // Padded rows: the 32 lanes of a ds_read_b32 group below differ in (tap bit, channel half, pixel half, channel vector); with
+  // the plain [tap][thread] layout all but the last are multiples of 32 floats apart -- 4 banks for 32 lanes, 16 LDS cycles
+  // per read instead of 2 (tools/lds_bank_model.py), 12 k of the flush's 17 k clocks.  +16 floats per tap row, +4 per channel
+  // half (36 with the room the pixel-half pad takes), +8 per pixel half put the 32 lanes on 32 banks; the sums and their order
+  // are unchanged.
+  constexpr int FB_DUMP_LD = FB_NTHR + 48, FB_DUMP_HH = 256 + 36, FB_DUMP_PT = 32 * DW_CV + 8;
+  float* dump = reinterpret_cast<float*>(tile);      // 27 * 560 floats = 60 KB <= 2 * 2 * NI * 16 B
+  const int dslot = tid + (FB_DUMP_HH - 256) * (tid >> 8) + (FB_DUMP_PT - 32 * DW_CV) * ((tid >> 7) & 1);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 27; ++k) dump[k * FB_NTHR + tid] = dwa[k][j >> 1][j & 1];
+    for (int k = 0; k < 27; ++k) dump[k * FB_DUMP_LD + dslot] = dwa[k][j >> 1][j & 1];
     __syncthreads();
     if (tid < 27 * 8 * 2) {
       const int o = tid >> 1, part = tid & 1;
       const int tap = o >> 3, v = o & 3, hh = (o >> 2) & 1;
-      const float* src = dump + tap * FB_NTHR + hh * 256 + part * 32 * DW_CV + v;
+      const float* src = dump + tap * FB_DUMP_LD + hh * FB_DUMP_HH + part * FB_DUMP_PT + v;
       float s = 0.f;
 #pragma unroll 8
       for (int k = 0; k < 32; ++k) s += src[k * DW_CV];
@@ -541,7 +561,7 @@ int launch_fused_t(const void* t1, const void* bb, const float* cA, const float*
                    const DwGeom& g, hipStream_t stream, const c3d_bn_fin& fin) {
   constexpr int NI = TT * FB_DH * FB_DW * DW_CV;
   const size_t lds = (27 * 32 + 7 * 32) * sizeof(float) + (size_t)2 * 2 * NI * sizeof(float4);
-  static_assert((size_t)2 * 2 * NI * sizeof(float4) >= (size_t)27 * FB_NTHR * sizeof(float), "dump region");
+  static_assert((size_t)2 * 2 * NI * sizeof(float4) >= (size_t)27 * (FB_NTHR + 48) * sizeof(float), "dump region");
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {

@@ -187,6 +187,10 @@ DW_PHASES = ["setup (weights, coefficients)", "barrier A (previous taps done)", 
              "issue a rows + next tile", "barrier B", "27 taps", "epilogue + store", "final sums flush"]
 
 
+FB_PHASES = ["setup (weights, coefficients, first loads)", "convert -> f32 LDS planes", "a_in + issue next tile / class", "barrier",
+             "27 taps (data + weight gradient)", "epilogue + store", "BN_a sums flush", "dW flush"]
+
+
 def main_fb():
     """csrc/dw_bwd_fused.hip (stride 1 and 2) at the three BCD stage shapes."""
     os.environ["C3D_LIB"] = CLK_LIB
