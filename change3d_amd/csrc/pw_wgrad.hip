@@ -38,7 +38,10 @@ template <typename T> struct MmaT;  // transposed-operand LDS tiles [channel][ro
 template <> struct MmaT<bf16_t> {
   typedef bf16_t lds_t;
   static constexpr int KSTEP = 32;
-  static constexpr int MPAD = 8;
+  // tile rows of MT + 16 elements = 32 B mod 64 B: the stride class on which the four 16-lane groups of a ds_read_b128 A / B
+  // fragment read (lane = channel row lane % 16, 8-row chunk lane / 16) fall on distinct bank quads; + 8 (16 B mod 64 B) made
+  // every fragment read 2-way conflicted (tools/lds_bank_model.py: conflict-free row strides are 16 B and 32 B mod 64 B)
+  static constexpr int MPAD = 16;
   typedef uint4 frag_t;
   static __device__ __forceinline__ frag_t load(const lds_t* base, int ch, int ks, int ml, int lane) {
     return *reinterpret_cast<const uint4*>(base + ch * ml + ks * 32 + (lane >> 4) * 8);
