@@ -170,11 +170,12 @@ def pmc_traffic(entry):
 def also_runs(a):
     """Short runs of the other workloads BASELINE.json names, each in its own process after the headline measurement
     (30 timed steps in three windows of 10 after 40 settling + 5 warm-up steps -- `value` is the 30-step mean, the per-window
-    ms/step give min / median; 120 s per child and 240 s in all, so the headline line is never held up for long): SCD (configs[3], B=16, T=5), CC (configs[4], B=16) in bf16, and the BCD workload on the
+    ms/step give min / median; 120 s per child and 300 s in all, so the headline line is never held up for long; a run whose
+    windows disagree by more than 5 % is measured once more and the better-agreeing run is kept, with the other recorded): SCD (configs[3], B=16, T=5), CC (configs[4], B=16) in bf16, and the BCD workload on the
     f32 storage path -- the path every bit-exact / 1e-4 parity statement is made on -- so that it has a price."""
     import subprocess
     res = {}
-    t_start, budget_s = time.time(), 240.0   # wall budget for all three children: the headline line must not wait longer
+    t_start, budget_s = time.time(), 300.0   # wall budget for all three children (+ at most one re-measurement each): the headline line must not wait longer
     for key, extra in (("scd", ["--task", "scd"]), ("cc", ["--task", "cc"]), ("bcd_f32", ["--task", "bcd", "--dtype", "f32"])):
         left = budget_s - (time.time() - t_start)
         if left < 30.0:
@@ -183,12 +184,29 @@ def also_runs(a):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "30", "--warmup", "5", "--size", str(a.size),
                "--no-cpu-baseline", "--no-kernel-profile", "--no-also", "--windows", "3"] + extra
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(120.0, left))
-            d = json.loads(r.stdout.strip().splitlines()[-1])
-            res[key] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+            best = None
+            for attempt in (0, 1):
+                left = budget_s - (time.time() - t_start)
+                if attempt and left < 40.0:
+                    break
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(120.0, left))
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                w = d["config"].get("ms_per_step_windows") or [d["ms_per_step"]]
+                spread = max(w) / max(min(w), 1e-9)
+                cand = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                         "warmup": d["warmup"], "dtype": d["dtype"], "global_batch": d["config"]["global_batch"],
                         "workload": d["config"]["workload"], "step_roofline_frac": d["step_roofline"]["frac"],
                         "ms_per_step_windows": d["config"].get("ms_per_step_windows")}
+                if attempt:
+                    cand["rerun_of_disturbed_run"] = {"ms_per_step_windows": best[1]["ms_per_step_windows"], "value": best[1]["value"]}
+                if best is None or spread < best[0]:
+                    best = (spread, cand)
+                # three windows of ten steps that disagree by more than 5 % mean the box was disturbed during the run (seen once
+                # in round 4: 25.3 / 28.1 / 31.1 ms where every other run gives 25.0 +- 0.1): measure once more, keep the run whose
+                # windows agree better, and say so in the record
+                if spread <= 1.05:
+                    break
+            res[key] = best[1]
         except Exception as e:  # noqa: BLE001  (an auxiliary number must never cost the headline line)
             res[key] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     return res
