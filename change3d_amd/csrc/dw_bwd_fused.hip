@@ -206,9 +206,14 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
 
   const int tid = threadIdx.x;
   FCLK_DECL
-  const int h = tid >> 8;                                 // channel half of the vector (wave-uniform)
+  // thread = [pixel][channel half][channel vector]: the 8 lanes of a pixel own its 32 channels, so the `a` rows they load and
+  // the `t2` rows they store are 64 contiguous bytes per pixel (half-vector loads of one channel half per wave -- h = tid >> 8
+  // until late round 4 -- were 8-byte pieces 16 B apart: twice the cache-line segments per instruction, and the stride-2
+  // classes four times).  LDS: a 16-lane read group covers 4 pixels x 4 vectors of ONE half each -- the two half planes are
+  // a multiple of 16 float4 apart, so the bank quad is the (pixel, vector) alone: conflict-free as before.
+  const int h = (tid >> 2) & 1;                           // channel half of the vector
   const int cv = tid & (DW_CV - 1);
-  const int pix = (tid & 255) >> 2;
+  const int pix = tid >> 3;
   const int px = pix & (FB_TW - 1), py = pix >> 3;
 
   const int tiles_x = (g.W + FB_TW * S - 1) / (FB_TW * S), tiles_y = (g.H + FB_TH * S - 1) / (FB_TH * S);   // tile: 8S x 8S input pixels
@@ -492,25 +497,25 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
 #undef FB_ISSUE_RAW
 #undef FB_ISSUE_A
 
-  // ---- flush the BN_a-backward sums: lanes of equal cv inside a wave, then the four waves of each half
+  // ---- flush the BN_a-backward sums: lanes of equal (half, vector) inside a wave, then the eight waves
   const int lane = tid & 63, wave = tid >> 6;
-  double* red64 = reinterpret_cast<double*>(tile);   // [8 waves][DW_CV][8]; the tile buffers are dead now
+  double* red64 = reinterpret_cast<double*>(tile);   // [8 waves][2 halves x DW_CV][8]; the tile buffers are dead now
   __syncthreads();
   double D1[4], D2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     D1[j] = (double)S1[j]; D2[j] = (double)S2[j];
 #pragma unroll
-    for (int o = DW_CV; o < 64; o <<= 1) {
+    for (int o = 2 * DW_CV; o < 64; o <<= 1) {   // the 8 pixels of the wave (lane bits 3-5)
       D1[j] += __shfl_xor(D1[j], o, 64);
       D2[j] += __shfl_xor(D2[j], o, 64);
     }
   }
-  if (lane < DW_CV) {
+  if (lane < 2 * DW_CV) {                        // lane = half * 4 + vector
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      red64[(wave * DW_CV + lane) * 8 + j] = D1[j];
-      red64[(wave * DW_CV + lane) * 8 + 4 + j] = D2[j];
+      red64[(wave * 2 * DW_CV + lane) * 8 + j] = D1[j];
+      red64[(wave * 2 * DW_CV + lane) * 8 + 4 + j] = D2[j];
     }
   }
   __syncthreads();
@@ -518,21 +523,20 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     const int v = tid >> 4, r = tid & 15;
     const int hh = r >> 3, which = (r >> 2) & 1, j = r & 3;
     double sacc = 0.0;
-    for (int wv = hh * 4; wv < hh * 4 + 4; ++wv) sacc += red64[(wv * DW_CV + v) * 8 + which * 4 + j];
+    for (int wv = 0; wv < FB_NTHR / 64; ++wv) sacc += red64[(wv * 2 * DW_CV + hh * DW_CV + v) * 8 + which * 4 + j];
     const int c = c0 + v * 8 + hh * 4 + j;
     if (c < g.C) atomicAdd(dsums + (size_t)which * g.C + c, sacc);
   }
   FCLK(6)
   // ---- weight gradient: dump [tap][thread] per channel-of-four, 64-pixel sums in fixed order, f32 atomics
   if (dw == nullptr) return;
-  // Padded rows: the 32 lanes of a ds_read_b32 group below differ in (tap bit, channel half, pixel half, channel vector); with
-  // the plain [tap][thread] layout all but the last are multiples of 32 floats apart -- 4 banks for 32 lanes, 16 LDS cycles
-  // per read instead of 2 (tools/lds_bank_model.py), 12 k of the flush's 17 k clocks.  +16 floats per tap row, +4 per channel
-  // half (36 with the room the pixel-half pad takes), +8 per pixel half put the 32 lanes on 32 banks; the sums and their order
-  // are unchanged.
-  constexpr int FB_DUMP_LD = FB_NTHR + 48, FB_DUMP_HH = 256 + 36, FB_DUMP_PT = 32 * DW_CV + 8;
+  // Bank-padded rows: thread t = [pixel][half][vector] dumps at t + 8 * (pixel half); the 32 lanes of a ds_read_b32 group
+  // below differ in (tap bit, pixel half, channel half, vector) = 16 * (LD = 560) + 8 * (264) + 4 + 1 floats mod 32: 32 banks
+  // (the plain [tap][thread] rows put them on 4: 16 LDS cycles per read instead of 2, 12 k of the flush's 17 k clocks,
+  // tools/lds_bank_model.py).  The 64-pixel sums keep their order.
+  constexpr int FB_DUMP_LD = FB_NTHR + 48, FB_DUMP_PT = FB_NTHR / 2 + 8;
   float* dump = reinterpret_cast<float*>(tile);      // 27 * 560 floats = 60 KB <= 2 * 2 * NI * 16 B
-  const int dslot = tid + (FB_DUMP_HH - 256) * (tid >> 8) + (FB_DUMP_PT - 32 * DW_CV) * ((tid >> 7) & 1);
+  const int dslot = tid + (FB_DUMP_PT - FB_NTHR / 2) * (tid >> 8);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     __syncthreads();
@@ -542,10 +546,10 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
     if (tid < 27 * 8 * 2) {
       const int o = tid >> 1, part = tid & 1;
       const int tap = o >> 3, v = o & 3, hh = (o >> 2) & 1;
-      const float* src = dump + tap * FB_DUMP_LD + hh * FB_DUMP_HH + part * FB_DUMP_PT + v;
+      const float* src = dump + tap * FB_DUMP_LD + part * FB_DUMP_PT + hh * DW_CV + v;
       float s = 0.f;
 #pragma unroll 8
-      for (int k = 0; k < 32; ++k) s += src[k * DW_CV];
+      for (int k = 0; k < 32; ++k) s += src[k * 2 * DW_CV];
       s += __shfl_xor(s, 1, 64);
       const int c = c0 + v * 8 + hh * 4 + j;
       if (part == 0 && c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, s);
