@@ -238,7 +238,12 @@ template <int TT> struct V2Geo {
   static constexpr int SL = (NI + 255) / 256;
 };
 
-template <typename T, int TT>
+// PK: every prefetch slot's tile-independent part -- (frame, row, column) of its item in the staged tile and the element
+// offset from the tile origin -- is decoded once into one packed register per slot; the per-tile request is then two adds,
+// two unsigned compares and one 64-bit address instead of two divisions by constants, a frame multiply and three 64-bit
+// multiply-adds per slot (9 slots: ~200 of a tile's ~1 060 VALU instructions in a kernel whose VALU is its busiest unit).
+// The launcher takes it when the offset fits 22 bits and the tensor 2^31 elements.
+template <typename T, int TT, bool PK>
 __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x, const float* __restrict__ ss,
                                                         const float* __restrict__ w, T* __restrict__ y,
                                                         double* __restrict__ nc, const DwGeom g,
@@ -286,8 +291,34 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
 
   typename RW::type raw[SL];
   unsigned vmask = 0;
+  unsigned dsc[PK ? SL : 1];   // rel << 10 | valid << 9 | ix << 4 | iy
+  if constexpr (PK) {
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int i_ = tid + sl * 256;
+      const int p_ = i_ >> 2;
+      const int ix_ = p_ % V2_IW, q_ = p_ / V2_IW;
+      const int iy_ = q_ % V2_IH, t_ = q_ / V2_IH;
+      const bool ok_ = i_ < NI && s_ok && t_ < g.T;
+      const unsigned rel_ = (unsigned)(((t_ * g.H + iy_) * g.W + ix_) * g.Cp + sbase);
+      dsc[sl] = ok_ ? (rel_ << 10) | 512u | ((unsigned)ix_ << 4) | (unsigned)iy_ : 0u;
+    }
+  }
 #define V2_ISSUE(TL)                                                                            \
-  {                                                                                             \
+  if constexpr (PK) {                                                                           \
+    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                       \
+    const int by_ = ty_ * V2_TH - 1, bx_ = tx_ * V2_TW - 1;                                     \
+    const T* xt_ = x + (ptrdiff_t)(((b * g.T * g.H + by_) * g.W + bx_) * g.Cp);   /* wave-uniform */ \
+    vmask = 0;                                                                                  \
+    _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                         \
+      const unsigned d_ = dsc[sl];                                                              \
+      const unsigned gy_ = (unsigned)(by_ + (int)(d_ & 15u)), gx_ = (unsigned)(bx_ + (int)((d_ >> 4) & 31u)); \
+      if ((d_ & 512u) && gy_ < (unsigned)g.H && gx_ < (unsigned)g.W) {                          \
+        raw[sl] = RW::load(xt_ + (d_ >> 10));                                                   \
+        vmask |= 1u << sl;                                                                      \
+      }                                                                                         \
+    }                                                                                           \
+  } else {                                                                                      \
     const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                       \
     vmask = 0;                                                                                  \
     _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                         \
@@ -383,6 +414,9 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
       }
     }
     const int ox = tx * V2_TW + lx;
+    // one 64-bit lane address per tile (row 0 of the lane, frame 0); rows and frames are wave-uniform strides
+    T* const dst0 = y + (((size_t)b * g.T * g.H + (ty * V2_TH + PYR * yp)) * g.W + ox) * g.Cp + cbase;
+    const int64_t row_st = (int64_t)g.W * g.Cp, frm_st = (int64_t)g.H * g.W * g.Cp;
 #pragma unroll
     for (int py = 0; py < PYR; ++py) {
       const int oy = ty * V2_TH + PYR * yp + py;
@@ -390,7 +424,7 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
           if (t < g.T) {
-            T* dst = y + ((((size_t)b * g.T + t) * g.H + oy) * g.W + ox) * g.Cp + cbase;
+            T* dst = dst0 + (t * frm_st + py * row_st);
             Vec8<T>::store(dst, acc[t][py]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -422,7 +456,7 @@ int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, doubl
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2_kernel<T, TT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2_kernel<T, TT, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -441,8 +475,23 @@ int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, doubl
   dim3 grid(chunk_order_grid((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), (long)((ntiles + tpw - 1) / tpw) * g.B));
   c3d_bn_fin f0;
   std::memset(&f0, 0, sizeof(f0));
-  dw_fwd_v2_kernel<T, TT><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
-                                                            reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
+  // packed slot descriptors (bf16): the largest tile-relative element offset in 22 bits, the tensor in 2^31 elements
+  const size_t rel_max = (((size_t)(g.T - 1) * g.H + V2Geo<TT>::IH) * g.W + V2_IW) * g.Cp + g.Cp;
+  const bool pk = sizeof(T) == 2 && rel_max < ((size_t)1 << 22) && (size_t)g.B * g.T * g.H * g.W * g.Cp < ((size_t)1 << 31);
+  if (pk) {
+    static bool attr_pk = false;
+    if (!attr_pk) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2_kernel<T, TT, sizeof(T) == 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_pk = true;
+    }
+    dw_fwd_v2_kernel<T, TT, sizeof(T) == 2><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
+                                                                             reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
+  } else {
+    dw_fwd_v2_kernel<T, TT, false><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
+                                                                     reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
+  }
   C3D_CHECK_LAUNCH();
   return 0;
 }
