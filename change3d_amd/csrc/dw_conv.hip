@@ -527,7 +527,9 @@ template <int TT> struct V2S2Geo {
   static constexpr int SL = (NI + 255) / 256;
 };
 
-template <typename T, int TT>
+// PK: packed slot descriptors, as in dw_fwd_v2_kernel (14 slots here: their per-tile decode was more VALU instructions than
+// the tile's 252 packed FMAs)
+template <typename T, int TT, bool PK>
 __global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ x, const float* __restrict__ ss,
                                                           const float* __restrict__ w, T* __restrict__ y,
                                                           double* __restrict__ nc, const DwGeom g,
@@ -570,8 +572,34 @@ __global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ 
   // per-slot constants of the staging role: offset inside the input tile (global) and inside the parity planes (LDS)
   typename RW::type raw[SL];
   unsigned vmask = 0;
+  unsigned dsc[PK ? SL : 1];   // (rel / 8) << 11 | valid << 10 | ix << 4 | iy   (rel is a multiple of 8 elements)
+  if constexpr (PK) {
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int i_ = tid + sl * 256;
+      const int p_ = i_ >> 2;
+      const int ix_ = p_ % S2_IW, q_ = p_ / S2_IW;
+      const int iy_ = q_ % S2_IH, t_ = q_ / S2_IH;
+      const bool ok_ = i_ < NI && s_ok && t_ < g.T;
+      const unsigned rel_ = (unsigned)(((t_ * g.H + iy_) * g.W + ix_) * g.Cp + sbase);
+      dsc[sl] = ok_ ? ((rel_ >> 3) << 11) | 1024u | ((unsigned)ix_ << 4) | (unsigned)iy_ : 0u;
+    }
+  }
 #define S2_ISSUE(TL)                                                                            \
-  {                                                                                             \
+  if constexpr (PK) {                                                                           \
+    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                       \
+    const int by_ = ty_ * (2 * S2_TH) - 1, bx_ = tx_ * (2 * S2_TW) - 1;                         \
+    const T* xt_ = x + (ptrdiff_t)(((b * g.T * g.H + by_) * g.W + bx_) * g.Cp);   /* wave-uniform */ \
+    vmask = 0;                                                                                  \
+    _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                         \
+      const unsigned d_ = dsc[sl];                                                              \
+      const unsigned gy_ = (unsigned)(by_ + (int)(d_ & 15u)), gx_ = (unsigned)(bx_ + (int)((d_ >> 4) & 63u)); \
+      if ((d_ & 1024u) && gy_ < (unsigned)g.H && gx_ < (unsigned)g.W) {                         \
+        raw[sl] = RW::load(xt_ + ((d_ >> 11) << 3));                                            \
+        vmask |= 1u << sl;                                                                      \
+      }                                                                                         \
+    }                                                                                           \
+  } else {                                                                                      \
     const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                       \
     vmask = 0;                                                                                  \
     _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                         \
@@ -695,8 +723,11 @@ int launch_fwd_v2s2(const void* x, const float* ss, const float* w, void* y, dou
   if (lds > 160 * 1024) return C3D_E_UNSUPPORTED;   // (five frames: 218 KB -- the v1 kernel)
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2s2_kernel<T, TT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2s2_kernel<T, TT, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2s2_kernel<T, TT, sizeof(T) == 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -708,8 +739,15 @@ int launch_fwd_v2s2(const void* x, const float* ss, const float* w, void* y, dou
   dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
   c3d_bn_fin f0;
   std::memset(&f0, 0, sizeof(f0));
-  dw_fwd_v2s2_kernel<T, TT><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
-                                                              reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
+  // packed slot descriptors (bf16): the largest tile-relative element offset / 8 in 21 bits, the tensor in 2^31 elements
+  const size_t rel_max = (((size_t)(g.T - 1) * g.H + S2_IH) * g.W + S2_IW) * g.Cp + g.Cp;
+  const bool pk = sizeof(T) == 2 && (rel_max >> 3) < ((size_t)1 << 21) && (size_t)g.B * g.T * g.H * g.W * g.Cp < ((size_t)1 << 31);
+  if (pk)
+    dw_fwd_v2s2_kernel<T, TT, sizeof(T) == 2><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
+                                                                               reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
+  else
+    dw_fwd_v2s2_kernel<T, TT, false><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
+                                                                       reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
   C3D_CHECK_LAUNCH();
   return 0;
 }
