@@ -19,6 +19,7 @@
 #include "pw_common.h"   // device_cus()
 #include "dw_common.h"
 #include "bn_fin.h"
+#include "launch_hints.h"
 #include "../../include/change3d_hip.h"
 #include <cstdlib>
 #include <type_traits>
@@ -185,6 +186,70 @@ __device__ __forceinline__ void fb_taps_s1(const float4* tp, const float* wlp, f
       }
       pin_acc<TT>(acc);
       pin_dw(dwa[ky * 3 + kx], dwa[9 + ky * 3 + kx], dwa[18 + ky * 3 + kx]);
+    }
+  }
+}
+
+// ---- end of a workgroup's walk (shared by the register-prefetch and the LDS-DMA ring kernels): BN_a-backward sums (lanes of
+// equal (half, vector) inside a wave, then the eight waves) and the weight gradient (dump [tap][thread] per channel-of-four,
+// 64-pixel sums in fixed order, f32 atomics).  `scratch` = the (dead) tile buffers: >= 27 * (FB_NTHR + 48) floats.
+__device__ __forceinline__ void fb_flush(void* scratch, const float (&S1)[4], const float (&S2)[4], const f32x2_t (&dwa)[27][2],
+                                         double* __restrict__ dsums, float* __restrict__ dw, const DwGeom& g, const int c0) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  double* red64 = reinterpret_cast<double*>(scratch);   // [8 waves][2 halves x DW_CV][8]
+  __syncthreads();
+  double D1[4], D2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    D1[j] = (double)S1[j]; D2[j] = (double)S2[j];
+#pragma unroll
+    for (int o = 2 * DW_CV; o < 64; o <<= 1) {   // the 8 pixels of the wave (lane bits 3-5)
+      D1[j] += __shfl_xor(D1[j], o, 64);
+      D2[j] += __shfl_xor(D2[j], o, 64);
+    }
+  }
+  if (lane < 2 * DW_CV) {                        // lane = half * 4 + vector
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red64[(wave * 2 * DW_CV + lane) * 8 + j] = D1[j];
+      red64[(wave * 2 * DW_CV + lane) * 8 + 4 + j] = D2[j];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int v = tid >> 4, r = tid & 15;
+    const int hh = r >> 3, which = (r >> 2) & 1, j = r & 3;
+    double sacc = 0.0;
+    for (int wv = 0; wv < FB_NTHR / 64; ++wv) sacc += red64[(wv * 2 * DW_CV + hh * DW_CV + v) * 8 + which * 4 + j];
+    const int c = c0 + v * 8 + hh * 4 + j;
+    if (c < g.C) atomicAdd(dsums + (size_t)which * g.C + c, sacc);
+  }
+  // ---- weight gradient
+  if (dw == nullptr) return;
+  // Bank-padded rows: thread t = [pixel][half][vector] dumps at t + 8 * (pixel half); the 32 lanes of a ds_read_b32 group
+  // below differ in (tap bit, pixel half, channel half, vector) = 16 * (LD = 560) + 8 * (264) + 4 + 1 floats mod 32: 32 banks
+  // (the plain [tap][thread] rows put them on 4: 16 LDS cycles per read instead of 2, 12 k of the flush's 17 k clocks,
+  // tools/lds_bank_model.py).  The 64-pixel sums keep their order.
+  constexpr int FB_DUMP_LD = FB_NTHR + 48, FB_DUMP_PT = FB_NTHR / 2 + 8;
+  float* dump = reinterpret_cast<float*>(scratch);      // 27 * 560 floats = 60 KB
+  const int dslot = tid + (FB_DUMP_PT - FB_NTHR / 2) * (tid >> 8);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 27; ++k) dump[k * FB_DUMP_LD + dslot] = dwa[k][j >> 1][j & 1];
+    __syncthreads();
+    if (tid < 27 * 8 * 2) {
+      const int o = tid >> 1, part = tid & 1;
+      const int tap = o >> 3, v = o & 3, hh = (o >> 2) & 1;
+      const float* src = dump + tap * FB_DUMP_LD + part * FB_DUMP_PT + hh * DW_CV + v;
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) s += src[k * 2 * DW_CV];
+      s += __shfl_xor(s, 1, 64);
+      const int c = c0 + v * 8 + hh * 4 + j;
+      if (part == 0 && c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, s);
     }
   }
 }
@@ -497,66 +562,371 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
 #undef FB_ISSUE_RAW
 #undef FB_ISSUE_A
 
-  // ---- flush the BN_a-backward sums: lanes of equal (half, vector) inside a wave, then the eight waves
-  const int lane = tid & 63, wave = tid >> 6;
-  double* red64 = reinterpret_cast<double*>(tile);   // [8 waves][2 halves x DW_CV][8]; the tile buffers are dead now
-  __syncthreads();
-  double D1[4], D2[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    D1[j] = (double)S1[j]; D2[j] = (double)S2[j];
-#pragma unroll
-    for (int o = 2 * DW_CV; o < 64; o <<= 1) {   // the 8 pixels of the wave (lane bits 3-5)
-      D1[j] += __shfl_xor(D1[j], o, 64);
-      D2[j] += __shfl_xor(D2[j], o, 64);
-    }
-  }
-  if (lane < 2 * DW_CV) {                        // lane = half * 4 + vector
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      red64[(wave * 2 * DW_CV + lane) * 8 + j] = D1[j];
-      red64[(wave * 2 * DW_CV + lane) * 8 + 4 + j] = D2[j];
-    }
-  }
-  __syncthreads();
-  if (tid < 64) {
-    const int v = tid >> 4, r = tid & 15;
-    const int hh = r >> 3, which = (r >> 2) & 1, j = r & 3;
-    double sacc = 0.0;
-    for (int wv = 0; wv < FB_NTHR / 64; ++wv) sacc += red64[(wv * 2 * DW_CV + hh * DW_CV + v) * 8 + which * 4 + j];
-    const int c = c0 + v * 8 + hh * 4 + j;
-    if (c < g.C) atomicAdd(dsums + (size_t)which * g.C + c, sacc);
-  }
-  FCLK(6)
-  // ---- weight gradient: dump [tap][thread] per channel-of-four, 64-pixel sums in fixed order, f32 atomics
-  if (dw == nullptr) return;
-  // Bank-padded rows: thread t = [pixel][half][vector] dumps at t + 8 * (pixel half); the 32 lanes of a ds_read_b32 group
-  // below differ in (tap bit, pixel half, channel half, vector) = 16 * (LD = 560) + 8 * (264) + 4 + 1 floats mod 32: 32 banks
-  // (the plain [tap][thread] rows put them on 4: 16 LDS cycles per read instead of 2, 12 k of the flush's 17 k clocks,
-  // tools/lds_bank_model.py).  The 64-pixel sums keep their order.
-  constexpr int FB_DUMP_LD = FB_NTHR + 48, FB_DUMP_PT = FB_NTHR / 2 + 8;
-  float* dump = reinterpret_cast<float*>(tile);      // 27 * 560 floats = 60 KB <= 2 * 2 * NI * 16 B
-  const int dslot = tid + (FB_DUMP_PT - FB_NTHR / 2) * (tid >> 8);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 27; ++k) dump[k * FB_DUMP_LD + dslot] = dwa[k][j >> 1][j & 1];
-    __syncthreads();
-    if (tid < 27 * 8 * 2) {
-      const int o = tid >> 1, part = tid & 1;
-      const int tap = o >> 3, v = o & 3, hh = (o >> 2) & 1;
-      const float* src = dump + tap * FB_DUMP_LD + part * FB_DUMP_PT + hh * DW_CV + v;
-      float s = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) s += src[k * 2 * DW_CV];
-      s += __shfl_xor(s, 1, 64);
-      const int c = c0 + v * 8 + hh * 4 + j;
-      if (part == 0 && c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, s);
-    }
-  }
+  fb_flush(tile, S1, S2, dwa, dsums, dw, g, c0);
   FCLK(7)
   FCLK_FLUSH
+}
+
+// =====================================================================================================================
+// LDS-DMA ring variant (bf16 storage, stride 1, T <= 3): the raw t1 / b rows of the db tile and the workgroup's `a` rows
+// arrive by global_load_lds_dwordx4 (1 KiB per wave instruction, no destination registers) TWO tiles ahead of the tap walk,
+// the requests carried across the tile barrier.  The register-prefetch kernel above holds ONE tile ahead in 24 + 6 VGPRs,
+// issues it in a burst and stalls 30 % of a wave's time in that burst; its exec-masked global loads also make the
+// compiler fall back to vmcnt(0) around them.  Here:
+//   * a ring slot = [t1 plane][b plane][a rows]: a raw bf16 8-channel vector of t1 plus one of b are 32 bytes, exactly the
+//     two f32 half-vector planes of db = A t1 + B[n] + C b -- the staging pass converts a slot IN PLACE (thread i reads
+//     plane0[i], plane1[i] and writes db[0..3] -> plane0[i], db[4..7] -> plane1[i]); three slots = 150 KB;
+//   * every wave converts exactly the pieces it requested (lane-linear DMA image = the staging index i = tid + 512 sl) and
+//     reads only its own pixels' `a` rows: a wave's counted vmcnt is the only ordering the landed data needs; the tile
+//     barrier (conversions visible to the tap walk) stays the one barrier per tile;
+//   * the DMA is issued from inline asm, invisible to the compiler's s_waitcnt bookkeeping (a compiler-visible LDS-DMA makes
+//     every later LDS access of the wave wait for vmcnt(0)); the waits on it are explicit and counted;
+//   * lanes without a source (halo outside the image, channel padding, the tail of the last piece) request a safe address
+//     instead of being masked off: every DMA instruction is always issued, so the counts are exact.
+// Arithmetic, summation order, tap walk and flush are the register-prefetch kernel's: bit-identical t2 / dw / sums.
+__device__ __forceinline__ void fb_glds16(const void* gsrc, const uint32_t lds_dst) {   // lds_dst: wave-uniform byte address
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void fb_wait_vm(const int n) {   // wave-uniform n: s_waitcnt vmcnt(n)
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+typedef __attribute__((address_space(3))) unsigned char* fb_lds_ptr_t;
+
+template <int TT>
+struct RingPlan {
+  static constexpr int NI = TT * FB_DH * FB_DW * DW_CV;       // staged 8-channel vectors per plane
+  static constexpr int NP = (NI + 63) / 64;                   // 1 KiB pieces per plane
+  static constexpr int NPL = NP * 64;                         // plane stride (vectors)
+  static constexpr int SL = (NP + 7) / 8;                     // pieces per wave and plane (at most)
+  static constexpr int NA = (TT * 8 * DW_CV + 63) / 64;       // `a` pieces per wave: TT frames x 8 pixels x 4 vectors
+  static constexpr int A_BYTES = 8 * TT * 8 * DW_CV * 16;     // 8 waves
+  static constexpr int SLOT_BYTES = 2 * NPL * 16 + A_BYTES;
+  static constexpr int R = 3;
+  static constexpr int HEAD_BYTES = (27 * 32 + 7 * 32) * 4;
+  static constexpr int LDS_BYTES = HEAD_BYTES + R * SLOT_BYTES;
+};
+
+template <int TT>
+__global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
+    const bf16_t* __restrict__ t1, const bf16_t* __restrict__ bb, const float* __restrict__ coefA,
+    const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
+    const bf16_t* __restrict__ a, const float* __restrict__ ss_a, const float* __restrict__ mr_a, bf16_t* __restrict__ t2,
+    double* __restrict__ dsums, float* __restrict__ dw, const DwGeom g, const int tiles_per_wg, const c3d_bn_fin fin) {
+  typedef bf16_t T;
+  typedef Raw4<T> R4;
+  typedef RingPlan<TT> P;
+  constexpr int NI = P::NI, NP = P::NP, NPL = P::NPL, SL = P::SL, NA = P::NA;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);             // [27][32]
+  float* cf = wl + 27 * 32;                               // [7][32]: cA, cB(sample), cC, sa, sb, ma, ra
+  unsigned char* ring = smem + P::HEAD_BYTES;             // [R slots]{[2 planes][NPL] 16 B, [8 waves][TT][8 pixels][4 vectors] 16 B}
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)(fb_lds_ptr_t)ring;
+
+  const int tid = threadIdx.x;
+  FCLK_DECL
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = (tid >> 2) & 1;                           // thread = [pixel][channel half][channel vector], as above
+  const int cv = tid & (DW_CV - 1);
+  const int pix = tid >> 3;
+  const int px = pix & (FB_TW - 1), py = pix >> 3;        // py == wave
+
+  const int tiles_x = (g.W + FB_TW - 1) / FB_TW, tiles_y = (g.H + FB_TH - 1) / FB_TH;
+  const int ntiles = tiles_x * tiles_y;
+  const int gx = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
+  const ChunkOrder co = chunk_order((g.Cp + DW_CV * 8 - 1) / (DW_CV * 8), gx * g.B);
+  if (co.group < 0) return;
+  const int b = co.group / gx, tg = co.group % gx;
+  const int c0 = co.chunk * DW_CV * 8;
+  const int cb8 = c0 + cv * 8;
+  const int cb4 = cb8 + h * 4;
+  const bool c_ok = cb8 < g.Cp;
+
+  for (int i = tid; i < 27 * 32; i += FB_NTHR) {
+    const int tap = i >> 5, c = c0 + (i & 31);
+    wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
+  }
+  if (fin.sums) {
+    if (tid < 128) {
+      float cA, cB, cC;
+      c3dfin::bn_b_bwd_coef_nc(fin, g.C, g.Cp, c0 + (tid >> 2), tid & 3, co.group == 0, cA, cB, cC);
+      if ((tid & 3) == 0) { cf[tid >> 2] = cA; cf[32 + (tid >> 2)] = cB; cf[64 + (tid >> 2)] = cC; }
+    }
+  }
+  for (int i = tid + (fin.sums ? 3 * 32 : 0); i < 7 * 32; i += FB_NTHR) {
+    const int k = i >> 5, c = c0 + (i & 31);
+    float v = 0.f;
+    if (c < g.Cp) {
+      v = k == 0 ? coefA[c] : k == 1 ? coefB[(size_t)b * g.Cp + c] : k == 2 ? coefC[c] : k == 3 ? ss_a[c]
+        : k == 4 ? ss_a[g.Cp + c] : k == 5 ? mr_a[c] : mr_a[g.Cp + c];
+    }
+    cf[i] = v;
+  }
+
+  float S1[4], S2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { S1[j] = 0.f; S2[j] = 0.f; }
+  f32x2_t dwa[27][2];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) { dwa[k][0] = f32x2_t{0.f, 0.f}; dwa[k][1] = f32x2_t{0.f, 0.f}; }
+
+  // staging descriptors of this thread's vectors i = tid + 512 sl = 64 (wave + 8 sl) + lane: element offset relative to the
+  // tile's db origin, (row, column) in the tile (0x7fff7fff: no source -> zero)
+  int rel[SL], yx[SL];
+#pragma unroll
+  for (int sl = 0; sl < SL; ++sl) {
+    const int i_ = tid + sl * FB_NTHR;
+    const int p_ = i_ / DW_CV;
+    const int ix_ = p_ % FB_DW, q_ = p_ / FB_DW;
+    const int iy_ = q_ % FB_DH, t_ = q_ / FB_DH;
+    const bool use_ = i_ < NI && c_ok && t_ < g.T;
+    rel[sl] = ((t_ * g.Ho + iy_) * g.Wo + ix_) * g.Cp + cb8;
+    yx[sl] = use_ ? (iy_ | (ix_ << 16)) : 0x7fff7fff;
+  }
+  const int rel_safe = (g.Wo + 1) * g.Cp + c0;            // the tile's first interior pixel, frame 0, first vector of the chunk
+  // `a` pieces of this wave: lane -> (frame, pixel of the wave's tile row, vector)
+  int arel[NA];
+  unsigned aok = 0;                                        // bit j: piece j of this lane has a source apart from the tile-edge test
+  int apx[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int idx = j * 64 + lane;
+    const int vec = idx & (DW_CV - 1), combo = idx >> 2;
+    const int p_ = combo & 7, t_ = combo >> 3;
+    arel[j] = ((t_ * g.H + wave) * g.W + p_) * g.Cp + c0 + vec * 8;
+    apx[j] = p_;
+    if (t_ < TT && t_ < g.T && c0 + vec * 8 < g.Cp) aok |= 1u << j;
+  }
+  const int orel = (py * g.W + px) * g.Cp + cb4, ofr = g.H * g.W * g.Cp;
+  const int n_raw = (NP - 1 - wave) / 8 + 1;               // pieces per plane of this wave (wave-uniform)
+  const int n_dma = 2 * n_raw + NA;                        // DMA instructions per tile of this wave
+
+  // requests of tile TL -> slot SIDX
+#define RB_ISSUE(TL, SIDX)                                                                        \
+  {                                                                                               \
+    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                         \
+    const int dy0_ = ty_ * FB_TH - 1, dx0_ = tx_ * FB_TW - 1;                                     \
+    const int64_t tb_ = ((((int64_t)b * g.T) * g.Ho + dy0_) * g.Wo + dx0_) * g.Cp;  /* wave-uniform */ \
+    const uint32_t sb_ = ring_lds + (uint32_t)(SIDX) * P::SLOT_BYTES;                             \
+    _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                           \
+      if (wave + 8 * sl < NP) {                                                                   \
+        const unsigned gy_ = (unsigned)(dy0_ + (yx[sl] & 0xffff));                                \
+        const unsigned gx_ = (unsigned)(dx0_ + (yx[sl] >> 16));                                   \
+        const int off_ = (gy_ < (unsigned)g.Ho && gx_ < (unsigned)g.Wo) ? rel[sl] : rel_safe;     \
+        fb_glds16(t1 + tb_ + off_, sb_ + (uint32_t)(wave + 8 * sl) * 1024u);                      \
+        fb_glds16(bb + tb_ + off_, sb_ + (uint32_t)(NPL * 16) + (uint32_t)(wave + 8 * sl) * 1024u); \
+      }                                                                                           \
+    }                                                                                             \
+    const int ay0_ = ty_ * FB_TH, ax0_ = tx_ * FB_TW;                                             \
+    const int64_t ab_ = ((((int64_t)b * g.T) * g.H + ay0_) * g.W + ax0_) * g.Cp;                  \
+    const bool row_ok_ = ay0_ + wave < g.H;                                                       \
+    _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                              \
+      if (j * 64 + lane < TT * 8 * DW_CV) {                                                       \
+        const int off_ = (row_ok_ && ((aok >> j) & 1u) && ax0_ + apx[j] < g.W) ? arel[j] : c0;    \
+        fb_glds16(a + ab_ + off_, sb_ + (uint32_t)(2 * NPL * 16) + (uint32_t)wave * (uint32_t)(TT * 8 * DW_CV * 16) + (uint32_t)j * 1024u); \
+      }                                                                                           \
+    }                                                                                             \
+  }
+  // in-place conversion of this thread's vectors of slot SIDX (tile TL): db = A t1 + B[n] + C b, zero outside the image
+#define RB_CONVERT(TL, SIDX)                                                                      \
+  {                                                                                               \
+    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                         \
+    const int dy0_ = ty_ * FB_TH - 1, dx0_ = tx_ * FB_TW - 1;                                     \
+    uint4* p0_ = reinterpret_cast<uint4*>(ring + (size_t)(SIDX) * P::SLOT_BYTES);                 \
+    float cA[8], cB[8], cC[8];                                                                    \
+    lds8(cf + 0 * 32 + cv * 8, cA);                                                               \
+    lds8(cf + 1 * 32 + cv * 8, cB);                                                               \
+    lds8(cf + 2 * 32 + cv * 8, cC);                                                               \
+    _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                           \
+      if (wave + 8 * sl < NP) {                                                                   \
+        const int i = tid + sl * FB_NTHR;                                                         \
+        const unsigned gy_ = (unsigned)(dy0_ + (yx[sl] & 0xffff));                                \
+        const unsigned gx_ = (unsigned)(dx0_ + (yx[sl] >> 16));                                   \
+        float f[8];                                                                               \
+        if (gy_ < (unsigned)g.Ho && gx_ < (unsigned)g.Wo) {                                       \
+          float f2[8];                                                                            \
+          Raw8<T>::cvt(p0_[i], f);                                                                \
+          Raw8<T>::cvt(p0_[NPL + i], f2);                                                         \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) f[j] = fmaf(cA[j], f[j], fmaf(cC[j], f2[j], cB[j])); \
+        } else {                                                                                  \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) f[j] = 0.f;                               \
+        }                                                                                         \
+        reinterpret_cast<float4*>(p0_)[i] = make_float4(f[0], f[1], f[2], f[3]);                  \
+        reinterpret_cast<float4*>(p0_)[NPL + i] = make_float4(f[4], f[5], f[6], f[7]);            \
+      }                                                                                           \
+    }                                                                                             \
+  }
+
+  const int tl0 = tg * tiles_per_wg;
+  int tl1 = tl0 + tiles_per_wg;
+  if (tl1 > ntiles) tl1 = ntiles;
+  if (tl0 < tl1) RB_ISSUE(tl0, 0)
+  if (tl0 + 1 < tl1) RB_ISSUE(tl0 + 1, 1)
+  __syncthreads();   // wl / cf staged
+  if (tl0 < tl1) {
+    fb_wait_vm(tl0 + 1 < tl1 ? n_dma : 0);
+    RB_CONVERT(tl0, 0)
+  }
+  FCLK(0)
+
+  int slot = 0;   // ring slot of tile tl
+  for (int tl = tl0; tl < tl1; ++tl) {
+    const int tx = tl % tiles_x, ty = tl / tiles_x;
+    const int y0 = ty * FB_TH, x0 = tx * FB_TW;
+    const int slot1 = slot + 1 == P::R ? 0 : slot + 1, slot2 = slot1 + 1 == P::R ? 0 : slot1 + 1;
+    __syncthreads();   // conversions of tile tl visible; every wave is past the tap walk of tile tl - 1 (slot2)
+    FCLK(3)
+    if (tl + 2 < tl1) RB_ISSUE(tl + 2, slot2)
+    FCLK(2)
+    const float4* tb = reinterpret_cast<const float4*>(ring + (size_t)slot * P::SLOT_BYTES);
+    // this thread's `a` rows: [wave][frame][pixel][vector] 16-byte vectors, its channel half
+    const uint2* ab = reinterpret_cast<const uint2*>(ring + (size_t)slot * P::SLOT_BYTES + 2 * NPL * 16 + wave * (TT * 8 * DW_CV * 16)) + (px * DW_CV + cv) * 2 + h;
+    typename R4::type arc[TT];
+    f32x2_t ain[TT][2];
+    f32x2_t acc[TT][2];
+    float sa[4], sb[4];
+    lds4(cf + 3 * 32 + cv * 8 + h * 4, sa);
+    lds4(cf + 4 * 32 + cv * 8 + h * 4, sb);
+    const bool p_ok = c_ok && y0 + py < g.H && x0 + px < g.W;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      if (p_ok && t < g.T) {
+        arc[t] = ab[t * 8 * DW_CV * 2];
+        float av[4];
+        R4::cvt(arc[t], av);
+        ain[t][0] = f32x2_t{fmaxf(fmaf(av[0], sa[0], sb[0]), 0.f), fmaxf(fmaf(av[1], sa[1], sb[1]), 0.f)};
+        ain[t][1] = f32x2_t{fmaxf(fmaf(av[2], sa[2], sb[2]), 0.f), fmaxf(fmaf(av[3], sa[3], sb[3]), 0.f)};
+      } else {
+        ain[t][0] = f32x2_t{0.f, 0.f}; ain[t][1] = f32x2_t{0.f, 0.f};
+      }
+      acc[t][0] = f32x2_t{0.f, 0.f}; acc[t][1] = f32x2_t{0.f, 0.f};
+    }
+    FCLK(1)
+    // ---- 27 taps (the register-prefetch kernel's walk: two fragment slots, LDS reads of step s+1 before the FMAs of step s)
+    const float4* tp = tb + (size_t)h * NPL + (py * FB_DW + px) * DW_CV + cv;
+    float4 wq[2][3], hq[2][TT];
+#define FB_LOAD(S, SLOT)                                                                                          \
+  {                                                                                                               \
+    constexpr int ky_ = (S) / 3, kx_ = (S) % 3;                                                                   \
+    _Pragma("unroll") for (int kt = 0; kt < 3; ++kt)                                                             \
+      wq[SLOT][kt] = *reinterpret_cast<const float4*>(wl + (kt * 9 + (S)) * 32 + cv * 8 + h * 4);                \
+    _Pragma("unroll") for (int to = 0; to < TT; ++to)                                                            \
+      hq[SLOT][to] = tp[((to * FB_DH + (2 - ky_)) * FB_DW + (2 - kx_)) * DW_CV];                                 \
+  }
+#define FB_STEP(S, SLOT)                                                                                          \
+  {                                                                                                               \
+    _Pragma("unroll") for (int to = 0; to < TT; ++to) {                                                          \
+      const f32x2_t v0 = {hq[SLOT][to].x, hq[SLOT][to].y}, v1 = {hq[SLOT][to].z, hq[SLOT][to].w};                 \
+      _Pragma("unroll") for (int kt = 0; kt < 3; ++kt) {                                                         \
+        const int ti = to + kt - 1;                                                                               \
+        if (ti >= 0 && ti < TT) {                                                                                 \
+          const f32x2_t w0 = {wq[SLOT][kt].x, wq[SLOT][kt].y}, w1 = {wq[SLOT][kt].z, wq[SLOT][kt].w};             \
+          acc[ti][0] = __builtin_elementwise_fma(v0, w0, acc[ti][0]);                                             \
+          acc[ti][1] = __builtin_elementwise_fma(v1, w1, acc[ti][1]);                                             \
+          dwa[kt * 9 + (S)][0] = __builtin_elementwise_fma(v0, ain[ti][0], dwa[kt * 9 + (S)][0]);                 \
+          dwa[kt * 9 + (S)][1] = __builtin_elementwise_fma(v1, ain[ti][1], dwa[kt * 9 + (S)][1]);                 \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+    pin_acc<TT>(acc);                                                                                             \
+    pin_dw(dwa[(S)], dwa[9 + (S)], dwa[18 + (S)]);                                                                \
+  }
+    FB_LOAD(0, 0)
+    FB_LOAD(1, 1) FB_STEP(0, 0)
+    FB_LOAD(2, 0) FB_STEP(1, 1)
+    FB_LOAD(3, 1) FB_STEP(2, 0)
+    FB_LOAD(4, 0) FB_STEP(3, 1)
+    FB_LOAD(5, 1) FB_STEP(4, 0)
+    FB_LOAD(6, 0) FB_STEP(5, 1)
+    FB_LOAD(7, 1) FB_STEP(6, 0)
+    FB_LOAD(8, 0) FB_STEP(7, 1)
+    FB_STEP(8, 0)
+#undef FB_LOAD
+#undef FB_STEP
+    FCLK(4)
+    // ---- the next tile's requests (issued one tile ago) have landed once at most this tile's requests are outstanding
+    if (tl + 1 < tl1) fb_wait_vm(tl + 2 < tl1 ? n_dma : 0);
+    FCLK(6)
+    // ---- mask, store t2, BN_a-backward sums
+    if (p_ok) {
+      float ma[4], ra[4];
+      lds4(cf + 5 * 32 + cv * 8 + h * 4, ma);
+      lds4(cf + 6 * 32 + cv * 8 + h * 4, ra);
+      T* ob = t2 + ((((int64_t)b * g.T) * g.H + y0) * g.W + x0) * g.Cp;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (t < g.T) {
+          float av[4], o[4];
+          R4::cvt(arc[t], av);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = round_as<T>(ain[t][j >> 1][j & 1] > 0.f ? acc[t][j >> 1][j & 1] : 0.f);
+            o[j] = d;
+            S1[j] += d; S2[j] += d * ((av[j] - ma[j]) * ra[j]);
+          }
+          R4::store(ob + (orel + t * ofr), o);
+        }
+      }
+    }
+    FCLK(5)
+    if (tl + 1 < tl1) RB_CONVERT(tl + 1, slot1)
+    FCLK(8)
+    slot = slot1;
+  }
+#undef RB_ISSUE
+#undef RB_CONVERT
+
+  fb_flush(ring, S1, S2, dwa, dsums, dw, g, c0);
+  FCLK(7)
+  FCLK_FLUSH
+}
+
+template <int TT>
+int launch_ring_t(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const float* w,
+                  const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw,
+                  const DwGeom& g, hipStream_t stream, const c3d_bn_fin& fin) {
+  typedef RingPlan<TT> P;
+  static_assert(P::LDS_BYTES <= 160 * 1024, "ring does not fit");
+  static_assert((size_t)P::R * P::SLOT_BYTES >= (size_t)27 * (FB_NTHR + 48) * sizeof(float), "dump region");
+  static_assert(2 * P::SL + P::NA <= 12, "fb_wait_vm covers counts up to 12");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_ring_kernel<TT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int ntiles = ((g.W + FB_TW - 1) / FB_TW) * ((g.H + FB_TH - 1) / FB_TH);
+  const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
+  static const int env_tpw = c3d_env("C3D_DWBF_TPW") ? atoi(c3d_env("C3D_DWBF_TPW")) : 0;
+  static const int env_max = c3d_env("C3D_DWBF_MAX") ? atoi(c3d_env("C3D_DWBF_MAX")) : 32;
+  int tpw = env_max;
+  while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 85L * device_cus() / 100) tpw >>= 1;
+  if (env_tpw > 0) tpw = env_tpw;
+  if (tpw > ntiles) tpw = ntiles;
+  dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
+  dw_bwd_ring_kernel<TT><<<grid, dim3(FB_NTHR), P::LDS_BYTES, stream>>>(
+      reinterpret_cast<const bf16_t*>(t1), reinterpret_cast<const bf16_t*>(bb), cA, cB, cC, w, reinterpret_cast<const bf16_t*>(a),
+      ss_a, mr_a, reinterpret_cast<bf16_t*>(t2), dsums, dw, g, tpw, fin);
+  C3D_CHECK_LAUNCH();
+  return 0;
 }
 
 template <typename T, int TT, int S>
@@ -609,6 +979,8 @@ int dispatch_fused(const void* t1, const void* b, const float* coefA, const floa
     FB_DISPATCH(float, 2)
   }
   if (dtype == C3D_DT_BF16) {
+    if (g.stride == 1 && g.T <= 3 && (c3d_option_dw_ring & 1))
+      return launch_ring_t<3>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
     if (g.stride == 1) { FB_DISPATCH(bf16_t, 1) }
     FB_DISPATCH(bf16_t, 2)
   }

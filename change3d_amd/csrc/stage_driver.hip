@@ -844,6 +844,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
 
 // ---- profile / runtime switches --------------------------------------------------------------------------------
 int c3d_option_stem_mfma = 2, c3d_option_convt_mfma = 1;   // read by stem.hip / decoder.hip (launch_hints.h)
+int c3d_option_dw_ring = 3;                                // read by dw_bwd_fused.hip / dw_conv.hip
 
 extern "C" int c3d_set_option(int32_t option, int32_t value) {
   switch (option) {
@@ -853,6 +854,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_FUSE_WGRAD: g_fuse_wgrad = value & 3; return 0;
     case C3D_OPT_FOLD_SE: g_fold_se = value ? 1 : 0; return 0;
     case C3D_OPT_MASK_IN_DGRAD: g_mask_in_dgrad = value ? 1 : 0; return 0;
+    case C3D_OPT_DW_RING: c3d_option_dw_ring = value & 3; return 0;
     default: return C3D_E_BADARG;
   }
 }

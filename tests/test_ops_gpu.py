@@ -481,6 +481,49 @@ def test_dw333_backward_walks(dtype, B, H, W, C, stride):
     _check_fused_dw(ops, t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2_ref, a, mean_a, rstd_a, w_r.grad.view(C, 27), B, T, H, W, C, dtype, stride)
 
 
+@pytest.mark.parametrize("B,H,W,C", [
+    (2, 16, 24, 54),        # two channel chunks, the second one short
+    (5, 20, 28, 216),       # ragged tiles, 7 chunks
+    (3, 40, 40, 108),       # 25 tiles per sample: walks of more than three tiles (every ring slot is reused)
+    (40, 24, 24, 54),       # walks across sample boundaries
+    (1100, 8, 8, 54),       # one tile per sample
+    (2, 8, 72, 24),         # a single tile row
+])
+def test_dw_bwd_ring_kernel_is_bit_identical_to_the_register_prefetch_kernel(B, H, W, C):
+    """C3D_OPT_DW_RING bit 0: the LDS-DMA ring variant of c3d_dw333_bwd_fused (bf16, stride 1, T = 3) changes how the raw rows
+    reach the workgroup, not one operation of the arithmetic: data gradient, BatchNorm_a sums and weight gradient must be
+    bit-identical to the register-prefetch kernel's (the f32 atomics of the flush commute only up to rounding across
+    workgroups: the weight gradient is compared at 1e-6 of its scale, everything else exactly)."""
+    _need_gpu()
+    from change3d_amd import ops
+    T, dtype = 3, torch.bfloat16
+    Cp = ops.cpad(C)
+    t1d = padc(q(rnd((B, T, H, W, C), 250), dtype), Cp).to(DEV, dtype).contiguous()
+    bd = padc(q(rnd((B, T, H, W, C), 251), dtype), Cp).to(DEV, dtype).contiguous()
+    ad = padc(q(rnd((B, T, H, W, C), 252), dtype), Cp).to(DEV, dtype).contiguous()
+    cAd, cCd = padc(rnd((C,), 253), Cp).to(DEV), padc(rnd((C,), 254, 0.1), Cp).to(DEV)
+    cBd = padc(rnd((B, C), 255, 0.1), Cp).to(DEV).contiguous()
+    wd = rnd((C, 27), 256, 0.3).to(DEV).contiguous()
+    ss = torch.cat([padc(rnd((C,), 257).abs() + 0.5, Cp), padc(rnd((C,), 258, 0.3), Cp)]).to(DEV)
+    mr = torch.cat([padc(rnd((C,), 259, 0.5), Cp), padc(rnd((C,), 260).abs() + 0.5, Cp)]).to(DEV)
+    out = {}
+    try:
+        for ring in (0, 1):
+            ops.set_option(ops.OPT_DW_RING, ring)
+            t2 = torch.full_like(ad, float("nan"))
+            ds = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+            dw = torch.zeros((C, 27), dtype=torch.float32, device=DEV)
+            ops.dw_bwd_fused(t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, ds, dw, B, T, H, W, C, ops.dt_code(dtype), 1)
+            torch.cuda.synchronize()
+            out[ring] = (t2, ds, dw)
+    finally:
+        ops.set_option(ops.OPT_DW_RING, 3)
+    assert torch.equal(out[0][0].view(torch.int16), out[1][0].view(torch.int16)), "data gradient differs"
+    assert torch.allclose(out[0][1], out[1][1], rtol=1e-12, atol=0), "BatchNorm_a sums differ"
+    scale = out[0][2].abs().max().item()
+    assert (out[0][2] - out[1][2]).abs().max().item() <= 1e-6 * scale, "weight gradient differs"
+
+
 # --------------------------------------------------------------------------- loss / optimizer
 def test_bce_dice_and_adam():
     _need_gpu()

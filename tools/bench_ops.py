@@ -14,6 +14,9 @@ B, T = int(os.environ.get("C3D_BENCH_B", "32")), 3   # C3D_BENCH_B=1 C3D_BENCH_D
 DIV = int(os.environ.get("C3D_BENCH_DIV", "1"))
 DT = torch.bfloat16
 dt = ops.dt_code(DT)
+for _ov in filter(None, os.environ.get("C3D_BENCH_OPT", "").split(",")):   # C3D_BENCH_OPT=DW_RING=0,FOLD_SE=1: c3d_set_option before timing
+    _n, _v = _ov.split("=")
+    ops.set_option(getattr(ops, "OPT_" + _n.upper()), int(_v))
 # (stage, H(in), Cin, Ci, Co) for identity blocks; block 0 has stride 2 from H*2
 STAGES = [(1, 128 // DIV, 24, 54, 24), (2, 64 // DIV, 48, 108, 48), (3, 32 // DIV, 96, 216, 96)]
 

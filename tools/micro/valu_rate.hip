@@ -21,6 +21,18 @@ template <int MODE> __global__ __launch_bounds__(256) void probe(float* out, uin
       if (MODE == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc2[i]) : "v"(f32x2_t{fa, fb}), "v"(f32x2_t{fb, fa}));
       if (MODE == 2) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
       if (MODE == 3) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(acc[i]) : "v"(a));
+      if (MODE == 4) asm volatile("v_exp_f32 %0, %1" : "=v"(acc[i]) : "v"(fa));
+      if (MODE == 5) asm volatile("v_rcp_f32 %0, %1" : "=v"(acc[i]) : "v"(fa));
+      if (MODE == 6) asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(acc[i]) : "v"(fa));
+      if (MODE == 7) asm volatile("v_fract_f32 %0, %1" : "=v"(acc[i]) : "v"(fa));
+      if (MODE == 8) asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa), "v"(fb));
+      if (MODE == 9) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(acc2[i]) : "v"(f32x2_t{fa, fb}));
+      if (MODE == 10) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(fa));
+      if (MODE == 11) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(acc[i]) : "v"(fa), "v"(fb));
+      if (MODE == 12) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(acc[i]) : "v"(a));
+      if (MODE == 13) asm volatile("v_exp_f16 %0, %1" : "=v"(acc[i]) : "v"(fa));
+      if (MODE == 14) asm volatile("v_rcp_f16 %0, %1" : "=v"(acc[i]) : "v"(fa));
+      if (MODE == 15) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa), "v"(fb));
     }
   }
   float s = 0.f;
@@ -54,6 +66,18 @@ int main() {
     run<1>("v_pk_fma_f32", out, w);
     run<2>("v_dot2c_f32_bf16", out, w);
     run<3>("v_lshlrev_b32", out, w);
+    run<4>("v_exp_f32", out, w);
+    run<5>("v_rcp_f32", out, w);
+    run<6>("v_cvt_u32_f32", out, w);
+    run<7>("v_fract_f32", out, w);
+    run<8>("v_med3_f32", out, w);
+    run<9>("v_pk_mul_f32", out, w);
+    run<10>("v_mul_f32", out, w);
+    run<11>("v_cvt_pk_bf16_f32", out, w);
+    run<12>("v_and_b32 literal", out, w);
+    run<13>("v_exp_f16", out, w);
+    run<14>("v_rcp_f16", out, w);
+    run<15>("v_pk_fma_f16", out, w);
   }
   return 0;
 }

@@ -187,8 +187,8 @@ DW_PHASES = ["setup (weights, coefficients)", "barrier A (previous taps done)", 
              "issue a rows + next tile", "barrier B", "27 taps", "epilogue + store", "final sums flush"]
 
 
-FB_PHASES = ["setup (weights, coefficients, first loads)", "convert -> f32 LDS planes", "a_in + issue next tile / class", "barrier",
-             "27 taps (data + weight gradient)", "epilogue + store", "BN_a sums flush", "dW flush"]
+FB_PHASES = ["setup (weights, coefficients, first loads)", "convert -> f32 LDS planes | ring: a_in", "a_in + issue next tile / class | ring: DMA issue (tile + 2)", "barrier",
+             "27 taps (data + weight gradient)", "epilogue + store", "ring: wait for tile + 1's DMA", "BN_a sums + dW flush", "ring: convert in place (tile + 1)"]
 
 
 def main_fb():
@@ -210,6 +210,10 @@ def main_fb():
     DEV, DT, B, T = "cuda:0", torch.bfloat16, 32, 3
     dt = ops.dt_code(DT)
     rt = lambda *s: torch.randn(*s, device=DEV).to(DT)  # noqa: E731
+    ring = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--ring=")]
+    if ring:
+        ops.set_option(ops.OPT_DW_RING, ring[0])
+        print(f"C3D_OPT_DW_RING = {ring[0]}")
     for st, H, Ci, stride in [(1, 128, 54, 1), (2, 64, 108, 1), (3, 32, 216, 1), (1, 256, 54, 2)]:
         Cip = ops.cpad(Ci)
         Ho = H // stride
