@@ -161,8 +161,13 @@ def pmc_traffic(entry):
         with open(files[-1]) as f:
             d = json.load(f)
         e = d["by_entry"][entry]
+        from change3d_amd._lib import csrc_digest
+        if d.get("csrc_sha16") != csrc_digest():   # counters of other kernels than the ones that just ran: not this run's traffic
+            return {"traffic": None,
+                    "traffic_source": f"profiles/{os.path.basename(files[-1])} was taken at kernel sources {d.get('csrc_sha16')}, this "
+                                      f"run has {csrc_digest()}: re-run tools/profile_round.sh"}
         return {"traffic": int(e["hbm_bytes_per_launch"]),
-                "traffic_source": f"profiles/{os.path.basename(files[-1])}: {d['corrections']}"}
+                "traffic_source": f"profiles/{os.path.basename(files[-1])} (kernel sources {d['csrc_sha16']} = this run's): {d['corrections']}"}
     except (KeyError, ValueError, OSError):
         return {}
 
@@ -248,6 +253,7 @@ def dry_run_ranks(a):
         raise SystemExit(f"process group has {dist.get_world_size()} ranks (GradSync {sync.world}) but --dry-run-ranks {a.gpus}")
     ok = True
     base = torch.linspace(-1.0, 1.0, arena.numel)
+    sync.timing = True
     dist.barrier()
     t0 = time.perf_counter()
     for it in range(a.steps):
@@ -256,8 +262,9 @@ def dry_run_ranks(a):
         sync.finish()
         want = base * (sum(r + 1 + it for r in range(world)) / world)
         ok = ok and bool(torch.allclose(arena.flat_grad, want, rtol=1e-5, atol=1e-6))
+    mine = time.perf_counter() - t0
     dist.barrier()
-    tt = torch.tensor([time.perf_counter() - t0, 0.0 if ok else 1.0], dtype=torch.float64)
+    tt = torch.tensor([time.perf_counter() - t0, 0.0 if ok else 1.0, mine, -mine], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank == 0:
         batch = a.batch if a.batch > 0 else 32
@@ -268,7 +275,10 @@ def dry_run_ranks(a):
                                      "global_batch": batch * world, "parallelism": f"dp{world}", "dist_world_size": dist.get_world_size(),
                                      "dist_backend": dist.get_backend(), "exchange_floats": arena.numel,
                                      "exchange_verified": tt[1].item() == 0.0,
-                                     "exchange_ms_per_step_host": round(tt[0].item() / max(a.steps, 1) * 1e3, 3)}}), flush=True)
+                                     "exchange_ms_per_step_host": round(tt[0].item() / max(a.steps, 1) * 1e3, 3)},
+                          "dp": {"ms_per_step_rank_max": round(tt[2].item() / max(a.steps, 1) * 1e3, 3),
+                                 "ms_per_step_rank_min": round(-tt[3].item() / max(a.steps, 1) * 1e3, 3),
+                                 "exposed_comm_ms_per_step": sync.exposed_ms_per_step()}}), flush=True)
     dist.destroy_process_group()
     if tt[1].item() != 0.0:
         raise SystemExit("dry run: the reduced gradient buffer is wrong")
@@ -467,7 +477,10 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    all_syncs = [s_ for s_ in getattr(sync, "syncs", [sync])]
     if world > 1:
+        for s_ in all_syncs:           # self-diagnosis of the exchange: event pairs per step, read after the timed region
+            s_.timing, s_.samples = True, []
         dist.barrier()
     torch.cuda.synchronize()
     state["host_s"] = 0.0
@@ -482,14 +495,24 @@ def main():
             windows.append(time.perf_counter())
     t_enqueued = state["host_s"]   # host time spent enqueueing the steps (loss read-backs excluded)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0      # this rank's K steps, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    dp_diag = None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, own_elapsed, -own_elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = float(tt[0].item())
+        for s_ in all_syncs:
+            s_.timing = False
+        # why the scaling efficiency is what it is: the spread of the ranks' own step times (a straggler shows here) and the
+        # communication the compute stream actually waited for (rank 0's event pairs: head = the non-overlapped all-reduce,
+        # tail_wait = what was left of the overlapped bucket when backward + head were done)
+        dp_diag = {"ms_per_step_rank_max": round(float(tt[1].item()) / a.steps * 1e3, 3),
+                   "ms_per_step_rank_min": round(-float(tt[2].item()) / a.steps * 1e3, 3),
+                   "exposed_comm_ms_per_step": [s_.exposed_ms_per_step() for s_ in all_syncs]}
     final_loss = float(state["loss"])
     if not (final_loss == final_loss):
         raise SystemExit("loss is NaN")
@@ -515,6 +538,7 @@ def main():
                    "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3),
                    "ms_per_step_windows": ([round((t_ - p_) / (a.steps // nwin) * 1e3, 3) for p_, t_ in zip([t0] + windows[:-1], windows)]
                                            if nwin > 1 else None)},
+        "dp": dp_diag,
         "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_sample": bytes_per_sample,
                           "achieved": round(value / world * bytes_per_sample / 1e9, 1), "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": round(value / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4)},

@@ -198,3 +198,19 @@ def check_exports():
 def check(rc, what):
     if rc != 0:
         raise Change3DHipError(f"{what} failed with code {rc}")
+
+
+def csrc_digest():
+    """sha256 (16 hex digits) over the kernel sources and the C header: what a counter summary under profiles/ was taken at
+    (tools/summarize_rocprof.py stores it, bench.py compares it -- the GPU box has no .git to ask for a commit hash)."""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(root, "csrc", "*.hip")) + glob.glob(os.path.join(root, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(root), "include", "change3d_hip.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -615,15 +615,22 @@ struct RingPlan {
   static constexpr int NP = (NI + 63) / 64;                   // 1 KiB pieces per plane
   static constexpr int NPL = NP * 64;                         // plane stride (vectors)
   static constexpr int SL = (NP + 7) / 8;                     // pieces per wave and plane (at most)
-  static constexpr int NA = (TT * 8 * DW_CV + 63) / 64;       // `a` pieces per wave: TT frames x 8 pixels x 4 vectors
-  static constexpr int A_BYTES = 8 * TT * 8 * DW_CV * 16;     // 8 waves
+  // three frames: the `a` rows ride in the slot too and the ring is three slots deep (two tiles ahead); five frames (SCD):
+  // a slot is 64 KB, two fit -- one tile ahead, like the register prefetch, but in no registers -- and the `a` rows stay
+  // register loads
+  static constexpr bool A_LDS = TT <= 3;
+  static constexpr int NA = A_LDS ? (TT * 8 * DW_CV + 63) / 64 : 0;   // `a` pieces per wave: TT frames x 8 pixels x 4 vectors
+  static constexpr int A_WAVE_BYTES = TT * 8 * DW_CV * 16;
+  static constexpr int A_BYTES = A_LDS ? 8 * A_WAVE_BYTES : 0;
   static constexpr int SLOT_BYTES = 2 * NPL * 16 + A_BYTES;
-  static constexpr int R = 3;
+  static constexpr int R = A_LDS ? 3 : 2;
+  static constexpr int AHEAD = R - 1;
   static constexpr int HEAD_BYTES = (27 * 32 + 7 * 32) * 4;
   static constexpr int LDS_BYTES = HEAD_BYTES + R * SLOT_BYTES;
 };
 
-template <int TT>
+// SPREAD: the requests of tile + AHEAD are issued one per (ky, kx) step of the tap walk instead of in a burst after the barrier
+template <int TT, bool SPREAD>
 __global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
     const bf16_t* __restrict__ t1, const bf16_t* __restrict__ bb, const float* __restrict__ coefA,
     const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
@@ -632,7 +639,8 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
   typedef bf16_t T;
   typedef Raw4<T> R4;
   typedef RingPlan<TT> P;
-  constexpr int NI = P::NI, NP = P::NP, NPL = P::NPL, SL = P::SL, NA = P::NA;
+  constexpr int NI = P::NI, NP = P::NP, NPL = P::NPL, SL = P::SL, NA = P::NA, AHEAD = P::AHEAD;
+  constexpr bool A_LDS = P::A_LDS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wl = reinterpret_cast<float*>(smem);             // [27][32]
   float* cf = wl + 27 * 32;                               // [7][32]: cA, cB(sample), cC, sa, sb, ma, ra
@@ -701,10 +709,10 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
     yx[sl] = use_ ? (iy_ | (ix_ << 16)) : 0x7fff7fff;
   }
   const int rel_safe = (g.Wo + 1) * g.Cp + c0;            // the tile's first interior pixel, frame 0, first vector of the chunk
-  // `a` pieces of this wave: lane -> (frame, pixel of the wave's tile row, vector)
-  int arel[NA];
+  // `a` pieces of this wave (A_LDS): lane -> (frame, pixel of the wave's tile row, vector)
+  int arel[NA > 0 ? NA : 1];
   unsigned aok = 0;                                        // bit j: piece j of this lane has a source apart from the tile-edge test
-  int apx[NA];
+  int apx[NA > 0 ? NA : 1];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int idx = j * 64 + lane;
@@ -714,34 +722,58 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
     apx[j] = p_;
     if (t_ < TT && t_ < g.T && c0 + vec * 8 < g.Cp) aok |= 1u << j;
   }
+  typename R4::type ar[A_LDS ? 1 : TT];                    // (!A_LDS) this thread's `a` rows of the next tile
   const int orel = (py * g.W + px) * g.Cp + cb4, ofr = g.H * g.W * g.Cp;
   const int n_raw = (NP - 1 - wave) / 8 + 1;               // pieces per plane of this wave (wave-uniform)
   const int n_dma = 2 * n_raw + NA;                        // DMA instructions per tile of this wave
 
-  // requests of tile TL -> slot SIDX
-#define RB_ISSUE(TL, SIDX)                                                                        \
+  // ---- requests of a tile: wave-uniform bases (RB_BASES), then one instruction per index Q (raw pieces 2 sl + plane, then
+  //      the `a` pieces); RB_ISSUE = all of them in a burst
+  int64_t ri_tb = 0, ri_ab = 0;
+  uint32_t ri_sb = 0;
+  int ri_dy0 = 0, ri_dx0 = 0;
+  bool ri_row_ok = false, ri_on = false;
+#define RB_BASES(TL, SIDX)                                                                        \
   {                                                                                               \
     const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                         \
-    const int dy0_ = ty_ * FB_TH - 1, dx0_ = tx_ * FB_TW - 1;                                     \
-    const int64_t tb_ = ((((int64_t)b * g.T) * g.Ho + dy0_) * g.Wo + dx0_) * g.Cp;  /* wave-uniform */ \
-    const uint32_t sb_ = ring_lds + (uint32_t)(SIDX) * P::SLOT_BYTES;                             \
-    _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                           \
-      if (wave + 8 * sl < NP) {                                                                   \
-        const unsigned gy_ = (unsigned)(dy0_ + (yx[sl] & 0xffff));                                \
-        const unsigned gx_ = (unsigned)(dx0_ + (yx[sl] >> 16));                                   \
-        const int off_ = (gy_ < (unsigned)g.Ho && gx_ < (unsigned)g.Wo) ? rel[sl] : rel_safe;     \
-        fb_glds16(t1 + tb_ + off_, sb_ + (uint32_t)(wave + 8 * sl) * 1024u);                      \
-        fb_glds16(bb + tb_ + off_, sb_ + (uint32_t)(NPL * 16) + (uint32_t)(wave + 8 * sl) * 1024u); \
+    ri_dy0 = ty_ * FB_TH - 1; ri_dx0 = tx_ * FB_TW - 1;                                           \
+    ri_tb = ((((int64_t)b * g.T) * g.Ho + ri_dy0) * g.Wo + ri_dx0) * g.Cp;  /* wave-uniform */    \
+    ri_sb = ring_lds + (uint32_t)(SIDX) * P::SLOT_BYTES;                                          \
+    ri_ab = ((((int64_t)b * g.T) * g.H + ty_ * FB_TH) * g.W + tx_ * FB_TW) * g.Cp;                \
+    ri_row_ok = ty_ * FB_TH + wave < g.H;                                                         \
+  }
+#define RB_ISSUE_Q(Q)                                                                             \
+  if (ri_on) {                                                                                    \
+    if constexpr ((Q) < 2 * SL) {                                                                 \
+      constexpr int sl_ = (Q) >> 1;                                                               \
+      if (wave + 8 * sl_ < NP) {                                                                  \
+        const unsigned gy_ = (unsigned)(ri_dy0 + (yx[sl_] & 0xffff));                             \
+        const unsigned gx_ = (unsigned)(ri_dx0 + (yx[sl_] >> 16));                                \
+        const int off_ = (gy_ < (unsigned)g.Ho && gx_ < (unsigned)g.Wo) ? rel[sl_] : rel_safe;    \
+        fb_glds16((((Q) & 1) ? bb : t1) + ri_tb + off_,                                           \
+                  ri_sb + (uint32_t)(((Q) & 1) * NPL * 16) + (uint32_t)(wave + 8 * sl_) * 1024u); \
+      }                                                                                           \
+    } else if constexpr ((Q) < 2 * SL + NA) {                                                     \
+      constexpr int j_ = (Q) - 2 * SL;                                                            \
+      if (j_ * 64 + lane < TT * 8 * DW_CV) {                                                      \
+        const int ax0_ = ri_dx0 + 1;                                                              \
+        const int off_ = (ri_row_ok && ((aok >> j_) & 1u) && ax0_ + apx[j_] < g.W) ? arel[j_] : c0; \
+        fb_glds16(a + ri_ab + off_, ri_sb + (uint32_t)(2 * NPL * 16) + (uint32_t)wave * (uint32_t)P::A_WAVE_BYTES + (uint32_t)j_ * 1024u); \
       }                                                                                           \
     }                                                                                             \
-    const int ay0_ = ty_ * FB_TH, ax0_ = tx_ * FB_TW;                                             \
-    const int64_t ab_ = ((((int64_t)b * g.T) * g.H + ay0_) * g.W + ax0_) * g.Cp;                  \
-    const bool row_ok_ = ay0_ + wave < g.H;                                                       \
-    _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                              \
-      if (j * 64 + lane < TT * 8 * DW_CV) {                                                       \
-        const int off_ = (row_ok_ && ((aok >> j) & 1u) && ax0_ + apx[j] < g.W) ? arel[j] : c0;    \
-        fb_glds16(a + ab_ + off_, sb_ + (uint32_t)(2 * NPL * 16) + (uint32_t)wave * (uint32_t)(TT * 8 * DW_CV * 16) + (uint32_t)j * 1024u); \
-      }                                                                                           \
+  }
+#define RB_ISSUE_ALL                                                                              \
+  { RB_ISSUE_Q(0) RB_ISSUE_Q(1) RB_ISSUE_Q(2) RB_ISSUE_Q(3) RB_ISSUE_Q(4) RB_ISSUE_Q(5) RB_ISSUE_Q(6) RB_ISSUE_Q(7) RB_ISSUE_Q(8) RB_ISSUE_Q(9) }
+  static_assert(2 * SL + NA <= 10, "RB_ISSUE_ALL covers ten request indices");
+  // (!A_LDS) this thread's `a` rows of tile TL -> ar (compiler-visible loads: its own vmcnt bookkeeping covers them; the
+  // hidden DMA requests in the queue only make its waits conservative)
+#define RB_ISSUE_A(TL)                                                                            \
+  if constexpr (!A_LDS) {                                                                         \
+    const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                         \
+    if (c_ok && ty_ * FB_TH + py < g.H && tx_ * FB_TW + px < g.W) {                               \
+      const T* ab_ = a + ((((int64_t)b * g.T) * g.H + ty_ * FB_TH) * g.W + tx_ * FB_TW) * g.Cp;   \
+      _Pragma("unroll") for (int t = 0; t < TT; ++t)                                              \
+        if (t < g.T) ar[t] = R4::load(ab_ + (orel + t * ofr));                                    \
     }                                                                                             \
   }
   // in-place conversion of this thread's vectors of slot SIDX (tile TL): db = A t1 + B[n] + C b, zero outside the image
@@ -777,11 +809,15 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
   const int tl0 = tg * tiles_per_wg;
   int tl1 = tl0 + tiles_per_wg;
   if (tl1 > ntiles) tl1 = ntiles;
-  if (tl0 < tl1) RB_ISSUE(tl0, 0)
-  if (tl0 + 1 < tl1) RB_ISSUE(tl0 + 1, 1)
+  ri_on = true;
+#pragma unroll
+  for (int d = 0; d < AHEAD; ++d)
+    if (tl0 + d < tl1) { RB_BASES(tl0 + d, d) RB_ISSUE_ALL }
+  if (tl0 < tl1) RB_ISSUE_A(tl0)
   __syncthreads();   // wl / cf staged
   if (tl0 < tl1) {
-    fb_wait_vm(tl0 + 1 < tl1 ? n_dma : 0);
+    const int younger = tl1 - tl0 - 1 < AHEAD - 1 ? tl1 - tl0 - 1 : AHEAD - 1;   // tiles requested after tile tl0
+    fb_wait_vm(A_LDS ? younger * n_dma : 0);
     RB_CONVERT(tl0, 0)
   }
   FCLK(0)
@@ -790,25 +826,37 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
   for (int tl = tl0; tl < tl1; ++tl) {
     const int tx = tl % tiles_x, ty = tl / tiles_x;
     const int y0 = ty * FB_TH, x0 = tx * FB_TW;
-    const int slot1 = slot + 1 == P::R ? 0 : slot + 1, slot2 = slot1 + 1 == P::R ? 0 : slot1 + 1;
-    __syncthreads();   // conversions of tile tl visible; every wave is past the tap walk of tile tl - 1 (slot2)
-    FCLK(3)
-    if (tl + 2 < tl1) RB_ISSUE(tl + 2, slot2)
-    FCLK(2)
+    const int slot1 = slot + 1 == P::R ? 0 : slot + 1;
+    const int slotn = slot + AHEAD >= P::R ? slot + AHEAD - P::R : slot + AHEAD;   // the slot of tile tl + AHEAD = of tile tl - 1
+    // this thread's `a` rows and BatchNorm_a parameters: the LDS reads go out before the barrier / the request burst
     const float4* tb = reinterpret_cast<const float4*>(ring + (size_t)slot * P::SLOT_BYTES);
-    // this thread's `a` rows: [wave][frame][pixel][vector] 16-byte vectors, its channel half
-    const uint2* ab = reinterpret_cast<const uint2*>(ring + (size_t)slot * P::SLOT_BYTES + 2 * NPL * 16 + wave * (TT * 8 * DW_CV * 16)) + (px * DW_CV + cv) * 2 + h;
     typename R4::type arc[TT];
     f32x2_t ain[TT][2];
     f32x2_t acc[TT][2];
     float sa[4], sb[4];
+    const bool p_ok = c_ok && y0 + py < g.H && x0 + px < g.W;
+    if constexpr (A_LDS) {
+      // [wave][frame][pixel][vector] 16-byte vectors, this thread's channel half (its own wave's requests: landed since the
+      // counted wait in front of the conversion of this slot)
+      const uint2* ab = reinterpret_cast<const uint2*>(ring + (size_t)slot * P::SLOT_BYTES + 2 * NPL * 16 + wave * P::A_WAVE_BYTES) + (px * DW_CV + cv) * 2 + h;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) arc[t] = ab[t * 8 * DW_CV * 2];
+    } else {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) arc[t] = ar[t];
+    }
     lds4(cf + 3 * 32 + cv * 8 + h * 4, sa);
     lds4(cf + 4 * 32 + cv * 8 + h * 4, sb);
-    const bool p_ok = c_ok && y0 + py < g.H && x0 + px < g.W;
+    __syncthreads();   // conversions of tile tl visible; every wave is past the tap walk of tile tl - 1 (slotn)
+    FCLK(3)
+    ri_on = tl + AHEAD < tl1;
+    if (ri_on) RB_BASES(tl + AHEAD, slotn)
+    if constexpr (!SPREAD) RB_ISSUE_ALL
+    if (tl + 1 < tl1) RB_ISSUE_A(tl + 1)
+    FCLK(2)
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       if (p_ok && t < g.T) {
-        arc[t] = ab[t * 8 * DW_CV * 2];
         float av[4];
         R4::cvt(arc[t], av);
         ain[t][0] = f32x2_t{fmaxf(fmaf(av[0], sa[0], sb[0]), 0.f), fmaxf(fmaf(av[1], sa[1], sb[1]), 0.f)};
@@ -821,7 +869,8 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
     FCLK(1)
     // ---- 27 taps (the register-prefetch kernel's walk: two fragment slots, LDS reads of step s+1 before the FMAs of step s)
     const float4* tp = tb + (size_t)h * NPL + (py * FB_DW + px) * DW_CV + cv;
-    float4 wq[2][3], hq[2][TT];
+    if constexpr (TT <= 3) {
+      float4 wq[2][3], hq[2][TT];
 #define FB_LOAD(S, SLOT)                                                                                          \
   {                                                                                                               \
     constexpr int ky_ = (S) / 3, kx_ = (S) % 3;                                                                   \
@@ -847,22 +896,30 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
     }                                                                                                             \
     pin_acc<TT>(acc);                                                                                             \
     pin_dw(dwa[(S)], dwa[9 + (S)], dwa[18 + (S)]);                                                                \
+    if constexpr (SPREAD) { RB_ISSUE_Q(S) if constexpr ((S) == 8) { RB_ISSUE_Q(9) } }                             \
   }
-    FB_LOAD(0, 0)
-    FB_LOAD(1, 1) FB_STEP(0, 0)
-    FB_LOAD(2, 0) FB_STEP(1, 1)
-    FB_LOAD(3, 1) FB_STEP(2, 0)
-    FB_LOAD(4, 0) FB_STEP(3, 1)
-    FB_LOAD(5, 1) FB_STEP(4, 0)
-    FB_LOAD(6, 0) FB_STEP(5, 1)
-    FB_LOAD(7, 1) FB_STEP(6, 0)
-    FB_LOAD(8, 0) FB_STEP(7, 1)
-    FB_STEP(8, 0)
+      FB_LOAD(0, 0)
+      FB_LOAD(1, 1) FB_STEP(0, 0)
+      FB_LOAD(2, 0) FB_STEP(1, 1)
+      FB_LOAD(3, 1) FB_STEP(2, 0)
+      FB_LOAD(4, 0) FB_STEP(3, 1)
+      FB_LOAD(5, 1) FB_STEP(4, 0)
+      FB_LOAD(6, 0) FB_STEP(5, 1)
+      FB_LOAD(7, 1) FB_STEP(6, 0)
+      FB_LOAD(8, 0) FB_STEP(7, 1)
+      FB_STEP(8, 0)
 #undef FB_LOAD
 #undef FB_STEP
+    } else {
+      fb_taps_s1<TT>(tp, wl + cv * 8 + h * 4, acc, dwa, ain);   // five frames (SCD): plain walk, plane stride NPL in `tp`
+      if constexpr (SPREAD) RB_ISSUE_ALL
+    }
     FCLK(4)
-    // ---- the next tile's requests (issued one tile ago) have landed once at most this tile's requests are outstanding
-    if (tl + 1 < tl1) fb_wait_vm(tl + 2 < tl1 ? n_dma : 0);
+    // ---- the next tile's requests have landed once at most the requests of the tiles after it are outstanding
+    if (tl + 1 < tl1) {
+      const int younger = tl1 - tl - 2 < AHEAD - 1 ? tl1 - tl - 2 : AHEAD - 1;   // tiles tl + 2 .. tl + AHEAD that exist
+      fb_wait_vm(A_LDS ? younger * n_dma : 0);
+    }
     FCLK(6)
     // ---- mask, store t2, BN_a-backward sums
     if (p_ok) {
@@ -890,7 +947,10 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
     FCLK(8)
     slot = slot1;
   }
-#undef RB_ISSUE
+#undef RB_BASES
+#undef RB_ISSUE_Q
+#undef RB_ISSUE_ALL
+#undef RB_ISSUE_A
 #undef RB_CONVERT
 
   fb_flush(ring, S1, S2, dwa, dsums, dw, g, c0);
@@ -898,17 +958,17 @@ __global__ __launch_bounds__(FB_NTHR) void dw_bwd_ring_kernel(
   FCLK_FLUSH
 }
 
-template <int TT>
+template <int TT, bool SPREAD>
 int launch_ring_t(const void* t1, const void* bb, const float* cA, const float* cB, const float* cC, const float* w,
                   const void* a, const float* ss_a, const float* mr_a, void* t2, double* dsums, float* dw,
                   const DwGeom& g, hipStream_t stream, const c3d_bn_fin& fin) {
   typedef RingPlan<TT> P;
   static_assert(P::LDS_BYTES <= 160 * 1024, "ring does not fit");
   static_assert((size_t)P::R * P::SLOT_BYTES >= (size_t)27 * (FB_NTHR + 48) * sizeof(float), "dump region");
-  static_assert(2 * P::SL + P::NA <= 12, "fb_wait_vm covers counts up to 12");
+  static_assert((P::AHEAD - 1) * (2 * P::SL + P::NA) <= 12, "fb_wait_vm covers counts up to 12");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_ring_kernel<TT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_ring_kernel<TT, SPREAD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -922,7 +982,7 @@ int launch_ring_t(const void* t1, const void* bb, const float* cA, const float* 
   if (env_tpw > 0) tpw = env_tpw;
   if (tpw > ntiles) tpw = ntiles;
   dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
-  dw_bwd_ring_kernel<TT><<<grid, dim3(FB_NTHR), P::LDS_BYTES, stream>>>(
+  dw_bwd_ring_kernel<TT, SPREAD><<<grid, dim3(FB_NTHR), P::LDS_BYTES, stream>>>(
       reinterpret_cast<const bf16_t*>(t1), reinterpret_cast<const bf16_t*>(bb), cA, cB, cC, w, reinterpret_cast<const bf16_t*>(a),
       ss_a, mr_a, reinterpret_cast<bf16_t*>(t2), dsums, dw, g, tpw, fin);
   C3D_CHECK_LAUNCH();
@@ -979,8 +1039,17 @@ int dispatch_fused(const void* t1, const void* b, const float* coefA, const floa
     FB_DISPATCH(float, 2)
   }
   if (dtype == C3D_DT_BF16) {
-    if (g.stride == 1 && g.T <= 3 && (c3d_option_dw_ring & 1))
-      return launch_ring_t<3>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
+    // LDS-DMA ring kernels (bit 2: requests spread over the tap walk; bit 3: three-frame maps under 64 x 64 too -- their
+    // 16-tile walks pay the two-tile ring fill: res4 of the BCD step 65.9 us with the register prefetch, 68.0 us with the
+    // ring; the five-frame register kernel spills, its ring variant wins on every map: SCD 663 -> 681 img/s)
+    if (g.stride == 1 && (c3d_option_dw_ring & 1) && ((c3d_option_dw_ring & 8) || g.T > 3 || (long)g.H * g.W >= 64 * 64)) {
+      if (g.T <= 3) {
+        if (c3d_option_dw_ring & 4) return launch_ring_t<3, true>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
+        return launch_ring_t<3, false>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
+      }
+      if (c3d_option_dw_ring & 4) return launch_ring_t<5, true>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
+      return launch_ring_t<5, false>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
+    }
     if (g.stride == 1) { FB_DISPATCH(bf16_t, 1) }
     FB_DISPATCH(bf16_t, 2)
   }

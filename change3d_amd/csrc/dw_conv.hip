@@ -792,8 +792,6 @@ int launch_fwd(const void* x, const float* ss, const float* w, void* y, double* 
   return launch_fwd_t<T, S, 5>(x, ss, w, y, nc, g, stream);
 }
 
-thread_local c3d_bn_fin g_bwd_data_fin = {};   // set by c3d_dw333_bwd_data_fin for the launch it wraps
-
 }  // namespace
 
 extern "C" int c3d_dw333_fwd(const void* x, const float* ss, const float* w, void* y, double* nc_sums, int32_t B,

@@ -14,4 +14,4 @@ extern thread_local int c3d_side_launch;
 extern int c3d_option_stem_mfma;    // 2: + c3d_stem_bwd_wx of bf16 storage on the bf16 matrix cores, 1: stem on the f32 matrix cores
                                     // (stem_mfma.hip), 0: scalar-FMA kernels (stem.hip)
 extern int c3d_option_convt_mfma;   // 1: bf16 ConvTranspose2d on the matrix cores (convt_mfma.hip), 0: decoder.hip's
-extern int c3d_option_dw_ring;      // bit 0: LDS-DMA ring kernel for the stride-1 three-frame bf16 depthwise backward, bit 1: for the forward
+extern int c3d_option_dw_ring;      // C3D_OPT_DW_RING (include/change3d_hip.h): LDS-DMA ring variant of the bf16 stride-1 depthwise backward

@@ -146,8 +146,9 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
     // a workgroup would span more samples than the in-kernel SE gate holds (tiny inputs): the separate finalize launch, then
     // the same GEMM reading scale / shift / gate from memory
     rc = c3d_bn_se_finalize(a.fin.sums, a.fin.batch, (double)a.rows_per_sample, a.fin.gamma, a.fin.beta, a.fin.running_mean,
-                            a.fin.running_var, a.fin.nbt, a.fin.momentum, a.fin.eps, a.K, a.Kp, 1, a.se_w1, a.se_b1, a.se_w2,
-                            a.se_b2, a.se_cr, a.fin.ss, a.fin.mr, const_cast<float*>(a.pro_gate), a.se_hid, stream);
+                            a.fin.running_var, a.fin.training ? a.fin.nbt : nullptr, a.fin.momentum, a.fin.eps, a.K, a.Kp,
+                            a.fin.training ? 1 : 0, a.se_w1, a.se_b1, a.se_w2, a.se_b2, a.se_cr, a.fin.ss, a.fin.mr,
+                            const_cast<float*>(a.pro_gate), a.se_hid, stream);
     if (rc != 0) return rc;
     c3d_pw_args b = a;
     std::memset(&b.fin, 0, sizeof(b.fin));

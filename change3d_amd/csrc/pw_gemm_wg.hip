@@ -2,6 +2,7 @@
 // instantiations of pw_gemm_impl.h's kernel, in their own translation unit (they compile beside pw_gemm.hip).
 // Replaces the (c3d_pw_gemm, c3d_pw_wgrad) launch pair for conv_a / conv_c of the res2 / res3 blocks (reference
 // model/x3d.py:173-175,214-216: one convolution_backward produces both gradients).
+#include <cstring>
 #include "pw_gemm_impl.h"
 
 namespace {
@@ -28,6 +29,33 @@ __attribute__((visibility("hidden"))) int c3d_detail_pw_gemm_wg(const c3d_pw_arg
   if (a.wg_mode == C3D_WG_SWISH && a.epi_mode == C3D_EPI_SWISH_SE_BWD) return dispatch_wg<C3D_EPI_SWISH_SE_BWD, C3D_WG_SWISH>(a, s);
   if (a.wg_mode == C3D_WG_ROWS && a.epi_mode == C3D_EPI_ADD) return dispatch_wg<C3D_EPI_ADD, C3D_WG_ROWS>(a, s);
   return C3D_E_UNSUPPORTED;
+}
+
+// Host-side plan check for the stage driver (csrc/stage_driver.hip fuse_wgrad): the same gates and the same LDS plan as the
+// launch path above, so that a shape whose f64 accumulator image does not fit beside the weights and the wave regions (e.g.
+// Kp = 112 with Np >= 80) keeps its c3d_pw_wgrad launch instead of failing c3d_stage_bwd with C3D_E_UNSUPPORTED.
+namespace {
+template <int EPI, int WG>
+bool plan_wg(const c3d_pw_args& a) {
+  PwLaunch L;
+  size_t lds = 0;
+  const int nt = (a.Np + 15) / 16;
+  if (nt <= 2) return plan_pw<bf16_t, 2, C3D_PRO_AFFINE2, EPI, 8, WG>(a, L, lds);
+  if (nt == 3 && WG == C3D_WG_ROWS) return plan_pw<bf16_t, 3, C3D_PRO_AFFINE2, EPI, 8, WG>(a, L, lds);
+  if (nt <= 4) return plan_pw<bf16_t, 4, C3D_PRO_AFFINE2, EPI, 8, WG>(a, L, lds);
+  return plan_pw<bf16_t, 7, C3D_PRO_AFFINE2, EPI, 8, WG>(a, L, lds);
+}
+}  // namespace
+
+__attribute__((visibility("hidden"))) bool c3d_detail_pw_gemm_wg_supported(int Kp, int Np, int wg_mode) {
+  if (Kp <= 0 || Np <= 0 || (Kp & 7) || (Np & 7) || Kp > 16 * WG_NTP_MAX || Np > 112) return false;
+  if (wg_mode == C3D_WG_SWISH && Kp > 16 * WG_NTP_MAX_SWISH) return false;
+  c3d_pw_args a;
+  std::memset(&a, 0, sizeof(a));
+  a.M = 1 << 20; a.K = a.Kp = Kp; a.N = a.Np = Np; a.dtype = C3D_DT_BF16; a.pro_mode = C3D_PRO_AFFINE2; a.wg_mode = wg_mode;
+  if (wg_mode == C3D_WG_SWISH) { a.epi_mode = C3D_EPI_SWISH_SE_BWD; return plan_wg<C3D_EPI_SWISH_SE_BWD, C3D_WG_SWISH>(a); }
+  if (wg_mode == C3D_WG_ROWS) { a.epi_mode = C3D_EPI_ADD; return plan_wg<C3D_EPI_ADD, C3D_WG_ROWS>(a); }
+  return false;
 }
 
 #ifdef C3D_PW_CLOCK

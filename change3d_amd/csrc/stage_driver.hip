@@ -19,6 +19,8 @@
 #include <mutex>
 #include <vector>
 
+bool c3d_detail_pw_gemm_wg_supported(int Kp, int Np, int wg_mode);   // pw_gemm_wg.hip: the fused kernel's own LDS plan
+
 namespace {
 
 inline int cpad(int c) { return (c + 7) / 8 * 8; }
@@ -93,8 +95,9 @@ struct Carver {
 
 // pointwise weight gradient inside the data-gradient launch (c3d_pw_args.wg_mode; csrc/pw_gemm_impl.h): bf16 layers whose
 // accumulator image fits in LDS beside the tiles -- the res2 / res3 shapes (K, N <= 112 padded)
-inline bool fuse_wgrad(const c3d_stage_desc* d, int Kp, int Np) {
-  return !(d->flags & C3D_STAGE_SEPARATE_WGRAD) && d->dtype == C3D_DT_BF16 && Kp <= 112 && Np <= 112 && c3d_knob("C3D_PW_WG", 1);
+inline bool fuse_wgrad(const c3d_stage_desc* d, int Kp, int Np, int wg_mode) {
+  return !(d->flags & C3D_STAGE_SEPARATE_WGRAD) && d->dtype == C3D_DT_BF16 && Kp <= 112 && Np <= 112 && c3d_knob("C3D_PW_WG", 1) &&
+         c3d_detail_pw_gemm_wg_supported(Kp, Np, wg_mode);
 }
 
 int g_mask_in_dgrad = 1;   // c3d_set_option(C3D_OPT_MASK_IN_DGRAD, ...)
@@ -176,8 +179,8 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
   int64_t wsf = 0, wsf_fused = 0;
   for (int i = 0; i < n; ++i) {
     const BlkGeom& G = P.g[i];
-    if (fuse_wgrad(d, G.Cop, G.Cip)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Co, G.Ci));
-    if (fuse_wgrad(d, G.Cip, G.Cinp)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Ci, G.Cin));
+    if (fuse_wgrad(d, G.Cop, G.Cip, C3D_WG_SWISH)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Co, G.Ci));
+    if (fuse_wgrad(d, G.Cip, G.Cinp, C3D_WG_ROWS)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Ci, G.Cin));
     mx_g = std::max(mx_g, (size_t)G.Mo * G.Cop * e);
     mx_t1 = std::max(mx_t1, (size_t)G.Mo * G.Cip * e);
     mx_t2 = std::max(mx_t2, (size_t)G.M * G.Cip * e);
@@ -745,7 +748,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     if (!consb) RC(coef(dsums_c, (double)G.Mo, k.bn_c, mr_c, G.Co, G.Cop, coef_c));
     // ---- conv_c data gradient, Swish / SE backward in the epilogue; weight gradient on the side stream (it needs
     //      coef_c, not the data gradient: it is forked BEFORE the data-gradient launch)
-    const bool fuse_wc = (g_fuse_wgrad & 2) && fuse_wgrad(d, G.Cop, G.Cip) && G.Cop <= 48;
+    const bool fuse_wc = (g_fuse_wgrad & 2) && fuse_wgrad(d, G.Cop, G.Cip, C3D_WG_SWISH) && G.Cop <= 48;
     if (!fuse_wc)
     RC(side_run(st, [&](hipStream_t s2) {
       WgCall w(g, b, k.dw_c, wgws, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
@@ -812,7 +815,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     }
     // ---- conv_a data gradient (+ shortcut gradient in the epilogue) and weight gradient (forked first: it needs the
     //      coefficients, not the data gradient)
-    const bool fuse_wa = (g_fuse_wgrad & 1) && fuse_wgrad(d, G.Cip, G.Cinp);
+    const bool fuse_wa = (g_fuse_wgrad & 1) && fuse_wgrad(d, G.Cip, G.Cinp, C3D_WG_ROWS);
     bool mask_next = false;
     if (!fuse_wa)
     RC(side_run(st, [&](hipStream_t s2) {
@@ -825,7 +828,17 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       PwCall p(t2, k.w_a, dx, G.M, G.Ci, G.Cin, 1, G.Cin, dt);
       if (fuse_wa) { p.a.wg_mode = C3D_WG_ROWS; p.a.wg_x3 = xin; p.a.wg_dw = k.dw_a; p.a.wg_ws = wgws_fused; }
       // xin is the previous block's output y: its ReLU mask goes onto dx here, c3d_block_out_bwd of that block only sums
-      mask_next = fuse_wa && i > 0 && g_mask_in_dgrad;
+      // ...provided nothing on the SIDE stream reads that block's g (= this dx, a ring slot): its conv_c weight gradient (when
+      // not fused) and its shortcut weight gradient would, and the ring's lifetime rule (block i - 2 overwrites the slot
+      // once the side marks of blocks >= i + 1 are joined) does not cover a reader forked by block i - 1.  Block 0 is the
+      // last block of the call: no later block overwrites the slot, the caller keeps the workspace until the full join.
+      bool next_g_main_only = false;
+      if (i > 0) {
+        const BlkGeom& Gn = P.g[i - 1];
+        const bool fuse_wc_n = (g_fuse_wgrad & 2) && fuse_wgrad(d, Gn.Cop, Gn.Cip, C3D_WG_SWISH) && Gn.Cop <= 48;
+        next_g_main_only = fuse_wc_n && (!Gn.sc_conv || i == 1);
+      }
+      mask_next = fuse_wa && i > 0 && g_mask_in_dgrad && next_g_main_only;
       p.a.wg_mask_out = mask_next ? 1 : 0;
       p.a.x2 = a; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_a;
       if (consb) p.a.fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, true);
@@ -844,7 +857,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
 
 // ---- profile / runtime switches --------------------------------------------------------------------------------
 int c3d_option_stem_mfma = 2, c3d_option_convt_mfma = 1;   // read by stem.hip / decoder.hip (launch_hints.h)
-int c3d_option_dw_ring = 3;                                // read by dw_bwd_fused.hip / dw_conv.hip
+int c3d_option_dw_ring = 5;                                // read by dw_bwd_fused.hip / dw_conv.hip
 
 extern "C" int c3d_set_option(int32_t option, int32_t value) {
   switch (option) {
@@ -854,7 +867,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_FUSE_WGRAD: g_fuse_wgrad = value & 3; return 0;
     case C3D_OPT_FOLD_SE: g_fold_se = value ? 1 : 0; return 0;
     case C3D_OPT_MASK_IN_DGRAD: g_mask_in_dgrad = value ? 1 : 0; return 0;
-    case C3D_OPT_DW_RING: c3d_option_dw_ring = value & 3; return 0;
+    case C3D_OPT_DW_RING: c3d_option_dw_ring = value & 15; return 0;
     default: return C3D_E_BADARG;
   }
 }

@@ -778,6 +778,7 @@ int wx_t(const float* x, const float* w_t, const void* dv, float* dw_t, float* d
     }
     stem_bwd_wx_bf16_kernel<TT><<<dim3(ntiles, bsplit), NTHR, lb, s>>>(x, w_t, reinterpret_cast<const bf16_t*>(dv), dw_t, dP, g,
                                                                       t_first, n_frames, per_sample);
+    C3D_CHECK_LAUNCH();
     return 0;
   }
   static bool attr_set = false;

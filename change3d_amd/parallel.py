@@ -14,6 +14,8 @@ stream while res3/res2/stem backward (the ~70 % of backward traffic that remains
 the head of the buffer follows at the end.  The payload is latency-bound on xGMI (7 MB ->
 ~0.9 MB per peer link), so two large collectives beat many small buckets.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -42,6 +44,13 @@ class GradSync:
         self.use_stream = arena.flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=arena.flat_grad.device) if self.use_stream else None
         self._tail_launched = False
+        # self-diagnosis (bench.py --gpus N): with `timing` on every step records how long the compute stream sat behind the
+        # exchange -- (tail) from the moment it reached the fence in finish() to the end of the overlapped bucket on the
+        # communication stream, (head) the duration of the non-overlapped all-reduce -- as event pairs (GPU) or host seconds
+        self.timing = False
+        self.samples = []       # per step: (ready_event, tail_end_event, head_start_event, head_end_event) or (tail_s, head_s)
+        self._tail_end = None
+        self._tail_host_s = 0.0
 
     # -- called from the last encoder stage's backward (model/x3d.py: stage.post_backward)
     def launch_tail(self):
@@ -53,8 +62,13 @@ class GradSync:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+                if self.timing:
+                    self._tail_end = torch.cuda.Event(enable_timing=True)
+                    self._tail_end.record()
         else:
+            t0 = time.perf_counter()
             dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+            self._tail_host_s = time.perf_counter() - t0   # no second stream on the host: the whole bucket is exposed
 
     def finish(self):
         """After backward: reduce what is left, average, and fence the compute stream."""
@@ -62,16 +76,50 @@ class GradSync:
             return
         self.arena.check_grads_attached()   # a detached p.grad would leave its real gradient out of the exchange
         g = self.arena.flat_grad
+        timed = self.timing
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if (timed and self.use_stream) else None
+        t0 = time.perf_counter()
+        if ev:
+            ev[0].record()                                   # the compute stream is ready for the reduced gradients here
         if self._tail_launched:
             head = g[:self.split]
             if head.numel():
                 dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)
+            if ev:
+                ev[1].record()
             if self.use_stream:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            if ev:
+                ev[1].record()
+        if timed:
+            if ev:
+                self.samples.append((ev[0], ev[1], self._tail_end))
+            else:
+                self.samples.append((self._tail_host_s, time.perf_counter() - t0))
+        self._tail_end, self._tail_host_s = None, 0.0
         g.mul_(1.0 / self.world)
         self._tail_launched = False
+
+    def exposed_ms_per_step(self):
+        """Mean over the recorded steps of {"head_allreduce": the non-overlapped all-reduce, "tail_wait": the part of the overlapped
+        bucket that was still running when the compute stream reached the fence} in ms (call after a device synchronise)."""
+        if not self.samples:
+            return None
+        head = tail = 0.0
+        for smp in self.samples:
+            if isinstance(smp[0], float):
+                tail += smp[0] * 1e3
+                head += smp[1] * 1e3
+            else:
+                ready, head_end, tail_end = smp
+                head += ready.elapsed_time(head_end)
+                if tail_end is not None:
+                    tail += max(0.0, head_end.elapsed_time(tail_end))   # what is left of the bucket after the head finished
+        n = len(self.samples)
+        return {"head_allreduce": round(head / n, 4), "tail_wait": round(tail / n, 4), "steps": n,
+                "tail_bytes": int((self.arena.numel - self.split) * 4), "head_bytes": int(self.split * 4)}
 
 
 _HOST_GROUP = None

@@ -505,9 +505,10 @@ int c3d_side_join(void* stream);
  *                         compute the gate of their samples, c3d_pw_args.se_w1)
  *   C3D_OPT_MASK_IN_DGRAD : 0 = c3d_block_out_bwd applies the ReLU mask itself everywhere (default 1: conv_a's fused data-gradient
  *                         launch of the NEXT block stores dx * (y > 0), c3d_block_out_bwd only sums)
- *   C3D_OPT_DW_RING     : bf16 depthwise kernels fed by LDS-DMA rings (global_load_lds_dwordx4 two tiles ahead) instead of
- *                         register prefetch: bit 0 = c3d_dw333_bwd_fused (stride 1, T <= 3), bit 1 = c3d_dw333_fwd; results
- *                         are bit-identical to the register-prefetch kernels; default = measured best                      */
+ *   C3D_OPT_DW_RING     : c3d_dw333_bwd_fused (bf16, stride 1) fed by an LDS-DMA ring (global_load_lds_dwordx4, two tiles ahead
+ *                         for T <= 3, one for T = 5) instead of register prefetch: bit 0 = on, bit 2 = the requests are issued
+ *                         one per tap step instead of in a burst, bit 3 = also on maps under 64 x 64; results are bit-identical
+ *                         to the register-prefetch kernel; default 5 = measured best                                          */
 enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3, C3D_OPT_FOLD_SE = 4,
        C3D_OPT_MASK_IN_DGRAD = 5, C3D_OPT_DW_RING = 6 };
 int c3d_set_option(int32_t option, int32_t value);

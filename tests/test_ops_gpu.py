@@ -489,14 +489,17 @@ def test_dw333_backward_walks(dtype, B, H, W, C, stride):
     (1100, 8, 8, 54),       # one tile per sample
     (2, 8, 72, 24),         # a single tile row
 ])
-def test_dw_bwd_ring_kernel_is_bit_identical_to_the_register_prefetch_kernel(B, H, W, C):
+@pytest.mark.parametrize("T,ring", [(3, 9), (3, 13), (5, 9), (5, 13)])   # ring bits: 1 on, 4 requests spread over the tap walk, 8 every map size
+def test_dw_bwd_ring_kernel_is_bit_identical_to_the_register_prefetch_kernel(B, H, W, C, T, ring):
     """C3D_OPT_DW_RING bit 0: the LDS-DMA ring variant of c3d_dw333_bwd_fused (bf16, stride 1, T = 3) changes how the raw rows
     reach the workgroup, not one operation of the arithmetic: data gradient, BatchNorm_a sums and weight gradient must be
     bit-identical to the register-prefetch kernel's (the f32 atomics of the flush commute only up to rounding across
-    workgroups: the weight gradient is compared at 1e-6 of its scale, everything else exactly)."""
+    workgroups: the weight gradient is compared at 1e-5 of its scale, everything else exactly)."""
     _need_gpu()
     from change3d_amd import ops
-    T, dtype = 3, torch.bfloat16
+    dtype = torch.bfloat16
+    if T == 5 and B > 100:
+        B = 300
     Cp = ops.cpad(C)
     t1d = padc(q(rnd((B, T, H, W, C), 250), dtype), Cp).to(DEV, dtype).contiguous()
     bd = padc(q(rnd((B, T, H, W, C), 251), dtype), Cp).to(DEV, dtype).contiguous()
@@ -508,20 +511,22 @@ def test_dw_bwd_ring_kernel_is_bit_identical_to_the_register_prefetch_kernel(B, 
     mr = torch.cat([padc(rnd((C,), 259, 0.5), Cp), padc(rnd((C,), 260).abs() + 0.5, Cp)]).to(DEV)
     out = {}
     try:
-        for ring in (0, 1):
-            ops.set_option(ops.OPT_DW_RING, ring)
+        for rv in (0, ring):
+            ops.set_option(ops.OPT_DW_RING, rv)
             t2 = torch.full_like(ad, float("nan"))
             ds = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
             dw = torch.zeros((C, 27), dtype=torch.float32, device=DEV)
             ops.dw_bwd_fused(t1d, bd, cAd, cBd, cCd, wd, ad, ss, mr, t2, ds, dw, B, T, H, W, C, ops.dt_code(dtype), 1)
             torch.cuda.synchronize()
-            out[ring] = (t2, ds, dw)
+            out[rv] = (t2, ds, dw)
     finally:
-        ops.set_option(ops.OPT_DW_RING, 3)
-    assert torch.equal(out[0][0].view(torch.int16), out[1][0].view(torch.int16)), "data gradient differs"
-    assert torch.allclose(out[0][1], out[1][1], rtol=1e-12, atol=0), "BatchNorm_a sums differ"
+        ops.set_option(ops.OPT_DW_RING, 5)
+    assert torch.equal(out[0][0].view(torch.int16), out[ring][0].view(torch.int16)), "data gradient differs"
+    assert torch.allclose(out[0][1], out[ring][1], rtol=1e-12, atol=0), "BatchNorm_a sums differ"
     scale = out[0][2].abs().max().item()
-    assert (out[0][2] - out[1][2]).abs().max().item() <= 1e-6 * scale, "weight gradient differs"
+    # (the flush adds one f32 atomic per workgroup and tap: 2 200 of them in arbitrary order at B = 1100 -- 1.3e-6 of the scale
+    # between two runs of the SAME kernel)
+    assert (out[0][2] - out[ring][2]).abs().max().item() <= 1e-5 * scale, "weight gradient differs"
 
 
 # --------------------------------------------------------------------------- loss / optimizer

@@ -101,7 +101,7 @@ for r in rows:
     elif ".norm_b.1.block." in n:
         k = "SE fc " + n.split(".")[-2] + "." + n.split(".")[-1]
     elif "conv_b" in n:
-        k = "depthwise conv_b (c3d_dw333_wgrad)"
+        k = "depthwise conv_b (c3d_dw333_bwd_fused)"
     elif "conv_a" in n or "conv_c" in n or "branch1_conv" in n or ".fc." in n:
         k = "pointwise " + n.split(".")[-2] + " (c3d_pw_wgrad)"
     elif "blocks.0" in n:

@@ -16,9 +16,12 @@ import re
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from change3d_amd._lib import csrc_digest  # noqa: E402
+
 ENTRY = [  # kernel-name prefix -> C-ABI entry point (bench.py's kernel table key)
     ("pw_gemm_kernel", "c3d_pw_gemm"), ("pw_wgrad_kernel", "c3d_pw_wgrad"), ("pw_wgrad_reduce", "c3d_pw_wgrad"),
-    ("dw_fwd", "c3d_dw333_fwd"), ("dw_bwd_fused", "c3d_dw333_bwd_fused"),
+    ("dw_fwd", "c3d_dw333_fwd"), ("dw_bwd_fused", "c3d_dw333_bwd_fused"), ("dw_bwd_ring", "c3d_dw333_bwd_fused"),
     ("block_out_fwd", "c3d_block_out_fwd"), ("block_out_bwd", "c3d_block_out_bwd"),
     ("se_bn_bwd_coef", "c3d_se_bn_bwd_coef"), ("bn_se_finalize", "c3d_bn_se_finalize"),
     ("bn_finalize", "c3d_bn_finalize"), ("bn_bwd_coef", "c3d_bn_bwd_coef"), ("stem_", "c3d_stem_*"),
@@ -96,6 +99,7 @@ def main():
                              "--no-cpu-baseline --no-graph --no-kernel-profile --steps 1 --warmup 1",
                    "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); WRITE_SIZE x1",
                    "note": f"{steps} steps of B=32 bf16 (one Adam launch per step); per-launch averages over all dispatches of an entry",
+                   "csrc_sha16": csrc_digest(),   # the kernel sources these counters were taken at (bench.py prints traffic: null when they differ)
                    "steps": steps, "hbm_bytes_per_step": round(total / steps),
                    "hbm_bytes_per_sample": round(total / steps / 32),
                    "by_entry_per_step": {e: round(sum(traffic.get(k, {}).get(e, {"bytes_total": 0})["bytes_total"] for k in ("fetch", "write")) / steps) for e in ents},
