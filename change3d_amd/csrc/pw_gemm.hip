@@ -137,6 +137,9 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
     if (wide) return C3D_E_UNSUPPORTED;
   }
   if (wide) return c3d_detail_pw_gemm_wide(args, stream);
+  // the wave-private-tile kernels address rows with 32-bit byte offsets into bounds-checked buffer resources (offset 2^31 =
+  // "nowhere"): every tensor of the call must stay under 2 GiB
+  if ((int64_t)a.M * (a.Kp > a.Np ? a.Kp : a.Np) * (a.dtype == C3D_DT_F32 ? 4 : 2) >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
   if (a.wg_mode != C3D_WG_NONE) return c3d_detail_pw_gemm_wg(args, stream);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = C3D_E_BADARG;

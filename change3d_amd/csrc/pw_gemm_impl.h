@@ -223,6 +223,49 @@ template <> struct Raw<float> {
   }
 };
 
+// Bounds-checked buffer addressing for every global access of the tile loop (round 5).  The loop used to guard its loads
+// and stores with exec-masked branches (`if (row exists) x = load; else x = 0`); the compiler's s_waitcnt insertion then
+// fell back to vmcnt(0) at the joins -- in the ISA of the round-4 kernels EVERY prefetch slot of the Swish forward waited for
+// the slot re-issued just before it (one memory round trip per 1 KB: 7 per 16 x 216 tile), the burst prefetch of the other
+// variants went out behind vmcnt(1) (two loads in flight), and each epilogue pass waited for the previous pass's store and the
+// whole next-tile prefetch.  With raw buffer instructions a lane that must not touch memory gets a byte offset past
+// num_records instead of a cleared exec bit: loads return 0 (exactly the RW::zero() the branches produced), stores are
+// dropped, and the code is straight-line, so the counted waits are exact.  Offsets are 32-bit: the entry point refuses
+// tensors of 2 GiB or more (PW_OOB = 2^31 is the "nowhere" offset).
+typedef uint32_t pw_u32x4_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t PW_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pw_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+template <typename T> struct BufIO;
+template <> struct BufIO<bf16_t> {
+  static __device__ __forceinline__ uint4 load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const pw_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  }
+  static __device__ __forceinline__ void store_raw(__amdgpu_buffer_rsrc_t r, uint32_t off, const uint4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(pw_u32x4_t{v.x, v.y, v.z, v.w}, r, off, 0, 0);
+  }
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, uint32_t off, const float (&f)[8]) {
+    __builtin_amdgcn_raw_buffer_store_b128(pw_u32x4_t{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                                                      pack_bf16x2(f[6], f[7])}, r, off, 0, 0);
+  }
+};
+template <> struct BufIO<float> {
+  static __device__ __forceinline__ Raw<float>::type load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const pw_u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    const pw_u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16u, 0, 0);   // PW_OOB + 16 is still out of range
+    Raw<float>::type t;
+    t.a = make_float4(__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3]));
+    t.b = make_float4(__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3]));
+    return t;
+  }
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, uint32_t off, const float (&f)[8]) {
+    __builtin_amdgcn_raw_buffer_store_b128(pw_u32x4_t{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])}, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(pw_u32x4_t{__float_as_uint(f[4]), __float_as_uint(f[5]), __float_as_uint(f[6]), __float_as_uint(f[7])}, r, off + 16u, 0, 0);
+  }
+};
+
 __device__ __forceinline__ void lds_ld8(const float* p, float (&f)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p);
   const float4 b = *reinterpret_cast<const float4*>(p + 4);
@@ -298,7 +341,10 @@ template <int NT, int PRO, int EPI> struct PwFragBatch {
 };
 template <int NT, int PRO, int EPI, int WAVES, int WG = 0> struct PwSlots {
   // (the fused weight gradient of the Swish/SE-backward variant needs ~16 more registers: 4 slots keep it out of scratch)
+  // (round 5: the wide Swish/SE-backward variants spilled 7-17 registers once the epilogue passes were unrolled, and every
+  // scratch reload is a VMEM access behind s_waitcnt vmcnt(0) -- in the middle of the prefetch burst: 4 slots, no scratch)
   static constexpr int value = (WG == C3D_WG_SWISH) ? 4 :
+                               (PRO == C3D_PRO_AFFINE2 && WAVES == 8 && EPI == C3D_EPI_SWISH_SE_BWD && NT >= 7) ? 4 :
                                (PRO == C3D_PRO_AFFINE2 && WAVES == 8 && (NT == 14 || EPI == C3D_EPI_SWISH_SE_BWD)) ? 6 : 8;
 };
 
@@ -423,6 +469,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   const T* X2 = reinterpret_cast<const T*>(a.x2);
   const T* E1 = reinterpret_cast<const T*>(a.e1);
   T* Y = reinterpret_cast<T*>(a.y);
+  // Buffer resources (wave-uniform: scalar registers).  The row streams are bounded by THIS wave's rows: a tile past t1
+  // (another wave's) or a row past M reads zeros, which is what the exec-masked loads assigned by hand.
+  constexpr uint32_t ES = (uint32_t)sizeof(T);
+  const uint32_t lim_rows = (uint32_t)(t1 * 16 < M32 ? t1 * 16 : M32);
+  const __amdgpu_buffer_rsrc_t rX = pw_rsrc(X, lim_rows * (uint32_t)Kp * ES);
+  const __amdgpu_buffer_rsrc_t rX2 = pw_rsrc(PRO == C3D_PRO_AFFINE2 ? X2 : nullptr, lim_rows * (uint32_t)Kp * ES);
+  const __amdgpu_buffer_rsrc_t rY = pw_rsrc(Y, (uint32_t)M32 * (uint32_t)Np * ES);
+  const __amdgpu_buffer_rsrc_t rPO = pw_rsrc(PRO == C3D_PRO_AFFINE2 ? a.pro_out : nullptr, (uint32_t)M32 * (uint32_t)Kp * ES);
+  const uint32_t lane_b = (uint32_t)lane * 8u * ES;   // this lane's 8-element vector inside a 64-vector (1 KB / 2 KB) piece
 
   typename RW::type xr[PW_SLOTS];
   typename RW::type x2r[PROis(PRO) ? PW_SLOTS : 1];
@@ -445,44 +500,28 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       }                                                                                        \
     }                                                                                          \
   }
-  // rows of tile tl that exist (0 beyond this wave's range), times Gi = number of valid flat vectors
-#define PW_LIM(TL) (((TL) < t1 ? (M32 - ((TL) << 4) > 16 ? 16 : M32 - ((TL) << 4)) : 0) * Gi)
+  // byte offset of slot J of the iteration starting at tile TILE0 (wave-uniform part in scalar registers + lane_b); slots
+  // the plan does not use go nowhere.  No branch, no exec mask: see BufIO.
+#define PW_SLOT_OFF(TILE0, J)                                                                  \
+  ((J) < nslots ? ((uint32_t)((TILE0) + slot_s[J]) * 16u * (uint32_t)Kp + 512u * (uint32_t)slot_q[J]) * ES + lane_b : PW_OOB)
 #define PW_ISSUE_DENSE(TILE0)                                                                  \
   {                                                                                            \
-    const T* xb_ = X + (int64_t)(TILE0) * 16 * Kp;               /* wave-uniform: SGPR pair */  \
-    const T* x2b_ = PRO == C3D_PRO_AFFINE2 ? X2 + (int64_t)(TILE0) * 16 * Kp : X;              \
-    int lo_ = lane * 8;                                                                        \
-    asm volatile("" : "+v"(lo_));   /* keeps (X + lane*8), (X2 + lane*8) from living in 4 VGPRs across the loop */ \
     _Pragma("unroll") for (int j = 0; j < PW_SLOTS; ++j) {                                     \
-      if (j < nslots) {                                                                        \
-        const int i_ = lane + 64 * slot_q[j];                                                  \
-        const int o_ = slot_s[j] * 16 * Kp + 512 * slot_q[j] + lo_;                            \
-        if (i_ < PW_LIM((TILE0) + slot_s[j])) {                                                \
-          xr[j] = RW::load(xb_ + o_);                                                          \
-          if (PRO == C3D_PRO_AFFINE2) x2r[PROis(PRO) ? j : 0] = RW::load(x2b_ + o_);           \
-        } else {                                                                               \
-          xr[j] = RW::zero();                                                                  \
-          if (PRO == C3D_PRO_AFFINE2) x2r[PROis(PRO) ? j : 0] = RW::zero();                    \
-        }                                                                                      \
-      }                                                                                        \
+      const uint32_t o_ = PW_SLOT_OFF(TILE0, j);                                               \
+      xr[j] = BufIO<T>::load(rX, o_);                                                          \
+      if (PRO == C3D_PRO_AFFINE2) x2r[PROis(PRO) ? j : 0] = BufIO<T>::load(rX2, o_);           \
     }                                                                                          \
   }
 #define PW_ISSUE(TILE0) if constexpr (DENSE) PW_ISSUE_DENSE(TILE0) else { PW_ISSUE_GENERIC(TILE0) }
   // One slot of PW_ISSUE_DENSE (the Swish-prologue forward re-requests a slot as soon as its registers are free: see the
   // convert loop)
-#define PW_ISSUE_DENSE_SLOT(TILE0, J, XB, LO)                                                  \
-  {                                                                                            \
-    const int i_ = lane + 64 * slot_q[J];                                                      \
-    const int o_ = slot_s[J] * 16 * Kp + 512 * slot_q[J] + (LO);                               \
-    if (i_ < PW_LIM((TILE0) + slot_s[J])) xr[J] = RW::load((XB) + o_);                         \
-    else xr[J] = RW::zero();                                                                   \
-  }
+#define PW_ISSUE_DENSE_SLOT(TILE0, J, ON) xr[J] = BufIO<T>::load(rX, (ON) ? PW_SLOT_OFF(TILE0, J) : PW_OOB);
   // conv_c forward (BatchNorm x SE x Swish on load: 13 VALU units per element, as long as the memory time of the tile): the
   // next iteration's rows are requested slot by slot, each right after the prologue that consumed its registers, so the
   // requests of the first slots are in flight under the activation arithmetic of the others
   constexpr bool SLOT_REISSUE = DENSE && PRO == C3D_PRO_BN_SE_SWISH && WG == 0 && sizeof(T) == 2;
 
-  if (t0 < t1) { PW_ISSUE(t0) }
+  PW_ISSUE(t0)   // (a wave without tiles reads zeros: its row bound is empty)
   CLK(9)
 
   // ---- stage weights: zero fill, then vectorised fill along W's contiguous dimension -------
@@ -604,17 +643,21 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   constexpr bool E1_PIPE = EPI == C3D_EPI_SWISH_SE_BWD || EPI == C3D_EPI_ADD;
   const bool e1_rows = E1_PIPE && (EPI == C3D_EPI_SWISH_SE_BWD || a.res_mode == 0);   // E1 has Y's row layout
   const int npass = (16 + RPo - 1) / RPo;
+  constexpr int RPO_MIN = 64 / (2 * NT), NPASS_MAX = (16 + RPO_MIN - 1) / RPO_MIN;
   const int v_oc = act_o ? v_o : 0;             // clamped: inactive lanes load a valid address (result unused)
   typename RW::type e1n = RW::zero();
   typename RW::type x3n = RW::zero();   // WG == C3D_WG_ROWS: this lane's row vector of wg_x3 (Y's row layout), one pass ahead like e1n
   const T* X3 = reinterpret_cast<const T*>(a.wg_x3);
   // this lane's E1 vector for pass P of the tile starting at ROW0: wave-uniform row base (scalar registers) + a
   // loop-invariant 32-bit lane offset; lanes without a row in this pass read the pass's first row (result unused)
-  const int e1_lane = rr_o * Np + v_oc * 8;
-#define PW_E1_PTR(ROW0, P)                                                                                          \
-  (E1 + (int64_t)((ROW0) + (P) * RPo < M32 ? (ROW0) + (P) * RPo : M32 - 1) * Np +                                   \
-   (((P) * RPo + rr_o < 16 && (ROW0) + (P) * RPo + rr_o < M32) ? e1_lane : v_oc * 8))
-#define PW_X3_PTR(ROW0, P) (X3 + (PW_E1_PTR(ROW0, P) - E1))
+  // (byte offsets into the bounds-checked resources rE1 / rX3: the requests are unconditional buffer loads, a resource
+  // without rows -- res_mode != 0, or no companion at all -- answers zeros)
+  const uint32_t e1_lane_b = (uint32_t)(rr_o * Np + v_oc * 8) * ES, e1_v_b = (uint32_t)(v_oc * 8) * ES;
+#define PW_E1_OFF(ROW0, P)                                                                                          \
+  ((uint32_t)((ROW0) + (P) * RPo < M32 ? (ROW0) + (P) * RPo : M32 - 1) * ((uint32_t)Np * ES) +                       \
+   (((P) * RPo + rr_o < 16 && (ROW0) + (P) * RPo + rr_o < M32) ? e1_lane_b : e1_v_b))
+  const __amdgpu_buffer_rsrc_t rE1 = pw_rsrc(e1_rows ? E1 : nullptr, (uint32_t)M32 * (uint32_t)Np * ES);
+  const __amdgpu_buffer_rsrc_t rX3 = pw_rsrc(WG == C3D_WG_ROWS ? X3 : nullptr, (uint32_t)M32 * (uint32_t)Np * ES);
 
   // Weight fragments: narrow outputs (NT <= 4) with K <= 64 keep ALL of them in registers (the per-tile MFMA phase
   // was LDS-read latency: X fragment, then each weight fragment, serially); wide outputs run two sub-tiles per
@@ -636,23 +679,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     CLK_WAITVM
     CLK(1)
     const bool reissue = SLOT_REISSUE && it0 + L.tpi < t1;
-    const T* xb_next = X + (int64_t)(it0 + L.tpi) * 16 * Kp;
-    int lo_next = lane * 8;
-    if constexpr (SLOT_REISSUE) asm volatile("" : "+v"(lo_next));
     // ---------------- convert + prologue -> LDS (all sub-tiles of this iteration) ------------
 #pragma unroll
     for (int j = 0; j < PW_SLOTS; ++j) {
-      if (j < nslots) {
-        const int i_ = lane + 64 * slot_q[j];
-        const int row_ = __float2int_rz(((float)i_ + 0.5f) * invGi);
-        const int v_ = i_ - row_ * Gi;
-        if (row_ < 16) {
-          const int tl_ = it0 + slot_s[j];
-          if constexpr (sizeof(T) == 2 && PRO == C3D_PRO_NONE) {   // no prologue: the raw bf16 vector IS the operand
-            *reinterpret_cast<uint4*>(Xs + (slot_s[j] * 16 + row_) * KL + v_ * 8) = xr[j];
-            continue;
-          }
-          float f[8];
+      const int i_ = lane + 64 * slot_q[j];
+      const int row_ = __float2int_rz(((float)i_ + 0.5f) * invGi);
+      const int v_ = i_ - row_ * Gi;
+      const int tl_ = it0 + slot_s[j];
+      [[maybe_unused]] uint32_t po_off = PW_OOB;   // where this slot's fused residual output goes (nowhere unless a real row)
+      [[maybe_unused]] float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (j < nslots && row_ < 16) {
+        if constexpr (sizeof(T) == 2 && PRO == C3D_PRO_NONE) {   // no prologue: the raw bf16 vector IS the operand
+          *reinterpret_cast<uint4*>(Xs + (slot_s[j] * 16 + row_) * KL + v_ * 8) = xr[j];
+        } else {
           RW::cvt(xr[j], f);
           if (PRO == C3D_PRO_BN_SE_SWISH) {
             float sc[8], sh[8], g[8];
@@ -691,7 +730,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
               // (bit-identical), also written out: the next block's shortcut and the backward pass read it
 #pragma unroll
               for (int e = 0; e < 8; ++e) f[e] = real ? fmaxf(fmaf(f[e], cA[e], cB[e]) + fmaf(f2[e], cC[e], 0.f), 0.f) : 0.f;
-              if (real) Vec8<T>::store(reinterpret_cast<T*>(a.pro_out) + (int64_t)((tl_ << 4) + row_) * Kp + v_ * 8, f);
+              if (real) po_off = ((uint32_t)((tl_ << 4) + row_) * (uint32_t)Kp + (uint32_t)v_ * 8u) * ES;
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) f[e] = real ? fmaf(cA[e], f[e], fmaf(cC[e], f2[e], cB[e])) : 0.f;
@@ -699,17 +738,22 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
           }
           MM::store8(Xs + (slot_s[j] * 16 + row_) * KL + v_ * 8, f);
         }
-        if constexpr (SLOT_REISSUE) {
-          if (reissue) PW_ISSUE_DENSE_SLOT(it0 + L.tpi, j, xb_next, lo_next)
-        }
       }
+      if constexpr (PRO == C3D_PRO_AFFINE2) {
+        if (a.pro_out) BufIO<T>::store(rPO, po_off, f);   // (kernel-uniform condition; lanes without a real row store nowhere)
+      }
+      // conv_c forward: the slot's registers are free -- request the same slot of the next iteration now
+      if constexpr (SLOT_REISSUE) PW_ISSUE_DENSE_SLOT(it0 + L.tpi, j, reissue)
     }
     CLK(2)
-    if (e1_rows) e1n = RW::load(PW_E1_PTR(it0 << 4, 0));
-    if constexpr (WG == C3D_WG_ROWS) x3n = RW::load(PW_X3_PTR(it0 << 4, 0));
+    if constexpr (E1_PIPE) e1n = BufIO<T>::load(rE1, PW_E1_OFF(it0 << 4, 0));
+    if constexpr (WG == C3D_WG_ROWS) x3n = BufIO<T>::load(rX3, PW_E1_OFF(it0 << 4, 0));
     // ---------------- prefetch the next iteration's rows -------------------------------------
+    // (DENSE: unconditionally -- past this wave's last tile the row bound answers zeros without touching memory; a prefetch
+    // under `if (more tiles)` left the epilogue's counted waits with two histories to cover: they came out as vmcnt(1))
     if constexpr (!SLOT_REISSUE) {
-      if (it0 + L.tpi < t1) { PW_ISSUE(it0 + L.tpi) }
+      if constexpr (DENSE) { PW_ISSUE_DENSE(it0 + L.tpi) }
+      else if (it0 + L.tpi < t1) { PW_ISSUE_GENERIC(it0 + L.tpi) }
     }
     CLK(3)
 
@@ -753,40 +797,48 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             const float4 g1 = *reinterpret_cast<const float4*>(gp + 4);
             eG[0] = g0.x; eG[1] = g0.y; eG[2] = g0.z; eG[3] = g0.w; eG[4] = g1.x; eG[5] = g1.y; eG[6] = g1.z; eG[7] = g1.w;
           }
+          // a sample changes once per few hundred tiles: let its gate loads (and the flush atomics) land HERE, so that no
+          // pending memory operation of this rare branch reaches the join below -- the compiler would otherwise guard the
+          // first use of eG in EVERY tile with s_waitcnt vmcnt(0), which also drains the next tile's prefetch
+#pragma unroll
+          for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(eG[j]));
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
-      for (int p = 0; p < npass; ++p) {
+      // fully unrolled over the most passes this NT can need (RPo >= 64 / (2 NT) row-lanes per channel vector): a pass past
+      // npass has no rows (row >= 16 for every lane), its load and store go nowhere.  As a runtime loop the companion-row
+      // pipeline (e1n) was a loop-carried register holding a pending load: the compiler's copies of it at the back edge waited
+      // for the load -- and, vmcnt retiring in order, for the prefetch burst behind it
+      auto epi_pass = [&](const int p) {
         const int row = p * RPo + rr_o;
         const int m = row0 + row;
         typename RW::type e1c = e1n;
-        if (e1_rows) {
-          if (p + 1 < npass) e1n = RW::load(PW_E1_PTR(row0, p + 1));
-          else if (has_next) e1n = RW::load(PW_E1_PTR(row0 + 16, 0));   // first pass of the next tile of this iteration
-        }
+        // next pass's companion rows (or the first pass of the next tile of this iteration; else nowhere), unconditionally
+        [[maybe_unused]] const uint32_t nxt_off = p + 1 < npass ? PW_E1_OFF(row0, p + 1) : ((p + 1 == npass && has_next) ? PW_E1_OFF(row0 + 16, 0) : PW_OOB);
+        if constexpr (E1_PIPE) e1n = BufIO<T>::load(rE1, nxt_off);
         typename RW::type x3c = x3n;
-        if constexpr (WG == C3D_WG_ROWS) {
-          if (p + 1 < npass) x3n = RW::load(PW_X3_PTR(row0, p + 1));
-          else if (has_next) x3n = RW::load(PW_X3_PTR(row0 + 16, 0));
-        }
+        if constexpr (WG == C3D_WG_ROWS) x3n = BufIO<T>::load(rX3, nxt_off);
         if constexpr (sizeof(T) == 2 && (EPI == C3D_EPI_STORE || EPI == C3D_EPI_STATS)) {
           // bf16 plain-store / statistics epilogue: the staged tile already holds the stored bits -- copy the 16 bytes
           // as they are (the f32 round trip cost 8 unpack + 8 re-round + 4 pack VALU per vector for an identity)
-          if (act_o && row < 16 && m < M32) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(Os + row * NL + v_o * 8);
+          const bool ok = act_o && row < 16 && m < M32;
+          uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+          if (ok) {
+            raw = *reinterpret_cast<const uint4*>(Os + row * NL + v_o * 8);
             if (EPI == C3D_EPI_STATS) {
               float f[8];
               RW::cvt(raw, f);
 #pragma unroll
               for (int j = 0; j < 8; ++j) { s0[j] += f[j]; s1[j] += f[j] * f[j]; }
             }
-            *reinterpret_cast<uint4*>(Y + (int64_t)m * Np + v_o * 8) = raw;
           }
-          continue;
+          if constexpr (sizeof(T) == 2) BufIO<bf16_t>::store_raw(rY, ok ? ((uint32_t)m * (uint32_t)Np + (uint32_t)v_o * 8u) * ES : PW_OOB, raw);
+          return;
         }
-        if (act_o && row < 16 && m < M32) {
-          float f[8];
+        const bool ok = act_o && row < 16 && m < M32;
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ok) {
           Vec8<os_t>::load(Os + row * NL + v_o * 8, f);
-          const int64_t yoff = (int64_t)m * Np + v_o * 8;
           if (EPI == C3D_EPI_STATS) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -838,9 +890,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
               for (int j = 0; j < 8; ++j) f[j] = ((xw[j >> 1] >> ((j & 1) * 16)) & 0x7fffu) != 0u && !((xw[j >> 1] >> ((j & 1) * 16)) & 0x8000u) ? f[j] : 0.f;
             }
           }
-          Vec8<T>::store(Y + yoff, f);
           if constexpr (WG == C3D_WG_ROWS) *reinterpret_cast<typename RW::type*>(Os + row * NL + v_o * 8) = x3c;
         }
+        BufIO<T>::store(rY, ok ? ((uint32_t)m * (uint32_t)Np + (uint32_t)v_o * 8u) * ES : PW_OOB, f);   // outside the branch: no exec-masked memory operation in the loop
+      };
+      if constexpr (WG == C3D_WG_SWISH && NT >= 7) {
+        for (int p = 0; p < npass; ++p) epi_pass(p);   // (the one variant the unrolled passes push into scratch: 12 registers)
+      } else {
+#pragma unroll
+        for (int p = 0; p < NPASS_MAX; ++p) epi_pass(p);
       }
       if constexpr (WG != 0) {
         CLK(6)
@@ -920,9 +978,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       }
     };
 
-    for (int sub = 0; sub < L.tpi; sub += MT) {
+    // (no `break` out of this loop: the compiler materialised the exit's undefined next-`sub` from a register with a load
+    // pending -- s_waitcnt vmcnt(0) in front of every tile, i.e. behind the prefetch burst just issued)
+    const int nsub = t1 - it0 < L.tpi ? t1 - it0 : L.tpi;
+    auto do_sub = [&](const int sub) {
       const int tile = it0 + sub;
-      if (tile >= t1) break;
       const int row0 = tile << 4;
       const lds_t* Xt = Xs + sub * 16 * KL;
       const bool two = MT == 2 && sub + 1 < L.tpi && tile + 1 < t1;          // wave-uniform
@@ -995,15 +1055,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         if (MT == 2 && two) finish_tile(acc2, row0 + 16, sub + 2 < L.tpi && tile + 2 < t1, Xt + 16 * KL, OsA, nullptr, nullptr, false);
       }
       CLK(6)
+    };
+    if constexpr (E1_PIPE && !(WG == C3D_WG_SWISH && NT >= 7)) {
+      // The first tile of an iteration is its own copy of the code: its first companion row was requested BEFORE the prefetch
+      // burst (17+ younger requests when it is consumed), a later tile's by the last pass of the tile before it (2 younger).
+      // Sharing one loop body made the compiler wait for the stricter of the two at every tile: vmcnt(1..2) in front of the
+      // first epilogue pass = the whole burst landed before the first store.
+      do_sub(0);
+      for (int sub = MT; sub < nsub; sub += MT) do_sub(sub);
+    } else {
+      for (int sub = 0; sub < nsub; sub += MT) do_sub(sub);
     }
   }
-#undef PW_X3_PTR
-#undef PW_E1_PTR
+#undef PW_E1_OFF
 #undef PW_ISSUE
 #undef PW_ISSUE_DENSE
 #undef PW_ISSUE_DENSE_SLOT
 #undef PW_ISSUE_GENERIC
-#undef PW_LIM
+#undef PW_SLOT_OFF
   CLK(7)
   if constexpr (WG != 0) {
     // this workgroup's dW partial -> wg_ws[blockIdx.x][K][N] (the reducer launched behind this kernel adds the partials in

@@ -1,0 +1,178 @@
+"""TEST INFRASTRUCTURE (oracle side; never imported by the product path): ReLU-kink bracketing for the strict
+end-to-end gradient comparisons.
+
+Why.  The reference network has ~120 ReLU layers (`nn.ReLU` after norm_a, after the residual add, in the stem and the
+decoders: reference model/x3d.py:176-183, 227-231, 94-106; model/change_decoder.py:30-55).  A pre-activation that lies
+within f32 rounding noise of zero takes either side depending on the summation order of whoever computes it -- torch-CPU
+itself changes sides with its thread count -- and ONE flipped unit moves the ~100 gradient tensors upstream of it by
+1e-4 .. 1e-3.  Comparing an f32 implementation with the f32 oracle to 1e-4 was therefore only possible on weight seeds that
+happened to have no such unit under both parties' exact roundings, and every change of a summation order in a kernel
+(a bank-conflict fix that re-associates a wave sum) had to be vetoed or the seeds re-scanned.
+
+What this module does instead (all of it on the oracle, in float64 unless stated):
+  1. `probe()` runs the oracle once in f64 with forward hooks on every `nn.ReLU` call and records the pre-activations;
+     the f32 oracle runs the test does anyway (one per thread count) record theirs: sigma_L = rms(pre_f32 - pre_f64) is the
+     f32 noise of ReLU call L as torch-CPU itself exhibits it.
+  2. A unit is AT RISK when |pre_f64| < k_sigma * sigma_L (default 6): f32 noise can put it on either side.
+  3. One more f64 run with every at-risk unit forced to the OTHER side (on -> off: output 0, gradient 0; off -> on: output
+     = pre, gradient 1) gives, per gradient tensor n, the bracket width s_n = relL2(g_flipped_n, g_n): how far the at-risk
+     units can move that tensor at all.
+  4. The comparison bound for tensor n is `tol + slack * s_n`: tensors no at-risk unit can move (s_n ~ 0: everything
+     downstream of the last at-risk unit, and every tensor of a case without at-risk units) keep the strict bound; the others
+     are listed (the "exclusion list") with the width they were granted.
+
+The bound is two-sided in spirit: an implementation that flips a unit which is NOT at risk (|pre| >= k_sigma sigma) fails
+exactly as before, and so does any error on a tensor that no at-risk unit reaches."""
+import contextlib
+
+import torch
+from torch import nn
+
+
+class _Recorder:
+    """Forward hooks on every nn.ReLU call of `model`: mode 'record' keeps the pre-activations (as float64, on the CPU);
+    mode 'flip' replaces the output of flagged units by the other branch."""
+
+    def __init__(self, model):
+        self.mods = [m for m in model.modules() if isinstance(m, nn.ReLU)]
+        self.pre, self.flags, self.mode, self.k = [], None, "record", 0
+
+    def _hook(self, mod, inp, out):
+        x = inp[0]
+        if self.mode == "record":
+            self.pre.append(x.detach().double().clone())
+            return None
+        f = self.flags[self.k]
+        self.k += 1
+        if f is None or not bool(f.any()):
+            return None
+        # other branch: on (x > 0) -> 0, off (x <= 0) -> x  ==  x - relu(x)
+        return torch.where(f, x - out, out)
+
+    @contextlib.contextmanager
+    def attached(self, mode, flags=None):
+        self.mode, self.flags, self.k, self.pre = mode, flags, 0, []
+        hs = [m.register_forward_hook(self._hook) for m in self.mods]
+        try:
+            yield self
+        finally:
+            for h in hs:
+                h.remove()
+
+
+def record(model, run):
+    """run() -> anything, executed with recording hooks on `model`; returns (run's result, [pre-activation per ReLU call])."""
+    rec = _Recorder(model)
+    for m in rec.mods:
+        assert not getattr(m, "inplace", False), "in-place ReLU: the hook would see the output"
+    with rec.attached("record"):
+        out = run()
+    return out, rec.pre
+
+
+def at_risk(pre64, pre32_runs, k_sigma=6.0):
+    """Flags per ReLU call: |pre_f64| < k_sigma * sigma_L, sigma_L = the largest rms(pre_f32 - pre_f64) over the given f32
+    runs, floored at one f32 ulp of the call's rms value."""
+    flags, report = [], []
+    for i, p in enumerate(pre64):
+        rms = float(p.pow(2).mean().sqrt())
+        sig = max([float((q[i] - p).pow(2).mean().sqrt()) for q in pre32_runs] + [rms * 2.0 ** -23])
+        f = p.abs() < k_sigma * sig
+        # exact zeros on both sides (padding, dead channels: pre == 0 in f64 AND in every f32 run) carry no gradient either way
+        dead = (p == 0)
+        for q in pre32_runs:
+            dead &= (q[i] == 0)
+        f &= ~dead
+        flags.append(f)
+        n = int(f.sum())
+        if n:
+            report.append((i, tuple(p.shape), n, sig / (rms + 1e-300)))
+    return flags, report
+
+
+def flipped_grads(model, run_backward, flags):
+    """run_backward() must zero the gradients, run forward + backward on `model`; executed with the flagged units forced to the
+    other branch.  Returns {name: grad clone}."""
+    rec = _Recorder(model)
+    with rec.attached("flip", flags):
+        run_backward()
+    assert rec.k == len(flags), (rec.k, len(flags))
+    return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).norm().item() / (b.norm().item() + 1e-300)
+
+
+def bracket_widths(g64, g64_flipped):
+    return {n: rel_l2(g64_flipped[n], g64[n]) for n in g64}
+
+
+def unit_list(flags, pre64, sig_rel=None):
+    """[(call index, flat element index, pre_f64)] of every flagged unit, deepest call first."""
+    units = []
+    for i in range(len(flags) - 1, -1, -1):
+        idx = flags[i].reshape(-1).nonzero().reshape(-1).tolist()
+        flat = pre64[i].reshape(-1)
+        units += [(i, j, float(flat[j])) for j in idx]
+    return units
+
+
+def single_unit_flags(flags, call, elem):
+    out = [None] * len(flags)
+    f = torch.zeros_like(flags[call]).reshape(-1)
+    f[elem] = True
+    out[call] = f.reshape(flags[call].shape)
+    return out
+
+
+def explain_flips(g_impl, g_base, units, delta_of, tol=1e-4, log=print):
+    """Which at-risk units did the implementation take on the other side?  g_impl / g_base: {name: gradient} of the
+    implementation under test and of the f32 oracle; delta_of(unit) -> {name: g64_flipped - g64} (one f64 run per unit).  The
+    residual g_impl - g_base is fitted by least squares with the units' deltas (every tensor weighted by 1 / |g_base tensor|: the
+    metric the bound is stated in); a unit whose coefficient comes out above 1/2 is taken as flipped and its delta added to the
+    base.  Returns (errs after the fit, accepted units).  A flip only moves tensors UPSTREAM of its layer, in a pattern fixed by
+    the network; a genuine implementation error is not of the form sum(delta_i) and stays in the residual."""
+    names = list(g_impl)
+    nrm = {n: g_base[n].detach().double().cpu().norm().item() + 1e-300 for n in names}
+    cur = {n: g_base[n].detach().double().cpu().clone() for n in names}
+    gi = {n: g_impl[n].detach().double().cpu() for n in names}
+
+    def errs_of(c):
+        return {n: (gi[n] - c[n]).norm().item() / nrm[n] for n in names}
+
+    def flat(d):
+        return torch.cat([(d[n].double() / nrm[n]).reshape(-1) for n in names])
+
+    errs = errs_of(cur)
+    if all(e < tol for e in errs.values()) or not units:
+        return errs, []
+    D = torch.stack([flat(delta_of(u)) for u in units], 1)            # [elements, units]
+    live = [i for i in range(len(units)) if D[:, i].norm().item() > 0.2 * tol]
+    accepted = []
+    for _ in range(3):                                                 # refit after taking the clear ones out
+        cand = [i for i in live if units[i] not in accepted]
+        if not cand or all(e < tol for e in errs.values()):
+            break
+        r = flat({n: gi[n] - cur[n] for n in names})
+        A = D[:, cand]
+        G = A.T @ A
+        x = torch.linalg.solve(G + 1e-6 * G.diagonal().mean() * torch.eye(len(cand), dtype=G.dtype), A.T @ r)
+        take = [cand[j] for j in range(len(cand)) if x[j].item() > 0.5]
+        if not take:
+            break
+        for i in take:
+            u, d = units[i], D[:, i]
+            off = 0
+            for n in names:
+                k = cur[n].numel()
+                cur[n] += (d[off:off + k] * nrm[n]).reshape(cur[n].shape)
+                off += k
+            accepted.append(u)
+        n_bad = sum(1 for e in errs.values() if e >= tol)
+        errs = errs_of(cur)
+        for i in take:
+            log(f"  kink: ReLU call {units[i][0]} element {units[i][1]} (pre_f64 {units[i][2]:+.3e}) taken on the other side")
+        log(f"  {len(take)} flip(s): {n_bad} -> {sum(1 for e in errs.values() if e >= tol)} tensors above {tol:g}")
+    return errs, accepted
