@@ -341,10 +341,7 @@ template <int NT, int PRO, int EPI> struct PwFragBatch {
 };
 template <int NT, int PRO, int EPI, int WAVES, int WG = 0> struct PwSlots {
   // (the fused weight gradient of the Swish/SE-backward variant needs ~16 more registers: 4 slots keep it out of scratch)
-  // (round 5: the wide Swish/SE-backward variants spilled 7-17 registers once the epilogue passes were unrolled, and every
-  // scratch reload is a VMEM access behind s_waitcnt vmcnt(0) -- in the middle of the prefetch burst: 4 slots, no scratch)
   static constexpr int value = (WG == C3D_WG_SWISH) ? 4 :
-                               (PRO == C3D_PRO_AFFINE2 && WAVES == 8 && EPI == C3D_EPI_SWISH_SE_BWD && NT >= 7) ? 4 :
                                (PRO == C3D_PRO_AFFINE2 && WAVES == 8 && (NT == 14 || EPI == C3D_EPI_SWISH_SE_BWD)) ? 6 : 8;
 };
 
@@ -439,17 +436,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   const int nslots = L.tpi * Q;
 
   // per-lane epilogue parameters / accumulators
-  float eS[8], eB[8], eM[8], eR[8], eG[8];
+  // (round 5: the Swish/SE-backward epilogue's per-channel scale | shift | mean | rstd live in LDS behind the prologue
+  // parameters, [4][Np], and are read per pass: as 32 registers per lane they pushed the wide variants into scratch -- and every
+  // scratch reload is a VMEM access behind s_waitcnt vmcnt(0), in the middle of the prefetch burst)
+  float* const Ep = Pp + 3 * Kp;
+  float eG[8];
   float s0[8], s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { eS[j] = 1.f; eB[j] = 0.f; eM[j] = 0.f; eR[j] = 0.f; eG[j] = 1.f; s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
-  if (EPI == C3D_EPI_SWISH_SE_BWD && act_o) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      eS[j] = a.epi_p[v_o * 8 + j]; eB[j] = a.epi_p[Np + v_o * 8 + j];
-      eM[j] = a.epi_q[v_o * 8 + j]; eR[j] = a.epi_q[Np + v_o * 8 + j];
-    }
-  }
+  for (int j = 0; j < 8; ++j) { eG[j] = 1.f; s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
 
   const int M32 = (int)a.M;                    // M < 2^31 (checked by the entry point)
   const int tiles = (M32 + 15) >> 4;
@@ -602,6 +596,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     } else if (PRO != C3D_PRO_NONE) {
       const int np = (PRO == C3D_PRO_AFFINE2 ? 3 : 2) * Kp;
       for (int i = tid; i < np; i += WAVES * 64) Pp[i] = a.pro_p[i];
+    }
+    if constexpr (EPI == C3D_EPI_SWISH_SE_BWD) {
+      for (int i = tid; i < 2 * Np; i += WAVES * 64) { Ep[i] = a.epi_p[i]; Ep[2 * Np + i] = a.epi_q[i]; }
     }
     CLK(10)
     if (img) {
@@ -846,8 +843,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
               s0[j] += r; s1[j] += r * r;
             }
           } else if (EPI == C3D_EPI_SWISH_SE_BWD) {
-            float bv[8], qs[8];
+            float bv[8], qs[8], eS[8], eB[8], eM[8], eR[8];
             RW::cvt(e1c, bv);
+            lds_ld8(Ep + v_o * 8, eS); lds_ld8(Ep + Np + v_o * 8, eB);
+            lds_ld8(Ep + 2 * Np + v_o * 8, eM); lds_ld8(Ep + 3 * Np + v_o * 8, eR);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const float pb = fmaf(bv[j], eS[j], eB[j]);
@@ -894,12 +893,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         }
         BufIO<T>::store(rY, ok ? ((uint32_t)m * (uint32_t)Np + (uint32_t)v_o * 8u) * ES : PW_OOB, f);   // outside the branch: no exec-masked memory operation in the loop
       };
-      if constexpr (WG == C3D_WG_SWISH && NT >= 7) {
-        for (int p = 0; p < npass; ++p) epi_pass(p);   // (the one variant the unrolled passes push into scratch: 12 registers)
-      } else {
 #pragma unroll
-        for (int p = 0; p < NPASS_MAX; ++p) epi_pass(p);
-      }
+      for (int p = 0; p < NPASS_MAX; ++p) epi_pass(p);
       if constexpr (WG != 0) {
         CLK(6)
         // ---------------- fused weight gradient ------------------------------------------------------
@@ -1056,7 +1051,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       }
       CLK(6)
     };
-    if constexpr (E1_PIPE && !(WG == C3D_WG_SWISH && NT >= 7)) {
+    if constexpr (E1_PIPE) {
       // The first tile of an iteration is its own copy of the code: its first companion row was requested BEFORE the prefetch
       // burst (17+ younger requests when it is consumed), a later tile's by the last pass of the tile before it (2 younger).
       // Sharing one loop body made the compiler wait for the stricter of the two at every tile: vmcnt(1..2) in front of the
@@ -1188,7 +1183,7 @@ bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   const int NL = NT * 16 + (sizeof(os_t) == 4 ? 4 : 8);
   const int Q = ((a.Kp >> 3) + 3) >> 2;
   const size_t w_bytes = al16((size_t)NT * 16 * KL * sizeof(typename MM::lds_t));
-  const size_t p_bytes = al16((size_t)3 * a.Kp * sizeof(float));
+  const size_t p_bytes = al16(((size_t)3 * a.Kp + (EPI == C3D_EPI_SWISH_SE_BWD ? (size_t)4 * a.Np : 0)) * sizeof(float));   // prologue [3][Kp] | epilogue [4][Np]
   const size_t os_bytes = al16((size_t)16 * NL * sizeof(os_t));
   const size_t gs_bytes = PRO == C3D_PRO_BN_SE_SWISH ? al16((size_t)a.Kp * sizeof(float)) : 0;   // per-wave gate copy
   // fused weight gradient: workgroup-shared f64 accumulators [ceil(Kp/16)*16][ceil(Np/16)*16 + 4] (row stride = 4 mod 8

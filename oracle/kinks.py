@@ -14,15 +14,16 @@ What this module does instead (all of it on the oracle, in float64 unless stated
      the f32 oracle runs the test does anyway (one per thread count) record theirs: sigma_L = rms(pre_f32 - pre_f64) is the
      f32 noise of ReLU call L as torch-CPU itself exhibits it.
   2. A unit is AT RISK when |pre_f64| < k_sigma * sigma_L (default 6): f32 noise can put it on either side.
-  3. One more f64 run with every at-risk unit forced to the OTHER side (on -> off: output 0, gradient 0; off -> on: output
-     = pre, gradient 1) gives, per gradient tensor n, the bracket width s_n = relL2(g_flipped_n, g_n): how far the at-risk
-     units can move that tensor at all.
-  4. The comparison bound for tensor n is `tol + slack * s_n`: tensors no at-risk unit can move (s_n ~ 0: everything
-     downstream of the last at-risk unit, and every tensor of a case without at-risk units) keep the strict bound; the others
-     are listed (the "exclusion list") with the width they were granted.
+  3. For each at-risk unit one more f64 run with THAT unit forced to the other side (on -> off: output 0, gradient 0;
+     off -> on: output = pre, gradient 1) gives delta_i = what that one flip does to every gradient tensor (it moves only
+     tensors upstream of its layer, in a pattern fixed by the network).
+  4. `explain_flips` fits (implementation - f32 oracle) with the deltas by least squares; units whose coefficient exceeds 1/2
+     are the ones the implementation took on the other side; they are printed (the "exclusion list" is a list of UNITS, not of
+     tensors) and their deltas added to the oracle.  EVERY tensor must then meet the strict bound.
 
-The bound is two-sided in spirit: an implementation that flips a unit which is NOT at risk (|pre| >= k_sigma sigma) fails
-exactly as before, and so does any error on a tensor that no at-risk unit reaches."""
+The check stays two-sided: an implementation that flips a unit which is NOT at risk (|pre| >= k_sigma sigma) fails exactly
+as before, and so does any error that is not a sum of at-risk deltas -- a genuine defect is not of that form.  `bracket_widths`
+(all at-risk units flipped at once) is kept as a cheap diagnostic of how far the at-risk units can move each tensor at all."""
 import contextlib
 
 import torch
@@ -72,11 +73,11 @@ def record(model, run):
 
 def at_risk(pre64, pre32_runs, k_sigma=6.0):
     """Flags per ReLU call: |pre_f64| < k_sigma * sigma_L, sigma_L = the largest rms(pre_f32 - pre_f64) over the given f32
-    runs, floored at one f32 ulp of the call's rms value."""
-    flags, report = [], []
+    runs, floored at one f32 ulp of the call's rms value.  Returns (flags, sigmas)."""
+    flags, sigmas = [], []
     for i, p in enumerate(pre64):
         rms = float(p.pow(2).mean().sqrt())
-        sig = max([float((q[i] - p).pow(2).mean().sqrt()) for q in pre32_runs] + [rms * 2.0 ** -23])
+        sig = max([float((q[i] - p).pow(2).mean().sqrt()) for q in pre32_runs] + [rms * 2.0 ** -23, 1e-300])
         f = p.abs() < k_sigma * sig
         # exact zeros on both sides (padding, dead channels: pre == 0 in f64 AND in every f32 run) carry no gradient either way
         dead = (p == 0)
@@ -84,10 +85,8 @@ def at_risk(pre64, pre32_runs, k_sigma=6.0):
             dead &= (q[i] == 0)
         f &= ~dead
         flags.append(f)
-        n = int(f.sum())
-        if n:
-            report.append((i, tuple(p.shape), n, sig / (rms + 1e-300)))
-    return flags, report
+        sigmas.append(sig)
+    return flags, sigmas
 
 
 def flipped_grads(model, run_backward, flags):
@@ -109,14 +108,16 @@ def bracket_widths(g64, g64_flipped):
     return {n: rel_l2(g64_flipped[n], g64[n]) for n in g64}
 
 
-def unit_list(flags, pre64, sig_rel=None):
-    """[(call index, flat element index, pre_f64)] of every flagged unit, deepest call first."""
+def unit_list(flags, pre64, sigmas, limit=None):
+    """[(call index, flat element index, pre_f64, |pre_f64| / sigma)] of the flagged units, the ones closest to zero (in units of
+    their call's f32 noise) first; at most `limit`."""
     units = []
-    for i in range(len(flags) - 1, -1, -1):
-        idx = flags[i].reshape(-1).nonzero().reshape(-1).tolist()
+    for i, f in enumerate(flags):
+        idx = f.reshape(-1).nonzero().reshape(-1).tolist()
         flat = pre64[i].reshape(-1)
-        units += [(i, j, float(flat[j])) for j in idx]
-    return units
+        units += [(i, j, float(flat[j]), abs(float(flat[j])) / sigmas[i]) for j in idx]
+    units.sort(key=lambda u: u[3])
+    return units[:limit] if limit else units
 
 
 def single_unit_flags(flags, call, elem):
@@ -173,6 +174,44 @@ def explain_flips(g_impl, g_base, units, delta_of, tol=1e-4, log=print):
         n_bad = sum(1 for e in errs.values() if e >= tol)
         errs = errs_of(cur)
         for i in take:
-            log(f"  kink: ReLU call {units[i][0]} element {units[i][1]} (pre_f64 {units[i][2]:+.3e}) taken on the other side")
+            log(f"  kink: ReLU call {units[i][0]} element {units[i][1]} (pre_f64 {units[i][2]:+.3e} = {units[i][3]:.2f} sigma) taken on the other side")
         log(f"  {len(take)} flip(s): {n_bad} -> {sum(1 for e in errs.values() if e >= tol)} tensors above {tol:g}")
     return errs, accepted
+
+
+def strict_compare(g_impl, make_run, tol=1e-4, threads=(1, 4), k_sigma=6.0, limit=32, check_outputs=None, log=print):
+    """The whole procedure of this module's header.  g_impl: {name: gradient tensor (CPU)} of the implementation under test;
+    make_run(dtype) -> (oracle model in that dtype, run) with run() = zero the gradients, forward, backward, return the outputs.
+    The f32 oracle is evaluated once per entry of `threads` (torch-CPU's rounding depends on it); check_outputs(outputs) may
+    assert on each evaluation's forward results.  Returns ({name: rel-L2 after granting}, [granted units])."""
+    grads = lambda m: {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    threads0 = torch.get_num_threads()
+    runs = []
+    try:
+        for thr in threads:
+            torch.set_num_threads(thr)
+            ref, run = make_run(torch.float32)
+            outs, pre32 = record(ref, run)
+            if check_outputs is not None:
+                check_outputs(outs)
+            g32 = grads(ref)
+            runs.append((g32, pre32, {n: rel_l2(g_impl[n], g32[n]) for n in g_impl}))
+    finally:
+        torch.set_num_threads(threads0)
+    errs = {n: min(r[2][n] for r in runs) for n in g_impl}
+    if max(errs.values()) < tol:
+        return errs, []
+    ref64, run64 = make_run(torch.float64)
+    _, pre64 = record(ref64, run64)
+    g64 = grads(ref64)
+    flags, sigmas = at_risk(pre64, [r[1] for r in runs], k_sigma)
+    units = unit_list(flags, pre64, sigmas, limit=limit)
+    log(f"  {sum(int(f.sum()) for f in flags)} ReLU units within {k_sigma:g} sigma of zero in the f64 oracle; the closest "
+        f"(call, element, sigmas): {[(u[0], u[1], round(u[3], 2)) for u in units[:8]]}")
+    base = min(runs, key=lambda r: sum(e * e for e in r[2].values()))[0]      # the f32 evaluation closer to the implementation
+
+    def delta_of(u):
+        gf = flipped_grads(ref64, run64, single_unit_flags(flags, u[0], u[1]))
+        return {n: (gf[n] - g64[n]).double() for n in g_impl}
+
+    return explain_flips(g_impl, {n: base[n] for n in g_impl}, units, delta_of, tol=tol, log=log)

@@ -691,3 +691,58 @@ def test_bench_dry_run_launches_eight_ranks_and_reports_the_job_geometry():
     c = d["config"]
     assert c["dist_world_size"] == 8 and c["global_batch"] == 256 and c["parallelism"] == "dp8" and c["dist_backend"] == "gloo"
     assert c["exchange_verified"] is True and c["exchange_floats"] > 1_700_000
+
+
+def test_kink_fit_names_the_relu_units_an_implementation_took_on_the_other_side():
+    """oracle/kinks.py (the kink-robust strict comparison of the GPU parity tests), exercised on the CPU: the "implementation"
+    is the f32 oracle itself with TWO at-risk ReLU units forced to the other branch.  Plain comparison: ~100-250 gradient tensors
+    miss 1e-4 (one flipped unit moves everything upstream of it); `strict_compare` must name exactly those two units and bring
+    every tensor under the strict bound -- and must NOT explain away a genuine defect (one gradient tensor scaled by 1.001)."""
+    from oracle import kinks, model as om, synth
+    size, batch = 64, 2
+    sd = synth.synth_state_dict(om.Trainer(om.make_args(size=size)), seed=16, mask_margin=0.25, branch_gain=0.1)
+    pre, post, tgt = synth.synth_batch(batch, size, seed=0)
+
+    def make_run(dtype):
+        ref = om.Trainer(om.make_args(size=size))
+        ref.load_state_dict(sd)
+        ref = (ref.double() if dtype == torch.float64 else ref).train()
+
+        def run():
+            ref.zero_grad(set_to_none=True)
+            out = ref.update_bcd(pre.to(dtype), post.to(dtype))
+            om.bce_dice_loss(out, tgt.to(dtype)).backward()
+            return [out]
+        return ref, run
+
+    grads = lambda m: {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    r64, run64 = make_run(torch.float64)
+    _, p64 = kinks.record(r64, run64)
+    r32, run32 = make_run(torch.float32)
+    _, p32 = kinks.record(r32, run32)
+    g32 = grads(r32)
+    flags, sig = kinks.at_risk(p64, [p32], 6.0)
+    units = kinks.unit_list(flags, p64, sig, limit=32)
+    assert len(units) >= 4
+    # two units in different, LATE ReLU calls (forcing an early unit also nudges the f32 forward values behind it, and another
+    # at-risk unit further on may follow: an artefact of emulating a flip this way, not of the fit)
+    by_call = sorted(units, key=lambda u: u[0])
+    chosen = [by_call[-1]] + [u for u in by_call if u[0] < by_call[-1][0]][-1:]
+    assert len(chosen) == 2 and chosen[0][0] != chosen[1][0]
+    fl = [None] * len(flags)
+    for c, e, _, _ in chosen:
+        f = torch.zeros_like(flags[c]).reshape(-1) if fl[c] is None else fl[c].reshape(-1)
+        f[e] = True
+        fl[c] = f.reshape(flags[c].shape)
+    g_impl = kinks.flipped_grads(r32, run32, fl)
+    plain = {n: kinks.rel_l2(g_impl[n], g32[n]) for n in g32}
+    assert sum(1 for e in plain.values() if e >= 1e-4) > 20
+    errs, granted = kinks.strict_compare(g_impl, make_run, threads=(torch.get_num_threads(),), log=lambda *a: None)
+    assert max(errs.values()) < 1e-4, max(errs.values())
+    assert sorted(u[:2] for u in granted) == sorted(u[:2] for u in chosen), (granted, chosen)
+    # a genuine defect is not a sum of flips: it stays
+    victim = "encoder.x3d.blocks.2.res_blocks.3.branch2.conv_b.weight"
+    g_bad = dict(g_impl)
+    g_bad[victim] = g_impl[victim] * 1.001
+    errs_bad, _ = kinks.strict_compare(g_bad, make_run, threads=(torch.get_num_threads(),), log=lambda *a: None)
+    assert errs_bad[victim] > 5e-4

@@ -277,13 +277,17 @@ def test_e2e_bcd_vs_oracle_size64():
             assert p.grad is None, n
 
 
-def _conditioned_case(task, wseed):
-    """One (task, weight seed) case of the conditioned-weights comparison: HIP f32 vs the fp32 oracle.  A ReLU can flip on
-    EITHER side: torch-CPU's own f32 rounding depends on its thread count (measured: the BCD seed-16 oracle at 1 thread is
-    5e-4 (median) away from the same oracle at 4 or 16 threads -- and from the HIP path, which agrees with those to 1e-6).
-    The oracle is therefore evaluated at two thread counts and every tensor is judged against the closer one: an oracle-side
-    flip in one evaluation cannot fail (or pass) the case.  Returns {parameter: gradient rel-L2}."""
-    from oracle import model as om, synth
+def _conditioned_case(task, wseed, tol=1e-4):
+    """One (task, weight seed) case of the conditioned-weights comparison: HIP f32 vs the fp32 oracle, EVERY gradient tensor
+    to `tol` relative L2 -- kink-robust (oracle/kinks.py).  A ReLU pre-activation within f32 noise of zero takes either side
+    depending on who sums in which order (torch-CPU itself changes sides with its thread count), and one flipped unit moves the
+    ~100 tensors upstream of it by 1e-4 .. 1e-3.  So: the oracle runs at two thread counts and every tensor is judged against
+    the closer one; if that already meets `tol`, done.  Otherwise the f64 oracle's pre-activations name the units AT RISK
+    (|pre| < 6 sigma of the f32 oracle's own noise at that ReLU call), one f64 run per unit gives what flipping it does to every
+    gradient, and a least-squares fit says which of them the HIP path took on the other side; those (printed) are granted,
+    and every tensor must meet `tol` against oracle + their deltas.  A flip of a unit that is not at risk, or an error that is
+    not a sum of such deltas, fails as before.  Returns ({parameter: gradient rel-L2}, [granted units])."""
+    from oracle import kinks, model as om, synth
     from change3d_amd.model.trainer import Trainer
     from change3d_amd.model.utils import BCEDiceLoss, hot_path_named_params
     size, batch = 64, 2
@@ -304,36 +308,40 @@ def _conditioned_case(task, wseed):
         outs_d = list(mine.update_scd(pre.to(DEV), post.to(DEV)))
         scd_loss(CrossEntropyLoss2d(ignore_index=0), ChangeSimilarity(), outs_d, labels.to(DEV))[0].backward()
     torch.cuda.synchronize()
-    threads0 = torch.get_num_threads()
-    errs = None
-    try:
-        for thr in (1, 4):
-            torch.set_num_threads(thr)
-            ref = om.Trainer(mk())
-            ref.load_state_dict(sd)
-            ref.train()
+    g_hip = {n: p.grad.detach().cpu() for n, p in hot_path_named_params(mine)}
+
+    def oracle_run(dtype):
+        ref = om.Trainer(mk())
+        ref.load_state_dict(sd)
+        ref = (ref.double() if dtype == torch.float64 else ref).train()
+
+        def run():
+            ref.zero_grad(set_to_none=True)
+            a, b = pre.to(dtype), post.to(dtype)
             if task == "bcd":
-                outs_r = [ref.update_bcd(pre, post)]
-                om.bce_dice_loss(outs_r[0], tgt).backward()
+                outs = [ref.update_bcd(a, b)]
+                om.bce_dice_loss(outs[0], tgt.to(dtype)).backward()
             else:
-                outs_r = list(ref.update_scd(pre, post))
-                om.scd_loss(*outs_r, labels).backward()
-            for od, orr in zip(outs_d, outs_r):
-                assert (od.detach().cpu() - orr.detach()).abs().max().item() < 1e-5 * max(1.0, orr.detach().abs().max().item())
-            pref = dict(ref.named_parameters())
-            e = {n: rel(p.grad, pref[n].grad) for n, p in hot_path_named_params(mine)}
-            errs = e if errs is None else {n: min(errs[n], e[n]) for n in e}
-    finally:
-        torch.set_num_threads(threads0)
-    return errs
+                outs = list(ref.update_scd(a, b))
+                om.scd_loss(*outs, labels).backward()
+            return outs
+        return ref, run
+
+    def check(outs_r):
+        for od, orr in zip(outs_d, outs_r):
+            assert (od.detach().cpu() - orr.detach()).abs().max().item() < 1e-5 * max(1.0, orr.detach().abs().max().item())
+
+    print(f"{task} seed {wseed}:")
+    return kinks.strict_compare(g_hip, oracle_run, tol=tol, check_outputs=check)
 
 
-def _summ(task, wseed, errs):
+def _summ(task, wseed, errs, granted=()):
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     over = [n for n, e in errs.items() if e >= 1e-4]
     med = sorted(errs.values())[len(errs) // 2]
     print(f"{task} conditioned (weight seed {wseed}): worst per-parameter gradient rel-L2 {[(n, f'{e:.1e}') for n, e in worst]}; "
-          f"median {med:.1e}; {len(over)}/{len(errs)} tensors above 1e-4")
+          f"median {med:.1e}; {len(over)}/{len(errs)} tensors above 1e-4; ReLU units granted the other side: "
+          f"{[(u[0], u[1], f'{u[3]:.2f} sigma') for u in granted]}")
     return worst[0][1], med, len(over)
 
 
@@ -342,36 +350,28 @@ def test_e2e_vs_oracle_conditioned_weights_every_gradient_bcd():
     ~1e-2), which is why the tests around this one judge errors against the fp32 reference's own distance from fp64.
     With every residual branch scaled by 0.1 (`branch_gain`: a trained-network-like, well-conditioned stack) fp32
     rounding stays in the linear regime and the HIP f32 path is compared DIRECTLY with the fp32 oracle: outputs to
-    1e-5, EVERY parameter gradient to 1e-4 relative L2 (measured: worst 2e-5)."""
+    1e-5, EVERY parameter gradient to 1e-4 relative L2 (measured: worst 2e-5), on four weight seeds, kink-robustly
+    (`_conditioned_case`): at most a handful of at-risk ReLU units may be granted the other side, and they are printed."""
     _need_gpu()
-    worst, _, _ = _summ("bcd", 16, _conditioned_case("bcd", 16))
-    assert worst < 1e-4, worst
+    for wseed in (16, 23, 26, 27):
+        errs, granted = _conditioned_case("bcd", wseed)
+        worst, _, _ = _summ("bcd", wseed, errs, granted)
+        assert worst < 1e-4 and len(granted) <= 6, (wseed, worst, granted)
 
 
 def test_e2e_vs_oracle_conditioned_weights_every_gradient_scd():
     """SCD (T=5, three decoders): the same STRICT bound -- every one of the 490 gradient tensors within 1e-4 of the fp32
-    oracle -- on ALL THREE kink-free weight seeds 23, 26, 27 (worst tensor 1.1e-5 .. 1.4e-5 on MI355X), nothing waived.
-    There are ~120 ReLU layers over 5/3 as many elements as BCD; when ONE pre-activation lands on the other side of the
-    kink (a last-bit difference in an early BatchNorm scale is enough, on either side) ~100 upstream tensors move by
-    1e-4 .. 1e-3 (tools/dbg_flip.py; tools/scan_scd_seed.py: 47 of 54 scanned weight seeds hit one), which is why the strict
-    cases are seeds found kink-free -- under two different roundings of the oracle (1 and 4 threads).  Should a future
-    last-bit change push one of the three across a kink, the failure message says which, and how the spare kink-free seeds
-    64 and 66 (1.6e-5 / 2.1e-5 at round 4; also 61) do: a regression moves all of them, a flip moves one -- which is then to be
-    replaced by a spare here, with the flip recorded.  Every case (and the kinked default seed 16) must also satisfy the
-    distribution bound: median < 2e-5, 70 % of the tensors < 1e-4, none above 5e-3."""
+    oracle -- on weight seeds 23, 26, 27 AND the default seed 16, nothing waived.  There are ~120 ReLU layers over 5/3 as many
+    elements as BCD; until round 5 the strict bound could only be asserted on seeds scanned to be kink-free under the kernels'
+    exact roundings (tools/scan_scd_seed.py: 47 of 54 scanned seeds had a unit that flipped), which let three seeds veto any
+    kernel change that re-associates a sum (the f32 depthwise forward had to keep a slower LDS layout than the bf16 one).
+    Now a flip is identified and granted by name (`_conditioned_case`, oracle/kinks.py): seed 16 -- the kinked one -- meets the
+    strict bound as well, and a regression still fails on every seed (it is not a sum of at-risk deltas)."""
     _need_gpu()
-    worst_of = {}
     for wseed in (23, 26, 27, 16):
-        errs = _conditioned_case("scd", wseed)
-        worst, med, n_over = _summ("scd", wseed, errs)
-        assert med < 2e-5 and n_over <= 0.3 * len(errs) and worst < 5e-3, (wseed, med, n_over, worst)
-        worst_of[wseed] = worst
-    failed = [w for w in (23, 26, 27) if worst_of[w] >= 1e-4]
-    if failed:
-        spare = {w: _summ("scd", w, _conditioned_case("scd", w))[0] for w in (64, 66)}
-        raise AssertionError(f"strict 1e-4 bound broken on weight seed(s) {failed}: worst tensor per seed {worst_of}; spare kink-free "
-                             f"seeds 64 / 66 now give {spare} -- all high = a regression, one seed high = a ReLU flip on that seed "
-                             f"(replace it by a spare and record the flip in this docstring)")
+        errs, granted = _conditioned_case("scd", wseed)
+        worst, med, n_over = _summ("scd", wseed, errs, granted)
+        assert worst < 1e-4 and med < 2e-5 and len(granted) <= 8, (wseed, worst, med, granted)
 
 
 @pytest.mark.parametrize("T,dtype,shape", [(3, torch.float32, (2, 64, 64)), (5, torch.float32, (2, 40, 72)),
