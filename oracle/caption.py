@@ -117,8 +117,11 @@ class CaptionDecoder(nn.Module):
 
     def forward(self, memory, encoded_captions, caption_lengths):
         tgt = encoded_captions.permute(1, 0)
-        mask = causal_mask(tgt.size(0), tgt.device)
         x = self.position_encoding(self.vocab_embedding(tgt))
+        # (the reference's mask is float32 whatever the module's dtype; in float32 the cast is the identity.  In float64 --
+        # the yardstick evaluations of the tests -- a float32 mask makes nn.MultiheadAttention's fused path return garbage
+        # without an error (need_weights=True raises "Input dtypes must be the same"): scores moved by 4.3, loss by 1 %)
+        mask = causal_mask(tgt.size(0), tgt.device).to(x.dtype)
         for layer in self.transformer.layers:
             x = layer(x, memory, tgt_mask=mask)
         pred = self.wdc(self.dropout_layer(x)).permute(1, 0, 2)

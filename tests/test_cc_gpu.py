@@ -175,59 +175,71 @@ def test_caption_decoder_dropout_is_reproducible_and_unbiased():
     assert torch.all((y == 0) | ((y - 1.0 / 0.9).abs() < 1e-6))
 
 
-@pytest.mark.parametrize("seed,strict", [(23, True), (21, False), (25, False)])
-def test_e2e_cc_vs_oracle_conditioned_weights(seed, strict):
-    """The default synthetic weights make the 70-block CC encoder chaotic (the fp32 reference's own gradient norms are
-    ~80-96 % away from its fp64 evaluation: see the fixture test above), which leaves only distribution-level checks.
+@pytest.mark.parametrize("seed", [23, 21, 25])
+def test_e2e_cc_vs_oracle_conditioned_weights(seed):
+    """With the default synthetic weights the 70-block CC encoder is ill-conditioned (the fp32 reference's own gradient norms
+    sit 0.1 % (median) .. 10 % (worst) away from its fp64 evaluation: the fixture test above judges against that yardstick --
+    NOTE: until round 5 the fixtures' fp64 yardstick itself was wrong, 80-96 %, because the reference's float32 attention mask
+    makes nn.MultiheadAttention's fused path return garbage on float64 queries; see oracle/gen_golden.py::ref_cc_forward).
     With every residual branch scaled by 0.1 (`branch_gain`, a trained-network-like stack) rounding stays in the linear
     regime and EVERY gradient of the whole path -- encoder blocks 0-4 through the caption decoder -- is compared
-    parameter by parameter with the fp32 oracle.
+    parameter by parameter with the fp32 oracle, to 1e-4 relative L2, on three weight seeds.
 
-    Seeds.  At 64x64 the res4 / res5 BatchNorms see 384 / 96 values per channel and some ReLU pre-activation of the 70
-    blocks sits within one ulp of zero for most weight draws: which side it falls on then depends on the summation
-    order of the statistics, and ONE flipped unit moves that block's gradients by ~1e-3 and everything below it by
-    ~1e-4 (signature: the worst tensors are that block's norm_a / norm_b bias).  Measured on MI355X with the round-2 and
-    the round-3 depthwise stride-2 kernels (same outputs, per-sample sums added in a different order):
-      seed 23: worst 1.7e-5 / 1.8e-5, median 3.1e-6 / 3.1e-6 -- off the kink under both: the STRICT case;
-      seed 21: worst 1.0e-5 / 1.7e-3 (res5 block 1 flips with the new order), median 3.9e-6 / 1.7e-4;
-      seed 25: worst 1.7e-3 / 1.7e-3 (res3 block 5 flips under both), median 4.3e-6 / 3.5e-6.
-    The last two keep the one-flip bound (tools/scan notes in DESIGN.md section 6)."""
+    Kinks.  At 64x64 the res4 / res5 BatchNorms see 384 / 96 values per channel and some ReLU pre-activation of the 70 blocks
+    sits within f32 noise of zero for most weight draws: which side it falls on depends on the summation order of the
+    statistics, and ONE flipped unit moves that block's gradients by ~1e-3 and everything below it by ~1e-4.  Until round 5
+    only seed 23 (off the kink under the kernels' exact roundings) carried the strict bound; seeds 21 (res5 block 1 flips)
+    and 25 (res3 block 5 flips) had a loose one.  Now all three are strict: `oracle/kinks.py::strict_compare` names the
+    at-risk units the HIP path took on the other side (printed) and requires every tensor to meet 1e-4 against the oracle
+    with exactly those units flipped."""
     _need_gpu()
-    from oracle import caption as oc, model as om
+    from oracle import caption as oc, kinks, model as om
     from change3d_amd import synthetic as synth
     from change3d_amd.model.caption_decoder import packed_cross_entropy
     from change3d_amd.model.utils import cc_named_params
     size, batch, vocab = 64, 2, 157
     args = synth.make_cc_args(size=size, vocab_size=vocab, dropout=0.0)
-    ora = om.Trainer(args)
-    sd = synth.synth_state_dict(ora, seed=seed, branch_gain=0.1)
-    sd["decoder.position_encoding.pe"] = ora.state_dict()["decoder.position_encoding.pe"].clone()
-    ora.load_state_dict(sd)
-    ora.train()
-    ora.decoder.position_encoding.dropout.p = 0.0
+    ora0 = om.Trainer(args)
+    sd = synth.synth_state_dict(ora0, seed=seed, branch_gain=0.1)
+    sd["decoder.position_encoding.pe"] = ora0.state_dict()["decoder.position_encoding.pe"].clone()
     net = _mirror(args, sd)
     pre, post, _ = synth.synth_batch(batch, size, seed=3)
     caps, caplens = synth.synth_captions(batch, seed=3, vocab_size=vocab)
-    lo, so, _, fo = oc.cc_forward_loss(ora, pre, post, caps, caplens)
-    lo.backward()
     feat = net.update_cc(pre.to(DEV), post.to(DEV))
     B, C, H, W = feat.shape
     lg = net.decoder.logits_seq_first(feat.permute(2, 3, 0, 1).reshape(H * W, B, C), caps.to(DEV))
     loss = packed_cross_entropy(lg, caps.to(DEV), caplens.to(DEV), vocab)
     loss.backward()
     torch.cuda.synchronize()
-    print(f"conditioned CC: feature rel-L2 {rel(feat, fo):.2e}, loss hip {loss.item():.6f} oracle {lo.item():.6f}")
-    assert rel(feat, fo) < 1e-4 and abs(loss.item() - lo.item()) < 1e-4
     enc_named, dec_named = cc_named_params(net)
-    po = dict(ora.named_parameters())
-    errs = {n: rel(p.grad, po[n].grad) for n, p in enc_named + dec_named}
+    g_hip = {n: p.grad.detach().cpu() for n, p in enc_named + dec_named}
+
+    def make_run(dtype):
+        ora = om.Trainer(args)
+        ora.load_state_dict(sd)
+        ora = (ora.double() if dtype == torch.float64 else ora).train()
+        ora.decoder.position_encoding.dropout.p = 0.0
+
+        def run():
+            ora.zero_grad(set_to_none=True)
+            lo, so, _, fo = oc.cc_forward_loss(ora, pre.to(dtype), post.to(dtype), caps, caplens)
+            lo.backward()
+            return [fo, lo]
+        return ora, run
+
+    def check(outs):
+        fo, lo = outs
+        print(f"conditioned CC: feature rel-L2 {rel(feat, fo):.2e}, loss hip {loss.item():.6f} oracle {lo.item():.6f}")
+        assert rel(feat, fo) < 1e-4 and abs(loss.item() - lo.item()) < 1e-4
+
+    errs, granted = kinks.strict_compare(g_hip, make_run, tol=1e-4, check_outputs=check)
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    print("conditioned CC: worst per-parameter gradient rel-L2:", [(n, f"{e:.1e}") for n, e in worst])
     med = float(np.median(list(errs.values())))
-    if strict:
-        assert med < 2e-5 and worst[0][1] < 1e-4, (med, worst)
-    else:   # at most a ReLU flip or two: a real defect (wrong tap, wrong coefficient) is >= 1e-1 on the tensors it touches
-        assert med < 1e-3 and worst[0][1] < 2e-2, (med, worst)
+    print(f"conditioned CC seed {seed}: worst per-parameter gradient rel-L2 {[(n, f'{e:.1e}') for n, e in worst]}; median {med:.1e}; "
+          f"ReLU units granted the other side: {[(u[0], u[1], f'{u[3]:.2f} sigma') for u in granted]}")
+    if worst[0][1] >= 1e-4 and os.path.isdir("gpurun_out"):
+        torch.save(g_hip, f"gpurun_out/kink_fail_cc_{seed}.pt")
+    assert med < 2e-5 and worst[0][1] < 1e-4 and len(granted) <= 8, (med, worst, granted)
 
 
 def _beam_decoder(sd, args, dtype=torch.float32):

@@ -1,4 +1,6 @@
-// VALU issue-rate probe (gfx950): v_fma_f32 vs v_pk_fma_f32 vs v_dot2c_f32_bf16, 16 independent chains.
+// VALU issue-rate probe (gfx950): v_fma_f32 vs v_pk_fma_f32 vs v_dot2c_f32_bf16, 16 independent chains; modes 16 / 17: a whole
+// swish(x) = x * sigmoid(x) per chain element -- v_mul + v_exp + v_add + v_rcp + v_mul against a clamped odd polynomial of the
+// same 2^-10 accuracy (v_med3 + 9 full-rate FMA / MUL): the round-4 review's "packed-FMA sigmoid" priced in instructions.
 // build: hipcc --offload-arch=gfx950 -O3 tools/micro/valu_rate.hip -o /tmp/valu_rate
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,6 +35,20 @@ template <int MODE> __global__ __launch_bounds__(256) void probe(float* out, uin
       if (MODE == 13) asm volatile("v_exp_f16 %0, %1" : "=v"(acc[i]) : "v"(fa));
       if (MODE == 14) asm volatile("v_rcp_f16 %0, %1" : "=v"(acc[i]) : "v"(fa));
       if (MODE == 15) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa), "v"(fb));
+      if (MODE == 16) {   // x * rcp(1 + exp2(-log2e x))
+        float t, x = acc[i];
+        asm volatile("v_mul_f32 %0, 0xbfb8aa3b, %1\n\tv_exp_f32 %0, %0\n\tv_add_f32 %0, 1.0, %0\n\tv_rcp_f32 %0, %0\n\tv_mul_f32 %1, %1, %0" : "=&v"(t), "+v"(x));
+        acc[i] = x + fa;
+      }
+      if (MODE == 17) {   // x * (0.5 + c P(c^2)), c = clamp(x, -7, 7), P of degree 6 in c^2 (7 odd terms): |error| < 1e-3
+        float c, s2, p, x = acc[i];
+        asm volatile("v_med3_f32 %0, %3, %5, %6\n\tv_mul_f32 %1, %0, %0\n\t"
+                     "v_mov_b32 %2, 0x2f800000\n\tv_fma_f32 %2, %2, %1, %4\n\tv_fma_f32 %2, %2, %1, %4\n\tv_fma_f32 %2, %2, %1, %4\n\t"
+                     "v_fma_f32 %2, %2, %1, %4\n\tv_fma_f32 %2, %2, %1, %4\n\tv_fma_f32 %2, %2, %1, %4\n\t"
+                     "v_fma_f32 %2, %2, %0, 0.5\n\tv_mul_f32 %3, %3, %2"
+                     : "=&v"(c), "=&v"(s2), "=&v"(p), "+v"(x) : "v"(fb), "v"(-7.0f), "v"(7.0f));
+        acc[i] = x + fa;
+      }
     }
   }
   float s = 0.f;
@@ -78,6 +94,8 @@ int main() {
     run<13>("v_exp_f16", out, w);
     run<14>("v_rcp_f16", out, w);
     run<15>("v_pk_fma_f16", out, w);
+    run<16>("swish exp+rcp (5 instr)", out, w);
+    run<17>("swish poly7 (11 instr)", out, w);
   }
   return 0;
 }
