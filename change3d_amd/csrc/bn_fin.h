@@ -175,6 +175,31 @@ __device__ __forceinline__ void bn_bwd_coef_consume(const c3d_bn_fin& f, int C, 
   if (acc && f.ss && c < Cp) { f.ss[c] = cA; f.ss[Cp + c] = cB; f.ss[2 * Cp + c] = cC; }
 }
 
+// Eight consecutive channels at once (no accumulation): every load is issued before the first result is computed.  Called in a
+// loop, bn_bwd_coef_consume's guarded loads came out as eight dependent memory round trips (five loads, s_waitcnt vmcnt(0),
+// arithmetic; next channel) in front of a kernel's first tile -- ~8 us of c3d_pw_wgrad's ~40 us on the 32 x 32 maps (round 5,
+// from the ISA).  Channels past C read channel C - 1 (a valid address) and are zeroed; per-channel arithmetic unchanged.
+__device__ __forceinline__ void bn_bwd_coef_consume8(const c3d_bn_fin& f, int C, int Cp, int c0, float (&cA)[8], float (&cB)[8],
+                                                     float (&cC)[8]) {
+  double s1[8], s2[8];
+  float mean[8], rstd[8], gam[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j < C ? c0 + j : C - 1;
+    s1[j] = f.sums[c]; s2[j] = f.sums[C + c];
+    mean[j] = f.mr[c]; rstd[j] = f.mr[Cp + c];
+    gam[j] = f.gamma[c];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double A = (double)gam[j] * (double)rstd[j];
+    const double Cc = -A * (double)rstd[j] * s2[j] / f.count;
+    const double Bc = -A * s1[j] / f.count - Cc * (double)mean[j];
+    const bool live = c0 + j < C;
+    cA[j] = live ? (float)A : 0.f; cB[j] = live ? (float)Bc : 0.f; cC[j] = live ? (float)Cc : 0.f;
+  }
+}
+
 // ---- BatchNorm_b of blocks without SqueezeExcitation: per-sample sums consumed directly -----------------------------
 // Forward.  nc f64 [B][Cp][2] (c3d_dw333_fwd) -> scale / shift of ALL channels into lds_sc / lds_sh; `owner` also writes
 // ss / mr / the running statistics.  Four adjacent lanes split the batch loop and combine with xor 1, xor 2 -- the

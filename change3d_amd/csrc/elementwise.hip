@@ -86,11 +86,23 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(const T* __restrict_
   // at a fraction of the f32 rate -- plus 48 accumulator registers made this elementwise pass run at 3.7 TB/s.)
   float s1[8], s2[8], s3[8];
   float mc[8], rc[8], m1[8], r1[8];
+  {
+    // eight 16-byte loads in ONE round trip (the rows are 32-byte aligned: Cp is a multiple of 8, the vectors come from the
+    // stage workspace).  As 32 scalar loads with `s ? mr_1[..] : 0` selects the compiler put s_waitcnt vmcnt(0) behind every
+    // pair: eight dependent memory round trips, ~8 us of a 27 us launch on the 32 x 32 maps (round 5, from the ISA)
+    const float* q1 = s ? mr_1 : mr_c;   // a valid address either way: the loads are unconditional
+    const float4 a0 = *reinterpret_cast<const float4*>(mr_c + v * 8), a1 = *reinterpret_cast<const float4*>(mr_c + v * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(mr_c + Cp + v * 8), b1 = *reinterpret_cast<const float4*>(mr_c + Cp + v * 8 + 4);
+    const float4 c0 = *reinterpret_cast<const float4*>(q1 + v * 8), c1 = *reinterpret_cast<const float4*>(q1 + v * 8 + 4);
+    const float4 d0 = *reinterpret_cast<const float4*>(q1 + Cp + v * 8), d1 = *reinterpret_cast<const float4*>(q1 + Cp + v * 8 + 4);
+    const float va[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float vc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, vd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    s1[j] = 0.f; s2[j] = 0.f; s3[j] = 0.f;
-    mc[j] = mr_c[v * 8 + j]; rc[j] = mr_c[Cp + v * 8 + j];
-    m1[j] = s ? mr_1[v * 8 + j] : 0.f; r1[j] = s ? mr_1[Cp + v * 8 + j] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      s1[j] = 0.f; s2[j] = 0.f; s3[j] = 0.f;
+      mc[j] = va[j]; rc[j] = vb[j];
+      m1[j] = s ? vc[j] : 0.f; r1[j] = s ? vd[j] : 0.f;
+    }
   }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   // The grid is capped (the closing same-address atomics): ~1.5 workgroups per CU, so the bytes in flight come from the
@@ -328,6 +340,7 @@ extern "C" int c3d_block_out_bwd_fin(const void* dy, const void* y, const void* 
                                      int32_t C, int32_t Cp, int32_t dtype, const c3d_bn_fin* fc, const c3d_bn_fin* f1,
                                      void* stream) {
   if (!dy || !c || !mr_c || !dsums_c || M <= 0 || (Cp & 7) || Cp > 256) return C3D_E_BADARG;
+  if (((uintptr_t)mr_c & 15) || (s_bn && ((uintptr_t)mr_1 & 15))) return C3D_E_BADARG;   // mean | rstd rows are read as 16-byte vectors
   if ((y == nullptr) != (g == nullptr)) return C3D_E_BADARG;   // both NULL: dy is already masked, only the sums are produced
   if ((s_bn == nullptr) != (dsums_1 == nullptr) || (s_bn && !mr_1)) return C3D_E_BADARG;
   if (fc && fc->ticket && (!fc->gamma || !fc->ss || !fc->mr || !(fc->count > 0))) return C3D_E_BADARG;

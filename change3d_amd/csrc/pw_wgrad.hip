@@ -183,8 +183,7 @@ __global__ __launch_bounds__(WG_THREADS) void pw_wgrad_kernel(const c3d_pw_wgrad
   for (int j = 0; j < 8; ++j) { cA[j] = 1.f; cB[j] = 0.f; cC[j] = 0.f; }
   if (HASP2 && p_act) {
     if (a.p_fin.sums) {   // coefficients rebuilt from the producer's sums (csrc/bn_fin.h); nothing is accumulated here
-#pragma unroll
-      for (int j = 0; j < 8; ++j) c3dfin::bn_bwd_coef_consume(a.p_fin, a.N, Np, vv * 8 + j, false, cA[j], cB[j], cC[j]);
+      c3dfin::bn_bwd_coef_consume8(a.p_fin, a.N, Np, vv * 8, cA, cB, cC);
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {

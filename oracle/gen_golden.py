@@ -359,6 +359,22 @@ def run_cc(size, batch):
     out["feat_lattice_f64"] = f64.detach()[:, :, ::stride, ::stride].numpy()
     out["scores_rows_f64"] = s64.detach()[::max(s64.shape[0] // 16, 1)].numpy()
     out["grad_norms_f64"] = np.array([n64[str(n)].grad.norm().item() for n in out["grad_names"]])
+    # (round 5) the float64 loss CURVE: how far the float32 reference's later losses drift from float64 once clipped-Adam
+    # steps (whose first update is lr * sign(g): a sign decided by rounding on near-zero gradients) have been applied --
+    # the yardstick for an implementation's step-2 loss, which the first loss alone does not give
+    enc64, dec64 = oc.make_cc_optimizers(ref64, CC_LR, CC_LR)
+    losses64 = [l64.item()]
+    for it in range(1, CC_STEPS + 1):
+        mu.clip_gradient(dec64, CC_CLIP)
+        mu.clip_gradient(enc64, CC_CLIP)
+        enc64.step(); dec64.step()
+        if it == CC_STEPS:
+            break
+        dec64.zero_grad(); enc64.zero_grad()
+        l64b = ref_cc_forward(ref64, pre.double(), post.double(), caps, caplens)[0]
+        l64b.backward()
+        losses64.append(l64b.item())
+    out["loss_curve_f64"] = np.array(losses64)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, f"cc_s{size}_b{batch}.npz")
     np.savez_compressed(path, **out)

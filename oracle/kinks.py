@@ -37,6 +37,17 @@ class _Recorder:
     def __init__(self, model):
         self.mods = [m for m in model.modules() if isinstance(m, nn.ReLU)]
         self.pre, self.flags, self.mode, self.k = [], None, "record", 0
+        # parameter name -> number of ReLU calls made before the FIRST forward of the module that owns it: a flipped unit of
+        # ReLU call c can only move parameters with position <= c (they are upstream of it)
+        self.owners = [(m, [f"{mn}.{pn}" if mn else pn for pn, _ in m.named_parameters(recurse=False)])
+                       for mn, m in model.named_modules() if any(True for _ in m.named_parameters(recurse=False))]
+        self.param_pos = {}
+
+    def _owner_hook(self, names):
+        def hook(mod, inp):
+            for n in names:
+                self.param_pos.setdefault(n, len(self.pre))
+        return hook
 
     def _hook(self, mod, inp, out):
         x = inp[0]
@@ -54,6 +65,9 @@ class _Recorder:
     def attached(self, mode, flags=None):
         self.mode, self.flags, self.k, self.pre = mode, flags, 0, []
         hs = [m.register_forward_hook(self._hook) for m in self.mods]
+        if mode == "record":
+            self.param_pos = {}
+            hs += [m.register_forward_pre_hook(self._owner_hook(names)) for m, names in self.owners]
         try:
             yield self
         finally:
@@ -68,6 +82,7 @@ def record(model, run):
         assert not getattr(m, "inplace", False), "in-place ReLU: the hook would see the output"
     with rec.attached("record"):
         out = run()
+    record.param_pos = dict(rec.param_pos)     # (of the latest recording: see explain_flips' `param_pos`)
     return out, rec.pre
 
 
@@ -128,57 +143,62 @@ def single_unit_flags(flags, call, elem):
     return out
 
 
-def explain_flips(g_impl, g_base, units, delta_of, tol=1e-4, log=print, max_flips=8):
+def explain_flips(g_impl, g_base, units, delta_of, tol=1e-4, log=print, max_flips=8, param_pos=None, tries_per_flip=12):
     """Which at-risk units did the implementation take on the other side?  g_impl / g_base: {name: gradient} of the
-    implementation under test and of the f32 oracle; delta_of(unit) -> {name: g64_flipped - g64} (one f64 run per unit).  The
-    residual g_impl - g_base (every tensor weighted by 1 / |g_base tensor|: the metric the bound is stated in) is explained
-    greedily: a flip enters with coefficient exactly 1 -- the unit whose delta takes the most out of the residual, as long as that
-    is at least 2 % of it -- and its delta is added to the base (matching pursuit over at most `max_flips` units).  Returns (errs after the fit, accepted units).  A flip only moves tensors UPSTREAM of its layer, in a pattern fixed by
-    the network; a genuine implementation error is not of the form sum(delta_i) and stays in the residual."""
+    implementation under test and of the f32 oracle; delta_of(unit) -> {name: g64_flipped - g64} (one f64 run per unit, so
+    they are evaluated lazily); units sorted by closeness to zero.  Matching pursuit with the network's structure as a
+    guide: a flip of ReLU call c moves only parameters upstream of it (`param_pos[name] <= c`), so the DEEPEST tensor that
+    misses `tol` bounds the call index of some flip from below; the candidates at or beyond it are tried closest-to-zero first
+    and the first one whose delta (coefficient exactly 1) halves the residual of the tensors it moves at or beyond that
+    position is granted; repeat.  A genuine implementation error is not a sum of such deltas and stays.
+    Returns (errs after granting, granted units)."""
     names = list(g_impl)
     nrm = {n: g_base[n].detach().double().cpu().norm().item() + 1e-300 for n in names}
     cur = {n: g_base[n].detach().double().cpu().clone() for n in names}
     gi = {n: g_impl[n].detach().double().cpu() for n in names}
+    pos = param_pos or {}
 
     def errs_of(c):
         return {n: (gi[n] - c[n]).norm().item() / nrm[n] for n in names}
 
-    def flat(d):
-        return torch.cat([(d[n].double() / nrm[n]).reshape(-1) for n in names])
-
     errs = errs_of(cur)
-    if all(e < tol for e in errs.values()) or not units:
-        return errs, []
-    D = torch.stack([flat(delta_of(u)) for u in units], 1)            # [elements, units]
-    dn = (D * D).sum(0)
-    live = [i for i in range(len(units)) if dn[i].item() ** 0.5 > 0.2 * tol]
-    accepted = []
-    r = flat({n: gi[n] - cur[n] for n in names})
-    for _ in range(max_flips):
-        cand = [i for i in live if units[i] not in accepted]
-        if not cand or all(e < tol for e in errs.values()):
+    granted, tried, evals = [], set(), 0
+    while len(granted) < max_flips:
+        bad = [n for n in names if errs[n] >= tol]
+        if not bad:
             break
-        # a flip enters with coefficient exactly 1: the unit whose delta takes the most out of the residual
-        gain = 2.0 * (D[:, cand].T @ r) - dn[cand]                    # |r|^2 - |r - d_i|^2
-        j = int(torch.argmax(gain))
-        if gain[j].item() < 0.02 * float(r @ r):
+        deepest = max(pos.get(n, 0) for n in bad)
+        # the parameters that feed ReLU call c sit at position c exactly: a flip most likely belongs to call `deepest` itself
+        cands = sorted([u for u in units if u[0] >= deepest and u[:2] not in tried], key=lambda u: (u[0] != deepest, u[3]))[:tries_per_flip]
+        hit = None
+        for u in cands:
+            tried.add(u[:2])
+            d = delta_of(u)
+            evals += 1
+            # judged on the tensors it moves AT OR BEYOND the deepest bad position: only flips of calls >= that position reach
+            # them, so another (shallower, possibly larger) flip still in the residual cannot mask this one
+            moved = [n for n in names if d[n].norm().item() / nrm[n] > 0.2 * tol and pos.get(n, 0) >= deepest]
+            if not moved:
+                continue
+            before = sum(errs[n] ** 2 for n in moved)
+            after = sum(((gi[n] - cur[n] - d[n]).norm().item() / nrm[n]) ** 2 for n in moved)
+            if after < 0.5 * before:
+                hit = (u, d)
+                break
+        if hit is None:
             break
-        i = cand[j]
-        r = r - D[:, i]
-        off = 0
+        u, d = hit
         for n in names:
-            k = cur[n].numel()
-            cur[n] += (D[off:off + k, i] * nrm[n]).reshape(cur[n].shape)
-            off += k
-        accepted.append(units[i])
-        n_bad = sum(1 for e in errs.values() if e >= tol)
+            cur[n] += d[n]
+        n_bad = len(bad)
         errs = errs_of(cur)
-        log(f"  kink: ReLU call {units[i][0]} element {units[i][1]} (pre_f64 {units[i][2]:+.3e} = {units[i][3]:.2f} sigma) taken on the "
-            f"other side: {n_bad} -> {sum(1 for e in errs.values() if e >= tol)} tensors above {tol:g}")
-    return errs, accepted
+        granted.append(u)
+        log(f"  kink: ReLU call {u[0]} element {u[1]} (pre_f64 {u[2]:+.3e} = {u[3]:.2f} sigma) taken on the other side: "
+            f"{n_bad} -> {sum(1 for e in errs.values() if e >= tol)} tensors above {tol:g}  [{evals} flip evaluations so far]")
+    return errs, granted
 
 
-def strict_compare(g_impl, make_run, tol=1e-4, threads=(1, 4), k_sigma=6.0, limit=32, check_outputs=None, log=print):
+def strict_compare(g_impl, make_run, tol=1e-4, threads=(1, 4), k_sigma=6.0, check_outputs=None, log=print):
     """The whole procedure of this module's header.  g_impl: {name: gradient tensor (CPU)} of the implementation under test;
     make_run(dtype) -> (oracle model in that dtype, run) with run() = zero the gradients, forward, backward, return the outputs.
     The f32 oracle is evaluated once per entry of `threads` (torch-CPU's rounding depends on it); check_outputs(outputs) may
@@ -203,19 +223,21 @@ def strict_compare(g_impl, make_run, tol=1e-4, threads=(1, 4), k_sigma=6.0, limi
     ref64, run64 = make_run(torch.float64)
     _, pre64 = record(ref64, run64)
     g64 = grads(ref64)
-    base = min(runs, key=lambda r: sum(e * e for e in r[2].values()))[0]      # the f32 evaluation closer to the implementation
-    errs, granted = errs, []
-    for ks, lim in ((k_sigma, limit), (2.0 * k_sigma, 3 * limit)):           # widen once if the closest units do not explain it
-        flags, sigmas = at_risk(pre64, [r[1] for r in runs], ks)
-        units = unit_list(flags, pre64, sigmas, limit=lim)
-        log(f"  {sum(int(f.sum()) for f in flags)} ReLU units within {ks:g} sigma of zero in the f64 oracle; the closest "
-            f"(call, element, sigmas): {[(u[0], u[1], round(u[3], 2)) for u in units[:8]]}")
+    base_run = min(runs, key=lambda r: sum(e * e for e in r[2].values()))      # the f32 evaluation closer to the implementation
+    base, base_pre = base_run[0], base_run[1]
+    param_pos = dict(record.param_pos)
+    flags, sigmas = at_risk(pre64, [r[1] for r in runs], 2.0 * k_sigma)
+    units = unit_list(flags, pre64, sigmas)
+    log(f"  {sum(1 for u in units if u[3] < k_sigma)} ReLU units within {k_sigma:g} sigma of zero in the f64 oracle ({len(units)} within "
+        f"{2 * k_sigma:g}); the closest (call, element, sigmas): {[(u[0], u[1], round(u[3], 2)) for u in units[:8]]}")
 
-        def delta_of(u):
-            gf = flipped_grads(ref64, run64, single_unit_flags(flags, u[0], u[1]))
-            return {n: (gf[n] - g64[n]).double() for n in g_impl}
+    def delta_of(u):
+        # what moving this unit from the side the BASE (f32 oracle) has it on to the other side does to every gradient.  The
+        # f64 run supplies the magnitude; where the f32 oracle itself already sits on the other side than the f64 oracle (it is
+        # at risk, after all), "the other side" of the base is the f64 side: the delta enters with the opposite sign.
+        gf = flipped_grads(ref64, run64, single_unit_flags(flags, u[0], u[1]))
+        same = bool(base_pre[u[0]].reshape(-1)[u[1]] > 0) == bool(pre64[u[0]].reshape(-1)[u[1]] > 0)
+        sgn = 1.0 if same else -1.0
+        return {n: sgn * (gf[n] - g64[n]).double() for n in g_impl}
 
-        errs, granted = explain_flips(g_impl, {n: base[n] for n in g_impl}, units, delta_of, tol=tol, log=log)
-        if max(errs.values()) < tol:
-            break
-    return errs, granted
+    return explain_flips(g_impl, {n: base[n] for n in g_impl}, units, delta_of, tol=tol, log=log, param_pos=param_pos)

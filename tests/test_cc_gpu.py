@@ -144,8 +144,12 @@ def test_e2e_cc_vs_reference_golden(size, golden_dir):
         enc_opt.step(); dec_opt.step()
         losses.append(loss.item())
     print(f"CC s{size}: loss curve hip {losses} ref32 {G['loss_curve']}")
-    l_tol = K_NOISE * abs(float(G["loss_curve"][0]) - float(G["loss_f64"])) + 2e-3
-    assert np.abs(np.array(losses) - G["loss_curve"]).max() <= 2 * l_tol
+    # every step's loss against the float64 reference curve, with the float32 reference's own distance from it as the yardstick
+    # (after one clipped-Adam step -- lr * sign(g) on near-zero gradients -- the float32 reference itself is 1.3e-2 (64 x 64) /
+    # 2.0e-1 (256 x 256) away from float64 at step 2; the first loss alone, 9e-5, says nothing about that)
+    for i, l in enumerate(losses):
+        l32, l64 = float(G["loss_curve"][i]), float(G["loss_curve_f64"][i])
+        assert abs(l - l64) <= K_NOISE * abs(l32 - l64) + 5e-3, (i, l, l32, l64)
 
 
 def test_caption_decoder_dropout_is_reproducible_and_unbiased():

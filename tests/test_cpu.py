@@ -722,7 +722,7 @@ def test_kink_fit_names_the_relu_units_an_implementation_took_on_the_other_side(
     _, p32 = kinks.record(r32, run32)
     g32 = grads(r32)
     flags, sig = kinks.at_risk(p64, [p32], 6.0)
-    units = kinks.unit_list(flags, p64, sig, limit=32)
+    units = kinks.unit_list(flags, p64, sig)
     assert len(units) >= 4
     # two units in different, LATE ReLU calls (forcing an early unit also nudges the f32 forward values behind it, and another
     # at-risk unit further on may follow: an artefact of emulating a flip this way, not of the fit)
