@@ -157,7 +157,9 @@ int64_t c3d_pw_gemm_wg_ws_floats(int32_t K, int32_t N);
 
 /* K, N <= 224 run the wave-private-tile kernel (pw_gemm_impl.h); wider layers (X3D res5: 432 inner channels; the
  * caption decoder's 192 -> 576 / vocabulary projections) or a non-NULL bias run the block-tiled kernel of
- * pw_wide.hip with the same prologues / epilogues (row modes DENSE and STRIDE2; no in-kernel finalisation). */
+ * pw_wide.hip with the same prologues / epilogues (row modes DENSE and STRIDE2; no in-kernel finalisation).
+ * The wave-private-tile kernels address rows through bounds-checked buffer resources with 32-bit byte offsets: a call
+ * whose largest operand (M * max(Kp, Np) elements) reaches 2 GiB returns C3D_E_UNSUPPORTED. */
 int c3d_pw_gemm(const c3d_pw_args* args, void* stream);
 
 /* Weight images for c3d_pw_args.w_img: the narrow kernel's LDS operand layout (f32: [NT*16][Kpad+pad]; bf16: 8-element
@@ -282,7 +284,8 @@ int c3d_block_out_fwd(const void* c, const float* ss_c, const void* shortcut, co
  * C = real channel count.  fin_1 is NULL unless sc_mode is BN.                                                     */
 int c3d_block_out_fwd_fin(const void* c, const c3d_bn_fin* fin_c, const void* shortcut, const c3d_bn_fin* fin_1,
                           int32_t sc_mode, void* y, int64_t M, int32_t C, int32_t Cp, int32_t dtype, void* stream);
-/* y == NULL and g == NULL: `dy` already IS dy * (y > 0) (masked by its producer, c3d_pw_args.wg_mask_out): only the sums. */
+/* y == NULL and g == NULL: `dy` already IS dy * (y > 0) (masked by its producer, c3d_pw_args.wg_mask_out): only the sums.
+ * mr_c / mr_1 (mean | rstd rows, Cp floats each) must be 16-byte aligned (C3D_E_BADARG otherwise). */
 int c3d_block_out_bwd(const void* dy, const void* y, const void* c, const void* s_bn, void* g,
                       const float* mr_c, const float* mr_1, double* dsums_c, double* dsums_1, int64_t M,
                       int32_t C, int32_t Cp, int32_t dtype, void* stream);
