@@ -976,7 +976,7 @@ int launch_ring_t(const void* t1, const void* bb, const float* cA, const float* 
   const int ntiles = ((g.W + FB_TW - 1) / FB_TW) * ((g.H + FB_TH - 1) / FB_TH);
   const int chunks = (g.Cp + DW_CV * 8 - 1) / (DW_CV * 8);
   static const int env_tpw = c3d_env("C3D_DWBF_TPW") ? atoi(c3d_env("C3D_DWBF_TPW")) : 0;
-  static const int env_max = c3d_env("C3D_DWBF_MAX") ? atoi(c3d_env("C3D_DWBF_MAX")) : 32;
+  static const int env_max = c3d_env("C3D_DWBF_MAX") ? atoi(c3d_env("C3D_DWBF_MAX")) : 64;
   int tpw = env_max;
   while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 85L * device_cus() / 100) tpw >>= 1;
   if (env_tpw > 0) tpw = env_tpw;
@@ -1012,7 +1012,9 @@ int launch_fused_t(const void* t1, const void* bb, const float* cA, const float*
   // measured on MI355X (B=32 bf16 step, side stream on): 4 / 8 / 16 / 32 / 64 tiles -> 32.9 / 31.3 / 30.6 / 30.4 / 31.2 ms
   // (12, 24: +0.3..1.2 ms -- ragged last groups)
   // -> the longest walk that still gives (almost) every CU a workgroup: 16 / 32 / 32 tiles for the 32x32 / 64x64 / 128x128 stages
-  static const int env_max = c3d_env("C3D_DWBF_MAX") ? atoi(c3d_env("C3D_DWBF_MAX")) : 32;
+  // (round 5, re-swept at 23.2 ms per step: cap 16 / 32 / 64 / 128 tiles -> 23.42 / 23.18 / 22.95 / 23.15 ms; with the narrower
+  // side-stream weight gradient, three interleaved repeats: 22.90 against 23.39 ms for the old pair of defaults)
+  static const int env_max = c3d_env("C3D_DWBF_MAX") ? atoi(c3d_env("C3D_DWBF_MAX")) : 64;
   int tpw = env_max / (S * S);   // a stride-2 tile is four pixels per thread
   while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 85L * device_cus() / 100) tpw >>= 1;
   if (env_tpw > 0) tpw = env_tpw;

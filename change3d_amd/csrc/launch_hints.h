@@ -6,7 +6,7 @@
 // kernel of the data-gradient chain that becomes ready meanwhile -- including its 1-8 workgroup coefficient kernels --
 // waiting for its whole duration (measured on MI355X, B=32 bf16: depthwise weight gradient on 128 instead of 256
 // workgroups: step 35.6 -> 34.1 ms, and the 40 us stall around c3d_se_bn_bwd_coef disappears).
-// The pointwise weight gradient takes 3/4 of the CUs in the same situation (256 -> 192 workgroups: 32.43 -> 31.69 ms;
+// The pointwise weight gradient takes 5/8 of the CUs in the same situation (round 2: 256 -> 192 workgroups: 32.43 -> 31.69 ms; round 5: 192 -> 160: 23.18 -> 22.86 ms;
 // profiles/r02_side_stream_width_final.json).
 extern thread_local int c3d_side_launch;
 

@@ -1262,7 +1262,7 @@ int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
 template <typename T, int NT, int PRO, int EPI, int WAVES>
 int launch_pw_w(const c3d_pw_args& a, hipStream_t stream) {
   // the dense-row specialisation exists for the throughput (bf16) path only; f32 (parity) uses the generic code
-  if (sizeof(T) == 2 && a.row_mode == C3D_ROWS_DENSE) return launch_pw_d<T, NT, PRO, EPI, WAVES, sizeof(T) == 2>(a, stream);
+  if (a.row_mode == C3D_ROWS_DENSE) return launch_pw_d<T, NT, PRO, EPI, WAVES, true>(a, stream);   // (f32 too since round 5: the straight-line buffer-addressed loop)
   return launch_pw_d<T, NT, PRO, EPI, WAVES, false>(a, stream);
 }
 

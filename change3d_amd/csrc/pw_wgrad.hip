@@ -501,7 +501,9 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
     // kernel at full width holds every CU for its whole duration (launch_hints.h); measured on MI355X, B=32 bf16,
     // 60-step runs: 256 / 208 / 192 / 176 / 160 / 128 workgroups -> 32.52 / 32.08 / 31.84 / 32.11 / 32.48 / 32.87 ms
     static const int side_env = c3d_env("C3D_PWWG_SIDE_WGS") ? atoi(c3d_env("C3D_PWWG_SIDE_WGS")) : 0;
-    const int64_t side_cap = side_env > 0 ? side_env : (int64_t)device_cus() * 3 / 4;
+    // round 5 (after the data-gradient kernels' waits became exact, same-call sweeps through the instrumented build): 128 / 144 /
+    // 160 / 176 / 192 / 256 workgroups -> 23.01 / 22.99 / 22.86 / 23.53 / 23.18 / 23.34 ms per step: 5/8 of the CUs
+    const int64_t side_cap = side_env > 0 ? side_env : (int64_t)device_cus() * 5 / 8;
     if (side_cap < cap) cap = side_cap;
   }
   if (taps > 1 && cap > WGRAD_MAX_PARTS / taps) cap = WGRAD_MAX_PARTS / taps;   // the workspace holds MAX_PARTS slabs
