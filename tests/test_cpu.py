@@ -746,3 +746,24 @@ def test_kink_fit_names_the_relu_units_an_implementation_took_on_the_other_side(
     g_bad[victim] = g_impl[victim] * 1.001
     errs_bad, _ = kinks.strict_compare(g_bad, make_run, threads=(torch.get_num_threads(),), log=lambda *a: None)
     assert errs_bad[victim] > 5e-4
+
+
+def test_pw_gemm_refuses_operands_of_two_gib_before_touching_the_device():
+    """The wave-private-tile pointwise kernels address rows with 32-bit byte offsets into bounds-checked buffer resources
+    (offset 2^31 = "nowhere"): `c3d_pw_gemm` must answer C3D_E_UNSUPPORTED for a narrow call whose largest operand reaches
+    2 GiB -- from its argument checks, without a launch (no GPU here: the pointers are never dereferenced)."""
+    import ctypes as C
+    from change3d_amd import _lib as L
+    buf = (C.c_float * 64)()
+    a = L.PwArgs()
+    p = C.cast(buf, C.c_void_p).value
+    a.x = a.y = a.w = p
+    a.K, a.Kp, a.N, a.Np = 216, 216, 96, 96
+    a.w_sn, a.w_sk = 216, 1
+    a.dtype = 1                      # C3D_DT_BF16
+    a.M = (1 << 31) // (216 * 2) + 1   # M * Kp * 2 bytes just past 2 GiB
+    rc = L.lib().c3d_pw_gemm(C.byref(a), None)
+    assert rc == -2, rc   # C3D_E_UNSUPPORTED (include/change3d_hip.h)
+    a.M = 1024
+    a.pro_mode, a.x2 = 2, None      # C3D_PRO_AFFINE2 without its second operand: C3D_E_BADARG, still no launch
+    assert L.lib().c3d_pw_gemm(C.byref(a), None) == -1
