@@ -919,3 +919,21 @@ def test_bn_b_finalize_folded_into_conv_c_and_fused_depthwise_backward_is_bit_id
         assert torch.equal(res[0][k], res[1][k]), f"backward: {k} differs"
     assert torch.isfinite(res[1]["t2"].float()).all() and float(res[1]["dgamma"].abs().max()) > 0
     close(res[1]["dw"], res[0]["dw"], dtype, "dw (f32 atomics)", scale=res[0]["dw"].abs().max().item())
+
+
+def test_block_out_bwd_refuses_misaligned_parameter_vectors():
+    """c3d_block_out_bwd reads the mean | rstd rows as 16-byte vectors (one round trip instead of eight dependent ones, round 5):
+    a misaligned `mr_c` is an argument error, not a fault."""
+    _need_gpu()
+    from change3d_amd import ops
+    from change3d_amd._lib import Change3DHipError
+    M, C = 64, 24
+    Cp = ops.cpad(C)
+    dy = torch.zeros(M, Cp, dtype=torch.bfloat16, device=DEV)
+    y, c, g = torch.ones_like(dy), torch.zeros_like(dy), torch.zeros_like(dy)
+    mr = torch.zeros(2 * Cp + 1, dtype=torch.float32, device=DEV)
+    ds = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    ops.block_out_bwd(dy, y, c, None, g, mr[:2 * Cp], None, ds, None, M, C, ops.dt_code(torch.bfloat16))   # aligned: fine
+    with pytest.raises(Change3DHipError):
+        ops.block_out_bwd(dy, y, c, None, g, mr[1:], None, ds, None, M, C, ops.dt_code(torch.bfloat16))
+    torch.cuda.synchronize()
