@@ -937,3 +937,29 @@ def test_block_out_bwd_refuses_misaligned_parameter_vectors():
     with pytest.raises(Change3DHipError):
         ops.block_out_bwd(dy, y, c, None, g, mr[1:], None, ds, None, M, C, ops.dt_code(torch.bfloat16))
     torch.cuda.synchronize()
+
+
+def test_pw_gemm_refuses_an_operand_of_two_gib():
+    """The tile loop addresses rows with 32-bit byte offsets into bounds-checked buffer resources whose origin is row 0 (offset
+    2^31 = "nowhere"): a call whose largest operand reaches 2 GiB is refused with C3D_E_UNSUPPORTED, not run (per-wave origins
+    would lift the limit and were measured: +1.1 .. +1.6 % on the B=32 step).  B <= 96 per GPU at
+    256 x 256 in bf16 stays under it."""
+    _need_gpu()
+    from change3d_amd import ops
+    from change3d_amd._lib import Change3DHipError
+    K, N = 56, 24
+    M = (1 << 31) // (K * 2) + 16
+    x = torch.zeros((M, K), dtype=torch.bfloat16, device=DEV)
+    y = torch.zeros((M, ops.cpad(N)), dtype=torch.bfloat16, device=DEV)
+    w = rnd((N, K), 2, 0.2).to(DEV)
+    with pytest.raises(Change3DHipError):
+        ops.pw_gemm(x, w, y, M=M, K=K, N=N, w_sn=K, w_sk=1, dtype=ops.dt_code(torch.bfloat16))
+    M2 = (1 << 31) // (K * 2) - 16        # just under: runs, and the last (ragged) rows are right
+    x[M2 - 40:M2] = torch.randn((40, K), device=DEV).to(torch.bfloat16)
+    ops.pw_gemm(x, w, y, M=M2, K=K, N=N, w_sn=K, w_sk=1, dtype=ops.dt_code(torch.bfloat16))
+    torch.cuda.synchronize()
+    ref = x[M2 - 40:M2].float() @ w.t()
+    got = y[M2 - 40:M2, :N].float()
+    assert (got - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    del x, y
+    torch.cuda.empty_cache()
