@@ -477,6 +477,8 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    from change3d_amd.hostopt import freeze_gc
+    freeze_gc()   # as the training scripts do after their first iterations: no 30 ms full collection inside the loop (hostopt.py)
     all_syncs = [s_ for s_ in getattr(sync, "syncs", [sync])]
     if world > 1:
         for s_ in all_syncs:           # self-diagnosis of the exchange: event pairs per step, read after the timed region

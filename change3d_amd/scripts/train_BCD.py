@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from change3d_amd.hostopt import freeze_gc  # noqa: E402
 from change3d_amd.data.transforms import DeviceBatchTransform, draw_augmentation_flags  # noqa: E402
 from change3d_amd.model.trainer import Trainer  # noqa: E402
 from change3d_amd.model.utils import BCEDiceLoss, FusedAdam, adjust_learning_rate  # noqa: E402
@@ -92,6 +93,8 @@ def train(args, train_loader, model, optimizer, sync, epoch, max_batches, cur_it
     losses = []
     lr = args.lr
     for iter_idx, (img, target) in enumerate(train_loader):
+        if iter_idx + cur_iter == 3:   # once per run, after the first iterations have built everything long-lived (hostopt.py)
+            freeze_gc()
         pre, post = img[:, 0:3].cuda().float(), img[:, 3:6].cuda().float()
         target = target.cuda().float()
         start = time.time()
