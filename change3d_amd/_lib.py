@@ -35,7 +35,8 @@ class PwArgs(C.Structure):
                 ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32),
                 ("pro_mode", i32), ("epi_mode", i32), ("res_mode", i32), ("dtype", i32), ("fin", BnFin), ("bias", vp), ("pro_out", vp), ("w_img", vp),
                 ("wg_x3", vp), ("wg_dw", vp), ("wg_ws", vp), ("wg_mode", i32), ("wg_mask_out", i32),
-                ("se_w1", vp), ("se_b1", vp), ("se_w2", vp), ("se_b2", vp), ("se_hid", vp), ("se_cr", i32), ("se_reserved", i32)]
+                ("se_w1", vp), ("se_b1", vp), ("se_w2", vp), ("se_b2", vp), ("se_hid", vp), ("se_cr", i32), ("se_reserved", i32),
+                ("add_c", vp), ("add_mr", vp), ("add_sums", vp)]
 
 
 class PwPackDesc(C.Structure):

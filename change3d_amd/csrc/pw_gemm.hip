@@ -126,9 +126,16 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   if (a.M >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
   if (a.w_img && ((uintptr_t)a.w_img & 15)) return C3D_E_BADARG;
   if (a.wg_mode != C3D_WG_NONE) {
-    if (a.wg_mode != C3D_WG_SWISH && a.wg_mode != C3D_WG_ROWS) return C3D_E_BADARG;
-    if (!a.wg_dw || !a.wg_ws || (a.wg_mode == C3D_WG_ROWS && !a.wg_x3)) return C3D_E_BADARG;
+    if (a.wg_mode != C3D_WG_SWISH && a.wg_mode != C3D_WG_ROWS && a.wg_mode != C3D_WG_MASKSUM) return C3D_E_BADARG;
+    if (a.wg_mode == C3D_WG_MASKSUM) {   // no weight gradient: the previous block's c3d_block_out_bwd in this epilogue
+      if (!a.wg_x3 || !a.add_sums || a.epi_mode != C3D_EPI_ADD || a.res_mode != 0) return C3D_E_BADARG;
+    } else if (!a.wg_dw || !a.wg_ws || (a.wg_mode == C3D_WG_ROWS && !a.wg_x3)) return C3D_E_BADARG;
     if (wide || a.dtype != C3D_DT_BF16) return C3D_E_UNSUPPORTED;
+  }
+  if (a.add_sums) {
+    if (!a.add_c || !a.add_mr || ((uintptr_t)a.add_mr & 15)) return C3D_E_BADARG;
+    if (a.wg_mode != C3D_WG_MASKSUM && !(a.wg_mode == C3D_WG_ROWS && a.wg_mask_out && a.epi_mode == C3D_EPI_ADD && a.res_mode == 0))
+      return C3D_E_BADARG;   // the sums are over the masked output: only where the mask is applied
   }
   if (a.se_w1) {
     if (a.pro_mode != C3D_PRO_BN_SE_SWISH || !a.fin.sums || a.fin.batch <= 0 || !a.pro_gate || !a.se_b1 || !a.se_w2 || !a.se_b2 ||

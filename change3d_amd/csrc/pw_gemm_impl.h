@@ -388,8 +388,14 @@ constexpr int WG_NTP_MAX_SWISH = 3;   // C3D_WG_SWISH: conv_c, K = the block's o
 template <typename T, int NT, int PRO, int EPI, int WAVES, bool DENSE, int WG = 0>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES == 8 ? 2 : 1, 2))) void pw_gemm_kernel(const c3d_pw_args a, const PwLaunch L) {
   static_assert(WG == 0 || (sizeof(T) == 2 && PRO == C3D_PRO_AFFINE2 && DENSE &&
-                            ((WG == C3D_WG_SWISH && EPI == C3D_EPI_SWISH_SE_BWD) || (WG == C3D_WG_ROWS && EPI == C3D_EPI_ADD))),
-                "fused weight gradient: bf16 data-gradient variants only");
+                            ((WG == C3D_WG_SWISH && EPI == C3D_EPI_SWISH_SE_BWD) ||
+                             ((WG == C3D_WG_ROWS || WG == C3D_WG_MASKSUM) && EPI == C3D_EPI_ADD))),
+                "fused weight gradient / fused block-output backward: bf16 data-gradient variants only");
+  // WGRAD: the weight gradient proper.  X3F: the previous block's output rows (wg_x3) ride along one pass ahead -- as the Q
+  // operand of the weight gradient (C3D_WG_ROWS), as the ReLU mask of the stored output, and for the BatchNorm_c-backward
+  // sums of that block (c3d_pw_args.add_sums: c3d_block_out_bwd folded into this epilogue)
+  constexpr bool WGRAD = WG == C3D_WG_SWISH || WG == C3D_WG_ROWS;
+  constexpr bool X3F = WG == C3D_WG_ROWS || WG == C3D_WG_MASKSUM;
   typedef Mma<T> MM;
   typedef typename MM::lds_t lds_t;
   typedef Raw<T> RW;
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   unsigned char* wreg = smem + L.wave_off + (size_t)wave * L.wave_bytes;
   lds_t* Xs = reinterpret_cast<lds_t*>(wreg);
   os_t* const OsA = reinterpret_cast<os_t*>(wreg + L.os_off);
-  os_t* const OsB = (WG != 0 && L.wg_pair) ? reinterpret_cast<os_t*>(wreg + L.os_off2) : OsA;   // odd tiles of an iteration (pairs)
+  os_t* const OsB = (WGRAD && L.wg_pair) ? reinterpret_cast<os_t*>(wreg + L.os_off2) : OsA;   // odd tiles of an iteration (pairs)
   float* Gs = reinterpret_cast<float*>(wreg + L.gs_off);  // gate of the current sample [Kp]
   double* dWs = reinterpret_cast<double*>(smem + L.dw_off);  // WG: f64 dW accumulators [ceil(Kp/16)*16][L.ldw], shared by the waves
   const int wg_ntp = (Kp + 15) >> 4, wg_ntq = (Np + 15) >> 4;
@@ -600,6 +606,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     if constexpr (EPI == C3D_EPI_SWISH_SE_BWD) {
       for (int i = tid; i < 2 * Np; i += WAVES * 64) { Ep[i] = a.epi_p[i]; Ep[2 * Np + i] = a.epi_q[i]; }
     }
+    if constexpr (X3F) {
+      if (a.add_sums)   // mean | rstd of the previous block's BatchNorm_c, read per epilogue pass
+        for (int i = tid; i < 2 * Np; i += WAVES * 64) Ep[i] = a.add_mr[i];
+    }
     CLK(10)
     if (img) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA chunks (and the first tile's rows, issued earlier)
@@ -620,7 +630,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         else stage_weights<T, 1, false, WAVES>(a.w, Ws, CL, OLn, ostride, KL, NT * 16, tid);
       }
     }
-    if constexpr (WG != 0) {
+    if constexpr (WGRAD) {
       for (int i = tid; i < wg_ntp * 16 * L.ldw; i += WAVES * 64) dWs[i] = 0.0;
     }
     CLK(12)
@@ -643,7 +653,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   constexpr int RPO_MIN = 64 / (2 * NT), NPASS_MAX = (16 + RPO_MIN - 1) / RPO_MIN;
   const int v_oc = act_o ? v_o : 0;             // clamped: inactive lanes load a valid address (result unused)
   typename RW::type e1n = RW::zero();
-  typename RW::type x3n = RW::zero();   // WG == C3D_WG_ROWS: this lane's row vector of wg_x3 (Y's row layout), one pass ahead like e1n
+  typename RW::type x3n = RW::zero();   // X3F: this lane's row vector of wg_x3 (Y's row layout), one pass ahead like e1n
+  typename RW::type c1n = RW::zero();   // X3F with add_sums: the same lane vector of add_c (the previous block's conv_c output)
   const T* X3 = reinterpret_cast<const T*>(a.wg_x3);
   // this lane's E1 vector for pass P of the tile starting at ROW0: wave-uniform row base (scalar registers) + a
   // loop-invariant 32-bit lane offset; lanes without a row in this pass read the pass's first row (result unused)
@@ -654,14 +665,18 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   ((uint32_t)((ROW0) + (P) * RPo < M32 ? (ROW0) + (P) * RPo : M32 - 1) * ((uint32_t)Np * ES) +                       \
    (((P) * RPo + rr_o < 16 && (ROW0) + (P) * RPo + rr_o < M32) ? e1_lane_b : e1_v_b))
   const __amdgpu_buffer_rsrc_t rE1 = pw_rsrc(e1_rows ? E1 : nullptr, (uint32_t)M32 * (uint32_t)Np * ES);
-  const __amdgpu_buffer_rsrc_t rX3 = pw_rsrc(WG == C3D_WG_ROWS ? X3 : nullptr, (uint32_t)M32 * (uint32_t)Np * ES);
+  const __amdgpu_buffer_rsrc_t rX3 = pw_rsrc(X3F ? X3 : nullptr, (uint32_t)M32 * (uint32_t)Np * ES);
+  const bool add_sums = X3F && a.add_sums != nullptr;   // kernel-uniform
+  const __amdgpu_buffer_rsrc_t rC1 = pw_rsrc(add_sums ? reinterpret_cast<const T*>(a.add_c) : nullptr, (uint32_t)M32 * (uint32_t)Np * ES);
 
   // Weight fragments: narrow outputs (NT <= 4) with K <= 64 keep ALL of them in registers (the per-tile MFMA phase
   // was LDS-read latency: X fragment, then each weight fragment, serially); wide outputs run two sub-tiles per
   // weight-fragment read when the register budget allows (the stage-3 MFMA phase was LDS-bandwidth bound: 8 waves
   // x 1 KB per MFMA).
   constexpr bool WREG = NT <= 4 && sizeof(T) == 2 && !(PRO == C3D_PRO_AFFINE2 && EPI == C3D_EPI_SWISH_SE_BWD);
-  constexpr int MT = PwPair<T, NT, PRO, EPI>::value;
+  // (C3D_WG_MASKSUM serves the wide-K conv_a data gradients -- res4: Kp = 216 = 7 slots per tile, one tile per iteration --
+  // where a second accumulator set would never be used: its 4 NT registers go to the epilogue's sums instead)
+  constexpr int MT = WG == C3D_WG_MASKSUM ? 1 : PwPair<T, NT, PRO, EPI>::value;
   typename MM::frag_t wr[WREG ? 2 * NT : 1];
   if (WREG && KS <= 2) {
 #pragma unroll
@@ -744,7 +759,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     }
     CLK(2)
     if constexpr (E1_PIPE) e1n = BufIO<T>::load(rE1, PW_E1_OFF(it0 << 4, 0));
-    if constexpr (WG == C3D_WG_ROWS) x3n = BufIO<T>::load(rX3, PW_E1_OFF(it0 << 4, 0));
+    if constexpr (X3F) { x3n = BufIO<T>::load(rX3, PW_E1_OFF(it0 << 4, 0)); c1n = BufIO<T>::load(rC1, PW_E1_OFF(it0 << 4, 0)); }
     // ---------------- prefetch the next iteration's rows -------------------------------------
     // (DENSE: unconditionally -- past this wave's last tile the row bound answers zeros without touching memory; a prefetch
     // under `if (more tiles)` left the epilogue's counted waits with two histories to cover: they came out as vmcnt(1))
@@ -811,10 +826,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         const int m = row0 + row;
         typename RW::type e1c = e1n;
         // next pass's companion rows (or the first pass of the next tile of this iteration; else nowhere), unconditionally
-        [[maybe_unused]] const uint32_t nxt_off = p + 1 < npass ? PW_E1_OFF(row0, p + 1) : ((p + 1 == npass && has_next) ? PW_E1_OFF(row0 + 16, 0) : PW_OOB);
+        // (a pass past npass -- the unroll covers the most passes this NT can need -- asks for the next tile's first rows AGAIN:
+        // with `p + 1 == npass` it overwrote them with the zeros of "nowhere", and the next tile of the iteration added no
+        // companion rows to its first pass: output widths of 72 / 80 and 136..168 channels, two or more tiles per iteration)
+        [[maybe_unused]] const uint32_t nxt_off = p + 1 < npass ? PW_E1_OFF(row0, p + 1) : (has_next ? PW_E1_OFF(row0 + 16, 0) : PW_OOB);
         if constexpr (E1_PIPE) e1n = BufIO<T>::load(rE1, nxt_off);
         typename RW::type x3c = x3n;
-        if constexpr (WG == C3D_WG_ROWS) x3n = BufIO<T>::load(rX3, nxt_off);
+        typename RW::type c1c = c1n;
+        if constexpr (X3F) { x3n = BufIO<T>::load(rX3, nxt_off); c1n = BufIO<T>::load(rC1, nxt_off); }
         if constexpr (sizeof(T) == 2 && (EPI == C3D_EPI_STORE || EPI == C3D_EPI_STATS)) {
           // bf16 plain-store / statistics epilogue: the staged tile already holds the stored bits -- copy the 16 bytes
           // as they are (the f32 round trip cost 8 unpack + 8 re-round + 4 pack VALU per vector for an identity)
@@ -882,11 +901,21 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
               }
             }
           }
-          if constexpr (WG == C3D_WG_ROWS) {
-            if (a.wg_mask_out) {   // g = dx * (y > 0) of the previous block's output y = wg_x3 (relu output: > 0 <=> nonzero bits)
+          if constexpr (X3F) {
+            if (WG == C3D_WG_MASKSUM || a.wg_mask_out) {   // g = dx * (y > 0) of the previous block's output y = wg_x3 (relu output: > 0 <=> nonzero bits)
               const uint32_t xw[4] = {x3c.x, x3c.y, x3c.z, x3c.w};
 #pragma unroll
               for (int j = 0; j < 8; ++j) f[j] = ((xw[j >> 1] >> ((j & 1) * 16)) & 0x7fffu) != 0u && !((xw[j >> 1] >> ((j & 1) * 16)) & 0x8000u) ? f[j] : 0.f;
+            }
+            if (add_sums) {   // that block's BatchNorm_c-backward sums over g AS STORED (what c3d_block_out_bwd read back)
+              float cv[8], eM[8], eR[8];
+              RW::cvt(c1c, cv);
+              lds_ld8(Ep + v_o * 8, eM); lds_ld8(Ep + Np + v_o * 8, eR);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float gq = round_as<T>(f[j]);
+                s0[j] += gq; s1[j] = fmaf(gq, (cv[j] - eM[j]) * eR[j], s1[j]);
+              }
             }
           }
           if constexpr (WG == C3D_WG_ROWS) *reinterpret_cast<typename RW::type*>(Os + row * NL + v_o * 8) = x3c;
@@ -895,7 +924,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       };
 #pragma unroll
       for (int p = 0; p < NPASS_MAX; ++p) epi_pass(p);
-      if constexpr (WG != 0) {
+      if constexpr (WGRAD) {
         CLK(6)
         // ---------------- fused weight gradient ------------------------------------------------------
         // Os now holds Q (rows past M and the padding columns kept the zero accumulators of zero operand rows / zero weight
@@ -1038,7 +1067,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         }
       }
       CLK(4)
-      if constexpr (WG != 0 && MT == 1) {
+      if constexpr (WGRAD && MT == 1) {
         // weight-gradient pairs: the even tile of an iteration defers its step when the odd one follows in the same iteration
         const bool nxt = sub + 1 < L.tpi && tile + 1 < t1;
         const bool odd = (sub & 1) != 0;
@@ -1069,7 +1098,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
 #undef PW_ISSUE_GENERIC
 #undef PW_SLOT_OFF
   CLK(7)
-  if constexpr (WG != 0) {
+  if constexpr (WGRAD) {
     // this workgroup's dW partial -> wg_ws[blockIdx.x][K][N] (the reducer launched behind this kernel adds the partials in
     // fixed order into wg_dw)
     __syncthreads();
@@ -1086,7 +1115,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   // RPo dependent ds_bpermute shuffles per value: 7-14 us per launch on the narrow layers, Go = 3..7.)
   constexpr int NV = EPI == C3D_EPI_SWISH_SE_BWD ? 24 : 16;   // partial sums per lane
   const int flush_shuffle_max = L.flush_shuffle_max;
-  if (EPI == C3D_EPI_STATS || EPI == C3D_EPI_SWISH_SE_BWD) {
+  if (EPI == C3D_EPI_STATS || EPI == C3D_EPI_SWISH_SE_BWD || add_sums) {
     // wide layers (2-3 row-lanes per channel vector): one or two shuffles per value beat the [NV][64] lane dump and
     // leave the cross-wave sum 8 reads per value instead of 16-24
     const bool dump = RPo > flush_shuffle_max && (size_t)L.wave_bytes >= (size_t)64 * NV * sizeof(float) + WAVES * sizeof(int);
@@ -1124,7 +1153,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
       for (int rr = 0; rr < RPo; ++rr) acc += base[(which * 8 + j) * 64 + rr * Go + v];
       return acc;
     };
-    if (EPI == C3D_EPI_STATS) {
+    if (EPI == C3D_EPI_ADD) {
+      // BatchNorm_c-backward sums of the previous block (single set, f64 [2][N]: the layout c3d_block_out_bwd fills)
+      for (int i = tid; i < 2 * a.N; i += WAVES * 64) {
+        const int which = i / a.N, c = i - which * a.N;
+        float acc = 0.f;
+        for (int wv = 0; wv < WAVES; ++wv) acc += wave_value(wv, which, c);
+        atomicAdd(a.add_sums + which * a.N + c, (double)acc);
+      }
+    } else if (EPI == C3D_EPI_STATS) {
       // into one of C3D_STAT_STRIPES accumulator sets (keeps same-address atomic contention low)
       double* dst = a.stats + (size_t)(blockIdx.x % C3D_STAT_STRIPES) * 2 * a.N;
       for (int i = tid; i < 2 * a.N; i += WAVES * 64) {
@@ -1183,19 +1220,19 @@ bool plan_pw(const c3d_pw_args& a, PwLaunch& L, size_t& lds) {
   const int NL = NT * 16 + (sizeof(os_t) == 4 ? 4 : 8);
   const int Q = ((a.Kp >> 3) + 3) >> 2;
   const size_t w_bytes = al16((size_t)NT * 16 * KL * sizeof(typename MM::lds_t));
-  const size_t p_bytes = al16(((size_t)3 * a.Kp + (EPI == C3D_EPI_SWISH_SE_BWD ? (size_t)4 * a.Np : 0)) * sizeof(float));   // prologue [3][Kp] | epilogue [4][Np]
+  const size_t p_bytes = al16(((size_t)3 * a.Kp + (EPI == C3D_EPI_SWISH_SE_BWD ? (size_t)4 * a.Np : (WG == C3D_WG_ROWS || WG == C3D_WG_MASKSUM) ? (size_t)2 * a.Np : 0)) * sizeof(float));   // prologue [3][Kp] | epilogue [4][Np] / [2][Np]
   const size_t os_bytes = al16((size_t)16 * NL * sizeof(os_t));
   const size_t gs_bytes = PRO == C3D_PRO_BN_SE_SWISH ? al16((size_t)a.Kp * sizeof(float)) : 0;   // per-wave gate copy
   // fused weight gradient: workgroup-shared f64 accumulators [ceil(Kp/16)*16][ceil(Np/16)*16 + 4] (row stride = 4 mod 8
   // doubles: the four 16-lane groups of a ds_add_f64 -- rows 4g + r -- fall on the two halves of the 64 banks alternately)
   const int ldw = ((a.Np + 15) / 16) * 16 + 4;
-  const size_t dw_bytes = WG != 0 ? al16((size_t)((a.Kp + 15) / 16) * 16 * ldw * sizeof(double)) : 0;
+  const size_t dw_bytes = (WG == C3D_WG_SWISH || WG == C3D_WG_ROWS) ? al16((size_t)((a.Kp + 15) / 16) * 16 * ldw * sizeof(double)) : 0;
   const size_t se_bytes = (PRO == C3D_PRO_BN_SE_SWISH && a.se_w1) ? al16((size_t)PW_SE_NS * (a.Kp + PW_SE_CR) * sizeof(float)) : 0;
   for (int tpi = PW_SLOTS / Q; tpi >= 1; --tpi) {
     const size_t xs_bytes = al16((size_t)tpi * 16 * KL * sizeof(typename MM::lds_t));
     size_t wave_bytes = xs_bytes + os_bytes + gs_bytes;
     // fused weight gradient: a second result-tile buffer per wave (tile pairs) when the iteration has >= 2 tiles and it fits
-    const bool pair = WG != 0 && tpi >= 2 && w_bytes + p_bytes + WAVES * (wave_bytes + os_bytes) + dw_bytes + se_bytes <= 160 * 1024;
+    const bool pair = (WG == C3D_WG_SWISH || WG == C3D_WG_ROWS) && tpi >= 2 && w_bytes + p_bytes + WAVES * (wave_bytes + os_bytes) + dw_bytes + se_bytes <= 160 * 1024;
     L.wg_pair = pair ? 1 : 0;
     L.os_off2 = (int)(xs_bytes + os_bytes + gs_bytes);
     if (pair) wave_bytes += os_bytes;
@@ -1232,7 +1269,7 @@ int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
   if (occ > 32 / WAVES) occ = 32 / WAVES;
   if (occ < 1) occ = 1;
   int64_t max_blocks = (int64_t)device_cus() * occ;
-  if (WG != 0 && max_blocks > PW_WG_MAX_PARTS) max_blocks = PW_WG_MAX_PARTS;
+  if ((WG == C3D_WG_SWISH || WG == C3D_WG_ROWS) && max_blocks > PW_WG_MAX_PARTS) max_blocks = PW_WG_MAX_PARTS;
   int64_t blocks = (tiles + (int64_t)WAVES * L.tpi - 1) / ((int64_t)WAVES * L.tpi);  // >= one iteration per wave
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks < 1) blocks = 1;
@@ -1254,7 +1291,7 @@ int launch_pw_d(const c3d_pw_args& a, hipStream_t stream) {
   L.flush_shuffle_max = fsm;
   pw_gemm_kernel<T, NT, PRO, EPI, WAVES, DENSE, WG><<<dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream>>>(a, L);
   C3D_CHECK_LAUNCH();
-  if (WG != 0)   // partials [blocks][K][N] -> dw[n*w_sn + k*w_sk] (+=), fixed order
+  if (WG == C3D_WG_SWISH || WG == C3D_WG_ROWS)   // partials [blocks][K][N] -> dw[n*w_sn + k*w_sk] (+=), fixed order
     return c3d_detail_pw_wgrad_reduce(a.wg_ws, a.wg_dw, a.K, a.N, (int)blocks, a.w_sk, a.w_sn, stream);
   return 0;
 }

@@ -23,8 +23,16 @@ int dispatch_wg(const c3d_pw_args& a, hipStream_t s) {
 __attribute__((visibility("hidden"))) int c3d_detail_pw_gemm_wg(const c3d_pw_args* args, void* stream) {
   const c3d_pw_args& a = *args;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (a.dtype != C3D_DT_BF16 || a.pro_mode != C3D_PRO_AFFINE2 || a.row_mode != C3D_ROWS_DENSE || a.Kp > 16 * WG_NTP_MAX || a.Np > 112)
-    return C3D_E_UNSUPPORTED;
+  if (a.dtype != C3D_DT_BF16 || a.pro_mode != C3D_PRO_AFFINE2 || a.row_mode != C3D_ROWS_DENSE || a.Np > 112) return C3D_E_UNSUPPORTED;
+  // no weight gradient, no K limit: the conv_a data gradient of the wider stages (res4: K = 216) with the previous block's
+  // c3d_block_out_bwd in its epilogue
+  // (instantiated for the 7-tile bucket only: res2 / res3 take C3D_WG_ROWS with the weight gradient fused as well)
+  if (a.wg_mode == C3D_WG_MASKSUM) {
+    const int nt = (a.Np + 15) / 16;
+    if (a.epi_mode != C3D_EPI_ADD || nt <= 4) return C3D_E_UNSUPPORTED;
+    return launch_pw_d<bf16_t, 7, C3D_PRO_AFFINE2, C3D_EPI_ADD, 8, true, C3D_WG_MASKSUM>(a, s);
+  }
+  if (a.Kp > 16 * WG_NTP_MAX) return C3D_E_UNSUPPORTED;
   if (a.wg_mode == C3D_WG_SWISH && a.Kp > 16 * WG_NTP_MAX_SWISH) return C3D_E_UNSUPPORTED;
   if (a.wg_mode == C3D_WG_SWISH && a.epi_mode == C3D_EPI_SWISH_SE_BWD) return dispatch_wg<C3D_EPI_SWISH_SE_BWD, C3D_WG_SWISH>(a, s);
   if (a.wg_mode == C3D_WG_ROWS && a.epi_mode == C3D_EPI_ADD) return dispatch_wg<C3D_EPI_ADD, C3D_WG_ROWS>(a, s);
@@ -56,6 +64,19 @@ __attribute__((visibility("hidden"))) bool c3d_detail_pw_gemm_wg_supported(int K
   if (wg_mode == C3D_WG_SWISH) { a.epi_mode = C3D_EPI_SWISH_SE_BWD; return plan_wg<C3D_EPI_SWISH_SE_BWD, C3D_WG_SWISH>(a); }
   if (wg_mode == C3D_WG_ROWS) { a.epi_mode = C3D_EPI_ADD; return plan_wg<C3D_EPI_ADD, C3D_WG_ROWS>(a); }
   return false;
+}
+
+// C3D_WG_MASKSUM (stage driver: fold c3d_block_out_bwd of the previous block into this conv_a data gradient): same gates
+// and LDS plan as the launch path
+__attribute__((visibility("hidden"))) bool c3d_detail_pw_gemm_masksum_supported(int Kp, int Np) {
+  if (Kp <= 0 || Np <= 0 || (Kp & 7) || (Np & 7) || Kp > 224 || Np > 112 || (Np + 15) / 16 <= 4) return false;
+  c3d_pw_args a;
+  std::memset(&a, 0, sizeof(a));
+  a.M = 1 << 20; a.K = a.Kp = Kp; a.N = a.Np = Np; a.dtype = C3D_DT_BF16; a.pro_mode = C3D_PRO_AFFINE2; a.wg_mode = C3D_WG_MASKSUM;
+  a.epi_mode = C3D_EPI_ADD;
+  PwLaunch L;
+  size_t lds = 0;
+  return plan_pw<bf16_t, 7, C3D_PRO_AFFINE2, C3D_EPI_ADD, 8, C3D_WG_MASKSUM>(a, L, lds);
 }
 
 #ifdef C3D_PW_CLOCK

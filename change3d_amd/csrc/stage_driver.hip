@@ -20,6 +20,7 @@
 #include <vector>
 
 bool c3d_detail_pw_gemm_wg_supported(int Kp, int Np, int wg_mode);   // pw_gemm_wg.hip: the fused kernel's own LDS plan
+bool c3d_detail_pw_gemm_masksum_supported(int Kp, int Np);           // pw_gemm_wg.hip: C3D_WG_MASKSUM
 
 namespace {
 
@@ -100,7 +101,8 @@ inline bool fuse_wgrad(const c3d_stage_desc* d, int Kp, int Np, int wg_mode) {
          c3d_detail_pw_gemm_wg_supported(Kp, Np, wg_mode);
 }
 
-int g_mask_in_dgrad = 1;   // c3d_set_option(C3D_OPT_MASK_IN_DGRAD, ...)
+int g_mask_in_dgrad = 3;   // c3d_set_option(C3D_OPT_MASK_IN_DGRAD, ...): bit 0 = the ReLU mask of the previous block's output in the conv_a data
+                           // gradient, bit 1 = that block's BatchNorm_c-backward sums there too (no c3d_block_out_bwd launch at all)
 int g_fold_se = 1;         // c3d_set_option(C3D_OPT_FOLD_SE, ...): SE gate computed by conv_c's workgroups (forward)
 int g_fuse_wgrad = 3;      // c3d_set_option(C3D_OPT_FUSE_WGRAD, ...): bit 0 conv_a, bit 1 conv_c
 
@@ -192,11 +194,16 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
   }
   Carver cb;
   const int R = bwd_ring();
-  size_t ring[BWD_RING_MAX][5];
+  size_t ring[BWD_RING_MAX][4];
   for (int r = 0; r < R; ++r) {
     ring[r][0] = cb.take(mx_g); ring[r][1] = cb.take(mx_t1); ring[r][2] = cb.take(mx_t2);
-    ring[r][3] = mx_dxs ? cb.take(mx_dxs) : SIZE_MAX; ring[r][4] = mx_dx ? cb.take(mx_dx) : SIZE_MAX;
+    ring[r][3] = mx_dxs ? cb.take(mx_dxs) : SIZE_MAX;
   }
+  // dx of block i is dy of block i - 1 -- and, when the conv_a data gradient masked it (c3d_pw_args.wg_mask_out /
+  // C3D_WG_MASKSUM), that block's g as well, which its SIDE-stream weight gradients read: one slot more than the ring, so that
+  // block i - R - 1 overwrites it after the side marks of blocks >= i - 1 are joined (c3d_stage_bwd's lag rule)
+  size_t ring_dx[BWD_RING_MAX + 1];
+  for (int r = 0; r < R + 1; ++r) ring_dx[r] = mx_dx ? cb.take(mx_dx) : SIZE_MAX;
   P.wgrad_ws = cb.take((size_t)wsf * 4);
   P.wgrad_ws_fused = wsf_fused ? cb.take((size_t)wsf_fused * 4) : SIZE_MAX;   // main stream: kernel, then its reducer
   for (int i = 0; i < n; ++i) {
@@ -204,7 +211,7 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
     BlkBwd& Bk = P.b[i];
     const int r = i % R;
     Bk.g = ring[r][0]; Bk.t1 = ring[r][1]; Bk.t2 = ring[r][2]; Bk.dxs = ring[r][3];
-    Bk.dx = i > 0 ? ring[r][4] : SIZE_MAX;
+    Bk.dx = i > 0 ? ring_dx[i % (R + 1)] : SIZE_MAX;
     Bk.coef_c = cb.take(3 * G.Cop * 4);
     Bk.coef_1 = G.sc_bn ? cb.take(3 * G.Cop * 4) : SIZE_MAX;
     Bk.coef_a = cb.take(3 * G.Cip * 4);
@@ -522,11 +529,11 @@ namespace {
 
 int pw_launch(const c3d_pw_args& a, hipStream_t st) {
   const double bytes = (double)a.M * ((double)a.Kp * (a.x2 ? 2 : 1) + (double)a.Np * (a.e1 ? 2 : 1) + (a.pro_out ? a.Kp : 0) +
-                                     (a.wg_mode == C3D_WG_ROWS ? a.Np : 0)) * (double)es(a.dtype);
+                                     ((a.wg_mode == C3D_WG_ROWS || a.wg_mode == C3D_WG_MASKSUM) ? a.Np : 0) + (a.add_sums ? a.Np : 0)) * (double)es(a.dtype);
   char nm[64];
   if (prof_detail())
     std::snprintf(nm, sizeof(nm), "c3d_pw_gemm[M=%lld K=%d N=%d pro=%d epi=%d rows=%d%s]", (long long)a.M, a.K, a.N, a.pro_mode,
-                  a.epi_mode, a.row_mode, a.wg_mode ? " +dW" : "");
+                  a.epi_mode, a.row_mode, a.wg_mode == C3D_WG_MASKSUM ? " +bob" : a.wg_mode ? (a.add_sums ? " +dW +bob" : " +dW") : "");
   else
     std::snprintf(nm, sizeof(nm), "c3d_pw_gemm");
   return prof_call(nm, bytes, st, [&] { return c3d_pw_gemm(&a, st); });
@@ -704,6 +711,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
   const void* cur_dy = dy;
   bool premasked = false;   // cur_dy is already dy * (y > 0): the conv_a data gradient of the block above stored it that way
+  bool sums_done = false;   // ...and accumulated this block's BatchNorm_c-backward sums too: no c3d_block_out_bwd for it
   std::deque<uint64_t> lag;   // side-stream marks of the blocks whose ring slots are still in flight
   for (int i = d->n_blocks - 1; i >= 0; --i) {
     const c3d_block_desc& k = d->blocks[i];
@@ -736,7 +744,9 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
         return c3d_bn_bwd_coef(dsums, 1, count, bn.gamma, mr, C, Cp, out, bn.dgamma, bn.dbeta, st); });
     };
     // ---- y = relu(bn_c(c) + shortcut)
-    if (premasked) {   // the mask was applied where dy was produced (c3d_pw_args.wg_mask_out): statistics only, g IS dy
+    if (premasked && sums_done) {   // c3d_block_out_bwd of this block ran inside the conv_a data gradient of the block above
+      g = const_cast<void*>(cur_dy);
+    } else if (premasked) {   // the mask was applied where dy was produced (c3d_pw_args.wg_mask_out): statistics only, g IS dy
       g = const_cast<void*>(cur_dy);
       RC(prof_call("c3d_block_out_bwd", (double)G.Mo * G.Cop * (scbn ? 3 : 2) * e, st, [&] {
         return c3d_block_out_bwd(cur_dy, nullptr, c, scbn ? sc : nullptr, nullptr, mr_c, scbn ? mr_1 : nullptr, dsums_c,
@@ -816,7 +826,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     // ---- conv_a data gradient (+ shortcut gradient in the epilogue) and weight gradient (forked first: it needs the
     //      coefficients, not the data gradient)
     const bool fuse_wa = (g_fuse_wgrad & 1) && fuse_wgrad(d, G.Cip, G.Cinp, C3D_WG_ROWS);
-    bool mask_next = false;
+    bool mask_next = false, sums_next = false;
     if (!fuse_wa)
     RC(side_run(st, [&](hipStream_t s2) {
       WgCall w(t2, xin, k.dw_a, wgws, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
@@ -827,19 +837,20 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     {
       PwCall p(t2, k.w_a, dx, G.M, G.Ci, G.Cin, 1, G.Cin, dt);
       if (fuse_wa) { p.a.wg_mode = C3D_WG_ROWS; p.a.wg_x3 = xin; p.a.wg_dw = k.dw_a; p.a.wg_ws = wgws_fused; }
-      // xin is the previous block's output y: its ReLU mask goes onto dx here, c3d_block_out_bwd of that block only sums
-      // ...provided nothing on the SIDE stream reads that block's g (= this dx, a ring slot): its conv_c weight gradient (when
-      // not fused) and its shortcut weight gradient would, and the ring's lifetime rule (block i - 2 overwrites the slot
-      // once the side marks of blocks >= i + 1 are joined) does not cover a reader forked by block i - 1.  Block 0 is the
-      // last block of the call: no later block overwrites the slot, the caller keeps the workspace until the full join.
-      bool next_g_main_only = false;
-      if (i > 0) {
-        const BlkGeom& Gn = P.g[i - 1];
-        const bool fuse_wc_n = (g_fuse_wgrad & 2) && fuse_wgrad(d, Gn.Cop, Gn.Cip, C3D_WG_SWISH) && Gn.Cop <= 48;
-        next_g_main_only = fuse_wc_n && (!Gn.sc_conv || i == 1);
-      }
-      mask_next = fuse_wa && i > 0 && g_mask_in_dgrad && next_g_main_only;
+      // xin is the previous block's output y: its ReLU mask goes onto dx here -- dx IS that block's g then (the dx slots
+      // outlive that block's side-stream weight gradients: make_plan) -- and, unless its shortcut has a BatchNorm of its own,
+      // its BatchNorm_c-backward sums are taken in the same epilogue (add_sums): no c3d_block_out_bwd launch for it.  Without
+      // the fused weight gradient the same epilogue is the C3D_WG_MASKSUM kernel (res4: the 7-tile bucket).
+      const bool masksum = !fuse_wa && dt == C3D_DT_BF16 && c3d_detail_pw_gemm_masksum_supported(G.Cip, G.Cinp);
+      mask_next = i > 0 && (g_mask_in_dgrad & 1) && res_mode == 0 && (fuse_wa || (masksum && (g_mask_in_dgrad & 2)));
+      sums_next = mask_next && (g_mask_in_dgrad & 2) && !P.g[i - 1].sc_bn;
+      if (mask_next && !fuse_wa && !sums_next) mask_next = false;   // (C3D_WG_MASKSUM always sums)
       p.a.wg_mask_out = mask_next ? 1 : 0;
+      if (mask_next && !fuse_wa) { p.a.wg_mode = C3D_WG_MASKSUM; p.a.wg_x3 = xin; }
+      if (sums_next) {
+        p.a.add_c = at(ws, P.f[i - 1].c); p.a.add_mr = atT<float>(ws, P.f[i - 1].mr_c);
+        p.a.add_sums = atT<double>(wb, P.b[i - 1].dsums_c);
+      }
       p.a.x2 = a; p.a.pro_mode = C3D_PRO_AFFINE2; p.a.pro_p = coef_a;
       if (consb) p.a.fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, true);
       p.a.epi_mode = C3D_EPI_ADD; p.a.e1 = res; p.a.res_mode = res_mode; p.a.H = G.H; p.a.W = G.W;
@@ -851,6 +862,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     if ((int)lag.size() >= bwd_ring()) { RC(side_join(st, lag.front())); lag.pop_front(); }
     cur_dy = dx;
     premasked = mask_next;
+    sums_done = sums_next;
   }
   return 0;
 }
@@ -866,7 +878,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_CONVT_MFMA: c3d_option_convt_mfma = value ? 1 : 0; return 0;
     case C3D_OPT_FUSE_WGRAD: g_fuse_wgrad = value & 3; return 0;
     case C3D_OPT_FOLD_SE: g_fold_se = value ? 1 : 0; return 0;
-    case C3D_OPT_MASK_IN_DGRAD: g_mask_in_dgrad = value ? 1 : 0; return 0;
+    case C3D_OPT_MASK_IN_DGRAD: g_mask_in_dgrad = value & 3; return 0;
     case C3D_OPT_DW_RING: c3d_option_dw_ring = value & 15; return 0;
     default: return C3D_E_BADARG;
   }

@@ -255,18 +255,22 @@ def fin_consume(sums, bn, count, ss, mr, batch=0):
     return f
 
 
-WG_NONE, WG_SWISH, WG_ROWS = 0, 1, 2
+WG_NONE, WG_SWISH, WG_ROWS, WG_MASKSUM = 0, 1, 2, 3
 
 
 def pw_gemm(x, w, y, *, M, K, N, w_sn, w_sk, dtype, x2=None, pro_mode=PRO_NONE, pro_p=None,
             pro_gate=None, epi_mode=EPI_STORE, e1=None, epi_p=None, epi_gate=None, epi_q=None, stats=None,
             rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, res_mode=0,
-            x_ptr=None, e1_ptr=None, fin=None, bias=None, pro_out=None, w_img=None, wg_mode=WG_NONE, wg_x3=None, wg_dw=None, wg_mask_out=0):
+            x_ptr=None, e1_ptr=None, fin=None, bias=None, pro_out=None, w_img=None, wg_mode=WG_NONE, wg_x3=None, wg_dw=None, wg_mask_out=0,
+            add_c=None, add_mr=None, add_sums=None):
     a = L.PwArgs()
     a.w_img = _p(w_img)
-    if wg_mode != WG_NONE:   # weight gradient fused into this data-gradient launch (include/change3d_hip.h c3d_pw_args.wg_mode)
+    if wg_mode == WG_MASKSUM:   # no weight gradient: the previous block's c3d_block_out_bwd in this epilogue (c3d_pw_args.add_sums)
+        a.wg_mode, a.wg_x3 = wg_mode, _p(wg_x3)
+    elif wg_mode != WG_NONE:   # weight gradient fused into this data-gradient launch (include/change3d_hip.h c3d_pw_args.wg_mode)
         a.wg_mode, a.wg_x3, a.wg_dw, a.wg_mask_out = wg_mode, _p(wg_x3), _p(wg_dw), int(wg_mask_out)
         a.wg_ws = _ws(wg_dw.device, L.lib().c3d_pw_gemm_wg_ws_floats(K, N)).data_ptr()
+    a.add_c, a.add_mr, a.add_sums = _p(add_c), _p(add_mr), _p(add_sums)
     if fin is not None:
         a.fin = fin
     a.bias = _p(bias)

@@ -149,10 +149,22 @@ typedef struct c3d_pw_args {
   float* se_hid;
   int32_t se_cr;
   int32_t se_reserved;
+  /* ---- c3d_block_out_bwd of the PREVIOUS block fused into this data-gradient launch (round 5; reference model/x3d.py:
+   * 229-236: y = relu(bn_c(c) + shortcut), whose backward is one masked pass over dy in autograd).  With C3D_EPI_ADD, dense
+   * rows, bf16 and wg_x3 = that block's output y:
+   *     wg_mode C3D_WG_ROWS + wg_mask_out, or wg_mode C3D_WG_MASKSUM (no weight gradient; any Kp <= 224, Np <= 112):
+   *     the stored output is g = (result + e1) * (wg_x3 > 0), and with add_sums != NULL (required by C3D_WG_MASKSUM) the
+   *     kernel also accumulates that block's BatchNorm_c-backward sums  add_sums f64 [2][N] += (sum g, sum g * chat),
+   *     chat = (add_c - mean) * rstd, add_c = its conv_c output [M][Np], add_mr = mean[Np] | rstd[Np] -- the sums of
+   *     c3d_block_out_bwd (g as stored, i.e. rounded to the storage type), which is then not launched at all.            */
+  const void* add_c;
+  const float* add_mr;
+  double* add_sums;
 } c3d_pw_args;
 #define C3D_WG_NONE 0
 #define C3D_WG_SWISH 1
 #define C3D_WG_ROWS 2
+#define C3D_WG_MASKSUM 3
 int64_t c3d_pw_gemm_wg_ws_floats(int32_t K, int32_t N);
 
 /* K, N <= 224 run the wave-private-tile kernel (pw_gemm_impl.h); wider layers (X3D res5: 432 inner channels; the

@@ -146,6 +146,20 @@ def test_conv_a_data_gradient_with_fused_weight_gradient(Ci, Cin, M, res_mode):
     torch.cuda.synchronize()
     assert torch.equal(g_full.view(torch.int16), dx_m.view(torch.int16))
     assert torch.allclose(s_full, s_pre, rtol=1e-12, atol=0)
+    # add_sums: the same launch also takes those sums (c3d_block_out_bwd is not launched at all); f32 partial sums per lane
+    # and wave, f64 across workgroups: the sums of the separate pass to ~1e-6 of their scale
+    if res_mode == 0:
+        dx_s = torch.full((M, Cinp), float("nan"), dtype=DT, device=DEV)
+        dw_s = torch.zeros((Ci, Cin), dtype=torch.float32, device=DEV)
+        s_fold = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+        ops.pw_gemm(t2d, wd, dx_s, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=ad, pro_mode=ops.PRO_AFFINE2, pro_p=coef,
+                    epi_mode=ops.EPI_ADD, e1=rd, wg_mode=ops.WG_ROWS, wg_dw=dw_s, wg_x3=xrd, wg_mask_out=1,
+                    add_c=cd_, add_mr=mr, add_sums=s_fold)
+        torch.cuda.synchronize()
+        assert torch.equal(dx_s.view(torch.int16), dx_m.view(torch.int16))
+        assert torch.equal(dw_s, dw_m)
+        scale = s_full.abs().max().item()
+        assert (s_fold - s_full).abs().max().item() < 2e-6 * scale + 1e-4, ((s_fold - s_full).abs().max().item(), scale)
 
 
 def test_fused_weight_gradient_refuses_shapes_it_does_not_take():
@@ -159,3 +173,66 @@ def test_fused_weight_gradient_refuses_shapes_it_does_not_take():
                     dtype=ops.dt_code(DT), x2=z(M, Ci), pro_mode=ops.PRO_AFFINE2, pro_p=torch.zeros(3 * Ci, device=DEV),
                     epi_mode=ops.EPI_ADD, e1=z(M, Cin), wg_mode=ops.WG_ROWS, wg_x3=z(M, Cin),
                     wg_dw=torch.zeros(Ci, Cin, device=DEV))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Ci,Cin", [(98304 // 8, 216, 96), (1000, 216, 96), (777, 120, 80), (50, 216, 112)])
+def test_block_out_bwd_folded_into_the_conv_a_data_gradient(M, Ci, Cin):
+    """C3D_WG_MASKSUM (no weight gradient; res4's conv_a data gradient): the stored output is g = (dx + residual) * (y > 0)
+    of the PREVIOUS block and the launch accumulates that block's BatchNorm_c-backward sums -- what the pair
+    (c3d_pw_gemm EPI_ADD, c3d_block_out_bwd) produces (reference model/x3d.py:229-236 backward)."""
+    _need_gpu()
+    from change3d_amd import ops
+    dt = ops.dt_code(DT)
+    Cip, Cinp = ops.cpad(Ci), ops.cpad(Cin)
+    t2, a_ = q(rnd((M, Ci), 41), DT), q(rnd((M, Ci), 42), DT)
+    A, Bc, Cc = rnd((Ci,), 43), rnd((Ci,), 44, 0.1), rnd((Ci,), 45, 0.1)
+    w = rnd((Ci, Cin), 46, 0.2)
+    y_prev = torch.relu(q(rnd((M, Cin), 47), DT))
+    res = q(rnd((M, Cin), 48), DT)
+    cten = q(rnd((M, Cin), 49), DT)
+    t2d, ad = (padc(t, Cip).to(DEV, DT).contiguous() for t in (t2, a_))
+    yd, rd, cd_ = (padc(t, Cinp).to(DEV, DT).contiguous() for t in (y_prev, res, cten))
+    coef = torch.cat([padc(A, Cip), padc(Bc, Cip), padc(Cc, Cip)]).to(DEV)
+    mr = torch.cat([padc(rnd((Cin,), 50, 0.5), Cinp), padc(rnd((Cin,), 51).abs() + 0.5, Cinp)]).to(DEV)
+    wd = w.to(DEV)
+    dx = torch.full((M, Cinp), float("nan"), dtype=DT, device=DEV)
+    ops.pw_gemm(t2d, wd, dx, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=ad, pro_mode=ops.PRO_AFFINE2, pro_p=coef,
+                epi_mode=ops.EPI_ADD, e1=rd)
+    g_ref = torch.empty_like(dx)
+    s_ref = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+    ops.block_out_bwd(dx, yd, cd_, None, g_ref, mr, None, s_ref, None, M, Cin, dt)
+    g = torch.full((M, Cinp), float("nan"), dtype=DT, device=DEV)
+    s = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+    ops.pw_gemm(t2d, wd, g, M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=ad, pro_mode=ops.PRO_AFFINE2, pro_p=coef,
+                epi_mode=ops.EPI_ADD, e1=rd, wg_mode=ops.WG_MASKSUM, wg_x3=yd, add_c=cd_, add_mr=mr, add_sums=s)
+    torch.cuda.synchronize()
+    assert torch.equal(g.view(torch.int16), g_ref.view(torch.int16))
+    scale = s_ref.abs().max().item()
+    assert (s - s_ref).abs().max().item() < 2e-6 * scale + 1e-4, ((s - s_ref).abs().max().item(), scale)
+    # and against plain arithmetic (f64 over the stored g)
+    gq = g_ref[:, :Cin].double().cpu()
+    chat = (cten.double() - mr[:Cin].double().cpu()) * mr[Cinp:Cinp + Cin].double().cpu()
+    want = torch.cat([gq.sum(0), (gq * chat).sum(0)])
+    assert (s.cpu() - want).abs().max().item() < 2e-6 * scale + 1e-4
+
+
+@pytest.mark.gpu
+def test_masksum_refuses_what_it_does_not_take():
+    _need_gpu()
+    from change3d_amd import ops
+    from change3d_amd._lib import Change3DHipError
+    z = lambda *s: torch.zeros(*s, dtype=DT, device=DEV)  # noqa: E731
+    M, Ci, Cin = 64, 216, 96
+    kw = dict(M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=ops.dt_code(DT), x2=z(M, Ci), pro_mode=ops.PRO_AFFINE2,
+              pro_p=torch.zeros(3 * Ci, device=DEV), epi_mode=ops.EPI_ADD, e1=z(M, Cin))
+    sums = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+    mr = torch.zeros(2 * Cin, device=DEV)
+    with pytest.raises(Change3DHipError):     # the sums are required
+        ops.pw_gemm(z(M, Ci), torch.zeros(Ci, Cin, device=DEV), z(M, Cin), wg_mode=ops.WG_MASKSUM, wg_x3=z(M, Cin), **kw)
+    with pytest.raises(Change3DHipError):     # sums without the mask
+        ops.pw_gemm(z(M, Ci), torch.zeros(Ci, Cin, device=DEV), z(M, Cin), add_c=z(M, Cin), add_mr=mr, add_sums=sums, **kw)
+    kw2 = dict(kw, N=48, w_sk=48, e1=z(M, 48))   # the narrow buckets take C3D_WG_ROWS (weight gradient fused as well)
+    with pytest.raises(Change3DHipError):
+        ops.pw_gemm(z(M, Ci), torch.zeros(Ci, 48, device=DEV), z(M, 48), wg_mode=ops.WG_MASKSUM, wg_x3=z(M, 48), add_c=z(M, 48),
+                    add_mr=torch.zeros(96, device=DEV), add_sums=torch.zeros(96, dtype=torch.float64, device=DEV), **kw2)
