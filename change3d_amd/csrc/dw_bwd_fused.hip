@@ -39,7 +39,17 @@ __device__ unsigned long long c3d_fb_clk[FCLK_WAVES][10];
 
 namespace {
 
-constexpr int FB_TH = 8, FB_TW = 8, FB_DH = FB_TH + 2, FB_DW = FB_TW + 2, FB_NTHR = 512;
+// C3D_FB_ROWS (build-time experiment, tools/experiments/): tile rows = waves per workgroup.  8 = the shipped geometry (8 x 8
+// pixels, 512 threads, one workgroup per CU); 4 = 4 x 8 pixels, 256 threads, two workgroups per CU out of phase.
+#ifndef C3D_FB_ROWS
+#define C3D_FB_ROWS 8
+#endif
+constexpr int FB_TH = C3D_FB_ROWS, FB_TW = 8, FB_DH = FB_TH + 2, FB_DW = FB_TW + 2, FB_NTHR = FB_TH * FB_TW * 8;
+#if C3D_FB_ROWS == 8
+#define FB_KATTR __launch_bounds__(FB_NTHR)
+#else
+#define FB_KATTR __launch_bounds__(FB_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 256 registers per wave: two workgroups per CU
+#endif
 
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> {
@@ -233,20 +243,20 @@ __device__ __forceinline__ void fb_flush(void* scratch, const float (&S1)[4], co
   // tools/lds_bank_model.py).  The 64-pixel sums keep their order.
   constexpr int FB_DUMP_LD = FB_NTHR + 48, FB_DUMP_PT = FB_NTHR / 2 + 8;
   float* dump = reinterpret_cast<float*>(scratch);      // 27 * 560 floats = 60 KB
-  const int dslot = tid + (FB_DUMP_PT - FB_NTHR / 2) * (tid >> 8);
+  const int dslot = tid + (FB_DUMP_PT - FB_NTHR / 2) * (tid / (FB_NTHR / 2));
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 27; ++k) dump[k * FB_DUMP_LD + dslot] = dwa[k][j >> 1][j & 1];
     __syncthreads();
-    if (tid < 27 * 8 * 2) {
-      const int o = tid >> 1, part = tid & 1;
+    for (int t2 = tid; t2 < 27 * 8 * 2; t2 += FB_NTHR) {   // (one trip with 512 threads)
+      const int o = t2 >> 1, part = t2 & 1;
       const int tap = o >> 3, v = o & 3, hh = (o >> 2) & 1;
       const float* src = dump + tap * FB_DUMP_LD + part * FB_DUMP_PT + hh * DW_CV + v;
       float s = 0.f;
 #pragma unroll 8
-      for (int k = 0; k < 32; ++k) s += src[k * 2 * DW_CV];
+      for (int k = 0; k < FB_NTHR / 16; ++k) s += src[k * 2 * DW_CV];
       s += __shfl_xor(s, 1, 64);
       const int c = c0 + v * 8 + hh * 4 + j;
       if (part == 0 && c < g.C) atomicAdd(dw + (size_t)c * 27 + tap, s);
@@ -255,7 +265,7 @@ __device__ __forceinline__ void fb_flush(void* scratch, const float (&S1)[4], co
 }
 
 template <typename T, int TT, int S>
-__global__ __launch_bounds__(FB_NTHR) void dw_bwd_fused_kernel(
+__global__ FB_KATTR void dw_bwd_fused_kernel(
     const T* __restrict__ t1, const T* __restrict__ bb, const float* __restrict__ coefA,
     const float* __restrict__ coefB, const float* __restrict__ coefC, const float* __restrict__ w,
     const T* __restrict__ a, const float* __restrict__ ss_a, const float* __restrict__ mr_a, T* __restrict__ t2,
@@ -1015,8 +1025,9 @@ int launch_fused_t(const void* t1, const void* bb, const float* cA, const float*
   // (round 5, re-swept at 23.2 ms per step: cap 16 / 32 / 64 / 128 tiles -> 23.42 / 23.18 / 22.95 / 23.15 ms; with the narrower
   // side-stream weight gradient, three interleaved repeats: 22.90 against 23.39 ms for the old pair of defaults)
   static const int env_max = c3d_env("C3D_DWBF_MAX") ? atoi(c3d_env("C3D_DWBF_MAX")) : 64;
-  int tpw = env_max / (S * S);   // a stride-2 tile is four pixels per thread
-  while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 85L * device_cus() / 100) tpw >>= 1;
+  int tpw = env_max / (S * S) * (8 / FB_TH);   // a stride-2 tile is four pixels per thread; (half-height tiles: twice as many)
+  constexpr int WGC = 512 / FB_NTHR;           // workgroups resident per CU
+  while (tpw > 4 && (long)((ntiles + tpw - 1) / tpw) * chunks * g.B < 85L * WGC * device_cus() / 100) tpw >>= 1;
   if (env_tpw > 0) tpw = env_tpw;
   if (tpw > ntiles) tpw = ntiles;
   dim3 grid(chunk_order_grid(chunks, (long)((ntiles + tpw - 1) / tpw) * g.B));
@@ -1044,7 +1055,7 @@ int dispatch_fused(const void* t1, const void* b, const float* coefA, const floa
     // LDS-DMA ring kernels (bit 2: requests spread over the tap walk; bit 3: three-frame maps under 64 x 64 too -- their
     // 16-tile walks pay the two-tile ring fill: res4 of the BCD step 65.9 us with the register prefetch, 68.0 us with the
     // ring; the five-frame register kernel spills, its ring variant wins on every map: SCD 663 -> 681 img/s)
-    if (g.stride == 1 && (c3d_option_dw_ring & 1) && ((c3d_option_dw_ring & 8) || g.T > 3 || (long)g.H * g.W >= 64 * 64)) {
+    if (C3D_FB_ROWS == 8 && g.stride == 1 && (c3d_option_dw_ring & 1) && ((c3d_option_dw_ring & 8) || g.T > 3 || (long)g.H * g.W >= 64 * 64)) {
       if (g.T <= 3) {
         if (c3d_option_dw_ring & 4) return launch_ring_t<3, true>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);
         return launch_ring_t<3, false>(t1, b, coefA, coefB, coefC, w, a, ss_a, mr_a, t2, dsums, dw, g, s, fin);

@@ -6,8 +6,9 @@
 // kernel of the data-gradient chain that becomes ready meanwhile -- including its 1-8 workgroup coefficient kernels --
 // waiting for its whole duration (measured on MI355X, B=32 bf16: depthwise weight gradient on 128 instead of 256
 // workgroups: step 35.6 -> 34.1 ms, and the 40 us stall around c3d_se_bn_bwd_coef disappears).
-// The pointwise weight gradient takes 5/8 of the CUs in the same situation (round 2: 256 -> 192 workgroups: 32.43 -> 31.69 ms; round 5: 192 -> 160: 23.18 -> 22.86 ms;
-// profiles/r02_side_stream_width_final.json).
+// The pointwise weight gradient takes 7/8 of the CUs in the same situation (round 2: 256 -> 192 workgroups: 32.43 -> 31.69 ms; round 5: 192 -> 160: 23.18 -> 22.86 ms,
+// then -- with c3d_block_out_bwd folded into the conv_a data gradient: nothing small left to run beside a narrow grid -- 160 -> 224: 22.70 -> 22.29 ms;
+// profiles/r02_side_stream_width_final.json, csrc/pw_wgrad.hip).
 extern thread_local int c3d_side_launch;
 
 // c3d_set_option (stage_driver.hip): kernel-family selectors with a parity test between the two implementations

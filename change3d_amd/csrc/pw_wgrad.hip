@@ -497,13 +497,16 @@ int launch_wgrad(const c3d_pw_wgrad_args& a, hipStream_t stream) {
   int64_t cap = device_cus() < WGRAD_MAX_PARTS ? device_cus() : WGRAD_MAX_PARTS;
   if (cap_env > 0 && cap_env <= WGRAD_MAX_PARTS) cap = cap_env;
   else if (c3d_side_launch) {
-    // beside the data-gradient chain (stage driver's side stream): three quarters of the CUs.  This single-round
+    // beside the data-gradient chain (stage driver's side stream): a cap on the workgroups (history below; 7/8 of the CUs now).  This single-round
     // kernel at full width holds every CU for its whole duration (launch_hints.h); measured on MI355X, B=32 bf16,
     // 60-step runs: 256 / 208 / 192 / 176 / 160 / 128 workgroups -> 32.52 / 32.08 / 31.84 / 32.11 / 32.48 / 32.87 ms
     static const int side_env = c3d_env("C3D_PWWG_SIDE_WGS") ? atoi(c3d_env("C3D_PWWG_SIDE_WGS")) : 0;
     // round 5 (after the data-gradient kernels' waits became exact, same-call sweeps through the instrumented build): 128 / 144 /
-    // 160 / 176 / 192 / 256 workgroups -> 23.01 / 22.99 / 22.86 / 23.53 / 23.18 / 23.34 ms per step: 5/8 of the CUs
-    const int64_t side_cap = side_env > 0 ? side_env : (int64_t)device_cus() * 5 / 8;
+    // 160 / 176 / 192 / 256 workgroups -> 23.01 / 22.99 / 22.86 / 23.53 / 23.18 / 23.34 ms per step: 5/8 of the CUs.
+    // ...and once c3d_block_out_bwd was folded into the conv_a data gradient (the elementwise pass that used to fill the CUs a
+    // narrow weight gradient left): 96 / 128 / 160 / 192 / 208 / 224 / 240 / 256 -> 23.46 / 22.81 / 22.70 / 22.53 / 22.34 / 22.29 /
+    // 22.33 / 22.34 ms (SCD and CC: 224 best by 0.5 % too): 7/8 of the CUs
+    const int64_t side_cap = side_env > 0 ? side_env : (int64_t)device_cus() * 7 / 8;
     if (side_cap < cap) cap = side_cap;
   }
   if (taps > 1 && cap > WGRAD_MAX_PARTS / taps) cap = WGRAD_MAX_PARTS / taps;   // the workspace holds MAX_PARTS slabs
