@@ -272,7 +272,11 @@ struct SideCtx {
   hipEvent_t ev() {
     if (pool.size() < 256) {
       hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      // fork / done marks between two streams of ONE device: no timing, and no system-scope fence -- the default event makes
+      // the recording queue write its caches back for the host and for peer devices at every mark (7-10 us of main-queue
+      // bubble per fork in the round-5 trace, two forks per residual block); what leaves the device (the gradient all-reduce,
+      // the host reading the loss) is ordered by the caller's own events / synchronisation behind c3d_side_join
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return nullptr;
       pool.push_back(e);
       return e;
     }
