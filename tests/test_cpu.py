@@ -767,3 +767,37 @@ def test_pw_gemm_refuses_operands_of_two_gib_before_touching_the_device():
     a.M = 1024
     a.pro_mode, a.x2 = 2, None      # C3D_PRO_AFFINE2 without its second operand: C3D_E_BADARG, still no launch
     assert L.lib().c3d_pw_gemm(C.byref(a), None) == -1
+
+
+def test_pw_gemm_checks_the_folded_block_output_backward_arguments_without_a_launch():
+    """`c3d_pw_args.add_sums` / C3D_WG_MASKSUM (c3d_block_out_bwd of the previous block in the conv_a data gradient's epilogue,
+    reference model/x3d.py:229-236): the sums are over the MASKED output, so they are an argument error without the mask, and the
+    variant without a weight gradient needs them, the previous block's output and its conv_c rows (no GPU here: C3D_E_BADARG comes
+    from the argument checks, the pointers are never dereferenced)."""
+    import ctypes as C
+    from change3d_amd import _lib as L
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p).value
+
+    def base():
+        a = L.PwArgs()
+        a.x = a.x2 = a.y = a.w = a.e1 = a.pro_p = p
+        a.K, a.Kp, a.N, a.Np = 216, 216, 96, 96
+        a.w_sn, a.w_sk = 1, 96
+        a.dtype, a.M = 1, 1024                    # C3D_DT_BF16
+        a.pro_mode, a.epi_mode = 2, 3             # C3D_PRO_AFFINE2, C3D_EPI_ADD
+        return a
+
+    call = lambda a: L.lib().c3d_pw_gemm(C.byref(a), None)  # noqa: E731
+    a = base(); a.wg_mode = 3                     # C3D_WG_MASKSUM without anything it needs
+    assert call(a) == -1
+    a = base(); a.wg_mode, a.wg_x3 = 3, p         # ...without the sums
+    assert call(a) == -1
+    a = base(); a.wg_mode, a.wg_x3, a.add_sums = 3, p, p   # ...without the conv_c rows / mean | rstd
+    assert call(a) == -1
+    a = base(); a.add_sums, a.add_c, a.add_mr = p, p, p    # sums without a mask (no wg_mode)
+    assert call(a) == -1
+    a = base(); a.wg_mode, a.wg_x3, a.add_sums, a.add_c, a.add_mr, a.res_mode = 3, p, p, p, p, 1   # half-resolution residual
+    assert call(a) == -1
+    a = base(); a.wg_mode = 4                     # not a mode
+    assert call(a) == -1
