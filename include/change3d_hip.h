@@ -499,9 +499,10 @@ int c3d_stage_ws_bytes(const c3d_stage_desc* d, int64_t* ws_fwd_bytes, int64_t* 
 int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws_fwd, void* y, void* stream);
 /* dy: gradient of y (same layout); dx: gradient of x (written).  x / y / ws_fwd as given to c3d_stage_fwd.
  * The weight gradients that are not fused into their data-gradient launch (c3d_pw_wgrad) are launched on the library's side stream, each forked ahead
- * of the data-gradient kernel that reads the same operands, with their grids capped at 3/4 and 1/2 of the CUs so
- * that the data-gradient chain always finds free CUs (csrc/launch_hints.h); ws_bwd holds a ring of three blocks'
- * temporaries, so the side stream may lag the chain by two blocks.                                              */
+ * of the data-gradient kernel that reads the same operands, with their grids capped (7/8 of the CUs for the pointwise
+ * kernel: csrc/launch_hints.h, csrc/pw_wgrad.hip) so that the data-gradient chain finds free CUs; ws_bwd holds a ring of
+ * three blocks' temporaries (one slot more for dx, which is also the next block's g: c3d_pw_args.add_sums), so the side
+ * stream may lag the chain by two blocks.                                                                        */
 int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void* y, const void* dy, void* ws_fwd, void* ws_bwd,
                   void* dx, void* stream);
 int c3d_side_join(void* stream);
