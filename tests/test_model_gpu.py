@@ -793,3 +793,61 @@ def test_folded_batchnorm_launches_are_bit_identical_end_to_end(flag):
     for n, e in bad:
         assert e <= 1e-5 * b["grads"][n].abs().max().item(), (n, e)
     assert sum(1 for n in a["grads"] if exact(n)) > 270
+
+
+def test_block_output_backward_folded_into_conv_a_agrees_with_the_separate_launches_end_to_end():
+    """C3D_OPT_MASK_IN_DGRAD = 3 (default: c3d_block_out_bwd of a block runs in the epilogue of the conv_a data gradient of the
+    block above it -- mask and BatchNorm_c-backward sums, c3d_pw_args.add_sums / C3D_WG_MASKSUM) against = 1 (mask only where the
+    weight gradient is fused, the sums by c3d_block_out_bwd launches): same forward, so the same loss to the last bit; the
+    BatchNorm_c-backward sums are accumulated in another order (per lane and wave in f32, then f64), which moves last bits of the
+    coefficients, flips bf16 roundings of stored gradient rows and is amplified down the 24 blocks below to the level of bf16
+    quantisation noise (median 5e-3, measured): the test pins that it ENTERS as a last-bit difference and stays at that level."""
+    _need_gpu()
+    import contextlib
+    import io
+    from change3d_amd import ops, synthetic as synth
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.utils import BCEDiceLoss
+    outs = []
+    try:
+        for opt in (1, 3):
+            ops.set_option(ops.OPT_MASK_IN_DGRAD, opt)
+            args = synth.make_args(size=64, act_dtype=torch.bfloat16)
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                net = Trainer(args)
+            net.load_state_dict(synth.synth_state_dict(net, seed=5, mask_margin=0.25, branch_gain=0.1))
+            net = net.to(DEV).train()
+            pre, post, tgt = (t.to(DEV) for t in synth.synth_batch(3, 64, seed=2))
+            loss = BCEDiceLoss(net.update_bcd(pre, post), tgt)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append({"loss": loss.detach().cpu(), "grads": {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None},
+                         "bufs": {n: b.cpu() for n, b in net.named_buffers()}})
+    finally:
+        ops.set_option(ops.OPT_MASK_IN_DGRAD, 3)
+    a, b = outs
+    assert torch.equal(a["loss"], b["loss"]) and torch.isfinite(a["loss"])
+    assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 400
+    assert all(torch.equal(a["bufs"][n], b["bufs"][n]) for n in a["bufs"])
+    rels = {}
+    for n in a["grads"]:
+        assert torch.isfinite(b["grads"][n]).all(), n
+        d = (a["grads"][n] - b["grads"][n]).double()
+        rels[n] = (d.norm() / a["grads"][n].double().norm().clamp_min(1e-30)).item()
+        if n.startswith("decoder"):
+            assert rels[n] < 1e-5, (n, rels[n])          # upstream of every residual stage in the backward pass
+    import re as _re
+    by = {}
+    for n, r in rels.items():
+        m = _re.search(r"blocks\.(\d+)\.res_blocks\.(\d+)", n)
+        by.setdefault((int(m.group(1)), int(m.group(2))) if m else (-1, 0), []).append(r)
+    med = {k: sorted(v)[len(v) // 2] for k, v in by.items()}
+    print("  per block of res4, last to first (median rel-L2):", " ".join(f"{med[k]:.1e}" for k in sorted(by, reverse=True) if k[0] == 3))
+    # where the difference ENTERS it is a last-bit one: the last block keeps its own c3d_block_out_bwd in both modes, the
+    # next two differ by f32 summation order only; from there on bf16 storage amplifies it to its quantisation level (~0.5 %)
+    last = max(k[1] for k in by if k[0] == 3)
+    assert max(by[(3, last)]) < 1e-6 and max(by[(3, last - 1)]) < 1e-6, (by[(3, last)], by[(3, last - 1)])
+    assert med[(3, last - 2)] < 1e-4, med[(3, last - 2)]
+    vals = sorted(rels.values())
+    print(f"fold vs separate: worst {vals[-1]:.2e}, 90th percentile {vals[len(vals) * 9 // 10]:.2e}, median {vals[len(vals) // 2]:.2e}")
+    assert vals[-1] < 8e-2 and vals[len(vals) * 9 // 10] < 2e-2 and vals[len(vals) // 2] < 1e-2, (vals[-1], vals[len(vals) * 9 // 10], vals[len(vals) // 2])
