@@ -540,6 +540,7 @@ __attribute__((visibility("hidden"))) int c3d_detail_pw_wgrad_reduce(const float
 extern "C" int64_t c3d_pw_wgrad_ws_floats(int32_t N, int32_t K) { return (int64_t)WGRAD_MAX_PARTS * N * K; }
 
 int c3d_detail_pw_wgrad_wide(const c3d_pw_wgrad_args* args, void* stream);   // pw_wide.hip
+int c3d_detail_pw_wgrad_v2(const c3d_pw_wgrad_args* args, hipStream_t stream);   // pw_wgrad_v2.hip: bf16, dense rows
 
 extern "C" int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream) {
   if (!args || !args->p || !args->q || !args->dw || !args->ws) return C3D_E_BADARG;
@@ -557,7 +558,11 @@ extern "C" int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = C3D_E_BADARG;
   if (a.dtype == C3D_DT_F32) rc = launch_wgrad<float>(a, s);
-  else if (a.dtype == C3D_DT_BF16) rc = launch_wgrad<bf16_t>(a, s);
+  else if (a.dtype == C3D_DT_BF16) {
+    // flat-staged, transposing-read kernel for dense rows (C3D_OPT_PW_WGRAD_V2); what it does not take runs here
+    rc = c3d_option_pw_wgrad_v2 ? c3d_detail_pw_wgrad_v2(args, s) : C3D_E_UNSUPPORTED;
+    if (rc == C3D_E_UNSUPPORTED) rc = launch_wgrad<bf16_t>(a, s);
+  }
   if (rc == C3D_E_UNSUPPORTED) rc = c3d_detail_pw_wgrad_wide(args, stream);   // shapes that do not fit its LDS plan
   return rc;
 }

@@ -329,6 +329,59 @@ def test_pw_wgrad_long_walks(K, N, rows):
     assert rel < 4e-3, rel      # bf16 operand rounding is 2^-9 per term and averages out over ~4e5 coherent terms
 
 
+# The flat-staged, transposing-read kernel (csrc/pw_wgrad_v2.hip, C3D_OPT_PW_WGRAD_V2) against the first kernel on the same
+# device buffers: same operand arithmetic, another summation order inside a k-step -> agreement to f32 rounding of the sums
+# (1e-5 of the largest entry), far inside what either is allowed against the f64 product.  Cases: the res4 layers at their
+# real rows_per_sample (a tile never straddles samples there), samples that end inside a tile, a ragged last tile, a block
+# without SqueezeExcitation (no gate), the plain-operand form (enhance / decoder 1x1), the narrow res2 / res3 widths, and
+# M small enough that most workgroups get no tile.
+@pytest.mark.parametrize("K,N,rows,B,mode", [
+    (216, 96, 3072, 4, "swish_gate"), (96, 216, 3072, 4, "affine2"), (216, 96, 200, 37, "swish_gate"),
+    (216, 96, 3072, 3, "swish_nogate"), (24, 24, 4096, 9, "plain"), (54, 24, 1027, 30, "swish_gate"),
+    (48, 108, 777, 21, "affine2"), (108, 48, 64, 50, "swish_gate"), (216, 96, 70, 3, "swish_gate"), (48, 216, 500, 11, "affine2")])
+def test_pw_wgrad_v2_matches_the_first_kernel(K, N, rows, B, mode):
+    _need_gpu()
+    from change3d_amd import ops
+    dtype = torch.bfloat16
+    M = B * rows - (3 if B > 3 else 0)
+    Kp, Np = ops.cpad(K), ops.cpad(N)
+    p, p2 = q(rnd((M, N), 60), dtype), q(rnd((M, N), 61), dtype)
+    A, Bc, Cc = rnd((N,), 62), rnd((N,), 63, 0.1), rnd((N,), 64, 0.1)
+    x = q(rnd((M, K), 65), dtype)
+    scale, shift = rnd((K,), 66).abs() + 0.5, rnd((K,), 67, 0.3)
+    gate = torch.sigmoid(rnd((B, K), 68))
+    kw = dict(M=M, K=K, N=N, dw_sn=K, dw_sk=1, dtype=ops.dt_code(dtype))
+    P = p.double()
+    if mode != "plain":
+        kw.update(p2=padc(p2, Np).to(DEV, dtype).contiguous(), p_coef=torch.cat([padc(A, Np), padc(Bc, Np), padc(Cc, Np)]).to(DEV))
+        P = (A * p + Bc + Cc * p2).double()
+    Q = x.double()
+    if mode.startswith("swish"):
+        kw.update(q_mode=ops.PRO_BN_SE_SWISH, q_ss=torch.cat([padc(scale, Kp), padc(shift, Kp)]).to(DEV), rows_per_sample=rows)
+        v = x * scale + shift
+        if mode == "swish_gate":
+            kw.update(q_gate=padc(gate, Kp).to(DEV).contiguous())
+            v = v * gate.repeat_interleave(rows, 0)[:M]
+        Q = (v * torch.sigmoid(v)).double()
+    ref = (P.t() @ Q).float()
+    pd, xd = padc(p, Np).to(DEV, dtype).contiguous(), padc(x, Kp).to(DEV, dtype).contiguous()
+    out = {}
+    try:
+        for v2 in (0, 1):
+            ops.set_option(ops.OPT_PW_WGRAD_V2, v2)
+            dw = torch.full((N, K), 0.5, dtype=torch.float32, device=DEV)   # accumulate semantics (+=)
+            ops.pw_wgrad(pd, xd, dw, **kw)
+            torch.cuda.synchronize()
+            out[v2] = dw.cpu() - 0.5
+    finally:
+        ops.set_option(ops.OPT_PW_WGRAD_V2, 1)
+    sc = ref.abs().max().item()
+    d12 = (out[1] - out[0]).abs().max().item()
+    e0, e1 = (out[0] - ref).abs().max().item(), (out[1] - ref).abs().max().item()
+    assert d12 <= 2e-5 * sc + 1e-4, f"v2 vs first kernel {d12:.3e} (scale {sc:.3e}; vs f64: first {e0:.3e}, v2 {e1:.3e})"
+    assert e1 <= 2.0 * e0 + 2e-5 * sc + 1e-4, f"v2 vs f64 product {e1:.3e}, first kernel {e0:.3e}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_pw_wgrad_row_modes(dtype):
     _need_gpu()
