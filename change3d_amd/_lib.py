@@ -49,7 +49,8 @@ class PwWgradArgs(C.Structure):
                 ("M", i64), ("gstride", i64), ("rows_per_sample", i64),
                 ("K", i32), ("Kp", i32), ("N", i32), ("Np", i32), ("dw_sn", i32), ("dw_sk", i32),
                 ("row_mode", i32), ("rpg", i32), ("H", i32), ("W", i32), ("dy", i32), ("dx", i32),
-                ("q_mode", i32), ("dtype", i32), ("taps", i32), ("dw_tap_stride", i32), ("p_fin", BnFin)]
+                ("q_mode", i32), ("dtype", i32), ("taps", i32), ("dw_tap_stride", i32), ("p_fin", BnFin),
+                ("chain", i32), ("reserved_", i32)]
 
 
 class BnPtrs(C.Structure):
@@ -89,6 +90,7 @@ SIGNATURES = {
     "c3d_pw_wgrad_ws_floats": (i64, [i32, i32]),
     "c3d_pw_gemm_wg_ws_floats": (i64, [i32, i32]),
     "c3d_pw_wgrad": (i32, [C.POINTER(PwWgradArgs), vp]),
+    "c3d_pw_wgrad_flush": (i32, [vp]),
     "c3d_bn_finalize": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp]),
     "c3d_bn_se_finalize": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp, vp,
                                  i32, vp, vp, vp, vp, vp]),

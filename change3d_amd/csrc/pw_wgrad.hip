@@ -541,6 +541,7 @@ extern "C" int64_t c3d_pw_wgrad_ws_floats(int32_t N, int32_t K) { return (int64_
 
 int c3d_detail_pw_wgrad_wide(const c3d_pw_wgrad_args* args, void* stream);   // pw_wide.hip
 int c3d_detail_pw_wgrad_v2(const c3d_pw_wgrad_args* args, hipStream_t stream);   // pw_wgrad_v2.hip: bf16, dense rows
+int c3d_detail_pw_wgrad_v2_flush(hipStream_t stream);                             // pending partials of a chained launch
 
 extern "C" int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream) {
   if (!args || !args->p || !args->q || !args->dw || !args->ws) return C3D_E_BADARG;
@@ -561,11 +562,17 @@ extern "C" int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream) {
   else if (a.dtype == C3D_DT_BF16) {
     // flat-staged, transposing-read kernel for dense rows (C3D_OPT_PW_WGRAD_V2); what it does not take runs here
     rc = c3d_option_pw_wgrad_v2 ? c3d_detail_pw_wgrad_v2(args, s) : C3D_E_UNSUPPORTED;
-    if (rc == C3D_E_UNSUPPORTED) rc = launch_wgrad<bf16_t>(a, s);
+    if (rc == C3D_E_UNSUPPORTED) {
+      // (a launch of this kernel may reuse the workspace pending partials sit in: they are reduced first)
+      if (a.chain) { const int rcf = c3d_detail_pw_wgrad_v2_flush(s); if (rcf != 0) return rcf; }
+      rc = launch_wgrad<bf16_t>(a, s);
+    }
   }
   if (rc == C3D_E_UNSUPPORTED) rc = c3d_detail_pw_wgrad_wide(args, stream);   // shapes that do not fit its LDS plan
   return rc;
 }
+
+extern "C" int c3d_pw_wgrad_flush(void* stream) { return c3d_detail_pw_wgrad_v2_flush(reinterpret_cast<hipStream_t>(stream)); }
 
 #ifdef C3D_PW_CLOCK
 extern "C" int c3d_debug_wgrad_clock(unsigned long long* out, int reset) {   // out[WCLK_WAVES][8]

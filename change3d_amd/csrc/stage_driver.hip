@@ -85,7 +85,7 @@ struct Plan {
   std::vector<BlkFwd> f;
   std::vector<BlkBwd> b;
   size_t fwd_acc_off = 0, fwd_acc_bytes = 0, fwd_total = 0;
-  size_t bwd_acc_off = 0, bwd_acc_bytes = 0, bwd_total = 0, wgrad_ws = 0, wgrad_ws_fused = 0;
+  size_t bwd_acc_off = 0, bwd_acc_bytes = 0, bwd_total = 0, wgrad_ws = 0, wgrad_ws2 = 0, wgrad_ws_fused = 0;
   size_t y_bytes = 0, dx_bytes = 0;
 };
 
@@ -105,6 +105,7 @@ int g_mask_in_dgrad = 3;   // c3d_set_option(C3D_OPT_MASK_IN_DGRAD, ...): bit 0 
                            // gradient, bit 1 = that block's BatchNorm_c-backward sums there too (no c3d_block_out_bwd launch at all)
 int g_fold_se = 1;         // c3d_set_option(C3D_OPT_FOLD_SE, ...): SE gate computed by conv_c's workgroups (forward)
 int g_fuse_wgrad = 3;      // c3d_set_option(C3D_OPT_FUSE_WGRAD, ...): bit 0 conv_a, bit 1 conv_c
+int g_wgrad_chain = 1;     // c3d_set_option(C3D_OPT_PW_WGRAD_V2, value): bit 1 clear = chained reduction of the separate weight gradients
 
 int make_plan(const c3d_stage_desc* d, Plan& P) {
   if (!d || d->n_blocks <= 0 || !d->blocks || d->B <= 0 || d->T <= 0 || d->H <= 0 || d->W <= 0) return C3D_E_BADARG;
@@ -205,6 +206,7 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
   size_t ring_dx[BWD_RING_MAX + 1];
   for (int r = 0; r < R + 1; ++r) ring_dx[r] = mx_dx ? cb.take(mx_dx) : SIZE_MAX;
   P.wgrad_ws = cb.take((size_t)wsf * 4);
+  P.wgrad_ws2 = cb.take((size_t)wsf * 4);   // chained weight-gradient launches alternate between the two (c3d_pw_wgrad_args.chain)
   P.wgrad_ws_fused = wsf_fused ? cb.take((size_t)wsf_fused * 4) : SIZE_MAX;   // main stream: kernel, then its reducer
   for (int i = 0; i < n; ++i) {
     const BlkGeom& G = P.g[i];
@@ -709,8 +711,10 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   const int dt = d->dtype, B = d->B, T = d->T;
   const double e = (double)es(dt);
   RC(zero_fill(at(wb, P.bwd_acc_off), P.bwd_acc_bytes, st));
-  float* wgws = atT<float>(wb, P.wgrad_ws);
+  float* const wgws_ab[2] = {atT<float>(wb, P.wgrad_ws), atT<float>(wb, P.wgrad_ws2)};
+  int wg_n = 0;   // weight-gradient launches of this call: launch k leaves its partials in workspace k & 1, launch k + 1 reduces them
   float* wgws_fused = atT<float>(wb, P.wgrad_ws_fused);
+  c3d_detail_pw_wgrad_v2_drop();   // (nothing may be pending from a call that returned early)
   const bool wimg = use_pw_img(d);   // transposed weight images written by this step's c3d_stage_fwd (training mode)
   auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
   const void* cur_dy = dy;
@@ -765,7 +769,8 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     const bool fuse_wc = (g_fuse_wgrad & 2) && fuse_wgrad(d, G.Cop, G.Cip, C3D_WG_SWISH) && G.Cop <= 48;
     if (!fuse_wc)
     RC(side_run(st, [&](hipStream_t s2) {
-      WgCall w(g, b, k.dw_c, wgws, G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
+      WgCall w(g, b, k.dw_c, wgws_ab[wg_n++ & 1], G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
+      w.a.chain = g_wgrad_chain;
       w.a.p2 = c; w.a.p_coef = coef_c; w.a.q_mode = C3D_PRO_BN_SE_SWISH; w.a.q_ss = ss_b; w.a.q_gate = gate;
       w.a.rows_per_sample = rps;
       if (consb) w.a.p_fin = fin_coef_consume(dsums_c, k.bn_c, (double)G.Mo, mr_c, false);
@@ -816,7 +821,8 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       }
       RC(pw_launch(p.a, st));
       RC(side_run(st, [&](hipStream_t s2) {
-        WgCall w(g, xin, k.dw_sc, wgws, G.Mo, G.Cin, G.Co, G.Cin, 1, dt);
+        WgCall w(g, xin, k.dw_sc, wgws_ab[wg_n++ & 1], G.Mo, G.Cin, G.Co, G.Cin, 1, dt);
+        w.a.chain = g_wgrad_chain;
         if (scbn) {
           w.a.p2 = sc; w.a.p_coef = coef_1;
           if (consb) w.a.p_fin = fin_coef_consume(dsums_1, k.bn_sc, (double)G.Mo, mr_1, false);
@@ -833,7 +839,8 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     bool mask_next = false, sums_next = false;
     if (!fuse_wa)
     RC(side_run(st, [&](hipStream_t s2) {
-      WgCall w(t2, xin, k.dw_a, wgws, G.M, G.Cin, G.Ci, G.Cin, 1, dt);
+      WgCall w(t2, xin, k.dw_a, wgws_ab[wg_n++ & 1], G.M, G.Cin, G.Ci, G.Cin, 1, dt);
+      w.a.chain = g_wgrad_chain;
       w.a.p2 = a; w.a.p_coef = coef_a;
       if (consb) w.a.p_fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, false);
       return wg_launch(w.a, s2);
@@ -868,6 +875,8 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     premasked = mask_next;
     sums_done = sums_next;
   }
+  // the last chained weight gradient's partials (its own reducer launch, on the stream it ran on)
+  if (wg_n) RC(side_run(st, [&](hipStream_t s2) { return c3d_pw_wgrad_flush(s2); }));
   return 0;
 }
 
@@ -885,7 +894,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_FOLD_SE: g_fold_se = value ? 1 : 0; return 0;
     case C3D_OPT_MASK_IN_DGRAD: g_mask_in_dgrad = value & 3; return 0;
     case C3D_OPT_DW_RING: c3d_option_dw_ring = value & 15; return 0;
-    case C3D_OPT_PW_WGRAD_V2: c3d_option_pw_wgrad_v2 = value ? 1 : 0; return 0;
+    case C3D_OPT_PW_WGRAD_V2: c3d_option_pw_wgrad_v2 = value & 1; g_wgrad_chain = (value & 2) ? 0 : 1; return 0;
     default: return C3D_E_BADARG;
   }
 }

@@ -317,13 +317,16 @@ def _ws(device, n_floats):
 
 def pw_wgrad(p, q, dw, *, M, K, N, dw_sn, dw_sk, dtype, p2=None, p_coef=None, q_mode=PRO_NONE, q_ss=None,
              q_gate=None, rows_per_sample=0, row_mode=ROWS_DENSE, rpg=0, gstride=0, H=0, W=0, dy=0, dx=0,
-             q_ptr=None, dw_ptr=None, taps=0, dw_tap_stride=0):
+             q_ptr=None, dw_ptr=None, taps=0, dw_tap_stride=0, chain_ws=None):
+    """chain_ws: a caller-owned workspace tensor (c3d_pw_wgrad_ws_floats(N, K) floats) -> a CHAINED launch (c3d_pw_wgrad_args.chain):
+    its partials stay pending in chain_ws until the next chained launch or pw_wgrad_flush(); alternate two workspaces."""
     a = L.PwWgradArgs()
     a.p, a.p2 = _p(p), _p(p2)
     a.q = q_ptr if q_ptr is not None else _p(q)
     a.dw = dw_ptr if dw_ptr is not None else _p(dw)
-    ws = _ws(p.device, L.lib().c3d_pw_wgrad_ws_floats(N, K))
+    ws = chain_ws if chain_ws is not None else _ws(p.device, L.lib().c3d_pw_wgrad_ws_floats(N, K))
     a.ws = ws.data_ptr()
+    a.chain = 1 if chain_ws is not None else 0
     a.p_coef, a.q_ss, a.q_gate = _p(p_coef), _p(q_ss), _p(q_gate)
     a.M, a.gstride, a.rows_per_sample = M, gstride, rows_per_sample
     a.K, a.Kp, a.N, a.Np = K, cpad(K), N, cpad(N)
@@ -332,6 +335,11 @@ def pw_wgrad(p, q, dw, *, M, K, N, dw_sn, dw_sk, dtype, p2=None, p_coef=None, q_
     a.q_mode, a.dtype = q_mode, dtype
     a.taps, a.dw_tap_stride = taps, dw_tap_stride
     _launch(_detail("c3d_pw_wgrad", a), a.M * (a.Np * (2 if p2 is not None else 1) + a.Kp) * _es(dtype), L.lib().c3d_pw_wgrad, C.byref(a), _stream())
+
+
+def pw_wgrad_flush():
+    """Reduce the pending partials of the last chained pw_wgrad launch (include/change3d_hip.h: c3d_pw_wgrad_flush)."""
+    L.check(L.lib().c3d_pw_wgrad_flush(_stream()), "c3d_pw_wgrad_flush")
 
 
 # ------------------------------------------------------------------------------- BN / SE

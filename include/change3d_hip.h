@@ -214,10 +214,19 @@ typedef struct c3d_pw_wgrad_args {
                                     /* dw + t*dw_tap_stride (reference model/change_decoder.py:30-45); 0/1 = dy,dx */
   c3d_bn_fin p_fin;                 /* p_fin.sums != NULL: the AFFINE2 coefficients are rebuilt from the completed   */
                                     /* single-stripe sums (gamma, mr, count as in c3d_bn_bwd_coef) instead of p_coef  */
+  int32_t chain;                    /* 1: the per-workgroup partials of this launch may stay PENDING in `ws` -- the next */
+  int32_t reserved_;                /* chained launch on the same stream adds them into dw in its prologue (same fixed  */
+                                    /* order as the reducer launch it replaces: bit-identical dw), c3d_pw_wgrad_flush    */
+                                    /* completes the last one.  The caller alternates between two `ws` buffers and does  */
+                                    /* not touch a pending `ws` / read `dw` before the flush.  0 (default): dw is        */
+                                    /* complete, in stream order, when c3d_pw_wgrad returns                              */
 } c3d_pw_wgrad_args;
 
 int64_t c3d_pw_wgrad_ws_floats(int32_t N, int32_t K);
 int c3d_pw_wgrad(const c3d_pw_wgrad_args* args, void* stream);
+/* Adds the pending partials of this thread's last chained c3d_pw_wgrad launch (if any) into its dw, on `stream` (the stream of
+ * that launch).  The stage driver calls it at the end of c3d_stage_bwd; a no-op when nothing is pending.                      */
+int c3d_pw_wgrad_flush(void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Train-mode BatchNorm3d split (reference model/x3d.py:97,179,207,220,298): statistics are
@@ -527,7 +536,9 @@ int c3d_side_join(void* stream);
  *                         to the register-prefetch kernel; default 5 = measured best
  *   C3D_OPT_PW_WGRAD_V2 : 0 = c3d_pw_wgrad of bf16 dense rows on the first kernel (operand-split staging, 32-row tiles;
  *                         csrc/pw_wgrad.hip) instead of the flat-staged, transposing-read one (csrc/pw_wgrad_v2.hip, default 1);
- *                         same operand arithmetic, products summed in another order (f32 rounding apart)                      */
+ *                         same operand arithmetic, products summed in another order (f32 rounding apart); bit 1 SET = the stage
+ *                         driver's separate weight gradients each launch their own reducer (default: chained,
+ *                         c3d_pw_wgrad_args.chain -- bit-identical gradients either way)                                       */
 enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3, C3D_OPT_FOLD_SE = 4,
        C3D_OPT_MASK_IN_DGRAD = 5, C3D_OPT_DW_RING = 6, C3D_OPT_PW_WGRAD_V2 = 7 };
 int c3d_set_option(int32_t option, int32_t value);

@@ -382,6 +382,58 @@ def test_pw_wgrad_v2_matches_the_first_kernel(K, N, rows, B, mode):
     assert e1 <= 2.0 * e0 + 2e-5 * sc + 1e-4, f"v2 vs f64 product {e1:.3e}, first kernel {e0:.3e}"
 
 
+# Chained launches (c3d_pw_wgrad_args.chain): the partials of launch k are added into dw_k by launch k + 1's prologue (the last
+# ones by c3d_pw_wgrad_flush) in the reducer kernel's order -- every dw must equal, BIT FOR BIT, what the same launches give
+# with a reducer launch each.  Sequence as the stage driver issues it: conv_c / conv_a of the res4 shapes alternating, a
+# strided shortcut gradient in between (first kernel: pending partials are flushed in front of it), two workspaces in turn.
+def test_pw_wgrad_chained_reduction_is_bit_identical():
+    _need_gpu()
+    from change3d_amd import ops
+    dtype = torch.bfloat16
+    B, rows = 6, 1024
+    M = B * rows
+    Ci, Co = 216, 96
+    Cip, Cop = ops.cpad(Ci), ops.cpad(Co)
+    dev = lambda t: t.to(DEV, dtype).contiguous()
+    t2, a_, b_ = dev(padc(rnd((M, Ci), 70), Cip)), dev(padc(rnd((M, Ci), 71), Cip)), dev(padc(rnd((M, Ci), 72), Cip))
+    g, c, x = dev(padc(rnd((M, Co), 73), Cop)), dev(padc(rnd((M, Co), 74), Cop)), dev(padc(rnd((M, Co), 75), Cop))
+    coef_a = torch.cat([padc(rnd((Ci,), 76), Cip), padc(rnd((Ci,), 77, 0.1), Cip), padc(rnd((Ci,), 78, 0.1), Cip)]).to(DEV)
+    coef_c = torch.cat([padc(rnd((Co,), 79), Cop), padc(rnd((Co,), 80, 0.1), Cop), padc(rnd((Co,), 81, 0.1), Cop)]).to(DEV)
+    ss = torch.cat([padc(rnd((Ci,), 82).abs() + 0.5, Cip), padc(rnd((Ci,), 83, 0.3), Cip)]).to(DEV)
+    gate = padc(torch.sigmoid(rnd((B, Ci), 84)), Cip).to(DEV).contiguous()
+    Hs = 32
+    xs = dev(rnd((B, Hs, Hs, 48), 85))                      # strided shortcut: rows (b, i, j) read pixel (2i, 2j)
+    gs = dev(rnd((B * (Hs // 2) * (Hs // 2), Cop), 86))
+    dt = ops.dt_code(dtype)
+    wsf = int(ops.L.lib().c3d_pw_wgrad_ws_floats(Ci, Cip))
+    ws2 = [torch.empty(wsf, dtype=torch.float32, device=DEV) for _ in range(2)]
+
+    def run(chained):
+        dws = [torch.full((Co, Ci), 0.25, device=DEV), torch.full((Ci, Co), 0.25, device=DEV), torch.full((Co, 48), 0.25, device=DEV),
+               torch.full((Co, Ci), 0.25, device=DEV), torch.full((Ci, Co), 0.25, device=DEV)]
+        k = [0]
+        def ws():
+            k[0] += 1
+            return ws2[k[0] & 1] if chained else None
+        conv_c = lambda dw: ops.pw_wgrad(g, b_, dw, M=M, K=Ci, N=Co, dw_sn=Ci, dw_sk=1, dtype=dt, p2=c, p_coef=coef_c,
+                                         q_mode=ops.PRO_BN_SE_SWISH, q_ss=ss, q_gate=gate, rows_per_sample=rows, chain_ws=ws())
+        conv_a = lambda dw: ops.pw_wgrad(t2, x, dw, M=M, K=Co, N=Ci, dw_sn=Co, dw_sk=1, dtype=dt, p2=a_, p_coef=coef_a, chain_ws=ws())
+        conv_c(dws[0]); conv_a(dws[1])
+        ops.pw_wgrad(gs, xs, dws[2], M=gs.shape[0], K=48, N=Co, dw_sn=48, dw_sk=1, dtype=dt, row_mode=ops.ROWS_STRIDE2, H=Hs, W=Hs,
+                     chain_ws=ws())
+        conv_c(dws[3]); conv_a(dws[4])
+        if chained:
+            ops.pw_wgrad_flush()
+        torch.cuda.synchronize()
+        return [d.cpu() for d in dws]
+
+    plain, chained = run(False), run(True)
+    for i, (u, v) in enumerate(zip(plain, chained)):
+        assert torch.isfinite(v).all() and (v - 0.25).abs().max().item() > 0, f"launch {i}: nothing was accumulated"
+        assert torch.equal(u, v), f"launch {i}: chained reduction differs from the reducer launch by {(u - v).abs().max().item():.3e}"
+    ops.pw_wgrad_flush()   # nothing pending: a no-op
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_pw_wgrad_row_modes(dtype):
     _need_gpu()
