@@ -243,8 +243,14 @@ template <int TT> struct V2Geo {
 // two unsigned compares and one 64-bit address instead of two divisions by constants, a frame multiply and three 64-bit
 // multiply-adds per slot (9 slots: ~200 of a tile's ~1 060 VALU instructions in a kernel whose VALU is its busiest unit).
 // The launcher takes it when the offset fits 22 bits and the tensor 2^31 elements.
-template <typename T, int TT, bool PK>
-__global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x, const float* __restrict__ ss,
+// HV (round 6, three frames): lane = (column, FOUR channels, four output rows) instead of (column, eight channels, two rows) --
+// the two halves of a wave read the two half-vector planes of its channel vector.  The tap walk then runs column tap -> frame ->
+// INPUT row: every staged value is read once per column tap and feeds all the output rows / frames it reaches (6 input rows
+// for 4 output rows), and the 9 weights of a column tap stay in registers: 81 ds_read_b128 per lane and tile for the same
+// 1 008 FMAs that took 162 (the kernel was co-limited by LDS reads and VALU issue at two waves per SIMD; the round-4 attempt
+// at more waves -- one row per lane -- doubled the reads per FMA and lost).
+template <typename T, int TT, bool PK, bool HV = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HV ? 2 : 1, 2))) void dw_fwd_v2_kernel(const T* __restrict__ x, const float* __restrict__ ss,
                                                         const float* __restrict__ w, T* __restrict__ y,
                                                         double* __restrict__ nc, const DwGeom g,
                                                         const int tiles_per_wg, const c3d_bn_fin fin) {
@@ -378,6 +384,80 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
     if (tl + 1 < tl1) V2_ISSUE(tl + 1)
     __syncthreads();
 
+    if constexpr (HV) {
+      static_assert(TT == 3 && PYR == 2, "half-vector lanes: three frames, 8 x 16 tiles");
+      const int hv_half = lane >> 5, hv_yp = (lane >> 4) & 1;
+      // columns of the second row group rotated by 8: the four 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, ...) mix
+      // lanes of both row groups, 4 rows x 18 float4 = 128 B (mod 256 B) apart -- unrotated, x = 4..11 of the one falls on the
+      // bank quads of x = 12..15, 0..3 of the other
+      const int hv_x = (lane + 8 * hv_yp) & 15;
+      float acc4[TT][4][4];
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc4[t][r][j] = 0.f;
+      const float4* pl = tile + (wcv * 2 + hv_half) * PLANE + (4 * hv_yp) * V2_IW + hv_x;
+      const float4* wl4 = reinterpret_cast<const float4*>(wl) + wcv * 2 + hv_half;   // tap k at wl4[8 k]
+#pragma unroll 1
+      for (int kx = 0; kx < 3; ++kx) {
+        float4 wk[3][3];   // [kt][ky] of this column tap
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) wk[kt][ky] = wl4[(kt * 9 + ky * 3 + kx) * 8];
+#pragma unroll
+        for (int ti = 0; ti < TT; ++ti) {
+#pragma unroll
+          for (int iy = 0; iy < 6; ++iy) {
+            const float4 v = pl[(ti * V2_IH + iy) * V2_IW + kx];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              const int oy = iy - ky;
+              if (oy >= 0 && oy < 4) {
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                  const int to = ti - kt + 1;  // out[to] += in[to + kt - 1] * w[kt]
+                  if (to >= 0 && to < TT) {
+                    acc4[to][oy][0] = fmaf(v.x, wk[kt][ky].x, acc4[to][oy][0]);
+                    acc4[to][oy][1] = fmaf(v.y, wk[kt][ky].y, acc4[to][oy][1]);
+                    acc4[to][oy][2] = fmaf(v.z, wk[kt][ky].z, acc4[to][oy][2]);
+                    acc4[to][oy][3] = fmaf(v.w, wk[kt][ky].w, acc4[to][oy][3]);
+                  }
+                }
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);   // one frame's six reads in flight, not all eighteen (registers)
+        }
+      }
+      const int ox = tx * V2_TW + hv_x;
+      T* const dst0 = y + (((size_t)b * g.T * g.H + (ty * V2_TH + 4 * hv_yp)) * g.W + ox) * g.Cp + cbase + hv_half * 4;
+      const int64_t row_st = (int64_t)g.W * g.Cp, frm_st = (int64_t)g.H * g.W * g.Cp;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oy = ty * V2_TH + 4 * hv_yp + r;
+        if (c_ok && oy < g.H && ox < g.W) {
+#pragma unroll
+          for (int t = 0; t < TT; ++t) {
+            if (t < g.T) {
+              T* dst = dst0 + (t * frm_st + r * row_st);
+              if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(acc4[t][r][0], acc4[t][r][1]), pack_bf16x2(acc4[t][r][2], acc4[t][r][3]));
+              } else {
+                *reinterpret_cast<float4*>(dst) = make_float4(acc4[t][r][0], acc4[t][r][1], acc4[t][r][2], acc4[t][r][3]);
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float rr = round_as<T>(acc4[t][r][j]);
+                s1[j] += rr; s2[j] = fmaf(rr, rr, s2[j]);
+              }
+            }
+          }
+        }
+      }
+    } else {
     float acc[TT][PYR][8];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
@@ -439,9 +519,24 @@ __global__ __launch_bounds__(256) void dw_fwd_v2_kernel(const T* __restrict__ x,
         }
       }
     }
+      }
   }
 #undef V2_ISSUE
   if (nc == nullptr) return;
+  if constexpr (HV) {   // a lane holds four channels: the 32 lanes of each half of the wave are summed
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r1 = s1[j], r2 = s2[j];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { r1 += __shfl_xor(r1, o, 64); r2 += __shfl_xor(r2, o, 64); }
+      const int c = cbase + (lane >> 5) * 4 + j;
+      if ((lane & 31) == 0 && c < g.C) {
+        atomicAdd(nc + ((size_t)b * g.Cp + c) * 2, (double)r1);
+        atomicAdd(nc + ((size_t)b * g.Cp + c) * 2 + 1, (double)r2);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float r1 = wave_sum(s1[j]), r2 = wave_sum(s2[j]);
@@ -482,7 +577,27 @@ int launch_fwd_v2(const void* x, const float* ss, const float* w, void* y, doubl
   // packed slot descriptors (bf16): the largest tile-relative element offset in 22 bits, the tensor in 2^31 elements
   const size_t rel_max = (((size_t)(g.T - 1) * g.H + V2Geo<TT>::IH) * g.W + V2_IW) * g.Cp + g.Cp;
   const bool pk = sizeof(T) == 2 && rel_max < ((size_t)1 << 22) && (size_t)g.B * g.T * g.H * g.W * g.Cp < ((size_t)1 << 31);
-  if (pk) {
+  // half-vector lanes (C3D_OPT_DW_FWD_HV: bit 0 bf16 storage, bit 1 f32 storage), three frames
+  constexpr bool HVT = TT == 3;
+  const bool hv = HVT && (c3d_option_dw_fwd_hv & (sizeof(T) == 2 ? 1 : 2)) != 0;
+  if (hv) {
+    static bool attr_hv = false;
+    if (!attr_hv) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2_kernel<T, TT, false, HVT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2_kernel<T, TT, sizeof(T) == 2, HVT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_hv = true;
+    }
+    if (pk)
+      dw_fwd_v2_kernel<T, TT, sizeof(T) == 2, HVT><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
+                                                                                    reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
+    else
+      dw_fwd_v2_kernel<T, TT, false, HVT><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
+                                                                            reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
+  } else if (pk) {
     static bool attr_pk = false;
     if (!attr_pk) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2_kernel<T, TT, sizeof(T) == 2>),

@@ -516,7 +516,10 @@ __attribute__((visibility("hidden"))) int c3d_detail_pw_wgrad_v2(const c3d_pw_wg
   static const int mt_env = c3d_env("C3D_WG2_MT") ? atoi(c3d_env("C3D_WG2_MT")) : 0;
   if (cap_env > 0 && cap_env <= W2_MAX_PARTS) cap = cap_env;
   else if (c3d_side_launch) {   // beside the data-gradient chain: 7/8 of the CUs (launch_hints.h)
-    const int64_t side_cap = side_env > 0 ? side_env : (int64_t)device_cus() * 7 / 8;
+#ifndef W2_SIDE_EIGHTHS
+#define W2_SIDE_EIGHTHS 7
+#endif
+    const int64_t side_cap = side_env > 0 ? side_env : (int64_t)device_cus() * W2_SIDE_EIGHTHS / 8;
     if (side_cap < cap) cap = side_cap;
   }
   // rows per tile: the tallest of 256 / 128 / 64 that fits the item budget, LDS and the two-samples-per-tile rule, and still

@@ -538,9 +538,13 @@ int c3d_side_join(void* stream);
  *                         csrc/pw_wgrad.hip) instead of the flat-staged, transposing-read one (csrc/pw_wgrad_v2.hip, default 1);
  *                         same operand arithmetic, products summed in another order (f32 rounding apart); bit 1 SET = the stage
  *                         driver's separate weight gradients each launch their own reducer (default: chained,
- *                         c3d_pw_wgrad_args.chain -- bit-identical gradients either way)                                       */
+ *                         c3d_pw_wgrad_args.chain -- bit-identical gradients either way)
+ *   C3D_OPT_DW_FWD_HV   : c3d_dw333_fwd, stride 1, three frames, on half-vector lanes (a lane = 4 channels x 4 output rows, tap
+ *                         walk column -> frame -> input row: half the LDS reads per FMA; csrc/dw_conv.hip): bit 0 = bf16
+ *                         storage, bit 1 = f32 storage; the taps are summed in another order than the 8-channel lanes (f32
+ *                         rounding apart)                                                                                   */
 enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3, C3D_OPT_FOLD_SE = 4,
-       C3D_OPT_MASK_IN_DGRAD = 5, C3D_OPT_DW_RING = 6, C3D_OPT_PW_WGRAD_V2 = 7 };
+       C3D_OPT_MASK_IN_DGRAD = 5, C3D_OPT_DW_RING = 6, C3D_OPT_PW_WGRAD_V2 = 7, C3D_OPT_DW_FWD_HV = 8 };
 int c3d_set_option(int32_t option, int32_t value);
 /* Per-launch profile of the stage driver: between c3d_prof_begin and c3d_prof_end every kernel c3d_stage_fwd /
  * c3d_stage_bwd enqueue is bracketed by a HIP event pair on its launch stream and billed its algorithmic bytes
