@@ -127,6 +127,14 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
     G.Cin = k.cin; G.Ci = k.cinner; G.Co = k.cout;
     G.Cinp = cpad(k.cin); G.Cip = cpad(k.cinner); G.Cop = cpad(k.cout);
     G.se = k.se_width > 0; G.Cr = k.se_width; G.sc_conv = k.has_sc_conv != 0; G.sc_bn = k.has_sc_bn != 0;
+    // The narrow pointwise kernels (channel counts up to 224) address rows with 32-bit byte offsets into bounds-checked buffer
+    // resources (csrc/pw_gemm.hip): a tensor of 2 GiB or more would be refused by the first launch that meets it, in the MIDDLE
+    // of a stage pass.  Refuse the stage here instead -- c3d_stage_ws_bytes is the caller's first contact with a geometry.
+    // (bf16, 256 x 256, T = 3: B <= 96 per GPU; f32: half of that.  The wide (res5) kernels have no such limit.)
+    {
+      const int cmax = std::max(std::max(G.Cinp, G.Cip), G.Cop);
+      if (cmax <= 224 && (int64_t)std::max(G.M, G.Mo) * cmax * (int64_t)e >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
+    }
     H = G.Ho; W = G.Wo;
   }
   // ---- forward workspace: activations, then f32 vectors, then ONE contiguous f64 accumulator region

@@ -644,6 +644,12 @@ class StageBinding:
     def sizes(self):
         out = [C.c_int64() for _ in range(4)]
         rc = L.lib().c3d_stage_ws_bytes(C.byref(self.desc), *[C.byref(v) for v in out])
+        if rc == -2:   # C3D_E_UNSUPPORTED: the one geometry limit of the stage API (include/change3d_hip.h)
+            d = self.desc
+            raise L.Change3DHipError(
+                f"stage geometry B={d.B} T={d.T} {d.H}x{d.W} is too large: an activation tensor of a stage with <= 224 channels "
+                f"must stay under 2 GiB (32-bit offsets in the pointwise kernels); reduce the per-GPU batch "
+                f"(bf16 at 256x256, T=3: B <= 96; f32: B <= 48)")
         if rc != 0:
             raise L.Change3DHipError(f"c3d_stage_ws_bytes failed with code {rc}")
         return tuple(int(v.value) for v in out)   # ws_fwd, ws_bwd, y, dx bytes

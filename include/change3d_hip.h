@@ -461,6 +461,9 @@ int c3d_cc_preprocess(const uint8_t* img, const uint8_t* swap, const float* lut,
  * backward temporaries.  Weight gradients run on an internal side stream that forks from / joins `stream`
  * with events (C3D_WGRAD_SIDE=0 disables it); c3d_side_join makes `stream` wait for everything issued
  * there so far (call it before reading parameter gradients and before freeing ws_fwd / ws_bwd).
+ * Size limit: every activation tensor of a stage whose channel counts are <= 224 must stay under 2 GiB (32-bit byte offsets in
+ * the narrow pointwise kernels); c3d_stage_ws_bytes / c3d_stage_fwd / c3d_stage_bwd return C3D_E_UNSUPPORTED for a larger
+ * geometry BEFORE touching the device (bf16 at 256 x 256, T = 3: B <= 96 per GPU; f32: B <= 48).
  * ------------------------------------------------------------------------------------ */
 typedef struct c3d_bn_ptrs {
   const float* gamma; const float* beta;       /* .weight / .bias                                       */
@@ -514,6 +517,14 @@ int c3d_stage_fwd(const c3d_stage_desc* d, const void* x, void* ws_fwd, void* y,
  * stream may lag the chain by two blocks.                                                                        */
 int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void* y, const void* dy, void* ws_fwd, void* ws_bwd,
                   void* dx, void* stream);
+/* c3d_side_join(stream): `stream` waits (on the device) for everything the library has issued on its side stream so far.
+ * CONTRACT: the fork / done events between the two streams are created with hipEventDisableSystemFence -- they order the two
+ * queues of ONE device and carry no system-scope release.  After c3d_side_join the weight gradients are visible to later work
+ * on `stream` on this device; a consumer OUTSIDE the device -- a peer GPU (RCCL), the host reading p.grad -- must be ordered
+ * behind `stream` by the caller's own system-scope operation: a default-flag event / hipStreamSynchronize / a stream-ordered
+ * D2H copy or collective enqueued on `stream` (each of these releases at system scope when it completes).  torch's
+ * stream.synchronize(), tensor.cpu() and torch.distributed collectives issued on `stream` all qualify
+ * (tests/test_dp_gpu.py::test_side_join_then_host_readback_and_allreduce).                                                    */
 int c3d_side_join(void* stream);
 /* Run-time options of the library (process-wide; not thread-safe; all default to 1).  These are the ONLY run-time
  * switches: the product library never reads the environment (tuning knobs exist in the -DC3D_TUNING build only).
@@ -528,8 +539,11 @@ int c3d_side_join(void* stream);
  *                         shape allows it (c3d_pw_args.wg_mode): bit 0 = conv_a, bit 1 = conv_c; default = measured best
  *   C3D_OPT_FOLD_SE     : 0 = c3d_bn_se_finalize launches for the blocks with SqueezeExcitation (default 1: conv_c's workgroups
  *                         compute the gate of their samples, c3d_pw_args.se_w1)
- *   C3D_OPT_MASK_IN_DGRAD : 0 = c3d_block_out_bwd applies the ReLU mask itself everywhere (default 1: conv_a's fused data-gradient
- *                         launch of the NEXT block stores dx * (y > 0), c3d_block_out_bwd only sums)
+ *   C3D_OPT_MASK_IN_DGRAD : a BITFIELD, default 3 (the value is masked with 3).  bit 0: conv_a's data-gradient launch of the block
+ *                         ABOVE stores dx * (y > 0) -- c3d_block_out_bwd of this block only sums; bit 1 (needs bit 0): the same
+ *                         epilogue also takes this block's BatchNorm_c-backward sums (c3d_pw_args.add_sums / C3D_WG_MASKSUM) and
+ *                         the c3d_block_out_bwd launch is gone (35 of 41 per BCD step).  0 = c3d_block_out_bwd does everything;
+ *                         1 = the round-4 mask-only path (a caller that passes 1 meaning "on" gets THAT, not the default)
  *   C3D_OPT_DW_RING     : c3d_dw333_bwd_fused (bf16, stride 1) fed by an LDS-DMA ring (global_load_lds_dwordx4, two tiles ahead
  *                         for T <= 3, one for T = 5) instead of register prefetch: bit 0 = on, bit 2 = the requests are issued
  *                         one per tap step instead of in a burst, bit 3 = also on maps under 64 x 64; results are bit-identical

@@ -244,6 +244,7 @@ def test_e2e_cc_vs_oracle_conditioned_weights(seed):
     if worst[0][1] >= 1e-4 and os.path.isdir("gpurun_out"):
         torch.save(g_hip, f"gpurun_out/kink_fail_cc_{seed}.pt")
     assert med < 2e-5 and worst[0][1] < 1e-4 and len(granted) <= 8, (med, worst, granted)
+    assert all(u[3] < 6.0 for u in granted), ("a granted unit must lie within 6 sigma of zero", granted)
 
 
 def _beam_decoder(sd, args, dtype=torch.float32):

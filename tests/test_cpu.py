@@ -769,6 +769,27 @@ def test_pw_gemm_refuses_operands_of_two_gib_before_touching_the_device():
     assert L.lib().c3d_pw_gemm(C.byref(a), None) == -1
 
 
+def test_stage_api_refuses_an_oversize_geometry_up_front():
+    """The 2 GiB limit of the narrow pointwise kernels must surface where a caller first meets a geometry --
+    `c3d_stage_ws_bytes` (and with it c3d_stage_fwd / c3d_stage_bwd, which plan before they launch) -- not in the middle of a
+    stage pass: res2 of X3D-L (54 inner channels -> 56 padded) at 256 x 256, T = 3 holds B x 3 x 128 x 128 x 56 x 2 B per
+    tensor in bf16: B = 96 fits, B = 400 does not; the f32 path hits the limit at half the batch (no GPU needed: planning only)."""
+    import ctypes as C
+    from change3d_amd import _lib as L
+    blk = (L.BlockDesc * 1)()
+    blk[0].cin, blk[0].cinner, blk[0].cout, blk[0].stride = 24, 54, 24, 1
+    d = L.StageDesc()
+    d.n_blocks, d.T, d.H, d.W, d.training = 1, 3, 128, 128, 1
+    d.blocks = C.cast(blk, C.POINTER(L.BlockDesc))
+    out = [C.c_int64() for _ in range(4)]
+    for dtype, ok_b, bad_b in ((1, 96, 400), (0, 48, 200)):     # C3D_DT_BF16, C3D_DT_F32
+        d.dtype = dtype
+        d.B = ok_b
+        assert L.lib().c3d_stage_ws_bytes(C.byref(d), *[C.byref(v) for v in out]) == 0
+        d.B = bad_b
+        assert L.lib().c3d_stage_ws_bytes(C.byref(d), *[C.byref(v) for v in out]) == -2   # C3D_E_UNSUPPORTED
+
+
 def test_pw_gemm_checks_the_folded_block_output_backward_arguments_without_a_launch():
     """`c3d_pw_args.add_sums` / C3D_WG_MASKSUM (c3d_block_out_bwd of the previous block in the conv_a data gradient's epilogue,
     reference model/x3d.py:229-236): the sums are over the MASKED output, so they are an argument error without the mask, and the

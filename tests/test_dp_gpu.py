@@ -185,3 +185,71 @@ def test_overlapped_allreduce_through_rccl_single_rank():
         assert fired, "the stage hook did not launch the tail bucket"
         err = np.linalg.norm(flat.astype(np.float64) - 0.5 * ref) / np.linalg.norm(0.5 * ref)
         assert err < 1e-4, err
+
+
+def test_side_join_then_host_readback_and_allreduce():
+    """The contract of c3d_side_join (include/change3d_hip.h): the fork / done marks between the caller's stream and the
+    library's side stream carry no system-scope fence, so whoever reads the weight gradients from OUTSIDE the device right
+    behind the join relies on the caller's own stream-ordered operation.  Two such consumers, with NO device synchronisation
+    between `backward()` (whose end-of-pass callback is the join) and the read: (1) an asynchronous device-to-host copy of the
+    whole flat gradient buffer enqueued on the compute stream, (2) a sum all-reduce of it through RCCL (one-member group).
+    Both must equal the buffer as read after a full device synchronisation, bit for bit, over several steps (the weight
+    gradients are the LAST kernels of the pass on the side stream: a missing release shows as stale values here)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_join_readback_worker, args=(29500 + ((os.getpid() + 777) % 2000), q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert res == "ok", res
+
+
+def _join_readback_worker(port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from change3d_amd import synthetic as synth
+        from change3d_amd.model.trainer import Trainer
+        from change3d_amd.model.utils import BCEDiceLoss, ParamArena
+        from change3d_amd.parallel import ordered_hot_params
+        args = synth.make_args(size=SIZE)
+        args.act_dtype = torch.bfloat16
+        net = Trainer(args)
+        net.load_state_dict(synth.synth_state_dict(net, seed=16, mask_margin=0.25))
+        net = net.to(dev).train()
+        named, _ = ordered_hot_params(net)
+        arena = ParamArena(named, dev)
+        host = torch.empty(arena.flat_grad.numel(), dtype=torch.float32).pin_memory()
+        red = torch.empty_like(arena.flat_grad)
+        for it in range(4):
+            pre, post, tgt = (t.to(dev) for t in synth.synth_batch(BATCH, SIZE, seed=it))
+            arena.zero_grad()
+            torch.cuda.synchronize()
+            BCEDiceLoss(net.update_bcd(pre, post), tgt).backward()      # ends with the side-stream join; nothing else waits
+            host.copy_(arena.flat_grad, non_blocking=True)               # (1) D2H right behind the join, same stream
+            red.copy_(arena.flat_grad)
+            dist.all_reduce(red)                                         # (2) RCCL right behind the join (sum over one rank)
+            torch.cuda.current_stream().synchronize()
+            got_host = host.clone()
+            torch.cuda.synchronize()
+            ref = arena.flat_grad.cpu()
+            if not torch.equal(got_host, ref):
+                q.put(f"step {it}: host read-back differs from the synchronised buffer by {(got_host - ref).abs().max().item():.3e}")
+                return
+            if not torch.equal(red.cpu(), ref):
+                q.put(f"step {it}: all-reduced buffer differs by {(red.cpu() - ref).abs().max().item():.3e}")
+                return
+            if not (torch.isfinite(ref).all() and ref.abs().max().item() > 0):
+                q.put(f"step {it}: empty gradient buffer")
+                return
+        q.put("ok")
+    finally:
+        dist.destroy_process_group()

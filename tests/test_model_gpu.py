@@ -356,10 +356,15 @@ def test_e2e_vs_oracle_conditioned_weights_every_gradient_bcd():
     1e-5, EVERY parameter gradient to 1e-4 relative L2 (measured: worst 2e-5), on four weight seeds, kink-robustly
     (`_conditioned_case`): at most a handful of at-risk ReLU units may be granted the other side, and they are printed."""
     _need_gpu()
+    n_granted = []
     for wseed in (16, 23, 26, 27):
         errs, granted = _conditioned_case("bcd", wseed)
         worst, _, _ = _summ("bcd", wseed, errs, granted)
         assert worst < 1e-4 and len(granted) <= 6, (wseed, worst, granted)
+        assert all(u[3] < 6.0 for u in granted), ("a granted unit must lie within 6 sigma of zero", wseed, granted)
+        n_granted.append(len(granted))
+    # canary: granting must stay the exception -- on at least one of the four seeds the strict bound holds with NO unit granted
+    assert min(n_granted) == 0, n_granted
 
 
 def test_e2e_vs_oracle_conditioned_weights_every_gradient_scd():
@@ -371,10 +376,14 @@ def test_e2e_vs_oracle_conditioned_weights_every_gradient_scd():
     Now a flip is identified and granted by name (`_conditioned_case`, oracle/kinks.py): seed 16 -- the kinked one -- meets the
     strict bound as well, and a regression still fails on every seed (it is not a sum of at-risk deltas)."""
     _need_gpu()
+    n_granted = []
     for wseed in (23, 26, 27, 16):
         errs, granted = _conditioned_case("scd", wseed)
         worst, med, n_over = _summ("scd", wseed, errs, granted)
         assert worst < 1e-4 and med < 2e-5 and len(granted) <= 8, (wseed, worst, med, granted)
+        assert all(u[3] < 6.0 for u in granted), ("a granted unit must lie within 6 sigma of zero", wseed, granted)
+        n_granted.append(len(granted))
+    assert min(n_granted) == 0, n_granted   # canary (see the BCD case)
 
 
 @pytest.mark.parametrize("T,dtype,shape", [(3, torch.float32, (2, 64, 64)), (5, torch.float32, (2, 40, 72)),
