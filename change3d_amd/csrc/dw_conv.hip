@@ -645,21 +645,29 @@ template <int TT> struct V2S2Geo {
 
 // PK: packed slot descriptors, as in dw_fwd_v2_kernel (14 slots here: their per-tile decode was more VALU instructions than
 // the tile's 252 packed FMAs)
-template <typename T, int TT, bool PK>
-__global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ x, const float* __restrict__ ss,
+// W8 (round 6): 512 threads on the same tile -- two waves per channel vector, each on one HALF vector (4 channels) of the 64
+// output pixels, the two half-vector planes of the vector being separate LDS planes anyway.  The tile is 131 KB (four parity
+// planes of 9 x 33 pixels x 3 frames x 32 channels in f32): ONE workgroup per CU, i.e. with 256 threads one wave per SIMD --
+// nothing ran beside a wave that waited for its rows or for LDS (2.2-2.5 TB/s on rows that stream from HBM).  Same LDS
+// reads per FMA, half the staging items and half the tap walk per wave, twice the waves.
+template <typename T, int TT, bool PK, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256) void dw_fwd_v2s2_kernel(const T* __restrict__ x, const float* __restrict__ ss,
                                                           const float* __restrict__ w, T* __restrict__ y,
                                                           double* __restrict__ nc, const DwGeom g,
                                                           const int tiles_per_wg, const c3d_bn_fin fin) {
   typedef RawD<T> RW;
   typedef V2S2Geo<TT> G;
-  constexpr int NI = G::NI, SL = G::SL, PLANE = G::PLANE, PAR = G::PAR;
+  constexpr int NTHR = W8 ? 512 : 256;
+  constexpr int NI = G::NI, SL = (G::NI + NTHR - 1) / NTHR, PLANE = G::PLANE, PAR = G::PAR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wl = reinterpret_cast<float*>(smem);                  // [27][32]
   float* fss = wl + 27 * 32;                                   // [2][32] scale | shift of this chunk (fin.sums mode)
   float4* tile = reinterpret_cast<float4*>(fss + 64);          // [4 cv][2 halves][PLANE]
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wcv = __builtin_amdgcn_readfirstlane(tid >> 6);    // this wave's channel vector
+  const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wcv = wave_ & 3;                                   // this wave's channel vector
+  [[maybe_unused]] const int whalf = wave_ >> 2;               // W8: its half of the vector (0 with four waves)
   // lane = output pixel (ly, lx) of the tile; the columns of odd rows are rotated by one so that the two half rows a
   // ds_read_b128 lane group joins (rows S2_HX = 17 float4 apart) fall on 16 distinct bank quads (see dw_fwd_v2_kernel)
   const int ly = lane >> 4;
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ 
   const int cbase = c0 + wcv * 8;       // compute role
   const bool c_ok = cbase < g.Cp;
 
-  for (int i = tid; i < 27 * 32; i += 256) {
+  for (int i = tid; i < 27 * 32; i += NTHR) {
     const int tap = i / 32, c = c0 + (i & 31);
     wl[i] = (c < g.C) ? w[(size_t)c * 27 + tap] : 0.f;
   }
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ 
   if constexpr (PK) {
 #pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
-      const int i_ = tid + sl * 256;
+      const int i_ = tid + sl * NTHR;
       const int p_ = i_ >> 2;
       const int ix_ = p_ % S2_IW, q_ = p_ / S2_IW;
       const int iy_ = q_ % S2_IH, t_ = q_ / S2_IH;
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ 
     const int tx_ = (TL) % tiles_x, ty_ = (TL) / tiles_x;                                       \
     vmask = 0;                                                                                  \
     _Pragma("unroll") for (int sl = 0; sl < SL; ++sl) {                                         \
-      const int i_ = tid + sl * 256;                                                            \
+      const int i_ = tid + sl * NTHR;                                                           \
       const int p_ = i_ >> 2;                                                                   \
       const int ix_ = p_ % S2_IW, q_ = p_ / S2_IW;                                              \
       const int iy_ = q_ % S2_IH, t_ = q_ / S2_IH;                                              \
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ 
   float sc[8], sh[8];
   if (fin.sums) {   // BatchNorm_a scale / shift rebuilt from conv_a's completed sums (csrc/bn_fin.h), as in the stride-1 kernel
     if (tid == 0 && co.chunk == 0 && co.group == 0 && fin.training && fin.nbt) *fin.nbt += 1;
-    c3dfin::bn_consume(fin, g.C, g.Cp, c0, 32, co.group == 0, fss, fss + 32, tid, 256);
+    c3dfin::bn_consume(fin, g.C, g.Cp, c0, 32, co.group == 0, fss, fss + 32, tid, NTHR);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = s_ok ? fss[scv * 8 + j] : 0.f; sh[j] = s_ok ? fss[32 + scv * 8 + j] : 0.f; }
   } else {
@@ -750,7 +758,7 @@ __global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ 
     __syncthreads();
 #pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
-      const int i = tid + sl * 256;
+      const int i = tid + sl * NTHR;
       if (i < NI) {
         float f[8];
         if ((vmask >> sl) & 1u) {
@@ -772,6 +780,59 @@ __global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ 
     if (tl + 1 < tl1) S2_ISSUE(tl + 1)
     __syncthreads();
 
+    if constexpr (W8) {
+      float acc4[TT][4];
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc4[t][j] = 0.f;
+      const float4* pl = tile + (wcv * 2 + whalf) * PLANE + ly * S2_HX + lx;
+      const float4* wl4 = reinterpret_cast<const float4*>(wl) + wcv * 2 + whalf;   // tap k at wl4[8 k]
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          float4 wk[3];
+#pragma unroll
+          for (int kt = 0; kt < 3; ++kt) wk[kt] = wl4[(kt * 9 + ky * 3 + kx) * 8];
+          const int off = ((ky & 1) * 2 + (kx & 1)) * PAR + (ky >> 1) * S2_HX + (kx >> 1);   // compile-time immediate
+#pragma unroll
+          for (int ti = 0; ti < TT; ++ti) {
+            const float4 v = pl[ti * 4 * PAR + off];
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+              const int to = ti - kt + 1;
+              if (to >= 0 && to < TT) {
+                acc4[to][0] = fmaf(v.x, wk[kt].x, acc4[to][0]); acc4[to][1] = fmaf(v.y, wk[kt].y, acc4[to][1]);
+                acc4[to][2] = fmaf(v.z, wk[kt].z, acc4[to][2]); acc4[to][3] = fmaf(v.w, wk[kt].w, acc4[to][3]);
+              }
+            }
+          }
+          if constexpr (TT == 3)   // (keeps the LDS reads of all nine steps from being hoisted above the first FMA: see pin_acc3)
+            asm volatile("" : "+v"(acc4[0][0]), "+v"(acc4[0][1]), "+v"(acc4[0][2]), "+v"(acc4[0][3]), "+v"(acc4[1][0]), "+v"(acc4[1][1]),
+                              "+v"(acc4[1][2]), "+v"(acc4[1][3]), "+v"(acc4[2][0]), "+v"(acc4[2][1]), "+v"(acc4[2][2]), "+v"(acc4[2][3]));
+        }
+      }
+      const int ox = tx * S2_TW + lx, oy = ty * S2_TH + ly;
+      if (c_ok && oy < g.Ho && ox < g.Wo) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          if (t < g.T) {
+            T* dst = y + ((((size_t)b * g.T + t) * g.Ho + oy) * g.Wo + ox) * g.Cp + cbase + whalf * 4;
+            if constexpr (sizeof(T) == 2) {
+              *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(acc4[t][0], acc4[t][1]), pack_bf16x2(acc4[t][2], acc4[t][3]));
+            } else {
+              *reinterpret_cast<float4*>(dst) = make_float4(acc4[t][0], acc4[t][1], acc4[t][2], acc4[t][3]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float r = round_as<T>(acc4[t][j]);
+              s1[j] += r; s2[j] = fmaf(r, r, s2[j]);
+            }
+          }
+        }
+      }
+    } else {
     float acc[TT][8];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
@@ -818,13 +879,14 @@ __global__ __launch_bounds__(256) void dw_fwd_v2s2_kernel(const T* __restrict__ 
         }
       }
     }
+      }
   }
 #undef S2_ISSUE
   if (nc == nullptr) return;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < (W8 ? 4 : 8); ++j) {
     const float r1 = wave_sum(s1[j]), r2 = wave_sum(s2[j]);
-    const int c = cbase + j;
+    const int c = cbase + (W8 ? whalf * 4 : 0) + j;
     if (lane == 0 && c < g.C) {
       atomicAdd(nc + ((size_t)b * g.Cp + c) * 2, (double)r1);
       atomicAdd(nc + ((size_t)b * g.Cp + c) * 2 + 1, (double)r2);
@@ -858,7 +920,26 @@ int launch_fwd_v2s2(const void* x, const float* ss, const float* w, void* y, dou
   // packed slot descriptors (bf16): the largest tile-relative element offset / 8 in 21 bits, the tensor in 2^31 elements
   const size_t rel_max = (((size_t)(g.T - 1) * g.H + S2_IH) * g.W + S2_IW) * g.Cp + g.Cp;
   const bool pk = sizeof(T) == 2 && (rel_max >> 3) < ((size_t)1 << 21) && (size_t)g.B * g.T * g.H * g.W * g.Cp < ((size_t)1 << 31);
-  if (pk)
+  // eight waves on the tile (C3D_OPT_DW_FWD_HV bit 2), bf16 storage
+  constexpr bool W8T = sizeof(T) == 2;
+  if (W8T && (c3d_option_dw_fwd_hv & 4)) {
+    static bool attr_w8 = false;
+    if (!attr_w8) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2s2_kernel<T, TT, false, W8T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fwd_v2s2_kernel<T, TT, W8T, W8T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_w8 = true;
+    }
+    if (pk)
+      dw_fwd_v2s2_kernel<T, TT, W8T, W8T><<<grid, dim3(512), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
+                                                                           reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
+    else
+      dw_fwd_v2s2_kernel<T, TT, false, W8T><<<grid, dim3(512), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
+                                                                             reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
+  } else if (pk)
     dw_fwd_v2s2_kernel<T, TT, sizeof(T) == 2><<<grid, dim3(256), lds, stream>>>(reinterpret_cast<const T*>(x), ss, w,
                                                                                reinterpret_cast<T*>(y), nc, g, tpw, fin ? *fin : f0);
   else

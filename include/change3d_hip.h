@@ -556,7 +556,9 @@ int c3d_side_join(void* stream);
  *   C3D_OPT_DW_FWD_HV   : c3d_dw333_fwd, stride 1, three frames, on half-vector lanes (a lane = 4 channels x 4 output rows, tap
  *                         walk column -> frame -> input row: half the LDS reads per FMA; csrc/dw_conv.hip): bit 0 = bf16
  *                         storage, bit 1 = f32 storage; the taps are summed in another order than the 8-channel lanes (f32
- *                         rounding apart)                                                                                   */
+ *                         rounding apart); bit 2 = the STRIDE-2 forward (bf16) on eight waves per tile instead of four -- two
+ *                         waves per channel vector, one half vector each; its 131 KB tile allows one workgroup per CU -- same
+ *                         tap order per channel: bit-identical outputs.  Default 5                                           */
 enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3, C3D_OPT_FOLD_SE = 4,
        C3D_OPT_MASK_IN_DGRAD = 5, C3D_OPT_DW_RING = 6, C3D_OPT_PW_WGRAD_V2 = 7, C3D_OPT_DW_FWD_HV = 8 };
 int c3d_set_option(int32_t option, int32_t value);
