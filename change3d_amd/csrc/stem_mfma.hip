@@ -248,7 +248,10 @@ __global__ __launch_bounds__(NTHR) void stem_fwd_mfma_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------------- backward: dv, d w_xy
 template <typename T, int TT>
-__global__ __launch_bounds__(NTHR) void stem_bwd_dv_mfma_kernel(
+#ifndef STEM_DV_OCC2
+#define STEM_DV_OCC2 0
+#endif
+__global__ __launch_bounds__(NTHR, (TT == 3 && STEM_DV_OCC2) ? 2 : 1) void stem_bwd_dv_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w_t, const float* __restrict__ w_xy,
     const T* __restrict__ g0, const T* __restrict__ u, const float* __restrict__ coef, T* __restrict__ dv,
     float* __restrict__ dw_xy, const Geom g, const int tiles_per_wg) {
