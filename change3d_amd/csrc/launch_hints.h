@@ -17,5 +17,6 @@ extern int c3d_option_stem_mfma;    // 2: + c3d_stem_bwd_wx of bf16 storage on t
 extern int c3d_option_convt_mfma;   // 1: bf16 ConvTranspose2d on the matrix cores (convt_mfma.hip), 0: decoder.hip's
 extern int c3d_option_dw_ring;      // C3D_OPT_DW_RING (include/change3d_hip.h): LDS-DMA ring variant of the bf16 stride-1 depthwise backward
 extern int c3d_option_dw_fwd_hv;     // C3D_OPT_DW_FWD_HV: stride-1 three-frame depthwise forward on half-vector lanes (bit 0 bf16, bit 1 f32 storage)
+extern int c3d_option_pw_cfwd;       // C3D_OPT_PW_CFWD: conv_c forward of the training path on csrc/pw_cfwd.hip
 extern int c3d_option_pw_wgrad_v2;  // C3D_OPT_PW_WGRAD_V2: 1 = c3d_pw_wgrad of bf16 dense rows on csrc/pw_wgrad_v2.hip, 0 = pw_wgrad.hip's kernel
 void c3d_detail_pw_wgrad_v2_drop();  // forget pending partials of a chained c3d_pw_wgrad launch WITHOUT reducing them (start of a stage pass)

@@ -2,6 +2,7 @@
 // pw_gemm_impl.h; the f32 (parity) instantiations are compiled in pw_gemm_f32.hip.
 #include <cstring>
 #include "pw_gemm_impl.h"
+#include "launch_hints.h"
 
 // f32 instantiations (pw_gemm_f32.hip); library-internal
 __attribute__((visibility("hidden"))) int c3d_detail_pw_gemm_f32(const c3d_pw_args* args, void* stream);
@@ -23,6 +24,7 @@ extern "C" int c3d_debug_pw_clock(unsigned long long* out, int reset) {   // out
 
 int c3d_detail_pw_gemm_wide(const c3d_pw_args* args, void* stream);   // pw_wide.hip
 __attribute__((visibility("hidden"))) int c3d_detail_pw_gemm_wg(const c3d_pw_args* args, void* stream);   // pw_gemm_wg.hip
+__attribute__((visibility("hidden"))) int c3d_detail_pw_cfwd(const c3d_pw_args* args, void* stream);      // pw_cfwd.hip
 
 // ------------------------------------------------------------------------------------------ weight images
 namespace {
@@ -148,6 +150,11 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   // "nowhere"): every tensor of the call must stay under 2 GiB
   if ((int64_t)a.M * (a.Kp > a.Np ? a.Kp : a.Np) * (a.dtype == C3D_DT_F32 ? 4 : 2) >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
   if (a.wg_mode != C3D_WG_NONE) return c3d_detail_pw_gemm_wg(args, stream);
+  if (c3d_option_pw_cfwd && a.pro_mode == C3D_PRO_BN_SE_SWISH && a.epi_mode == C3D_EPI_STATS) {
+    // conv_c forward of the training path: the workgroup-cooperative kernel (csrc/pw_cfwd.hip) where it applies
+    const int rcf = c3d_detail_pw_cfwd(args, stream);
+    if (rcf != C3D_E_UNSUPPORTED) return rcf;
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = C3D_E_BADARG;
   if (a.dtype == C3D_DT_F32) rc = c3d_detail_pw_gemm_f32(args, stream);

@@ -61,13 +61,16 @@ struct BlkFwd {   // byte offsets into ws_fwd
 
 // Ring depth of the backward temporaries: block i shares its slot with block i+R, so the side stream (weight gradients)
 // may run up to R-1 blocks behind the data-gradient chain before the main stream has to wait for it.
-constexpr int BWD_RING_MAX = 4;
+#ifndef C3D_BWD_RING_DEFAULT
+#define C3D_BWD_RING_DEFAULT 3
+#endif
+constexpr int BWD_RING_MAX = 8;
 int bwd_ring() {
   static const int r = [] {
     const char* s = c3d_env("C3D_BWD_RING");
     // measured on MI355X (B=32 bf16): 2, 3, 4 slots -> 34.04 / 34.10 / 34.32 ms per step before the weight gradients were
     // forked ahead of their data gradients; 32.62 / 32.45 ms for 2 / 3 slots after (three interleaved repeats each)
-    const int v = s ? atoi(s) : 3;
+    const int v = s ? atoi(s) : C3D_BWD_RING_DEFAULT;
     return v < 2 ? 2 : (v > BWD_RING_MAX ? BWD_RING_MAX : v);
   }();
   return r;
@@ -892,6 +895,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
 int c3d_option_stem_mfma = 2, c3d_option_convt_mfma = 1;   // read by stem.hip / decoder.hip (launch_hints.h)
 int c3d_option_dw_ring = 5;                                // read by dw_bwd_fused.hip / dw_conv.hip
 int c3d_option_pw_wgrad_v2 = 1;                            // read by pw_wgrad.hip
+int c3d_option_pw_cfwd = 1;                                // read by pw_gemm.hip
 int c3d_option_dw_fwd_hv = 5;                              // read by dw_conv.hip
 
 extern "C" int c3d_set_option(int32_t option, int32_t value) {
@@ -904,6 +908,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_MASK_IN_DGRAD: g_mask_in_dgrad = value & 3; return 0;
     case C3D_OPT_DW_RING: c3d_option_dw_ring = value & 15; return 0;
     case C3D_OPT_DW_FWD_HV: c3d_option_dw_fwd_hv = value & 7; return 0;
+    case C3D_OPT_PW_CFWD: c3d_option_pw_cfwd = value ? 1 : 0; return 0;
     case C3D_OPT_PW_WGRAD_V2: c3d_option_pw_wgrad_v2 = value & 1; g_wgrad_chain = (value & 2) ? 0 : 1; return 0;
     default: return C3D_E_BADARG;
   }

@@ -558,9 +558,12 @@ int c3d_side_join(void* stream);
  *                         storage, bit 1 = f32 storage; the taps are summed in another order than the 8-channel lanes (f32
  *                         rounding apart); bit 2 = the STRIDE-2 forward (bf16) on eight waves per tile instead of four -- two
  *                         waves per channel vector, one half vector each; its 131 KB tile allows one workgroup per CU -- same
- *                         tap order per channel: bit-identical outputs.  Default 5                                           */
+ *                         tap order per channel: bit-identical outputs.  Default 5
+ *   C3D_OPT_PW_CFWD     : 0 = conv_c forward of the training path (C3D_PRO_BN_SE_SWISH + C3D_EPI_STATS, BatchNorm_b / SE gate
+ *                         rebuilt from the per-sample sums) on the wave-private-tile kernel instead of the workgroup-
+ *                         cooperative one (csrc/pw_cfwd.hip, default 1): bit-identical outputs, statistics to f32 rounding     */
 enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3, C3D_OPT_FOLD_SE = 4,
-       C3D_OPT_MASK_IN_DGRAD = 5, C3D_OPT_DW_RING = 6, C3D_OPT_PW_WGRAD_V2 = 7, C3D_OPT_DW_FWD_HV = 8 };
+       C3D_OPT_MASK_IN_DGRAD = 5, C3D_OPT_DW_RING = 6, C3D_OPT_PW_WGRAD_V2 = 7, C3D_OPT_DW_FWD_HV = 8, C3D_OPT_PW_CFWD = 9 };
 int c3d_set_option(int32_t option, int32_t value);
 /* Per-launch profile of the stage driver: between c3d_prof_begin and c3d_prof_end every kernel c3d_stage_fwd /
  * c3d_stage_bwd enqueue is bracketed by a HIP event pair on its launch stream and billed its algorithmic bytes

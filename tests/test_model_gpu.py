@@ -804,6 +804,64 @@ def test_folded_batchnorm_launches_are_bit_identical_end_to_end(flag):
     assert sum(1 for n in a["grads"] if exact(n)) > 270
 
 
+def test_conv_c_forward_on_the_cooperative_kernel_end_to_end():
+    """C3D_OPT_PW_CFWD (csrc/pw_cfwd.hip: conv_c forward of the training path on workgroup-cooperative tiles) against the
+    wave-private-tile kernel, through a whole bf16 BCD train step on conditioned weights (128 x 128, so that res2 / res3 / res4
+    all take the new kernel).  conv_c's OUTPUT is bit-identical between the two (tests/test_ops_gpu.py::
+    test_conv_c_forward_kernels_agree_bit_for_bit); its BatchNorm_c statistics group their f32 partial sums differently (1e-7),
+    which moves last bits of a few scale / shift values, flips isolated bf16 roundings and is amplified down the network to the
+    level of bf16 quantisation noise -- the same signature as C3D_OPT_MASK_IN_DGRAD (test below).  Pinned: the loss to 2e-3, the
+    change probabilities to 2e-2 (bf16 activations), every gradient finite, parameter gradients within sqrt(2) x the bf16 gradient
+    noise of this network (median < 1e-1, flat-gradient cosine > 0.99), running statistics to 5e-3 of their largest entry."""
+    _need_gpu()
+    import contextlib
+    import io
+    from change3d_amd import ops, synthetic as synth
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.utils import BCEDiceLoss
+    outs = []
+    try:
+        for opt in (0, 1):
+            ops.set_option(ops.OPT_PW_CFWD, opt)
+            args = synth.make_args(size=128, act_dtype=torch.bfloat16)
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                net = Trainer(args)
+            net.load_state_dict(synth.synth_state_dict(net, seed=5, mask_margin=0.25, branch_gain=0.1))
+            net = net.to(DEV).train()
+            pre, post, tgt = (t.to(DEV) for t in synth.synth_batch(3, 128, seed=2))
+            prob = net.update_bcd(pre, post)
+            loss = BCEDiceLoss(prob, tgt)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append({"loss": loss.detach().cpu(), "prob": prob.detach().float().cpu(),
+                         "grads": {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None},
+                         "bufs": {n: b.float().cpu() for n, b in net.named_buffers()}})
+    finally:
+        ops.set_option(ops.OPT_PW_CFWD, 1)
+    a, b = outs
+    assert torch.isfinite(b["loss"]) and abs(a["loss"].item() - b["loss"].item()) < 2e-3 * abs(a["loss"].item()), (a["loss"], b["loss"])
+    assert (a["prob"] - b["prob"]).abs().max().item() < 2e-2
+    assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 400
+    worst_buf = max(((a["bufs"][n] - b["bufs"][n]).abs().max().item() / (a["bufs"][n].abs().max().item() + 1e-3), n) for n in a["bufs"])
+    assert worst_buf[0] < 5e-3, worst_buf   # running statistics of layers BELOW the first flipped rounding see bf16-level differences
+    rels = []
+    for n in a["grads"]:
+        assert torch.isfinite(b["grads"][n]).all(), n
+        d = (a["grads"][n] - b["grads"][n]).double()
+        rels.append((d.norm() / a["grads"][n].double().norm().clamp_min(1e-30)).item())
+    rels.sort()
+    print(f"  PW_CFWD 0 vs 1: |d loss| {abs(a['loss'].item() - b['loss'].item()):.2e}, parameter-gradient rel-L2 median {rels[len(rels) // 2]:.1e}, "
+          f"90 % {rels[len(rels) * 9 // 10]:.1e}, worst {rels[-1]:.1e}")
+    # Two bf16 runs whose roundings have decorrelated differ by sqrt(2) x the bf16 gradient noise of this network (median 4e-2
+    # against the f64 oracle on conditioned weights, DESIGN.md section 1): measured 5.7e-2 median, 1.1e-1 at 90 %, 2.3e-1 worst;
+    # the flat gradient stays aligned
+    assert rels[len(rels) // 2] < 1e-1 and rels[len(rels) * 9 // 10] < 2.5e-1 and rels[-1] < 0.6, (rels[len(rels) // 2], rels[len(rels) * 9 // 10], rels[-1])
+    fa = torch.cat([a["grads"][n].double().flatten() for n in sorted(a["grads"])])
+    fb = torch.cat([b["grads"][n].double().flatten() for n in sorted(b["grads"])])
+    cos = (fa @ fb / (fa.norm() * fb.norm())).item()
+    assert cos > 0.99, cos
+
+
 def test_block_output_backward_folded_into_conv_a_agrees_with_the_separate_launches_end_to_end():
     """C3D_OPT_MASK_IN_DGRAD = 3 (default: c3d_block_out_bwd of a block runs in the epilogue of the conv_a data gradient of the
     block above it -- mask and BatchNorm_c-backward sums, c3d_pw_args.add_sums / C3D_WG_MASKSUM) against = 1 (mask only where the

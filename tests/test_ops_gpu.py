@@ -329,6 +329,72 @@ def test_pw_wgrad_long_walks(K, N, rows):
     assert rel < 4e-3, rel      # bf16 operand rounding is 2^-9 per term and averages out over ~4e5 coherent terms
 
 
+# conv_c forward of the training path: the workgroup-cooperative kernel (csrc/pw_cfwd.hip, C3D_OPT_PW_CFWD) against the
+# wave-private-tile kernel on the same device buffers.  Same converted operand, same weight fragments, same k order of the MFMA
+# chain: the output must be BIT-identical; BatchNorm_b scale / shift, the SE gate and the running statistics come from the same
+# device functions (identical); the BatchNorm_c statistics group their f32 partial sums differently (1e-6).  Shapes: the three
+# stages' layers (two / three / six output tiles), samples that end inside a tile, a ragged last tile, with and without SE.
+@pytest.mark.parametrize("se", [False, True])
+@pytest.mark.parametrize("K,N,B,rps", [(216, 96, 8, 768), (108, 48, 4, 3072), (54, 24, 4, 3072), (216, 96, 5, 1008), (108, 48, 3, 784)])
+def test_conv_c_forward_kernels_agree_bit_for_bit(K, N, B, rps, se):
+    _need_gpu()
+    import ctypes as C
+    from change3d_amd import ops, _lib as L
+    Kp, Np = ops.cpad(K), ops.cpad(N)
+    M = B * rps
+    if rps % 16:
+        pytest.skip("rows_per_sample must be a multiple of 16 for the narrow kernels")
+    x = padc(rnd((M, K), 90), Kp).to(DEV).to(torch.bfloat16)
+    w = rnd((N, K), 91, 0.1).to(DEV)
+    xs = x.float().view(B, rps, Kp).double()
+    nc = torch.stack([xs.sum(1), (xs * xs).sum(1)], dim=2).contiguous()       # [B][Kp][2] per-sample sums, as c3d_dw333_fwd leaves them
+    gamma, beta = (rnd((K,), 92).abs() + 0.5).to(DEV), rnd((K,), 93, 0.2).to(DEV)
+    Cr = 16
+    w1, b1, w2, b2 = rnd((Cr, K), 94, 0.1).to(DEV), rnd((Cr,), 95, 0.1).to(DEV), rnd((K, Cr), 96, 0.1).to(DEV), rnd((K,), 97, 0.1).to(DEV)
+    img = torch.empty(ops.pw_weight_image_bytes(N, K, ops.DT_BF16), dtype=torch.uint8, device=DEV)
+    ops.pw_pack_weights([(w, img, N, K, K, 1)], ops.DT_BF16)
+    ptr = lambda t: t.data_ptr()
+    res = {}
+    try:
+        for opt in (0, 1):
+            ops.set_option(ops.OPT_PW_CFWD, opt)
+            y = torch.full((M, Np), 7.0, device=DEV).to(torch.bfloat16)
+            stats = torch.zeros(ops.STAT_STRIPES * 2 * N, dtype=torch.float64, device=DEV)
+            rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+            nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+            ss, mr = torch.zeros(2 * Kp, device=DEV), torch.zeros(2 * Kp, device=DEV)
+            gate, hid = torch.zeros(B, Kp, device=DEV), torch.zeros(B, Cr, device=DEV)
+            a = L.PwArgs()
+            a.x, a.y, a.w, a.w_img = ptr(x), ptr(y), ptr(w), ptr(img)
+            a.M, a.K, a.Kp, a.N, a.Np, a.w_sn, a.w_sk = M, K, Kp, N, Np, K, 1
+            a.rows_per_sample, a.dtype = rps, ops.DT_BF16
+            a.pro_mode, a.epi_mode = ops.PRO_BN_SE_SWISH, ops.EPI_STATS
+            a.pro_p, a.stats = ptr(ss), ptr(stats)
+            f = L.BnFin()
+            f.gamma, f.beta, f.running_mean, f.running_var, f.nbt, f.ss, f.mr = ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt), ptr(ss), ptr(mr)
+            f.count, f.momentum, f.eps, f.training, f.batch, f.sums = float(M), 0.1, 1e-5, 1, B, ptr(nc)
+            a.fin = f
+            if se:
+                a.pro_gate = ptr(gate)
+                a.se_w1, a.se_b1, a.se_w2, a.se_b2, a.se_hid, a.se_cr = ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(hid), Cr
+            rc = L.lib().c3d_pw_gemm(C.byref(a), ops._stream())
+            torch.cuda.synchronize()
+            assert rc == 0, rc
+            res[opt] = dict(y=y.cpu(), stats=stats.cpu().view(ops.STAT_STRIPES, 2, N).sum(0), ss=ss.cpu(), mr=mr.cpu(), gate=gate.cpu(),
+                            hid=hid.cpu(), rm=rm.cpu(), rv=rv.cpu(), nbt=int(nbt))
+    finally:
+        ops.set_option(ops.OPT_PW_CFWD, 1)
+    r0, r1 = res[0], res[1]
+    assert torch.isfinite(r1["y"].float()).all() and r1["y"].float().abs().max().item() > 0
+    assert torch.equal(r0["y"], r1["y"]), f"{int((r0['y'] != r1['y']).sum())} output elements differ"
+    for k in ("ss", "mr", "gate", "hid", "rm", "rv"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert r0["nbt"] == r1["nbt"] == 1
+    yq = r1["y"].float().double()[:, :N]
+    assert torch.allclose(r1["stats"][0], yq.sum(0), rtol=1e-5, atol=1e-2) and torch.allclose(r1["stats"][1], (yq * yq).sum(0), rtol=1e-5, atol=1e-2)
+    assert torch.allclose(r0["stats"], r1["stats"], rtol=2e-6, atol=1e-3)
+
+
 # The flat-staged, transposing-read kernel (csrc/pw_wgrad_v2.hip, C3D_OPT_PW_WGRAD_V2) against the first kernel on the same
 # device buffers: same operand arithmetic, another summation order inside a k-step -> agreement to f32 rounding of the sums
 # (1e-5 of the largest entry), far inside what either is allowed against the f64 product.  Cases: the res4 layers at their
