@@ -150,8 +150,9 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   // "nowhere"): every tensor of the call must stay under 2 GiB
   if ((int64_t)a.M * (a.Kp > a.Np ? a.Kp : a.Np) * (a.dtype == C3D_DT_F32 ? 4 : 2) >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
   if (a.wg_mode != C3D_WG_NONE) return c3d_detail_pw_gemm_wg(args, stream);
-  if (c3d_option_pw_cfwd && a.pro_mode == C3D_PRO_BN_SE_SWISH && a.epi_mode == C3D_EPI_STATS) {
-    // conv_c forward of the training path: the workgroup-cooperative kernel (csrc/pw_cfwd.hip) where it applies
+  if (a.epi_mode == C3D_EPI_STATS && ((a.pro_mode == C3D_PRO_BN_SE_SWISH && (c3d_option_pw_cfwd & 1)) ||
+                                      (a.pro_mode == C3D_PRO_AFFINE2 && a.pro_out && (c3d_option_pw_cfwd & 2)))) {
+    // conv_c / conv_a forward of the training path: the workgroup-cooperative kernel (csrc/pw_cfwd.hip) where it applies
     const int rcf = c3d_detail_pw_cfwd(args, stream);
     if (rcf != C3D_E_UNSUPPORTED) return rcf;
   }

@@ -895,7 +895,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
 int c3d_option_stem_mfma = 2, c3d_option_convt_mfma = 1;   // read by stem.hip / decoder.hip (launch_hints.h)
 int c3d_option_dw_ring = 5;                                // read by dw_bwd_fused.hip / dw_conv.hip
 int c3d_option_pw_wgrad_v2 = 1;                            // read by pw_wgrad.hip
-int c3d_option_pw_cfwd = 1;                                // read by pw_gemm.hip
+int c3d_option_pw_cfwd = 3;                                // read by pw_gemm.hip
 int c3d_option_dw_fwd_hv = 5;                              // read by dw_conv.hip
 
 extern "C" int c3d_set_option(int32_t option, int32_t value) {
@@ -908,7 +908,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_MASK_IN_DGRAD: g_mask_in_dgrad = value & 3; return 0;
     case C3D_OPT_DW_RING: c3d_option_dw_ring = value & 15; return 0;
     case C3D_OPT_DW_FWD_HV: c3d_option_dw_fwd_hv = value & 7; return 0;
-    case C3D_OPT_PW_CFWD: c3d_option_pw_cfwd = value ? 1 : 0; return 0;
+    case C3D_OPT_PW_CFWD: c3d_option_pw_cfwd = value & 3; return 0;
     case C3D_OPT_PW_WGRAD_V2: c3d_option_pw_wgrad_v2 = value & 1; g_wgrad_chain = (value & 2) ? 0 : 1; return 0;
     default: return C3D_E_BADARG;
   }

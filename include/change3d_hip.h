@@ -559,9 +559,11 @@ int c3d_side_join(void* stream);
  *                         rounding apart); bit 2 = the STRIDE-2 forward (bf16) on eight waves per tile instead of four -- two
  *                         waves per channel vector, one half vector each; its 131 KB tile allows one workgroup per CU -- same
  *                         tap order per channel: bit-identical outputs.  Default 5
- *   C3D_OPT_PW_CFWD     : 0 = conv_c forward of the training path (C3D_PRO_BN_SE_SWISH + C3D_EPI_STATS, BatchNorm_b / SE gate
- *                         rebuilt from the per-sample sums) on the wave-private-tile kernel instead of the workgroup-
- *                         cooperative one (csrc/pw_cfwd.hip, default 1): bit-identical outputs, statistics to f32 rounding     */
+ *   C3D_OPT_PW_CFWD     : bit field, which forward GEMMs of the training path run on the workgroup-cooperative kernel
+ *                         (csrc/pw_cfwd.hip) instead of the wave-private-tile one.  bit 0: conv_c (C3D_PRO_BN_SE_SWISH +
+ *                         C3D_EPI_STATS, BatchNorm_b / SE gate rebuilt from the per-sample sums); bit 1: conv_a with the
+ *                         previous block's residual add in its prologue (C3D_PRO_AFFINE2 + pro_out + C3D_EPI_STATS).
+ *                         Outputs (and pro_out) bit-identical, BatchNorm statistics to f32 rounding.  Default 3             */
 enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3, C3D_OPT_FOLD_SE = 4,
        C3D_OPT_MASK_IN_DGRAD = 5, C3D_OPT_DW_RING = 6, C3D_OPT_PW_WGRAD_V2 = 7, C3D_OPT_DW_FWD_HV = 8, C3D_OPT_PW_CFWD = 9 };
 int c3d_set_option(int32_t option, int32_t value);

@@ -747,21 +747,28 @@ def test_folded_batchnorm_launches_are_bit_identical_end_to_end(flag):
     from change3d_amd.model.utils import BCEDiceLoss
     from change3d_amd.model.x3d import X3DResStage
     outs = []
-    for flags in (0, getattr(ops, flag)):
-        args = synth.make_args(size=64, act_dtype=torch.bfloat16)
-        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
-            net = Trainer(args)
-        net.load_state_dict(synth.synth_state_dict(net, seed=5, mask_margin=0.25, branch_gain=0.1))
-        net = net.to(DEV).train()
-        for m in net.modules():
-            if isinstance(m, X3DResStage):
-                m.driver_flags = flags
-        pre, post, tgt = (t.to(DEV) for t in synth.synth_batch(3, 64, seed=2))
-        loss = BCEDiceLoss(net.update_bcd(pre, post), tgt)
-        loss.backward()
-        torch.cuda.synchronize()
-        outs.append({"loss": loss.detach().cpu(), "grads": {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None},
-                     "bufs": {n: b.cpu() for n, b in net.named_buffers()}})
+    # (the workgroup-cooperative conv_a / conv_c forward kernels take only the default sequence's argument forms and group the
+    # f32 partial sums of the BatchNorm statistics differently from the first kernel -- 1e-6, tests/test_ops_gpu.py; both runs
+    # of this comparison use the first kernel)
+    ops.set_option(ops.OPT_PW_CFWD, 0)
+    try:
+        for flags in (0, getattr(ops, flag)):
+            args = synth.make_args(size=64, act_dtype=torch.bfloat16)
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                net = Trainer(args)
+            net.load_state_dict(synth.synth_state_dict(net, seed=5, mask_margin=0.25, branch_gain=0.1))
+            net = net.to(DEV).train()
+            for m in net.modules():
+                if isinstance(m, X3DResStage):
+                    m.driver_flags = flags
+            pre, post, tgt = (t.to(DEV) for t in synth.synth_batch(3, 64, seed=2))
+            loss = BCEDiceLoss(net.update_bcd(pre, post), tgt)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append({"loss": loss.detach().cpu(), "grads": {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None},
+                         "bufs": {n: b.cpu() for n, b in net.named_buffers()}})
+    finally:
+        ops.set_option(ops.OPT_PW_CFWD, 3)
     a, b = outs
     assert torch.equal(a["loss"], b["loss"]) and torch.isfinite(a["loss"])
     assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 400
@@ -837,7 +844,7 @@ def test_conv_c_forward_on_the_cooperative_kernel_end_to_end():
                          "grads": {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None},
                          "bufs": {n: b.float().cpu() for n, b in net.named_buffers()}})
     finally:
-        ops.set_option(ops.OPT_PW_CFWD, 1)
+        ops.set_option(ops.OPT_PW_CFWD, 3)
     a, b = outs
     assert torch.isfinite(b["loss"]) and abs(a["loss"].item() - b["loss"].item()) < 2e-3 * abs(a["loss"].item()), (a["loss"], b["loss"])
     assert (a["prob"] - b["prob"]).abs().max().item() < 2e-2

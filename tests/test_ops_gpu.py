@@ -383,13 +383,75 @@ def test_conv_c_forward_kernels_agree_bit_for_bit(K, N, B, rps, se):
             res[opt] = dict(y=y.cpu(), stats=stats.cpu().view(ops.STAT_STRIPES, 2, N).sum(0), ss=ss.cpu(), mr=mr.cpu(), gate=gate.cpu(),
                             hid=hid.cpu(), rm=rm.cpu(), rv=rv.cpu(), nbt=int(nbt))
     finally:
-        ops.set_option(ops.OPT_PW_CFWD, 1)
+        ops.set_option(ops.OPT_PW_CFWD, 3)
     r0, r1 = res[0], res[1]
     assert torch.isfinite(r1["y"].float()).all() and r1["y"].float().abs().max().item() > 0
     assert torch.equal(r0["y"], r1["y"]), f"{int((r0['y'] != r1['y']).sum())} output elements differ"
     for k in ("ss", "mr", "gate", "hid", "rm", "rv"):
         assert torch.equal(r0[k], r1[k]), k
     assert r0["nbt"] == r1["nbt"] == 1
+    yq = r1["y"].float().double()[:, :N]
+    assert torch.allclose(r1["stats"][0], yq.sum(0), rtol=1e-5, atol=1e-2) and torch.allclose(r1["stats"][1], (yq * yq).sum(0), rtol=1e-5, atol=1e-2)
+    assert torch.allclose(r0["stats"], r1["stats"], rtol=2e-6, atol=1e-3)
+
+
+# conv_a forward with the previous block's residual add in its prologue (c3d_pw_args.pro_out) on the cooperative kernel
+# (C3D_OPT_PW_CFWD bit 1) against the wave-private-tile kernel: y = relu(bn_c(c) + shortcut) written out, the GEMM's output, the
+# BatchNorm_c scale / shift / running statistics of the previous block -- all BIT-identical; BatchNorm_a's statistics to 1e-6.
+@pytest.mark.parametrize("K,N,M", [(96, 216, 8 * 768), (48, 108, 4 * 3072), (24, 54, 4 * 3072), (96, 216, 5000), (48, 108, 2345), (24, 54, 1031)])
+def test_conv_a_forward_kernels_agree_bit_for_bit(K, N, M):
+    _need_gpu()
+    import ctypes as C
+    from change3d_amd import ops, _lib as L
+    Kp, Np = ops.cpad(K), ops.cpad(N)
+    c = padc(rnd((M, K), 80), Kp).to(DEV).to(torch.bfloat16)
+    sc = padc(rnd((M, K), 81), Kp).to(DEV).to(torch.bfloat16)
+    w = rnd((N, K), 82, 0.1).to(DEV)
+    cd = c.float().double()[:, :K]
+    tot = torch.stack([cd.sum(0), (cd * cd).sum(0)])                           # [2][K]
+    frac = torch.rand(ops.STAT_STRIPES, 1, 1, dtype=torch.float64, device=DEV)
+    sums = (tot[None] * frac / frac.sum()).contiguous()                        # [stripes][2][K], as the producer's epilogue leaves them
+    gamma, beta = (rnd((K,), 83).abs() + 0.5).to(DEV), rnd((K,), 84, 0.2).to(DEV)
+    img = torch.empty(ops.pw_weight_image_bytes(N, K, ops.DT_BF16), dtype=torch.uint8, device=DEV)
+    ops.pw_pack_weights([(w, img, N, K, K, 1)], ops.DT_BF16)
+    ptr = lambda t: t.data_ptr()
+    res = {}
+    try:
+        for opt in (1, 3):
+            ops.set_option(ops.OPT_PW_CFWD, opt)
+            y = torch.full((M, Np), 7.0, device=DEV).to(torch.bfloat16)
+            po = torch.full((M, Kp), 5.0, device=DEV).to(torch.bfloat16)
+            stats = torch.zeros(ops.STAT_STRIPES * 2 * N, dtype=torch.float64, device=DEV)
+            rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+            nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+            ss, mr = torch.zeros(2 * Kp, device=DEV), torch.zeros(2 * Kp, device=DEV)
+            a = L.PwArgs()
+            a.x, a.x2, a.y, a.w, a.w_img, a.pro_out = ptr(c), ptr(sc), ptr(y), ptr(w), ptr(img), ptr(po)
+            a.M, a.K, a.Kp, a.N, a.Np, a.w_sn, a.w_sk = M, K, Kp, N, Np, K, 1
+            a.dtype = ops.DT_BF16
+            a.pro_mode, a.epi_mode = ops.PRO_AFFINE2, ops.EPI_STATS
+            a.pro_p, a.stats = ptr(ss), ptr(stats)
+            f = L.BnFin()
+            f.gamma, f.beta, f.running_mean, f.running_var, f.nbt, f.ss, f.mr = ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt), ptr(ss), ptr(mr)
+            f.count, f.momentum, f.eps, f.training, f.batch, f.sums = float(M), 0.1, 1e-5, 1, 0, ptr(sums)
+            a.fin = f
+            rc = L.lib().c3d_pw_gemm(C.byref(a), ops._stream())
+            torch.cuda.synchronize()
+            assert rc == 0, rc
+            res[opt] = dict(y=y.cpu(), po=po.cpu(), stats=stats.cpu().view(ops.STAT_STRIPES, 2, N).sum(0), ss=ss.cpu(), mr=mr.cpu(),
+                            rm=rm.cpu(), rv=rv.cpu(), nbt=int(nbt))
+    finally:
+        ops.set_option(ops.OPT_PW_CFWD, 3)
+    r0, r1 = res[1], res[3]
+    assert torch.isfinite(r1["y"].float()).all() and r1["y"].float().abs().max().item() > 0
+    assert torch.equal(r0["po"], r1["po"]), f"{int((r0['po'] != r1['po']).sum())} residual-output elements differ"
+    assert torch.equal(r0["y"], r1["y"]), f"{int((r0['y'] != r1['y']).sum())} output elements differ"
+    for k in ("ss", "mr", "rm", "rv"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert r0["nbt"] == r1["nbt"] == 1
+    # and the residual output is what it should be: relu(scale * c + shift + shortcut), bf16-rounded
+    ref = torch.relu(c.float().cpu()[:, :K] * r1["ss"][:K] + r1["ss"][Kp:Kp + K] + sc.float().cpu()[:, :K])
+    assert (r1["po"].float()[:, :K] - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-6
     yq = r1["y"].float().double()[:, :N]
     assert torch.allclose(r1["stats"][0], yq.sum(0), rtol=1e-5, atol=1e-2) and torch.allclose(r1["stats"][1], (yq * yq).sum(0), rtol=1e-5, atol=1e-2)
     assert torch.allclose(r0["stats"], r1["stats"], rtol=2e-6, atol=1e-3)
