@@ -15,7 +15,7 @@ EPI_STORE, EPI_STATS, EPI_SWISH_SE_BWD, EPI_ADD = 0, 1, 2, 3
 ROWS_DENSE, ROWS_FRAME, ROWS_STRIDE2, ROWS_S2SHIFT = 0, 1, 2, 3
 SC_NONE, SC_IDENTITY, SC_BN, SC_RAW = 0, 1, 2, 3
 STAT_STRIPES = 16
-OPT_SIDE_STREAM, OPT_STEM_MFMA, OPT_CONVT_MFMA, OPT_FUSE_WGRAD, OPT_FOLD_SE, OPT_MASK_IN_DGRAD, OPT_DW_RING, OPT_PW_WGRAD_V2, OPT_DW_FWD_HV, OPT_PW_CFWD = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_SIDE_STREAM, OPT_STEM_MFMA, OPT_CONVT_MFMA, OPT_FUSE_WGRAD, OPT_FOLD_SE, OPT_MASK_IN_DGRAD, OPT_DW_RING, OPT_PW_WGRAD_V2, OPT_DW_FWD_HV, OPT_PW_CFWD, OPT_PW_CDG = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 STAGE_SEPARATE_FINALIZE, STAGE_NO_WEIGHT_IMAGES, STAGE_SEPARATE_RESIDUAL, STAGE_SEPARATE_WGRAD = 1, 2, 4, 8
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double

@@ -1,0 +1,496 @@
+// conv_a DATA gradient of the X3D bottleneck WITH its weight gradient on the workgroup-cooperative tile loop (round 6): bf16
+// storage, dense rows,
+//
+//     P[m, k]  = A[k] * t2[m, k] + B[k] + C[k] * a[m, k]                      (BatchNorm_a backward on load)
+//     dx[m, n] = (sum_k P[m, k] * W_a[k, n] + res[m, n]) * (y_prev[m, n] > 0)  (+ the previous block's BatchNorm_c-backward sums)
+//     dW_a[k, n] += sum_m P[m, k] * y_prev[m, n]
+//
+// (reference model/x3d.py:173-183: conv_a -> norm_a -> ReLU; one convolution_backward produces both gradients).  Same
+// arguments as the C3D_PRO_AFFINE2 / C3D_EPI_ADD / C3D_WG_ROWS form of c3d_pw_gemm, which dispatches here (C3D_OPT_PW_CDG) and
+// keeps everything this kernel does not take.
+//
+// Why.  The wave-private-tile kernel (csrc/pw_gemm_impl.h) holds its fused weight gradient as an f64 accumulator image in LDS
+// (LDS atomics): K <= 112, so the 32 x 32 stage (K = 216) ran the data gradient (42 us) and a separate weight-gradient launch
+// on the side stream (29 us) that reads t2 and a AGAIN; its res2 / res3 instantiations sit at 54 / 70 % of their byte floor.
+// The forward kernels of this round (csrc/pw_cfwd.hip) showed that the cooperative loop streams at ~5 TB/s; here the same
+// loop keeps BOTH products of a tile: the converted rows P (row-major LDS tile) are the B operand of the data gradient (rows
+// as output index, packed weight image as A) and, read through gfx950's transposing LDS read, the A operand of the weight
+// gradient (rows as contraction index) against the y_prev rows the mask needs anyway.  The weight-gradient accumulators
+// (K x N / 8 waves: 48 registers at 216 x 96) live in registers for the whole walk; partial sums per workgroup, reduced in
+// fixed order by the reducer launch of the first kernel's fused variant (c3d_detail_pw_wgrad_reduce).
+//
+// Results: operand conversion, weight fragments, k order of the MFMA chain, bf16 staging of the product and the epilogue
+// arithmetic are the first kernel's -- dx is bit-identical to it; the BatchNorm sums group their f32 partial sums differently
+// and the weight gradient is summed in f32 per workgroup instead of f64 per tile pair (agreement to f32 rounding).
+#include "common.h"
+#include "../../include/change3d_hip.h"
+#include "pw_common.h"
+#include "launch_hints.h"
+#include "bn_fin.h"
+#include <cstdlib>
+#include <cstring>
+
+thread_local int c3d_cdg_defer_reduce = 0, c3d_cdg_parts = 0;
+
+namespace {
+
+constexpr int CD_THREADS = 512;
+constexpr uint32_t CD_OOB = 0x80000000u;
+constexpr int CD_MAX_PARTS = 512;     // = PW_WG_MAX_PARTS: the fused-variant workspace holds this many K x N partials
+
+struct CdPlan {
+  int MT, WR, WC;            // rows per tile = 16 WR; wave grid WR x WC = 8 (data gradient)
+  int QG;                    // weight gradient: waves = PG x QG, wave (pg, qg) holds P tiles pg * NPW .., Q tiles qg * NQW ..
+  int tiles_per_wg;
+  int KL, QL;                // row strides (elements) of the converted P tile and of the y_prev tile
+  int img_rows;              // rows of the packed weight image per 8-element k-chunk
+  int w_off, a_off, a_bytes, q_off, q_bytes;   // weight image | two P tiles | two y_prev tiles
+  int os_off, os_wave;       // per-wave result staging [16][NLw]
+  int par_off, dump_off;     // A | B | C [Kp] each, mean | rstd [Np] each; dump
+};
+
+typedef uint32_t cd_u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* cd_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* cd_glb_ptr_t;
+typedef short cd_s16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) cd_s16x4_t* cd_lds_s16x4_ptr_t;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cd_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+__device__ __forceinline__ uint4 cd_load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  const cd_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void cd_cvt(const uint4& v, float (&f)[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ void cd_ld8(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// KS: k-steps of 32 of the data gradient (Kpad / 32); NTW: its output tiles (16 channels) per wave; NPW x NQW: weight-
+// gradient tiles (P channels x y_prev channels) per wave; RP / RQ: 16-byte items per thread and tile of the P streams / of
+// the y_prev stream (prefetch registers); K2: k-steps of 32 rows of the weight gradient (MT / 32)
+template <int KS, int NTW, int NPW, int NQW, int RP, int RQ, int K2>
+__global__ __launch_bounds__(CD_THREADS) void pw_cdg_a_kernel(const c3d_pw_args a, const CdPlan L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Kp = a.Kp, Np = a.Np, Gq = Kp >> 3, Gn = Np >> 3, MT = L.MT, KL = L.KL, QL = L.QL;
+  bf16_t* const Ws = reinterpret_cast<bf16_t*>(smem + L.w_off);
+  float* const Pp = reinterpret_cast<float*>(smem + L.par_off);       // A | B | C
+  float* const Ep = Pp + 3 * Kp;                                      // mean | rstd of the previous block's BatchNorm_c
+  bf16_t* const dump = reinterpret_cast<bf16_t*>(smem + L.dump_off) + tid * 8;
+
+  const int M32 = (int)a.M;
+  const int tiles = (M32 + MT - 1) / MT;
+  int t0 = (int)blockIdx.x * L.tiles_per_wg;
+  if (t0 > tiles) t0 = tiles;
+  int t1 = t0 + L.tiles_per_wg;
+  if (t1 > tiles) t1 = tiles;
+  const uint32_t row_hi = (uint32_t)(t1 * MT < M32 ? t1 * MT : M32);
+  const __amdgpu_buffer_rsrc_t rX = cd_rsrc(a.x, row_hi * (uint32_t)Kp * 2u);
+  const __amdgpu_buffer_rsrc_t rX2 = cd_rsrc(a.x2, row_hi * (uint32_t)Kp * 2u);
+  const __amdgpu_buffer_rsrc_t rQ = cd_rsrc(a.wg_x3, row_hi * (uint32_t)Np * 2u);
+  const __amdgpu_buffer_rsrc_t rE1 = cd_rsrc(a.e1, (uint32_t)M32 * (uint32_t)Np * 2u);
+  const __amdgpu_buffer_rsrc_t rC1 = cd_rsrc(a.add_sums ? a.add_c : nullptr, (uint32_t)M32 * (uint32_t)Np * 2u);
+  const __amdgpu_buffer_rsrc_t rY = cd_rsrc(a.y, (uint32_t)M32 * (uint32_t)Np * 2u);
+
+  // ---- item maps: item i = tid + 512 r of a tile <-> (row = i / G, vector = i % G); its bytes sit at tile base + 16 i
+  int p_desc[RP], q_desc[RQ];
+  uint32_t p_go[RP], q_go[RQ];
+  {
+    const float invG = 1.0f / (float)Gq, invN = 1.0f / (float)Gn;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+      const int i = tid + CD_THREADS * r;
+      const int row = __float2int_rz(((float)i + 0.5f) * invG);
+      const bool ok = i < MT * Gq;
+      p_desc[r] = ok ? (row << 5) | (i - row * Gq) : 0;
+      p_go[r] = ok ? (uint32_t)i * 16u : CD_OOB;
+    }
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) {
+      const int i = tid + CD_THREADS * r;
+      const int row = __float2int_rz(((float)i + 0.5f) * invN);
+      const bool ok = i < MT * Gn;
+      q_desc[r] = ok ? (row << 5) | (i - row * Gn) : 0;
+      q_go[r] = ok ? (uint32_t)i * 16u : CD_OOB;
+    }
+  }
+  const bool p_last = (wave * 64 + CD_THREADS * (RP - 1)) < MT * Gq;   // (wave-uniform: the last round has an item for this wave)
+  const bool q_last = (wave * 64 + CD_THREADS * (RQ - 1)) < MT * Gn;
+  uint4 rawp[RP], rawp2[RP], rawq[RQ];
+  const uint32_t tbp = (uint32_t)(MT * Kp * 2), tbq = (uint32_t)(MT * Np * 2);
+  {
+    const uint32_t bp = (uint32_t)t0 * tbp, bq = (uint32_t)t0 * tbq;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) { rawp[r] = cd_load(rX, p_go[r] + bp); rawp2[r] = cd_load(rX2, p_go[r] + bp); }
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) rawq[r] = cd_load(rQ, q_go[r] + bq);
+  }
+
+  // ---- lane maps of the data gradient and of its epilogue (csrc/pw_cfwd.hip)
+  const int wr = wave % L.WR, wc = wave / L.WR;
+  const int nt0 = wc * NTW;                               // first output tile of this wave
+  constexpr int NLW = NTW * 16 + 8;                       // row stride (elements) of the wave's result staging
+  bf16_t* const Os = reinterpret_cast<bf16_t*>(smem + L.os_off + wave * L.os_wave);
+  constexpr int GOW = NTW * 2, RPO = 64 / GOW, NPASS = (16 + RPO - 1) / RPO;
+  const int rr_o = lane / GOW, v_o = lane - rr_o * GOW;
+  const int cvec = nt0 * 2 + v_o;                         // 8-channel vector of the output row
+  const bool act_o = lane < GOW * RPO && cvec * 8 < Np;
+  // companion rows of the epilogue (res, and c of the previous block for its BatchNorm_c-backward sums): one request per pass
+  // and lane, a tile ahead
+  uint4 e1r[NPASS], c1r[NPASS];
+#define CD_EOFF(TILE, P) ((act_o && (P) * RPO + rr_o < 16 && (TILE) * MT + wr * 16 + (P) * RPO + rr_o < M32)                        \
+                              ? ((uint32_t)((TILE) * MT + wr * 16 + (P) * RPO + rr_o) * (uint32_t)Np + (uint32_t)cvec * 8u) * 2u : CD_OOB)
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) { const uint32_t o = t0 < t1 ? CD_EOFF(t0, p) : CD_OOB; e1r[p] = cd_load(rE1, o); c1r[p] = cd_load(rC1, o); }
+
+  // ---- weight image -> LDS (LDS-DMA, 1 KB per wave instruction; the chunk order rotated by the workgroup index)
+  {
+    const int wbytes = (KS * 4) * L.img_rows * 16;
+    const int nchunk = (wbytes + 1023) >> 10;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(a.w_img);
+    const int rot = (int)blockIdx.x % nchunk;
+    for (int c = wave; c < nchunk; c += 8) {
+      int r = c + rot;
+      if (r >= nchunk) r -= nchunk;
+      const int off = r * 1024 + lane * 16;
+      if (off < wbytes)
+        __builtin_amdgcn_global_load_lds((cd_glb_ptr_t)(src + off), (cd_lds_ptr_t)(smem + L.w_off + r * 1024), 16, 0, 0);
+    }
+  }
+  // all four tiles zeroed once: the padding columns are never written again (k padding of P: 0 x weight row; channel padding
+  // of y_prev: weight-gradient columns nobody stores)
+  for (int i = tid * 16; i < 2 * L.a_bytes; i += CD_THREADS * 16) *reinterpret_cast<uint4*>(smem + L.a_off + i) = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid * 16; i < 2 * L.q_bytes; i += CD_THREADS * 16) *reinterpret_cast<uint4*>(smem + L.q_off + i) = make_uint4(0u, 0u, 0u, 0u);
+
+  // ---- BatchNorm_a-backward coefficients: rebuilt from the producer's completed sums (csrc/bn_fin.h; workgroup 0 accumulates
+  // d gamma / d beta and writes the vector for other readers) or read from memory -- the first kernel's prologue
+  if (a.fin.sums) {
+    for (int c = tid; c < Kp; c += CD_THREADS) {
+      float cA, cB, cC;
+      c3dfin::bn_bwd_coef_consume(a.fin, a.K, Kp, c, blockIdx.x == 0, cA, cB, cC);
+      Pp[c] = cA; Pp[Kp + c] = cB; Pp[2 * Kp + c] = cC;
+    }
+  } else {
+    for (int i = tid; i < 3 * Kp; i += CD_THREADS) Pp[i] = a.pro_p[i];
+  }
+  for (int i = tid; i < 2 * Np; i += CD_THREADS) Ep[i] = a.add_sums ? a.add_mr[i] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA chunks (and the first tile's rows)
+  __syncthreads();
+
+  float s0[8], s1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+  const uint32_t mask_on = a.wg_mask_out ? 0xffffffffu : 0u;
+  const uint32_t sums_on = a.add_sums ? 0xffffffffu : 0u;
+  const bf16_t* const wfrag = Ws + ((size_t)(lane >> 4) * L.img_rows + nt0 * 16 + (lane & 15)) * 8;   // + (ks * 4 * img_rows + t * 16) * 8
+  const int xfrag = (wr * 16 + (lane & 15)) * KL + (lane >> 4) * 8;                                  // + ks * 32
+
+  // ---- weight gradient: wave (pg, qg); transposing read: lane l addresses the 8-byte chunk (row 4 (l / 16) + (l % 16) / 4,
+  // channels 4 (l % 4) ..) of a 16 x 16 block and receives rows 4 (l / 16) .. + 3 of channel l % 16
+  const int qg = wave % L.QG, pg = wave / L.QG;
+  const int g4 = lane >> 4, li = lane & 15;
+  const int pl = (4 * g4 + (li >> 2)) * KL + 4 * (li & 3) + pg * NPW * 16;
+  const int ql = (4 * g4 + (li >> 2)) * QL + 4 * (li & 3) + qg * NQW * 16;
+  f32x4_t dacc[NPW][NQW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NQW; ++j) dacc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // ---- one tile: conversion -> row-major LDS tiles.  Branch-free (an item a lane does not have is converted all the same --
+  // its request answered zeros -- and written to the lane's 16 bytes of a dump region): ONE basic block the scheduler can
+  // interleave with the matrix-core work of the previous tile.  A slot is requested again for the next tile as soon as it
+  // is converted.
+#define CD_CONVERT(TILE, CP, CQ)                                                                                    \
+  {                                                                                                                 \
+    const int rowg0_ = (TILE) * MT;                                                                                 \
+    const uint32_t bpn_ = (uint32_t)((TILE) + 1) * tbp, bqn_ = (uint32_t)((TILE) + 1) * tbq;                        \
+    _Pragma("unroll") for (int r = 0; r < RP; ++r) {                                                                \
+      if (r == RP - 1 && !p_last) continue;                                                                         \
+      const int row = p_desc[r] >> 5, v = p_desc[r] & 31;                                                           \
+      bf16_t* dst = p_go[r] != CD_OOB ? (CP) + row * KL + v * 8 : dump;                                             \
+      float f[8], f2[8], cA[8], cB[8], cC[8];                                                                       \
+      cd_cvt(rawp[r], f); cd_cvt(rawp2[r], f2);                                                                     \
+      cd_ld8(Pp + v * 8, cA); cd_ld8(Pp + Kp + v * 8, cB); cd_ld8(Pp + 2 * Kp + v * 8, cC);                         \
+      /* a row past the tensor's end is zero x A + B: zeroed by a bit mask (`real ? fma : 0` compiles to a branch) */ \
+      const uint32_t keep = rowg0_ + row < M32 ? 0xffffffffu : 0u;                                                  \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                                 \
+        f[e] = __uint_as_float(__float_as_uint(fmaf(cA[e], f[e], fmaf(cC[e], f2[e], cB[e]))) & keep);               \
+      Vec8<bf16_t>::store(dst, f);                                                                                  \
+      rawp[r] = cd_load(rX, p_go[r] + bpn_);   /* (past this workgroup's last row: zeros, no memory access) */       \
+      rawp2[r] = cd_load(rX2, p_go[r] + bpn_);                                                                      \
+    }                                                                                                               \
+    _Pragma("unroll") for (int r = 0; r < RQ; ++r) {                                                                \
+      if (r == RQ - 1 && !q_last) continue;                                                                         \
+      const int row = q_desc[r] >> 5, v = q_desc[r] & 31;                                                           \
+      bf16_t* dst = q_go[r] != CD_OOB ? (CQ) + row * QL + v * 8 : dump;                                             \
+      *reinterpret_cast<uint4*>(dst) = rawq[r];                                                                     \
+      rawq[r] = cd_load(rQ, q_go[r] + bqn_);                                                                        \
+    }                                                                                                               \
+  }
+  // data gradient of one tile: A = weight fragment (packed image), B = data fragment (row-major P tile)
+#define CD_MULT(CA)                                                                                                 \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                             \
+      const uint4 xb = *reinterpret_cast<const uint4*>((CA) + xfrag + ks * 32);                                     \
+      _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                             \
+        const uint4 wa = *reinterpret_cast<const uint4*>(wfrag + ((size_t)ks * 4 * L.img_rows + t * 16) * 8);       \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xb), acc[t], 0, 0, 0); \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+  // weight gradient of one tile: rows are the contraction index (k-steps of 32 rows)
+#define CD_WGRAD(CA, CQ)                                                                                            \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int k2 = 0; k2 < K2; ++k2) {                                                             \
+      uint4 pa[NPW], qb[NQW];                                                                                       \
+      const bf16_t* pb_ = (CA) + k2 * 32 * KL + pl;                                                                 \
+      const bf16_t* qb_ = (CQ) + k2 * 32 * QL + ql;                                                                 \
+      _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                             \
+        const cd_s16x4_t lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_lds_s16x4_ptr_t)(pb_ + i * 16));        \
+        const cd_s16x4_t hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_lds_s16x4_ptr_t)(pb_ + 16 * KL + i * 16)); \
+        pa[i] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7));               \
+      }                                                                                                             \
+      _Pragma("unroll") for (int j = 0; j < NQW; ++j) {                                                             \
+        const cd_s16x4_t lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_lds_s16x4_ptr_t)(qb_ + j * 16));        \
+        const cd_s16x4_t hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_lds_s16x4_ptr_t)(qb_ + 16 * QL + j * 16)); \
+        qb[j] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7));               \
+      }                                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < NPW; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NQW; ++j)                                                             \
+          dacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa[i]), __builtin_bit_cast(bf16x8_t, qb[j]), \
+                                                               dacc[i][j], 0, 0, 0);                               \
+    }                                                                                                               \
+  }
+  // result tile -> the wave's staging rows ([row = lane & 15][channel], bf16 as the first kernel stages it) -> 16-byte row
+  // vectors: + res, ReLU mask of y_prev (read from its LDS tile), the previous block's BatchNorm_c-backward sums, store
+#define CD_EPI(TILE, CQ, NEXT_ON)                                                                                   \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                                                 \
+      *reinterpret_cast<uint2*>(Os + (lane & 15) * NLW + t * 16 + (lane >> 4) * 4) =                                \
+          make_uint2(pack_bf16x2(acc[t][0], acc[t][1]), pack_bf16x2(acc[t][2], acc[t][3]));                         \
+    const int row0_ = (TILE) * MT + wr * 16;                                                                        \
+    _Pragma("unroll") for (int p = 0; p < NPASS; ++p) {                                                             \
+      const int row = p * RPO + rr_o;                                                                               \
+      const int rowc = row < 16 ? row : 0;                                                                          \
+      const int m = row0_ + row;                                                                                    \
+      const bool ok = act_o && row < 16 && m < M32;                                                                 \
+      const uint32_t keep = ok ? 0xffffffffu : 0u;                                                                  \
+      const uint4 rawo = *reinterpret_cast<const uint4*>(Os + rowc * NLW + v_o * 8);                                \
+      const uint4 x3 = *reinterpret_cast<const uint4*>((CQ) + (wr * 16 + rowc) * QL + (act_o ? cvec : 0) * 8);      \
+      float f[8], rv[8], cv[8], eM[8], eR[8];                                                                       \
+      cd_cvt(rawo, f); cd_cvt(e1r[p], rv); cd_cvt(c1r[p], cv);                                                      \
+      cd_ld8(Ep + (act_o ? cvec : 0) * 8, eM); cd_ld8(Ep + Np + (act_o ? cvec : 0) * 8, eR);                        \
+      const uint32_t xw[4] = {x3.x, x3.y, x3.z, x3.w};                                                              \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                               \
+        const uint32_t hx = (xw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;                                               \
+        /* y_prev > 0 (a ReLU output: nonzero magnitude, sign clear); without the mask every element passes */      \
+        const uint32_t pass = ((hx & 0x7fffu) != 0u && !(hx & 0x8000u)) ? 0xffffffffu : ~mask_on;                   \
+        const float d = __uint_as_float(__float_as_uint(f[j] + rv[j]) & pass);                                      \
+        f[j] = d;                                                                                                   \
+        const float gq = __uint_as_float(__float_as_uint(round_as<bf16_t>(d)) & keep & sums_on);                    \
+        s0[j] += gq; s1[j] = fmaf(gq, (cv[j] - eM[j]) * eR[j], s1[j]);                                              \
+      }                                                                                                             \
+      const uint4 pk = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])); \
+      __builtin_amdgcn_raw_buffer_store_b128(cd_u32x4_t{pk.x, pk.y, pk.z, pk.w}, rY,                                \
+                                             ok ? ((uint32_t)m * (uint32_t)Np + (uint32_t)cvec * 8u) * 2u : CD_OOB, 0, 0); \
+      const uint32_t no_ = (NEXT_ON) ? CD_EOFF((TILE) + 1, p) : CD_OOB;                                             \
+      e1r[p] = cd_load(rE1, no_); c1r[p] = cd_load(rC1, no_);                                                       \
+    }                                                                                                               \
+  }
+
+  bf16_t* const bufP0 = reinterpret_cast<bf16_t*>(smem + L.a_off);
+  bf16_t* const bufP1 = reinterpret_cast<bf16_t*>(smem + L.a_off + L.a_bytes);
+  bf16_t* const bufQ0 = reinterpret_cast<bf16_t*>(smem + L.q_off);
+  bf16_t* const bufQ1 = reinterpret_cast<bf16_t*>(smem + L.q_off + L.q_bytes);
+  if (t0 < t1) CD_CONVERT(t0, bufP0, bufQ0)
+  int cur = 0;
+  for (int tile = t0; tile < t1; ++tile, cur ^= 1) {
+    bf16_t* const curP = cur ? bufP1 : bufP0;
+    bf16_t* const nxtP = cur ? bufP0 : bufP1;
+    bf16_t* const curQ = cur ? bufQ1 : bufQ0;
+    bf16_t* const nxtQ = cur ? bufQ0 : bufQ1;
+    __syncthreads();   // the only barrier per tile: tile `tile` is complete, every wave is past the products that read the other buffers
+    f32x4_t acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (tile + 1 < t1) {
+      // both products + store + sums of this tile and the conversion of the next one: ONE basic block
+      CD_MULT(curP)
+      CD_WGRAD(curP, curQ)
+      CD_CONVERT(tile + 1, nxtP, nxtQ)
+      CD_EPI(tile, curQ, true)
+#ifndef CD_VPM
+#define CD_VPM 10
+#endif
+#ifndef CD_SCHED
+#define CD_SCHED 1
+#endif
+#pragma unroll
+      for (int i = 0; i < (CD_SCHED ? NTW * KS + K2 * NPW * NQW : 0); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, CD_VPM, 0);   // VALU instructions of the conversion / the epilogue
+        if (i & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a re-request
+      }
+    } else {
+      CD_MULT(curP)
+      CD_WGRAD(curP, curQ)
+      CD_EPI(tile, curQ, false)
+    }
+  }
+#undef CD_CONVERT
+#undef CD_MULT
+#undef CD_WGRAD
+#undef CD_EPI
+#undef CD_EOFF
+
+  // ---- this workgroup's dW partial -> wg_ws[blockIdx.x][K][N] (the reducer launched behind this kernel adds the partials in
+  // fixed order into wg_dw)
+  {
+    float* wsb = a.wg_ws + (size_t)blockIdx.x * a.K * a.N;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+#pragma unroll
+      for (int j = 0; j < NQW; ++j) {
+        const int n = (qg * NQW + j) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = (pg * NPW + i) * 16 + (lane >> 4) * 4 + r;
+          if (k < a.K && n < a.N) wsb[(size_t)k * a.N + n] = dacc[i][j][r];
+        }
+      }
+    }
+  }
+
+  // ---- BatchNorm_c-backward sums of the previous block (single set, f64 [2][N]: the layout c3d_block_out_bwd fills): lanes
+  // -> LDS ([value][lane] per wave; the converted tiles are dead) -> one thread per (which, channel) adds the row-lanes of the
+  // WR waves of its column group -> ONE f64 atomic per value and workgroup
+  if (a.add_sums) {
+    __syncthreads();
+    float* mine = reinterpret_cast<float*>(smem + L.a_off) + (size_t)wave * 16 * 64;   // [16][64]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mine[j * 64 + lane] = s0[j]; mine[(8 + j) * 64 + lane] = s1[j]; }
+    __syncthreads();
+    for (int i = tid; i < 2 * a.N; i += CD_THREADS) {
+      const int which = i / a.N, c = i - which * a.N;
+      const int cv = c >> 3, j = c & 7;                    // channel = vector cv, element j
+      const int wcg = cv / GOW, vo = cv - wcg * GOW;       // column group of the vector, its index inside the group
+      float accv = 0.f;
+      for (int w_ = 0; w_ < L.WR; ++w_) {
+        const float* base = reinterpret_cast<const float*>(smem + L.a_off) + (size_t)(wcg * L.WR + w_) * 16 * 64 + (which * 8 + j) * 64;
+        for (int rr = 0; rr < RPO; ++rr) accv += base[rr * GOW + vo];
+      }
+      atomicAdd(a.add_sums + which * a.N + c, (double)accv);
+    }
+  }
+}
+
+template <int KS, int NTW, int NPW, int NQW, int RP, int RQ, int K2>
+int cd_launch(const c3d_pw_args& a, const CdPlan& L, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_cdg_a_kernel<KS, NTW, NPW, NQW, RP, RQ, K2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  pw_cdg_a_kernel<KS, NTW, NPW, NQW, RP, RQ, K2><<<grid, dim3(CD_THREADS), lds, s>>>(a, L);
+  return 0;
+}
+
+// shape -> instantiation: 0 = none.  1: 216 -> 96 (32 x 32 stage), 2: 108 -> 48, 3: 54 -> 24
+int cd_variant(int Kp, int Np) {
+  const int KS = (Kp + 31) / 32, ntn = (Np + 15) >> 4, ntp = (Kp + 15) >> 4;
+  if (KS == 7 && ntn >= 5 && ntn <= 6 && ntp <= 16) return 1;
+  if (KS == 4 && ntn == 3 && ntp <= 8) return 2;
+  if (KS == 2 && ntn == 2 && ntp <= 4) return 3;
+  return 0;
+}
+
+int cd_plan(const c3d_pw_args& a, CdPlan& L, int64_t& blocks, size_t& lds) {
+  const int var = cd_variant(a.Kp, a.Np);
+  if (!var) return 0;
+  const int Kpad = (a.Kp + 31) / 32 * 32, KS = Kpad / 32, ntn = (a.Np + 15) >> 4;
+  L.img_rows = (ntn <= 2 ? 2 : ntn <= 4 ? 4 : ntn <= 7 ? 7 : 14) * 16;
+  int NTW;
+  // (216 -> 96: 32-row tiles, 2 row slabs x 4 column groups of two output tiles -- the fourth group is padding: with 64-row tiles
+  // the prefetch registers of three row streams beside 48 weight-gradient accumulators spilled, and LDS was full)
+  if (var == 1) { L.WR = 2; L.WC = 4; NTW = 2; L.QG = 2; }
+  else if (var == 2) { L.WR = 8; L.WC = 1; NTW = 3; L.QG = 1; }
+  else { L.WR = 8; L.WC = 1; NTW = 2; L.QG = 2; }
+  L.MT = 16 * L.WR;
+  L.KL = Kpad + 8;
+  L.QL = ntn * 16 + 8;
+  const int64_t tiles = (a.M + L.MT - 1) / L.MT;
+  blocks = device_cus();
+  if (blocks > (tiles + 1) / 2) blocks = (tiles + 1) / 2;
+  if (blocks > CD_MAX_PARTS) blocks = CD_MAX_PARTS;
+  if (blocks < 1) blocks = 1;
+  const int tpw = (int)((tiles + blocks - 1) / blocks);
+  blocks = (tiles + tpw - 1) / tpw;
+  L.tiles_per_wg = tpw;
+  auto al = [](size_t v) { return (v + 1023) / 1024 * 1024; };
+  size_t off = 0;
+  L.w_off = 0; off += al((size_t)KS * 4 * L.img_rows * 16);
+  L.a_off = (int)off; L.a_bytes = (int)al((size_t)L.MT * L.KL * 2); off += 2 * (size_t)L.a_bytes;
+  L.q_off = (int)off; L.q_bytes = (int)al((size_t)L.MT * L.QL * 2); off += 2 * (size_t)L.q_bytes;
+  if (2 * (size_t)L.a_bytes + 2 * (size_t)L.q_bytes < (size_t)8 * 16 * 64 * 4) return 0;   // (the statistics dump at the end reuses the tiles)
+  L.os_wave = 16 * (NTW * 16 + 8) * 2; L.os_off = (int)off; off += al((size_t)8 * L.os_wave);
+  L.par_off = (int)off; off += al(((size_t)3 * a.Kp + 2 * a.Np) * 4);
+  L.dump_off = (int)off; off += (size_t)CD_THREADS * 16;
+  if (off > 160 * 1024) return 0;
+  lds = off;
+  return var;
+}
+
+}  // namespace
+
+// Host-side check for the stage driver: would c3d_detail_pw_cdg_a take this layer (bf16, dense rows, res_mode 0)?
+__attribute__((visibility("hidden"))) bool c3d_detail_pw_cdg_a_supported(int Kp, int Np, int64_t M) {
+  if (Kp <= 0 || Np <= 0 || (Kp & 7) || (Np & 7)) return false;
+  if (M < 1024 || (M + 512) * (int64_t)(Kp > Np ? Kp : Np) * 2 >= ((int64_t)1 << 31)) return false;
+  c3d_pw_args a;
+  std::memset(&a, 0, sizeof(a));
+  a.M = M; a.K = a.Kp = Kp; a.N = a.Np = Np;
+  CdPlan L;
+  int64_t blocks = 0;
+  size_t lds = 0;
+  return cd_plan(a, L, blocks, lds) != 0;
+}
+
+// Returns C3D_E_UNSUPPORTED for what it does not take (c3d_pw_gemm then runs the first kernel's fused variant).
+__attribute__((visibility("hidden"))) int c3d_detail_pw_cdg_a(const c3d_pw_args* args, void* stream) {
+  const c3d_pw_args& a = *args;
+  if (a.dtype != C3D_DT_BF16 || a.row_mode != C3D_ROWS_DENSE || a.pro_mode != C3D_PRO_AFFINE2 || a.epi_mode != C3D_EPI_ADD ||
+      a.wg_mode != C3D_WG_ROWS || a.res_mode != 0)
+    return C3D_E_UNSUPPORTED;
+  if (!a.w_img || !a.x2 || !a.e1 || !a.wg_x3 || !a.wg_dw || !a.wg_ws || a.pro_out || a.bias || a.fin.ticket) return C3D_E_UNSUPPORTED;
+  if (a.fin.sums ? (a.fin.training != 0 || !a.fin.mr || !a.fin.gamma) : !a.pro_p) return C3D_E_UNSUPPORTED;
+  if (a.add_sums && (!a.add_c || !a.add_mr || !a.wg_mask_out)) return C3D_E_UNSUPPORTED;
+  if (a.M < 1024 || (a.M + 512) * (int64_t)(a.Kp > a.Np ? a.Kp : a.Np) * 2 >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
+  CdPlan L;
+  int64_t blocks = 0;
+  size_t lds = 0;
+  const int var = cd_plan(a, L, blocks, lds);
+  if (!var) return C3D_E_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)blocks);
+  int rc = C3D_E_UNSUPPORTED;
+  if (var == 1) rc = cd_launch<7, 2, 4, 3, 2, 1, 1>(a, L, grid, lds, s);        // 216 -> 96: 14 x 6 weight-gradient tiles, 4 x 3 per wave
+  else if (var == 2) rc = cd_launch<4, 3, 1, 3, 4, 2, 4>(a, L, grid, lds, s);   // 108 -> 48: 7 x 3, 1 x 3 per wave
+  else if (var == 3) rc = cd_launch<2, 2, 1, 1, 2, 1, 4>(a, L, grid, lds, s);   // 54 -> 24: 4 x 2, 1 x 1 per wave
+  if (rc != 0) return rc;
+  C3D_CHECK_LAUNCH();
+  if (c3d_cdg_defer_reduce) { c3d_cdg_parts = (int)blocks; return 0; }   // (the stage driver reduces on its side stream)
+  return c3d_detail_pw_wgrad_reduce(a.wg_ws, a.wg_dw, a.K, a.N, (int)blocks, a.w_sk, a.w_sn, s);
+}

@@ -149,6 +149,11 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
   // the wave-private-tile kernels address rows with 32-bit byte offsets into bounds-checked buffer resources (offset 2^31 =
   // "nowhere"): every tensor of the call must stay under 2 GiB
   if ((int64_t)a.M * (a.Kp > a.Np ? a.Kp : a.Np) * (a.dtype == C3D_DT_F32 ? 4 : 2) >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
+  if (a.wg_mode == C3D_WG_ROWS && (c3d_option_pw_cdg & 1)) {
+    // conv_a data gradient + weight gradient: the workgroup-cooperative kernel (csrc/pw_cdgrad.hip) where it applies
+    const int rcd = c3d_detail_pw_cdg_a(args, stream);
+    if (rcd != C3D_E_UNSUPPORTED) return rcd;
+  }
   if (a.wg_mode != C3D_WG_NONE) return c3d_detail_pw_gemm_wg(args, stream);
   if (a.epi_mode == C3D_EPI_STATS && ((a.pro_mode == C3D_PRO_BN_SE_SWISH && (c3d_option_pw_cfwd & 1)) ||
                                       (a.pro_mode == C3D_PRO_AFFINE2 && a.pro_out && (c3d_option_pw_cfwd & 2)))) {

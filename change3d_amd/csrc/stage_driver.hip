@@ -88,7 +88,7 @@ struct Plan {
   std::vector<BlkFwd> f;
   std::vector<BlkBwd> b;
   size_t fwd_acc_off = 0, fwd_acc_bytes = 0, fwd_total = 0;
-  size_t bwd_acc_off = 0, bwd_acc_bytes = 0, bwd_total = 0, wgrad_ws = 0, wgrad_ws2 = 0, wgrad_ws_fused = 0;
+  size_t bwd_acc_off = 0, bwd_acc_bytes = 0, bwd_total = 0, wgrad_ws = 0, wgrad_ws2 = 0, wgrad_ws_fused = 0, wgrad_ws_fused_slot = 0;
   size_t y_bytes = 0, dx_bytes = 0;
 };
 
@@ -195,6 +195,8 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
     const BlkGeom& G = P.g[i];
     if (fuse_wgrad(d, G.Cop, G.Cip, C3D_WG_SWISH)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Co, G.Ci));
     if (fuse_wgrad(d, G.Cip, G.Cinp, C3D_WG_ROWS)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Ci, G.Cin));
+    // (the cooperative conv_a data + weight gradient, csrc/pw_cdgrad.hip: reserved whatever C3D_OPT_PW_CDG says right now)
+    if (d->dtype == C3D_DT_BF16 && c3d_detail_pw_cdg_a_supported(G.Cip, G.Cinp, G.M)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Ci, G.Cin));
     mx_g = std::max(mx_g, (size_t)G.Mo * G.Cop * e);
     mx_t1 = std::max(mx_t1, (size_t)G.Mo * G.Cip * e);
     mx_t2 = std::max(mx_t2, (size_t)G.M * G.Cip * e);
@@ -218,7 +220,10 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
   for (int r = 0; r < R + 1; ++r) ring_dx[r] = mx_dx ? cb.take(mx_dx) : SIZE_MAX;
   P.wgrad_ws = cb.take((size_t)wsf * 4);
   P.wgrad_ws2 = cb.take((size_t)wsf * 4);   // chained weight-gradient launches alternate between the two (c3d_pw_wgrad_args.chain)
-  P.wgrad_ws_fused = wsf_fused ? cb.take((size_t)wsf_fused * 4) : SIZE_MAX;   // main stream: kernel, then its reducer
+  // slot 0: the wave-private kernel's fused variant (kernel, then its reducer, on the main stream); slots 1..3: the cooperative
+  // kernel's partials, reduced on the side stream -- launch k uses slot 1 + k % 3, the side stream lags at most two blocks
+  P.wgrad_ws_fused = wsf_fused ? cb.take((size_t)wsf_fused * 4 * 4) : SIZE_MAX;
+  P.wgrad_ws_fused_slot = (size_t)wsf_fused * 4;
   for (int i = 0; i < n; ++i) {
     const BlkGeom& G = P.g[i];
     BlkBwd& Bk = P.b[i];
@@ -725,6 +730,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   float* const wgws_ab[2] = {atT<float>(wb, P.wgrad_ws), atT<float>(wb, P.wgrad_ws2)};
   int wg_n = 0;   // weight-gradient launches of this call: launch k leaves its partials in workspace k & 1, launch k + 1 reduces them
   float* wgws_fused = atT<float>(wb, P.wgrad_ws_fused);
+  int cdg_n = 0;   // cooperative data + weight gradient launches of this call (workspace slot 1 + cdg_n % 3)
   c3d_detail_pw_wgrad_v2_drop();   // (nothing may be pending from a call that returned early)
   const bool wimg = use_pw_img(d);   // transposed weight images written by this step's c3d_stage_fwd (training mode)
   auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
@@ -846,7 +852,11 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     }
     // ---- conv_a data gradient (+ shortcut gradient in the epilogue) and weight gradient (forked first: it needs the
     //      coefficients, not the data gradient)
-    const bool fuse_wa = (g_fuse_wgrad & 1) && fuse_wgrad(d, G.Cip, G.Cinp, C3D_WG_ROWS);
+    // ... or fused into the data-gradient launch: the wave-private kernel's variant (K, N <= 112) or the cooperative kernel
+    // (csrc/pw_cdgrad.hip: any of the three stage widths, dense shortcut gradient, packed weight image)
+    const bool coop_wa = (c3d_option_pw_cdg & 1) && dt == C3D_DT_BF16 && !(d->flags & C3D_STAGE_SEPARATE_WGRAD) && res_mode == 0 &&
+                         imgp(F.img_at) != nullptr && c3d_detail_pw_cdg_a_supported(G.Cip, G.Cinp, G.M);
+    const bool fuse_wa = coop_wa || ((g_fuse_wgrad & 1) && fuse_wgrad(d, G.Cip, G.Cinp, C3D_WG_ROWS));
     bool mask_next = false, sums_next = false;
     if (!fuse_wa)
     RC(side_run(st, [&](hipStream_t s2) {
@@ -877,7 +887,23 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       if (consb) p.a.fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, true);
       p.a.epi_mode = C3D_EPI_ADD; p.a.e1 = res; p.a.res_mode = res_mode; p.a.H = G.H; p.a.W = G.W;
       p.a.w_img = imgp(F.img_at);
-      RC(pw_launch(p.a, st));
+      if (coop_wa && side_enabled() && bwd_ring() <= 3) {
+        // the reducer of the cooperative kernel's partials runs on the side stream (5 us per launch off the data-gradient chain)
+        float* const wsk = wgws_fused + (size_t)(1 + cdg_n % 3) * (P.wgrad_ws_fused_slot / 4);
+        p.a.wg_ws = wsk;
+        c3d_cdg_defer_reduce = 1; c3d_cdg_parts = 0;
+        const int rcl = pw_launch(p.a, st);
+        c3d_cdg_defer_reduce = 0;
+        RC(rcl);
+        const int parts = c3d_cdg_parts;
+        if (parts > 0) {
+          ++cdg_n;
+          const c3d_pw_args pa = p.a;
+          RC(side_run(st, [&](hipStream_t s2) { return c3d_detail_pw_wgrad_reduce(wsk, pa.wg_dw, pa.K, pa.N, parts, pa.w_sk, pa.w_sn, s2); }));
+        }
+      } else {
+        RC(pw_launch(p.a, st));
+      }
     }
     // the side stream may lag by ring-1 blocks: block i-1 reuses the ring slot of block i-1+ring
     lag.push_back(side_mark());
@@ -896,6 +922,7 @@ int c3d_option_stem_mfma = 2, c3d_option_convt_mfma = 1;   // read by stem.hip /
 int c3d_option_dw_ring = 5;                                // read by dw_bwd_fused.hip / dw_conv.hip
 int c3d_option_pw_wgrad_v2 = 1;                            // read by pw_wgrad.hip
 int c3d_option_pw_cfwd = 3;                                // read by pw_gemm.hip
+int c3d_option_pw_cdg = 1;                                 // read by pw_gemm.hip and c3d_stage_bwd
 int c3d_option_dw_fwd_hv = 5;                              // read by dw_conv.hip
 
 extern "C" int c3d_set_option(int32_t option, int32_t value) {
@@ -909,6 +936,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_DW_RING: c3d_option_dw_ring = value & 15; return 0;
     case C3D_OPT_DW_FWD_HV: c3d_option_dw_fwd_hv = value & 7; return 0;
     case C3D_OPT_PW_CFWD: c3d_option_pw_cfwd = value & 3; return 0;
+    case C3D_OPT_PW_CDG: c3d_option_pw_cdg = value & 1; return 0;
     case C3D_OPT_PW_WGRAD_V2: c3d_option_pw_wgrad_v2 = value & 1; g_wgrad_chain = (value & 2) ? 0 : 1; return 0;
     default: return C3D_E_BADARG;
   }

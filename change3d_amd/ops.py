@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib as L
-from ._lib import (OPT_CONVT_MFMA, OPT_DW_FWD_HV, OPT_DW_RING, OPT_FOLD_SE, OPT_FUSE_WGRAD, OPT_MASK_IN_DGRAD, OPT_PW_CFWD, OPT_PW_WGRAD_V2, OPT_SIDE_STREAM, OPT_STEM_MFMA, STAGE_NO_WEIGHT_IMAGES, STAGE_SEPARATE_FINALIZE,  # noqa: F401
+from ._lib import (OPT_CONVT_MFMA, OPT_DW_FWD_HV, OPT_DW_RING, OPT_FOLD_SE, OPT_FUSE_WGRAD, OPT_MASK_IN_DGRAD, OPT_PW_CDG, OPT_PW_CFWD, OPT_PW_WGRAD_V2, OPT_SIDE_STREAM, OPT_STEM_MFMA, STAGE_NO_WEIGHT_IMAGES, STAGE_SEPARATE_FINALIZE,  # noqa: F401
                    STAGE_SEPARATE_RESIDUAL, STAGE_SEPARATE_WGRAD)
 from ._lib import (DT_BF16, DT_F32, EPI_ADD, EPI_STATS, EPI_STORE, EPI_SWISH_SE_BWD, PRO_AFFINE2,  # noqa: F401
                    PRO_BN_SE_SWISH, PRO_NONE, ROWS_DENSE, ROWS_FRAME, ROWS_S2SHIFT, ROWS_STRIDE2, SC_BN,

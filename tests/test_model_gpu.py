@@ -747,10 +747,11 @@ def test_folded_batchnorm_launches_are_bit_identical_end_to_end(flag):
     from change3d_amd.model.utils import BCEDiceLoss
     from change3d_amd.model.x3d import X3DResStage
     outs = []
-    # (the workgroup-cooperative conv_a / conv_c forward kernels take only the default sequence's argument forms and group the
-    # f32 partial sums of the BatchNorm statistics differently from the first kernel -- 1e-6, tests/test_ops_gpu.py; both runs
-    # of this comparison use the first kernel)
+    # (the workgroup-cooperative kernels -- conv_a / conv_c forward, conv_a data + weight gradient -- take only the default
+    # sequence's argument forms and group f32 partial sums differently from the first kernel -- 1e-6, tests/test_ops_gpu.py,
+    # tests/test_pw_wg_gpu.py; both runs of this comparison use the first kernel)
     ops.set_option(ops.OPT_PW_CFWD, 0)
+    ops.set_option(ops.OPT_PW_CDG, 0)
     try:
         for flags in (0, getattr(ops, flag)):
             args = synth.make_args(size=64, act_dtype=torch.bfloat16)
@@ -769,6 +770,7 @@ def test_folded_batchnorm_launches_are_bit_identical_end_to_end(flag):
                          "bufs": {n: b.cpu() for n, b in net.named_buffers()}})
     finally:
         ops.set_option(ops.OPT_PW_CFWD, 3)
+        ops.set_option(ops.OPT_PW_CDG, 1)
     a, b = outs
     assert torch.equal(a["loss"], b["loss"]) and torch.isfinite(a["loss"])
     assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 400
@@ -845,6 +847,7 @@ def test_conv_c_forward_on_the_cooperative_kernel_end_to_end():
                          "bufs": {n: b.float().cpu() for n, b in net.named_buffers()}})
     finally:
         ops.set_option(ops.OPT_PW_CFWD, 3)
+        ops.set_option(ops.OPT_PW_CDG, 1)
     a, b = outs
     assert torch.isfinite(b["loss"]) and abs(a["loss"].item() - b["loss"].item()) < 2e-3 * abs(a["loss"].item()), (a["loss"], b["loss"])
     assert (a["prob"] - b["prob"]).abs().max().item() < 2e-2

@@ -236,3 +236,65 @@ def test_masksum_refuses_what_it_does_not_take():
     with pytest.raises(Change3DHipError):
         ops.pw_gemm(z(M, Ci), torch.zeros(Ci, 48, device=DEV), z(M, 48), wg_mode=ops.WG_MASKSUM, wg_x3=z(M, 48), add_c=z(M, 48),
                     add_mr=torch.zeros(96, device=DEV), add_sums=torch.zeros(96, dtype=torch.float64, device=DEV), **kw2)
+
+
+# The workgroup-cooperative conv_a data + weight gradient (csrc/pw_cdgrad.hip, C3D_OPT_PW_CDG) against the wave-private kernels
+# on the same device buffers: the three stage widths of X3D-L (216 -> 96 has no fused form in the first kernel: there the
+# reference is its C3D_WG_MASKSUM data gradient plus a separate c3d_pw_wgrad), whole and ragged row counts, with the ReLU mask
+# and the folded BatchNorm_c-backward sums and without.  dx must be BIT-identical; sums and dW agree to f32 rounding.
+@pytest.mark.parametrize("Ci,Cin,M", [(216, 96, 98304 // 8), (216, 96, 5000 - 7), (108, 48, 16 * 300 - 9), (108, 48, 128 * 40),
+                                      (54, 24, 16 * 400 - 3), (54, 24, 128 * 33), (216, 96, 1024)])
+@pytest.mark.parametrize("mask", [1, 0])
+def test_cooperative_conv_a_data_and_weight_gradient(Ci, Cin, M, mask):
+    _need_gpu()
+    from change3d_amd import ops
+    dt = ops.dt_code(DT)
+    Cip, Cinp = ops.cpad(Ci), ops.cpad(Cin)
+    t2, a_ = q(rnd((M, Ci), 61), DT), q(rnd((M, Ci), 62), DT)
+    A, Bc, Cc = rnd((Ci,), 63), rnd((Ci,), 64, 0.1), rnd((Ci,), 65, 0.1)
+    w = rnd((Ci, Cin), 66, 0.2)
+    y_prev = torch.relu(q(rnd((M, Cin), 67), DT))
+    res = q(rnd((M, Cin), 68), DT)
+    cten = q(rnd((M, Cin), 69), DT)
+    t2d, ad = (padc(t, Cip).to(DEV, DT).contiguous() for t in (t2, a_))
+    yd, rd, cd_ = (padc(t, Cinp).to(DEV, DT).contiguous() for t in (y_prev, res, cten))
+    coef = torch.cat([padc(A, Cip), padc(Bc, Cip), padc(Cc, Cip)]).to(DEV)
+    mr = torch.cat([padc(rnd((Cin,), 70, 0.5), Cinp), padc(rnd((Cin,), 71).abs() + 0.5, Cinp)]).to(DEV)
+    wd = w.to(DEV)
+    img = torch.zeros(ops.pw_weight_image_bytes(Cin, Ci, dt), dtype=torch.uint8, device=DEV)
+    ops.pw_pack_weights([(wd, img, Cin, Ci, 1, Cin)], dt)
+    base = dict(M=M, K=Ci, N=Cin, w_sn=1, w_sk=Cin, dtype=dt, x2=ad, pro_mode=ops.PRO_AFFINE2, pro_p=coef, epi_mode=ops.EPI_ADD,
+                e1=rd, w_img=img)
+
+    def run(opt):
+        ops.set_option(ops.OPT_PW_CDG, opt)
+        dx = torch.full((M, Cinp), float("nan"), dtype=DT, device=DEV)
+        dw = torch.ones((Ci, Cin), dtype=torch.float32, device=DEV)          # += onto ones
+        s = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+        sums = dict(add_c=cd_, add_mr=mr, add_sums=s) if mask else {}
+        if opt == 0 and Ci > 112:      # no fused form: masked data gradient (or plain), then the separate weight gradient
+            if mask:
+                ops.pw_gemm(t2d, wd, dx, wg_mode=ops.WG_MASKSUM, wg_x3=yd, **sums, **base)
+            else:
+                ops.pw_gemm(t2d, wd, dx, **base)
+            ops.pw_wgrad(t2d, yd, dw, M=M, K=Cin, N=Ci, dw_sn=Cin, dw_sk=1, dtype=dt, p2=ad, p_coef=coef)
+        else:
+            ops.pw_gemm(t2d, wd, dx, wg_mode=ops.WG_ROWS, wg_dw=dw, wg_x3=yd, wg_mask_out=mask, **sums, **base)
+        torch.cuda.synchronize()
+        return dx, dw, s
+
+    try:
+        dx0, dw0, s0 = run(0)
+        dx1, dw1, s1 = run(1)
+    finally:
+        ops.set_option(ops.OPT_PW_CDG, 1)
+    assert torch.isfinite(dx1.float()).all() and dx1.float().abs().max().item() > 0
+    assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16)), f"{int((dx0.view(torch.int16) != dx1.view(torch.int16)).sum())} elements of dx differ"
+    if mask:
+        assert (dx1[:, :Cin][yd[:, :Cin] == 0] == 0).all()
+        scale = s0.abs().max().item()
+        assert (s1 - s0).abs().max().item() < 2e-6 * scale + 1e-4, ((s1 - s0).abs().max().item(), scale)
+    assert _rel(dw1, dw0) < 2e-5, _rel(dw1, dw0)
+    P = q(A * t2 + Bc + Cc * a_, DT).double()
+    ref = (P.t() @ y_prev.double() + 1.0).float()
+    assert _rel(dw1, ref) < 5e-5, _rel(dw1, ref)      # (this reference rounds P from another association of the two multiply-adds)
