@@ -21,9 +21,11 @@ extern int c3d_option_convt_mfma;   // 1: bf16 ConvTranspose2d on the matrix cor
 extern int c3d_option_dw_ring;      // C3D_OPT_DW_RING (include/change3d_hip.h): LDS-DMA ring variant of the bf16 stride-1 depthwise backward
 extern int c3d_option_dw_fwd_hv;     // C3D_OPT_DW_FWD_HV: stride-1 three-frame depthwise forward on half-vector lanes (bit 0 bf16, bit 1 f32 storage)
 extern int c3d_option_pw_cfwd;       // C3D_OPT_PW_CFWD: conv_c forward of the training path on csrc/pw_cfwd.hip
-extern int c3d_option_pw_cdg;        // C3D_OPT_PW_CDG: conv_a data + weight gradient on csrc/pw_cdgrad.hip
+extern int c3d_option_pw_cdg;        // C3D_OPT_PW_CDG: conv_a (bit 0) / conv_c (bit 1) data + weight gradient on csrc/pw_cdgrad.hip
 int c3d_detail_pw_cdg_a(const c3d_pw_args* args, void* stream);
 bool c3d_detail_pw_cdg_a_supported(int Kp, int Np, int64_t M);
+int c3d_detail_pw_cdg_c(const c3d_pw_args* args, void* stream);
+bool c3d_detail_pw_cdg_c_supported(int Kp, int Np, int64_t M, int64_t rows_per_sample);
 // Set by the stage driver around a c3d_pw_gemm call: the cooperative kernel then leaves its weight-gradient partials in
 // wg_ws WITHOUT launching the reducer and reports their count in c3d_cdg_parts (0: another kernel ran, which reduced on its
 // own) -- the driver launches the reducer on its side stream (c3d_detail_pw_wgrad_reduce).

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_a_kernel(const c3d_pw_args 
 #define CD_VPM 10
 #endif
 #ifndef CD_SCHED
-#define CD_SCHED 1
+#define CD_SCHED 0   // (measured: the compiler's own order of this block is 0.09 ms per step better than the paced one of csrc/pw_cfwd.hip)
 #endif
 #pragma unroll
       for (int i = 0; i < (CD_SCHED ? NTW * KS + K2 * NPW * NQW : 0); ++i) {
@@ -453,6 +453,392 @@ int cd_plan(const c3d_pw_args& a, CdPlan& L, int64_t& blocks, size_t& lds) {
   return var;
 }
 
+
+// =====================================================================================================================
+// conv_c DATA gradient with its weight gradient, same loop:
+//
+//     P[m, k]   = A[k] * g[m, k] + B[k] + C[k] * c[m, k]                      (BatchNorm_c backward on load)
+//     d[m, n]   = sum_k P[m, k] * W_c[k, n]                                   (gradient at the Swish output)
+//     pb = b * scale + shift, q = gate * pb, sg = sigmoid(q):   dq = d * sg * (1 + q (1 - sg)),   t1 = dq * gate  (stored)
+//     per (sample, channel): sum dq * pb (d gate), sum t1, sum t1 * bhat       (SE / BatchNorm_b backward)
+//     dW_c[k, n] += sum_m P[m, k] * (q sg)[m, n]                              (q sg = the forward operand of conv_c)
+//
+// (reference model/x3d.py:203-216 backward; the C3D_PRO_AFFINE2 / C3D_EPI_SWISH_SE_BWD / C3D_WG_SWISH form of c3d_pw_gemm).
+// The weight gradient's second operand is a PRODUCT of the epilogue: the epilogue of tile t writes its q sg rows (bf16, as the
+// first kernel's fused variant does) into a row-major LDS tile, and the weight-gradient MFMAs of tile t run in the block of
+// tile t + 1 (behind that iteration's barrier) -- three P tiles, two q sg tiles.  A tile lies inside one sample
+// (rows_per_sample is a multiple of the tile's rows: else the first kernel takes the call); the per-lane sums are combined by
+// row-lane shuffles and one small LDS pass when the sample changes and at the end.
+// Results: t1 equals the first kernel's bit for bit on the 48- and 24-channel layers; at 96 -> 216 one element in ~600 000 is
+// one bf16 ulp away (same instruction chain in both disassemblies; deterministic; tests/test_pw_wg_gpu.py bounds it); sums and
+// dW agree to f32 rounding.
+struct CcPlan {
+  int MT, WR, WC, QG;
+  int tiles_per_wg;
+  int KL, QL;
+  int img_rows;
+  int w_off, a_off, a_bytes, q_off, q_bytes, os_off, os_wave, par_off, red_off, dump_off;
+};
+
+template <int KS, int NPW, int NQW, int K2>
+__global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args a, const CcPlan L) {
+  constexpr int NTW = 4;                                  // output tiles per wave (all three widths): 8 vectors x 8 row-lanes
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Kp = a.Kp, Np = a.Np, Gq = Kp >> 3, MT = L.MT, KL = L.KL, QL = L.QL;
+  bf16_t* const Ws = reinterpret_cast<bf16_t*>(smem + L.w_off);
+  float* const Pp = reinterpret_cast<float*>(smem + L.par_off);       // A | B | C [Kp]
+  float* const Ep = Pp + 3 * Kp;                                      // scale | shift | mean | rstd [Np] of BatchNorm_b
+  float* const red = reinterpret_cast<float*>(smem + L.red_off);      // [8 waves][24][8]
+  float* const Gs = Ep + 4 * Np;                                      // SE gate of the current sample [Np] (ones without SE)
+  bf16_t* const dump = reinterpret_cast<bf16_t*>(smem + L.dump_off) + tid * 8;
+
+  const int M32 = (int)a.M;
+  const int tiles = (M32 + MT - 1) / MT;
+  int t0 = (int)blockIdx.x * L.tiles_per_wg;
+  if (t0 > tiles) t0 = tiles;
+  int t1 = t0 + L.tiles_per_wg;
+  if (t1 > tiles) t1 = tiles;
+  const uint32_t row_hi = (uint32_t)(t1 * MT < M32 ? t1 * MT : M32);
+  const __amdgpu_buffer_rsrc_t rX = cd_rsrc(a.x, row_hi * (uint32_t)Kp * 2u);
+  const __amdgpu_buffer_rsrc_t rX2 = cd_rsrc(a.x2, row_hi * (uint32_t)Kp * 2u);
+  const __amdgpu_buffer_rsrc_t rE1 = cd_rsrc(a.e1, (uint32_t)M32 * (uint32_t)Np * 2u);
+  const __amdgpu_buffer_rsrc_t rY = cd_rsrc(a.y, (uint32_t)M32 * (uint32_t)Np * 2u);
+  const uint32_t rps = (uint32_t)a.rows_per_sample;
+
+  // ---- item map of the P streams (one round: MT x Kp / 8 <= 512 items)
+  int p_desc;
+  uint32_t p_go;
+  {
+    const int row = __float2int_rz(((float)tid + 0.5f) * (1.0f / (float)Gq));
+    const bool ok = tid < MT * Gq;
+    p_desc = ok ? (row << 5) | (tid - row * Gq) : 0;
+    p_go = ok ? (uint32_t)tid * 16u : CD_OOB;
+  }
+  const uint32_t tbp = (uint32_t)(MT * Kp * 2);
+  uint4 rawp = cd_load(rX, p_go + (uint32_t)t0 * tbp), rawp2 = cd_load(rX2, p_go + (uint32_t)t0 * tbp);
+
+  // ---- lane maps of the data gradient and of its epilogue
+  const int wr = wave % L.WR, wc = wave / L.WR;
+  const int nt0 = wc * NTW;
+  constexpr int NLW = NTW * 16 + 8;
+  bf16_t* const Os = reinterpret_cast<bf16_t*>(smem + L.os_off + wave * L.os_wave);
+  constexpr int GOW = NTW * 2, RPO = 64 / GOW, NPASS = 16 / RPO;   // 8 vectors x 8 row-lanes, two passes
+  const int rr_o = lane >> 3, v_o = lane & 7;
+  const int cvec = nt0 * 2 + v_o;
+  const bool act_o = cvec * 8 < Np;
+  const int cve = act_o ? cvec : 0;                       // (parameter / gate reads of lanes beyond the row stay inside the arrays)
+  uint4 e1r[NPASS];
+#define CC_EOFF(TILE, P) ((act_o && (TILE) * MT + wr * 16 + (P) * RPO + rr_o < M32)                                                \
+                              ? ((uint32_t)((TILE) * MT + wr * 16 + (P) * RPO + rr_o) * (uint32_t)Np + (uint32_t)cvec * 8u) * 2u : CD_OOB)
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) e1r[p] = cd_load(rE1, t0 < t1 ? CC_EOFF(t0, p) : CD_OOB);
+
+  // ---- weight image -> LDS
+  {
+    const int wbytes = (KS * 4) * L.img_rows * 16;
+    const int nchunk = (wbytes + 1023) >> 10;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(a.w_img);
+    const int rot = (int)blockIdx.x % nchunk;
+    for (int c = wave; c < nchunk; c += 8) {
+      int r = c + rot;
+      if (r >= nchunk) r -= nchunk;
+      const int off = r * 1024 + lane * 16;
+      if (off < wbytes)
+        __builtin_amdgcn_global_load_lds((cd_glb_ptr_t)(src + off), (cd_lds_ptr_t)(smem + L.w_off + r * 1024), 16, 0, 0);
+    }
+  }
+  // the five tiles zeroed once (k padding of P; columns of q sg nobody writes)
+  for (int i = tid * 16; i < 3 * L.a_bytes; i += CD_THREADS * 16) *reinterpret_cast<uint4*>(smem + L.a_off + i) = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid * 16; i < 2 * L.q_bytes; i += CD_THREADS * 16) *reinterpret_cast<uint4*>(smem + L.q_off + i) = make_uint4(0u, 0u, 0u, 0u);
+  // ---- BatchNorm_c-backward coefficients (csrc/bn_fin.h: workgroup 0 accumulates d gamma / d beta) and the epilogue's vectors
+  if (a.fin.sums) {
+    for (int c = tid; c < Kp; c += CD_THREADS) {
+      float cA, cB, cC;
+      c3dfin::bn_bwd_coef_consume(a.fin, a.K, Kp, c, blockIdx.x == 0, cA, cB, cC);
+      Pp[c] = cA; Pp[Kp + c] = cB; Pp[2 * Kp + c] = cC;
+    }
+  } else {
+    for (int i = tid; i < 3 * Kp; i += CD_THREADS) Pp[i] = a.pro_p[i];
+  }
+  for (int i = tid; i < 2 * Np; i += CD_THREADS) { Ep[i] = a.epi_p[i]; Ep[2 * Np + i] = a.epi_q[i]; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float s0[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  int cur_n = -1;
+  const bf16_t* const wfrag = Ws + ((size_t)(lane >> 4) * L.img_rows + nt0 * 16 + (lane & 15)) * 8;
+  const int xfrag = (wr * 16 + (lane & 15)) * KL + (lane >> 4) * 8;
+  const int qg = wave % L.QG, pg = wave / L.QG;
+  const int g4 = lane >> 4, li = lane & 15;
+  const int pl = (4 * g4 + (li >> 2)) * KL + 4 * (li & 3) + pg * NPW * 16;
+  const int ql = (4 * g4 + (li >> 2)) * QL + 4 * (li & 3) + qg * NQW * 16;
+  f32x4_t dacc[NPW][NQW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NQW; ++j) dacc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // per-(sample, channel) sums of the sample `cur_n`: row-lanes by shuffles, the WR waves of a column group through LDS, one f64
+  // atomic per value and workgroup (every thread of the workgroup calls this)
+  auto flush = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float r0 = s0[j], r1 = s1[j], r2 = s2[j];
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { r0 += __shfl_xor(r0, o, 64); r1 += __shfl_xor(r1, o, 64); r2 += __shfl_xor(r2, o, 64); }
+      if (lane < 8) { red[(wave * 24 + j) * 8 + lane] = r0; red[(wave * 24 + 8 + j) * 8 + lane] = r1; red[(wave * 24 + 16 + j) * 8 + lane] = r2; }
+      s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * Np; i += CD_THREADS) {
+      const int which = i / Np, c = i - which * Np;
+      const int cv = c >> 3, j = c & 7;
+      const int wcg = cv >> 3, vo = cv & 7;
+      float accv = 0.f;
+      for (int w_ = 0; w_ < L.WR; ++w_) accv += red[((wcg * L.WR + w_) * 24 + which * 8 + j) * 8 + vo];
+      atomicAdd(a.stats + ((int64_t)cur_n * Np + c) * 3 + which, (double)accv);
+    }
+    __syncthreads();
+  };
+
+#define CC_CONVERT(TILE, CP)                                                                                        \
+  {                                                                                                                 \
+    const int rowg0_ = (TILE) * MT;                                                                                 \
+    const uint32_t bpn_ = (uint32_t)((TILE) + 1) * tbp;                                                             \
+    const int row = p_desc >> 5, v = p_desc & 31;                                                                   \
+    bf16_t* dst = p_go != CD_OOB ? (CP) + row * KL + v * 8 : dump;                                                  \
+    float f[8], f2[8], cA[8], cB[8], cC[8];                                                                         \
+    cd_cvt(rawp, f); cd_cvt(rawp2, f2);                                                                             \
+    cd_ld8(Pp + v * 8, cA); cd_ld8(Pp + Kp + v * 8, cB); cd_ld8(Pp + 2 * Kp + v * 8, cC);                           \
+    const uint32_t keep = rowg0_ + row < M32 ? 0xffffffffu : 0u;                                                    \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                                   \
+      f[e] = __uint_as_float(__float_as_uint(fmaf(cA[e], f[e], fmaf(cC[e], f2[e], cB[e]))) & keep);                 \
+    Vec8<bf16_t>::store(dst, f);                                                                                    \
+    rawp = cd_load(rX, p_go + bpn_);                                                                                \
+    rawp2 = cd_load(rX2, p_go + bpn_);                                                                              \
+  }
+#define CC_MULT(CA)                                                                                                 \
+  {                                                                                                                 \
+    /* two output tiles at a time, each pair staged to the wave's result rows at once (8 accumulator registers live, not 16) */ \
+    _Pragma("unroll") for (int th = 0; th < NTW; th += 2) {                                                         \
+      f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};                                  \
+      _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                           \
+        const uint4 xb = *reinterpret_cast<const uint4*>((CA) + xfrag + ks * 32);                                   \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                             \
+          const uint4 wa = *reinterpret_cast<const uint4*>(wfrag + ((size_t)ks * 4 * L.img_rows + (th + t) * 16) * 8); \
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xb), acc[t], 0, 0, 0); \
+        }                                                                                                           \
+      }                                                                                                             \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                 \
+        *reinterpret_cast<uint2*>(Os + (lane & 15) * NLW + (th + t) * 16 + (lane >> 4) * 4) =                       \
+            make_uint2(pack_bf16x2(acc[t][0], acc[t][1]), pack_bf16x2(acc[t][2], acc[t][3]));                       \
+    }                                                                                                               \
+  }
+#define CC_WGRAD(CA, CQ)                                                                                            \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int k2 = 0; k2 < K2; ++k2) {                                                             \
+      uint4 pa[NPW], qb[NQW];                                                                                       \
+      const bf16_t* pb_ = (CA) + k2 * 32 * KL + pl;                                                                 \
+      const bf16_t* qb_ = (CQ) + k2 * 32 * QL + ql;                                                                 \
+      _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                             \
+        const cd_s16x4_t lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_lds_s16x4_ptr_t)(pb_ + i * 16));        \
+        const cd_s16x4_t hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_lds_s16x4_ptr_t)(pb_ + 16 * KL + i * 16)); \
+        pa[i] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7));               \
+      }                                                                                                             \
+      _Pragma("unroll") for (int j = 0; j < NQW; ++j) {                                                             \
+        const cd_s16x4_t lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_lds_s16x4_ptr_t)(qb_ + j * 16));        \
+        const cd_s16x4_t hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_lds_s16x4_ptr_t)(qb_ + 16 * QL + j * 16)); \
+        qb[j] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7));               \
+      }                                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < NPW; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NQW; ++j)                                                             \
+          dacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa[i]), __builtin_bit_cast(bf16x8_t, qb[j]), \
+                                                               dacc[i][j], 0, 0, 0);                               \
+    }                                                                                                               \
+  }
+  // result tile -> staging rows (bf16) -> row vectors: Swish / SE backward (the first kernel's arithmetic), t1 stored, q sg
+  // left in the LDS tile CQ for the weight gradient
+#define CC_EPI(TILE, CQ, NEXT_ON)                                                                                   \
+  {                                                                                                                 \
+    const int row0_ = (TILE) * MT + wr * 16;                                                                        \
+    _Pragma("unroll") for (int p = 0; p < NPASS; ++p) {                                                             \
+      const int row = p * RPO + rr_o;                                                                               \
+      const int m = row0_ + row;                                                                                    \
+      const bool ok = act_o && m < M32;                                                                             \
+      const uint32_t keep = ok ? 0xffffffffu : 0u;                                                                  \
+      const uint4 rawo = *reinterpret_cast<const uint4*>(Os + row * NLW + v_o * 8);                                 \
+      float f[8], bv[8], qs[8];                                                                                     \
+      cd_cvt(rawo, f); cd_cvt(e1r[p], bv);                                                                          \
+      /* four channels at a time, the halves and the passes in program order (sched_barrier): the 7 x 8 temporaries of a whole   \
+         vector beside the weight-gradient accumulators spilled 77 registers at 96 -> 216 */                       \
+      _Pragma("unroll") for (int h = 0; h < 8; h += 4) {                                                            \
+        const float4 eS = *reinterpret_cast<const float4*>(Ep + cve * 8 + h), eB = *reinterpret_cast<const float4*>(Ep + Np + cve * 8 + h); \
+        const float4 eM = *reinterpret_cast<const float4*>(Ep + 2 * Np + cve * 8 + h), eR = *reinterpret_cast<const float4*>(Ep + 3 * Np + cve * 8 + h); \
+        const float eS_[4] = {eS.x, eS.y, eS.z, eS.w}, eB_[4] = {eB.x, eB.y, eB.z, eB.w};                           \
+        const float eM_[4] = {eM.x, eM.y, eM.z, eM.w}, eR_[4] = {eR.x, eR.y, eR.z, eR.w};                           \
+        const float4 eGv = *reinterpret_cast<const float4*>(Gs + cve * 8 + h);                                      \
+        const float eG_[4] = {eGv.x, eGv.y, eGv.z, eGv.w};                                                          \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                             \
+          const int j = h + u;                                                                                      \
+          const float pb = fmaf(bv[j], eS_[u], eB_[u]);                                                             \
+          const float q = eG_[u] * pb;                                                                              \
+          const float sg = sigmoid_t<bf16_t>(q);                                                                    \
+          const float dq = __uint_as_float(__float_as_uint(f[j] * sg * (1.f + q * (1.f - sg))) & keep);             \
+          const float t = round_as<bf16_t>(dq * eG_[u]);                                                            \
+          s0[j] += dq * pb;                                                                                         \
+          s1[j] += t;                                                                                               \
+          s2[j] += t * ((bv[j] - eM_[u]) * eR_[u]);                                                                 \
+          f[j] = t;                                                                                                 \
+          qs[j] = __uint_as_float(__float_as_uint(q * sg) & keep);                                                  \
+        }                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+      }                                                                                                             \
+      const uint4 pk = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])); \
+      __builtin_amdgcn_raw_buffer_store_b128(cd_u32x4_t{pk.x, pk.y, pk.z, pk.w}, rY,                                \
+                                             ok ? ((uint32_t)m * (uint32_t)Np + (uint32_t)cvec * 8u) * 2u : CD_OOB, 0, 0); \
+      Vec8<bf16_t>::store((CQ) + (wr * 16 + row) * QL + cvec * 8, qs);                                              \
+      e1r[p] = cd_load(rE1, (NEXT_ON) ? CC_EOFF((TILE) + 1, p) : CD_OOB);                                           \
+    }                                                                                                               \
+  }
+
+#ifndef CC_SECTIONS
+#define CC_SECTIONS 1
+#endif
+#if CC_SECTIONS
+#define CC_SECTION __builtin_amdgcn_sched_barrier(0);
+#else
+#define CC_SECTION
+#endif
+  bf16_t* pP = reinterpret_cast<bf16_t*>(smem + L.a_off);                     // P of the tile before
+  bf16_t* cP = reinterpret_cast<bf16_t*>(smem + L.a_off + L.a_bytes);         // P of this tile
+  bf16_t* nP = reinterpret_cast<bf16_t*>(smem + L.a_off + 2 * L.a_bytes);     // P of the next tile
+  bf16_t* const bufQ0 = reinterpret_cast<bf16_t*>(smem + L.q_off);
+  bf16_t* const bufQ1 = reinterpret_cast<bf16_t*>(smem + L.q_off + L.q_bytes);
+  if (t0 < t1) CC_CONVERT(t0, cP)
+  int cur = 0;
+  for (int tile = t0; tile < t1; ++tile, cur ^= 1) {
+    bf16_t* const curQ = cur ? bufQ1 : bufQ0;
+    bf16_t* const prvQ = cur ? bufQ0 : bufQ1;
+    const int n_tile = (int)((uint32_t)(tile * MT) / rps);
+    if (n_tile != cur_n) {   // (workgroup-uniform; once per sample)
+      if (cur_n >= 0) flush();
+      cur_n = n_tile;
+      // the sample's gate -> LDS (read per half vector by the epilogue: as 8 registers per lane it was the last 9 spilled ones)
+      for (int i = tid; i < Np; i += CD_THREADS) Gs[i] = a.epi_gate ? a.epi_gate[(int64_t)cur_n * Np + i] : 1.f;
+    }
+    __syncthreads();   // tile `tile` is converted, the q sg rows of tile - 1 are complete, every wave is past the products of the iteration before
+    if (tile > t0 && tile + 1 < t1) {
+      // the steady state: data gradient + epilogue of this tile, weight gradient of the tile before, conversion of the next: ONE block
+      CC_MULT(cP)
+      CC_SECTION
+      CC_WGRAD(pP, prvQ)
+      CC_SECTION
+      CC_CONVERT(tile + 1, nP)
+      CC_SECTION
+      CC_EPI(tile, curQ, true)
+    } else if (tile + 1 < t1) {   // the first of several tiles (straight-line copies: with `if (first)` / `if (last)` around the
+      CC_MULT(cP)                 // parts of ONE copy the accumulators of the weight gradient crossed the joins: 81 spilled registers)
+      CC_CONVERT(tile + 1, nP)
+      CC_EPI(tile, curQ, true)
+    } else if (tile > t0) {       // the last of several
+      CC_MULT(cP)
+      CC_WGRAD(pP, prvQ)
+      CC_EPI(tile, curQ, false)
+    } else {                      // a single tile
+      CC_MULT(cP)
+      CC_EPI(tile, curQ, false)
+    }
+    bf16_t* const tmp = pP; pP = cP; cP = nP; nP = tmp;
+  }
+  if (t0 < t1) {
+    __syncthreads();
+    CC_WGRAD(pP, (cur ? bufQ0 : bufQ1))   // the last tile's (its q sg rows sit in the buffer the loop just left)
+  }
+#undef CC_CONVERT
+#undef CC_MULT
+#undef CC_WGRAD
+#undef CC_EPI
+#undef CC_EOFF
+
+  {
+    float* wsb = a.wg_ws + (size_t)blockIdx.x * a.K * a.N;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+#pragma unroll
+      for (int j = 0; j < NQW; ++j) {
+        const int n = (qg * NQW + j) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = (pg * NPW + i) * 16 + (lane >> 4) * 4 + r;
+          if (k < a.K && n < a.N) wsb[(size_t)k * a.N + n] = dacc[i][j][r];
+        }
+      }
+    }
+  }
+  if (cur_n >= 0) flush();
+}
+
+template <int KS, int NPW, int NQW, int K2>
+int cc_launch(const c3d_pw_args& a, const CcPlan& L, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_cdg_c_kernel<KS, NPW, NQW, K2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  pw_cdg_c_kernel<KS, NPW, NQW, K2><<<grid, dim3(CD_THREADS), lds, s>>>(a, L);
+  return 0;
+}
+
+// 1: 96 -> 216 (32 x 32 stage), 2: 48 -> 108, 3: 24 -> 54
+int cc_variant(int Kp, int Np) {
+  const int KS = (Kp + 31) / 32, ntn = (Np + 15) >> 4, ntp = (Kp + 15) >> 4;
+  if (KS == 3 && ntn >= 13 && ntn <= 14 && ntp <= 6) return 1;
+  if (KS == 2 && ntn == 7 && ntp <= 3) return 2;
+  if (KS == 1 && ntn == 4 && ntp <= 2) return 3;
+  return 0;
+}
+
+int cc_plan(const c3d_pw_args& a, CcPlan& L, int64_t& blocks, size_t& lds) {
+  const int var = cc_variant(a.Kp, a.Np);
+  if (!var) return 0;
+  const int Kpad = (a.Kp + 31) / 32 * 32, KS = Kpad / 32, ntn = (a.Np + 15) >> 4;
+  L.img_rows = (ntn <= 2 ? 2 : ntn <= 4 ? 4 : ntn <= 7 ? 7 : 14) * 16;
+  if (var == 1) { L.WR = 2; L.WC = 4; L.QG = 4; }
+  else if (var == 2) { L.WR = 4; L.WC = 2; L.QG = 8; }
+  else { L.WR = 8; L.WC = 1; L.QG = 4; }
+  L.MT = 16 * L.WR;
+  if ((L.MT * (a.Kp >> 3)) > CD_THREADS) return 0;
+  if (a.rows_per_sample <= 0 || a.rows_per_sample % L.MT) return 0;   // a tile inside one sample
+  L.KL = Kpad + 8;
+  L.QL = L.WC * 4 * 16 + 8;
+  const int64_t tiles = (a.M + L.MT - 1) / L.MT;
+  blocks = device_cus();
+  if (blocks > (tiles + 1) / 2) blocks = (tiles + 1) / 2;
+  if (blocks > CD_MAX_PARTS) blocks = CD_MAX_PARTS;
+  if (blocks < 1) blocks = 1;
+  const int tpw = (int)((tiles + blocks - 1) / blocks);
+  blocks = (tiles + tpw - 1) / tpw;
+  L.tiles_per_wg = tpw;
+  auto al = [](size_t v) { return (v + 1023) / 1024 * 1024; };
+  size_t off = 0;
+  L.w_off = 0; off += al((size_t)KS * 4 * L.img_rows * 16);
+  L.a_off = (int)off; L.a_bytes = (int)al((size_t)L.MT * L.KL * 2); off += 3 * (size_t)L.a_bytes;
+  L.q_off = (int)off; L.q_bytes = (int)al((size_t)L.MT * L.QL * 2); off += 2 * (size_t)L.q_bytes;
+  L.os_wave = 16 * (4 * 16 + 8) * 2; L.os_off = (int)off; off += al((size_t)8 * L.os_wave);
+  L.par_off = (int)off; off += al(((size_t)3 * a.Kp + 5 * a.Np) * 4);
+  L.red_off = (int)off; off += al((size_t)8 * 24 * 8 * 4);
+  L.dump_off = (int)off; off += (size_t)CD_THREADS * 16;
+  if (off > 160 * 1024) return 0;
+  lds = off;
+  return var;
+}
+
 }  // namespace
 
 // Host-side check for the stage driver: would c3d_detail_pw_cdg_a take this layer (bf16, dense rows, res_mode 0)?
@@ -492,5 +878,45 @@ __attribute__((visibility("hidden"))) int c3d_detail_pw_cdg_a(const c3d_pw_args*
   if (rc != 0) return rc;
   C3D_CHECK_LAUNCH();
   if (c3d_cdg_defer_reduce) { c3d_cdg_parts = (int)blocks; return 0; }   // (the stage driver reduces on its side stream)
+  return c3d_detail_pw_wgrad_reduce(a.wg_ws, a.wg_dw, a.K, a.N, (int)blocks, a.w_sk, a.w_sn, s);
+}
+
+// conv_c: host-side check for the stage driver, and the launch
+__attribute__((visibility("hidden"))) bool c3d_detail_pw_cdg_c_supported(int Kp, int Np, int64_t M, int64_t rows_per_sample) {
+  if (Kp <= 0 || Np <= 0 || (Kp & 7) || (Np & 7)) return false;
+  if (M < 1024 || (M + 512) * (int64_t)(Kp > Np ? Kp : Np) * 2 >= ((int64_t)1 << 31)) return false;
+  c3d_pw_args a;
+  std::memset(&a, 0, sizeof(a));
+  a.M = M; a.K = a.Kp = Kp; a.N = a.Np = Np; a.rows_per_sample = rows_per_sample;
+  CcPlan L;
+  int64_t blocks = 0;
+  size_t lds = 0;
+  return cc_plan(a, L, blocks, lds) != 0;
+}
+
+__attribute__((visibility("hidden"))) int c3d_detail_pw_cdg_c(const c3d_pw_args* args, void* stream) {
+  const c3d_pw_args& a = *args;
+  if (a.dtype != C3D_DT_BF16 || a.row_mode != C3D_ROWS_DENSE || a.pro_mode != C3D_PRO_AFFINE2 || a.epi_mode != C3D_EPI_SWISH_SE_BWD ||
+      a.wg_mode != C3D_WG_SWISH)
+    return C3D_E_UNSUPPORTED;
+  if (!a.w_img || !a.x2 || !a.e1 || !a.epi_p || !a.epi_q || !a.stats || !a.wg_dw || !a.wg_ws || a.pro_out || a.bias || a.fin.ticket ||
+      a.add_sums)
+    return C3D_E_UNSUPPORTED;
+  if (a.fin.sums ? (a.fin.training != 0 || !a.fin.mr || !a.fin.gamma) : !a.pro_p) return C3D_E_UNSUPPORTED;
+  if (a.M < 1024 || (a.M + 512) * (int64_t)(a.Kp > a.Np ? a.Kp : a.Np) * 2 >= ((int64_t)1 << 31)) return C3D_E_UNSUPPORTED;
+  CcPlan L;
+  int64_t blocks = 0;
+  size_t lds = 0;
+  const int var = cc_plan(a, L, blocks, lds);
+  if (!var) return C3D_E_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)blocks);
+  int rc = C3D_E_UNSUPPORTED;
+  if (var == 1) rc = cc_launch<3, 3, 4, 1>(a, L, grid, lds, s);        // 96 -> 216: 6 x 14 weight-gradient tiles, 3 x 4 per wave
+  else if (var == 2) rc = cc_launch<2, 3, 1, 2>(a, L, grid, lds, s);   // 48 -> 108: 3 x 7, 3 x 1 per wave
+  else if (var == 3) rc = cc_launch<1, 1, 1, 4>(a, L, grid, lds, s);   // 24 -> 54: 2 x 4, 1 x 1 per wave
+  if (rc != 0) return rc;
+  C3D_CHECK_LAUNCH();
+  if (c3d_cdg_defer_reduce) { c3d_cdg_parts = (int)blocks; return 0; }
   return c3d_detail_pw_wgrad_reduce(a.wg_ws, a.wg_dw, a.K, a.N, (int)blocks, a.w_sk, a.w_sn, s);
 }

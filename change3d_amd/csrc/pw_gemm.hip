@@ -154,6 +154,10 @@ extern "C" int c3d_pw_gemm(const c3d_pw_args* args, void* stream) {
     const int rcd = c3d_detail_pw_cdg_a(args, stream);
     if (rcd != C3D_E_UNSUPPORTED) return rcd;
   }
+  if (a.wg_mode == C3D_WG_SWISH && (c3d_option_pw_cdg & 2)) {
+    const int rcd = c3d_detail_pw_cdg_c(args, stream);   // conv_c data gradient + weight gradient, cooperative (csrc/pw_cdgrad.hip)
+    if (rcd != C3D_E_UNSUPPORTED) return rcd;
+  }
   if (a.wg_mode != C3D_WG_NONE) return c3d_detail_pw_gemm_wg(args, stream);
   if (a.epi_mode == C3D_EPI_STATS && ((a.pro_mode == C3D_PRO_BN_SE_SWISH && (c3d_option_pw_cfwd & 1)) ||
                                       (a.pro_mode == C3D_PRO_AFFINE2 && a.pro_out && (c3d_option_pw_cfwd & 2)))) {

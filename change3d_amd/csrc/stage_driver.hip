@@ -197,6 +197,8 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
     if (fuse_wgrad(d, G.Cip, G.Cinp, C3D_WG_ROWS)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Ci, G.Cin));
     // (the cooperative conv_a data + weight gradient, csrc/pw_cdgrad.hip: reserved whatever C3D_OPT_PW_CDG says right now)
     if (d->dtype == C3D_DT_BF16 && c3d_detail_pw_cdg_a_supported(G.Cip, G.Cinp, G.M)) wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Ci, G.Cin));
+    if (d->dtype == C3D_DT_BF16 && c3d_detail_pw_cdg_c_supported(G.Cop, G.Cip, G.Mo, (int64_t)d->T * G.Ho * G.Wo))
+      wsf_fused = std::max(wsf_fused, c3d_pw_gemm_wg_ws_floats(G.Co, G.Ci));
     mx_g = std::max(mx_g, (size_t)G.Mo * G.Cop * e);
     mx_t1 = std::max(mx_t1, (size_t)G.Mo * G.Cip * e);
     mx_t2 = std::max(mx_t2, (size_t)G.M * G.Cip * e);
@@ -220,9 +222,10 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
   for (int r = 0; r < R + 1; ++r) ring_dx[r] = mx_dx ? cb.take(mx_dx) : SIZE_MAX;
   P.wgrad_ws = cb.take((size_t)wsf * 4);
   P.wgrad_ws2 = cb.take((size_t)wsf * 4);   // chained weight-gradient launches alternate between the two (c3d_pw_wgrad_args.chain)
-  // slot 0: the wave-private kernel's fused variant (kernel, then its reducer, on the main stream); slots 1..3: the cooperative
-  // kernel's partials, reduced on the side stream -- launch k uses slot 1 + k % 3, the side stream lags at most two blocks
-  P.wgrad_ws_fused = wsf_fused ? cb.take((size_t)wsf_fused * 4 * 4) : SIZE_MAX;
+  // slot 0: the wave-private kernel's fused variant (kernel, then its reducer, on the main stream); slots 1..6: the cooperative
+  // kernels' partials, reduced on the side stream -- launch k uses slot 1 + k % 6: two launches per block, and the side stream
+  // lags at most two blocks (the lag rule of c3d_stage_bwd with <= 3 ring slots)
+  P.wgrad_ws_fused = wsf_fused ? cb.take((size_t)wsf_fused * 4 * 7) : SIZE_MAX;
   P.wgrad_ws_fused_slot = (size_t)wsf_fused * 4;
   for (int i = 0; i < n; ++i) {
     const BlkGeom& G = P.g[i];
@@ -730,7 +733,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   float* const wgws_ab[2] = {atT<float>(wb, P.wgrad_ws), atT<float>(wb, P.wgrad_ws2)};
   int wg_n = 0;   // weight-gradient launches of this call: launch k leaves its partials in workspace k & 1, launch k + 1 reduces them
   float* wgws_fused = atT<float>(wb, P.wgrad_ws_fused);
-  int cdg_n = 0;   // cooperative data + weight gradient launches of this call (workspace slot 1 + cdg_n % 3)
+  int cdg_n = 0;   // cooperative data + weight gradient launches of this call (workspace slot 1 + cdg_n % 6)
   c3d_detail_pw_wgrad_v2_drop();   // (nothing may be pending from a call that returned early)
   const bool wimg = use_pw_img(d);   // transposed weight images written by this step's c3d_stage_fwd (training mode)
   auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
@@ -783,7 +786,9 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     if (!consb) RC(coef(dsums_c, (double)G.Mo, k.bn_c, mr_c, G.Co, G.Cop, coef_c));
     // ---- conv_c data gradient, Swish / SE backward in the epilogue; weight gradient on the side stream (it needs
     //      coef_c, not the data gradient: it is forked BEFORE the data-gradient launch)
-    const bool fuse_wc = (g_fuse_wgrad & 2) && fuse_wgrad(d, G.Cop, G.Cip, C3D_WG_SWISH) && G.Cop <= 48;
+    const bool coop_wc = (c3d_option_pw_cdg & 2) && dt == C3D_DT_BF16 && !(d->flags & C3D_STAGE_SEPARATE_WGRAD) && imgp(F.img_ct) != nullptr &&
+                         c3d_detail_pw_cdg_c_supported(G.Cop, G.Cip, G.Mo, rps);
+    const bool fuse_wc = coop_wc || ((g_fuse_wgrad & 2) && fuse_wgrad(d, G.Cop, G.Cip, C3D_WG_SWISH) && G.Cop <= 48);
     if (!fuse_wc)
     RC(side_run(st, [&](hipStream_t s2) {
       WgCall w(g, b, k.dw_c, wgws_ab[wg_n++ & 1], G.Mo, G.Ci, G.Co, G.Ci, 1, dt);
@@ -800,7 +805,22 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       if (consb) p.a.fin = fin_coef_consume(dsums_c, k.bn_c, (double)G.Mo, mr_c, true);
       p.a.epi_mode = C3D_EPI_SWISH_SE_BWD; p.a.e1 = b; p.a.epi_p = ss_b; p.a.epi_gate = gate; p.a.epi_q = mr_b;
       p.a.stats = nc3; p.a.rows_per_sample = rps; p.a.w_img = imgp(F.img_ct);
-      RC(pw_launch(p.a, st));
+      if (coop_wc && side_enabled() && bwd_ring() <= 3) {   // (the partials' reducer on the side stream: see conv_a below)
+        float* const wsk = wgws_fused + (size_t)(1 + cdg_n % 6) * (P.wgrad_ws_fused_slot / 4);
+        p.a.wg_ws = wsk;
+        c3d_cdg_defer_reduce = 1; c3d_cdg_parts = 0;
+        const int rcl = pw_launch(p.a, st);
+        c3d_cdg_defer_reduce = 0;
+        RC(rcl);
+        const int parts = c3d_cdg_parts;
+        if (parts > 0) {
+          ++cdg_n;
+          const c3d_pw_args pa = p.a;
+          RC(side_run(st, [&](hipStream_t s2) { return c3d_detail_pw_wgrad_reduce(wsk, pa.wg_dw, pa.K, pa.N, parts, pa.w_sk, pa.w_sn, s2); }));
+        }
+      } else {
+        RC(pw_launch(p.a, st));
+      }
     }
     // BatchNorm_b / SE backward coefficients.  Blocks without SE (stride 1 always): the fused depthwise backward kernel
     // rebuilds A | B | C from the per-sample sums in its prologue -- no coefficient launch on the critical path
@@ -889,7 +909,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       p.a.w_img = imgp(F.img_at);
       if (coop_wa && side_enabled() && bwd_ring() <= 3) {
         // the reducer of the cooperative kernel's partials runs on the side stream (5 us per launch off the data-gradient chain)
-        float* const wsk = wgws_fused + (size_t)(1 + cdg_n % 3) * (P.wgrad_ws_fused_slot / 4);
+        float* const wsk = wgws_fused + (size_t)(1 + cdg_n % 6) * (P.wgrad_ws_fused_slot / 4);
         p.a.wg_ws = wsk;
         c3d_cdg_defer_reduce = 1; c3d_cdg_parts = 0;
         const int rcl = pw_launch(p.a, st);
@@ -922,7 +942,7 @@ int c3d_option_stem_mfma = 2, c3d_option_convt_mfma = 1;   // read by stem.hip /
 int c3d_option_dw_ring = 5;                                // read by dw_bwd_fused.hip / dw_conv.hip
 int c3d_option_pw_wgrad_v2 = 1;                            // read by pw_wgrad.hip
 int c3d_option_pw_cfwd = 3;                                // read by pw_gemm.hip
-int c3d_option_pw_cdg = 1;                                 // read by pw_gemm.hip and c3d_stage_bwd
+int c3d_option_pw_cdg = 3;                                 // read by pw_gemm.hip and c3d_stage_bwd
 int c3d_option_dw_fwd_hv = 5;                              // read by dw_conv.hip
 
 extern "C" int c3d_set_option(int32_t option, int32_t value) {
@@ -936,7 +956,7 @@ extern "C" int c3d_set_option(int32_t option, int32_t value) {
     case C3D_OPT_DW_RING: c3d_option_dw_ring = value & 15; return 0;
     case C3D_OPT_DW_FWD_HV: c3d_option_dw_fwd_hv = value & 7; return 0;
     case C3D_OPT_PW_CFWD: c3d_option_pw_cfwd = value & 3; return 0;
-    case C3D_OPT_PW_CDG: c3d_option_pw_cdg = value & 1; return 0;
+    case C3D_OPT_PW_CDG: c3d_option_pw_cdg = value & 3; return 0;
     case C3D_OPT_PW_WGRAD_V2: c3d_option_pw_wgrad_v2 = value & 1; g_wgrad_chain = (value & 2) ? 0 : 1; return 0;
     default: return C3D_E_BADARG;
   }

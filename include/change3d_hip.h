@@ -564,11 +564,13 @@ int c3d_side_join(void* stream);
  *                         C3D_EPI_STATS, BatchNorm_b / SE gate rebuilt from the per-sample sums); bit 1: conv_a with the
  *                         previous block's residual add in its prologue (C3D_PRO_AFFINE2 + pro_out + C3D_EPI_STATS).
  *                         Outputs (and pro_out) bit-identical, BatchNorm statistics to f32 rounding.  Default 3
- *   C3D_OPT_PW_CDG      : bit 0: the conv_a data gradient with its weight gradient fused (C3D_PRO_AFFINE2 + C3D_EPI_ADD +
- *                         C3D_WG_ROWS, dense shortcut gradient) runs on the workgroup-cooperative kernel (csrc/pw_cdgrad.hip)
- *                         where it applies -- all three stage widths of X3D-L, K = 216 included, which the wave-private
- *                         kernel's fused variant (K <= 112) left to a separate c3d_pw_wgrad launch; c3d_stage_bwd then asks
- *                         for the fused form there too.  dx bit-identical, sums / dW to f32 rounding.  Default 1            */
+ *   C3D_OPT_PW_CDG      : bit field.  bit 0: the conv_a data gradient with its weight gradient fused (C3D_PRO_AFFINE2 +
+ *                         C3D_EPI_ADD + C3D_WG_ROWS, dense shortcut gradient), bit 1: the conv_c one (C3D_PRO_AFFINE2 +
+ *                         C3D_EPI_SWISH_SE_BWD + C3D_WG_SWISH, rows_per_sample a multiple of the tile's rows) run on the
+ *                         workgroup-cooperative kernels (csrc/pw_cdgrad.hip) where they apply -- all three stage widths of
+ *                         X3D-L, the 216-wide layers included, which the wave-private kernel's fused variant (accumulator
+ *                         image in LDS) left to separate c3d_pw_wgrad launches; c3d_stage_bwd then asks for the fused form
+ *                         there too.  Data gradients bit-identical, sums / dW to f32 rounding.  Default 3                  */
 enum { C3D_OPT_SIDE_STREAM = 0, C3D_OPT_STEM_MFMA = 1, C3D_OPT_CONVT_MFMA = 2, C3D_OPT_FUSE_WGRAD = 3, C3D_OPT_FOLD_SE = 4,
        C3D_OPT_MASK_IN_DGRAD = 5, C3D_OPT_DW_RING = 6, C3D_OPT_PW_WGRAD_V2 = 7, C3D_OPT_DW_FWD_HV = 8, C3D_OPT_PW_CFWD = 9,
        C3D_OPT_PW_CDG = 10 };
