@@ -517,7 +517,11 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
     p_go = ok ? (uint32_t)tid * 16u : CD_OOB;
   }
   const uint32_t tbp = (uint32_t)(MT * Kp * 2);
-  uint4 rawp = cd_load(rX, p_go + (uint32_t)t0 * tbp), rawp2 = cd_load(rX2, p_go + (uint32_t)t0 * tbp);
+  // two tiles of the row streams in flight (the waves of these kernels are parked ~50 % of their cycles with one): register set
+  // s holds tile t0 + s (+ 2, + 4 ..); the tile loop is unrolled by two so that the sets are named statically
+  uint4 rawp[2], rawp2[2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) { rawp[s_] = cd_load(rX, p_go + (uint32_t)(t0 + s_) * tbp); rawp2[s_] = cd_load(rX2, p_go + (uint32_t)(t0 + s_) * tbp); }
 
   // ---- lane maps of the data gradient and of its epilogue
   const int wr = wave % L.WR, wc = wave / L.WR;
@@ -529,11 +533,13 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
   const int cvec = nt0 * 2 + v_o;
   const bool act_o = cvec * 8 < Np;
   const int cve = act_o ? cvec : 0;                       // (parameter / gate reads of lanes beyond the row stay inside the arrays)
-  uint4 e1r[NPASS];
-#define CC_EOFF(TILE, P) ((act_o && (TILE) * MT + wr * 16 + (P) * RPO + rr_o < M32)                                                \
+  uint4 e1r[2][NPASS];
+#define CC_EOFF(TILE, P) ((act_o && (TILE) < t1 && (TILE) * MT + wr * 16 + (P) * RPO + rr_o < M32)                                                \
                               ? ((uint32_t)((TILE) * MT + wr * 16 + (P) * RPO + rr_o) * (uint32_t)Np + (uint32_t)cvec * 8u) * 2u : CD_OOB)
 #pragma unroll
-  for (int p = 0; p < NPASS; ++p) e1r[p] = cd_load(rE1, t0 < t1 ? CC_EOFF(t0, p) : CD_OOB);
+  for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) e1r[s_][p] = cd_load(rE1, CC_EOFF(t0 + s_, p));
 
   // ---- weight image -> LDS
   {
@@ -605,21 +611,21 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
     __syncthreads();
   };
 
-#define CC_CONVERT(TILE, CP)                                                                                        \
+#define CC_CONVERT(TILE, CP, S)                                                                                      \
   {                                                                                                                 \
     const int rowg0_ = (TILE) * MT;                                                                                 \
-    const uint32_t bpn_ = (uint32_t)((TILE) + 1) * tbp;                                                             \
+    const uint32_t bpn_ = (uint32_t)((TILE) + 2) * tbp;   /* the slot is requested again for the tile after the next */  \
     const int row = p_desc >> 5, v = p_desc & 31;                                                                   \
     bf16_t* dst = p_go != CD_OOB ? (CP) + row * KL + v * 8 : dump;                                                  \
     float f[8], f2[8], cA[8], cB[8], cC[8];                                                                         \
-    cd_cvt(rawp, f); cd_cvt(rawp2, f2);                                                                             \
+    cd_cvt(rawp[S], f); cd_cvt(rawp2[S], f2);                                                                       \
     cd_ld8(Pp + v * 8, cA); cd_ld8(Pp + Kp + v * 8, cB); cd_ld8(Pp + 2 * Kp + v * 8, cC);                           \
     const uint32_t keep = rowg0_ + row < M32 ? 0xffffffffu : 0u;                                                    \
     _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                                   \
       f[e] = __uint_as_float(__float_as_uint(fmaf(cA[e], f[e], fmaf(cC[e], f2[e], cB[e]))) & keep);                 \
     Vec8<bf16_t>::store(dst, f);                                                                                    \
-    rawp = cd_load(rX, p_go + bpn_);                                                                                \
-    rawp2 = cd_load(rX2, p_go + bpn_);                                                                              \
+    rawp[S] = cd_load(rX, p_go + bpn_);                                                                             \
+    rawp2[S] = cd_load(rX2, p_go + bpn_);                                                                           \
   }
 #define CC_MULT(CA)                                                                                                 \
   {                                                                                                                 \
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
   }
   // result tile -> staging rows (bf16) -> row vectors: Swish / SE backward (the first kernel's arithmetic), t1 stored, q sg
   // left in the LDS tile CQ for the weight gradient
-#define CC_EPI(TILE, CQ, NEXT_ON)                                                                                   \
+#define CC_EPI(TILE, CQ, S)                                                                                         \
   {                                                                                                                 \
     const int row0_ = (TILE) * MT + wr * 16;                                                                        \
     _Pragma("unroll") for (int p = 0; p < NPASS; ++p) {                                                             \
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
       const uint32_t keep = ok ? 0xffffffffu : 0u;                                                                  \
       const uint4 rawo = *reinterpret_cast<const uint4*>(Os + row * NLW + v_o * 8);                                 \
       float f[8], bv[8], qs[8];                                                                                     \
-      cd_cvt(rawo, f); cd_cvt(e1r[p], bv);                                                                          \
+      cd_cvt(rawo, f); cd_cvt(e1r[S][p], bv);                                                                       \
       /* four channels at a time, the halves and the passes in program order (sched_barrier): the 7 x 8 temporaries of a whole   \
          vector beside the weight-gradient accumulators spilled 77 registers at 96 -> 216 */                       \
       _Pragma("unroll") for (int h = 0; h < 8; h += 4) {                                                            \
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
       __builtin_amdgcn_raw_buffer_store_b128(cd_u32x4_t{pk.x, pk.y, pk.z, pk.w}, rY,                                \
                                              ok ? ((uint32_t)m * (uint32_t)Np + (uint32_t)cvec * 8u) * 2u : CD_OOB, 0, 0); \
       Vec8<bf16_t>::store((CQ) + (wr * 16 + row) * QL + cvec * 8, qs);                                              \
-      e1r[p] = cd_load(rE1, (NEXT_ON) ? CC_EOFF((TILE) + 1, p) : CD_OOB);                                           \
+      e1r[S][p] = cd_load(rE1, CC_EOFF((TILE) + 2, p));                                                             \
     }                                                                                                               \
   }
 
@@ -718,45 +724,39 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
   bf16_t* nP = reinterpret_cast<bf16_t*>(smem + L.a_off + 2 * L.a_bytes);     // P of the next tile
   bf16_t* const bufQ0 = reinterpret_cast<bf16_t*>(smem + L.q_off);
   bf16_t* const bufQ1 = reinterpret_cast<bf16_t*>(smem + L.q_off + L.q_bytes);
-  if (t0 < t1) CC_CONVERT(t0, cP)
-  int cur = 0;
-  for (int tile = t0; tile < t1; ++tile, cur ^= 1) {
-    bf16_t* const curQ = cur ? bufQ1 : bufQ0;
-    bf16_t* const prvQ = cur ? bufQ0 : bufQ1;
-    const int n_tile = (int)((uint32_t)(tile * MT) / rps);
-    if (n_tile != cur_n) {   // (workgroup-uniform; once per sample)
-      if (cur_n >= 0) flush();
-      cur_n = n_tile;
-      // the sample's gate -> LDS (read per half vector by the epilogue: as 8 registers per lane it was the last 9 spilled ones)
-      for (int i = tid; i < Np; i += CD_THREADS) Gs[i] = a.epi_gate ? a.epi_gate[(int64_t)cur_n * Np + i] : 1.f;
-    }
-    __syncthreads();   // tile `tile` is converted, the q sg rows of tile - 1 are complete, every wave is past the products of the iteration before
-    if (tile > t0 && tile + 1 < t1) {
-      // the steady state: data gradient + epilogue of this tile, weight gradient of the tile before, conversion of the next: ONE block
-      CC_MULT(cP)
-      CC_SECTION
-      CC_WGRAD(pP, prvQ)
-      CC_SECTION
-      CC_CONVERT(tile + 1, nP)
-      CC_SECTION
-      CC_EPI(tile, curQ, true)
-    } else if (tile + 1 < t1) {   // the first of several tiles (straight-line copies: with `if (first)` / `if (last)` around the
-      CC_MULT(cP)                 // parts of ONE copy the accumulators of the weight gradient crossed the joins: 81 spilled registers)
-      CC_CONVERT(tile + 1, nP)
-      CC_EPI(tile, curQ, true)
-    } else if (tile > t0) {       // the last of several
-      CC_MULT(cP)
-      CC_WGRAD(pP, prvQ)
-      CC_EPI(tile, curQ, false)
-    } else {                      // a single tile
-      CC_MULT(cP)
-      CC_EPI(tile, curQ, false)
-    }
-    bf16_t* const tmp = pP; pP = cP; cP = nP; nP = tmp;
+  bf16_t* lastQ = bufQ0;
+  if (t0 < t1) CC_CONVERT(t0, cP, 0)
+  // One iteration, the same for every tile: data gradient + epilogue of this tile, weight gradient of the tile before (the first
+  // tile multiplies the zeroed buffers), conversion of the next (past the workgroup's last tile: rows the stream bounds answer
+  // with zeros, written to a buffer nobody reads) -- straight-line code, no first / last copies.
+#define CC_ITER(TILE, S, CURQ, PRVQ)                                                                                \
+  {                                                                                                                 \
+    const int n_tile = (int)((uint32_t)((TILE) * MT) / rps);                                                        \
+    if (n_tile != cur_n) {   /* (workgroup-uniform; once per sample) */                                             \
+      if (cur_n >= 0) flush();                                                                                      \
+      cur_n = n_tile;                                                                                               \
+      /* the sample's gate -> LDS (read per half vector by the epilogue: as 8 registers per lane it was the last 9 spilled ones) */ \
+      for (int i = tid; i < Np; i += CD_THREADS) Gs[i] = a.epi_gate ? a.epi_gate[(int64_t)cur_n * Np + i] : 1.f;    \
+    }                                                                                                               \
+    __syncthreads();   /* tile TILE is converted, the q sg rows of the tile before are complete, every wave is past the products of the iteration before */ \
+    CC_MULT(cP)                                                                                                     \
+    CC_SECTION                                                                                                      \
+    CC_WGRAD(pP, PRVQ)                                                                                              \
+    CC_SECTION                                                                                                      \
+    CC_CONVERT((TILE) + 1, nP, 1 - (S))                                                                             \
+    CC_SECTION                                                                                                      \
+    CC_EPI(TILE, CURQ, S)                                                                                           \
+    bf16_t* const tmp = pP; pP = cP; cP = nP; nP = tmp;                                                             \
+    lastQ = (CURQ);                                                                                                 \
   }
+  for (int tile = t0; tile < t1; tile += 2) {
+    CC_ITER(tile, 0, bufQ0, bufQ1)
+    if (tile + 1 < t1) CC_ITER(tile + 1, 1, bufQ1, bufQ0)
+  }
+#undef CC_ITER
   if (t0 < t1) {
     __syncthreads();
-    CC_WGRAD(pP, (cur ? bufQ0 : bufQ1))   // the last tile's (its q sg rows sit in the buffer the loop just left)
+    CC_WGRAD(pP, lastQ)   // the last tile's
   }
 #undef CC_CONVERT
 #undef CC_MULT
