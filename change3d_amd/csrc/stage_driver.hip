@@ -939,7 +939,7 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
 
 // ---- profile / runtime switches --------------------------------------------------------------------------------
 int c3d_option_stem_mfma = 2, c3d_option_convt_mfma = 1;   // read by stem.hip / decoder.hip (launch_hints.h)
-int c3d_option_dw_ring = 5;                                // read by dw_bwd_fused.hip / dw_conv.hip
+int c3d_option_dw_ring = 13;                               // read by dw_bwd_fused.hip / dw_conv.hip
 int c3d_option_pw_wgrad_v2 = 1;                            // read by pw_wgrad.hip
 int c3d_option_pw_cfwd = 3;                                // read by pw_gemm.hip
 int c3d_option_pw_cdg = 3;                                 // read by pw_gemm.hip and c3d_stage_bwd

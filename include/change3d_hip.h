@@ -547,7 +547,7 @@ int c3d_side_join(void* stream);
  *   C3D_OPT_DW_RING     : c3d_dw333_bwd_fused (bf16, stride 1) fed by an LDS-DMA ring (global_load_lds_dwordx4, two tiles ahead
  *                         for T <= 3, one for T = 5) instead of register prefetch: bit 0 = on, bit 2 = the requests are issued
  *                         one per tap step instead of in a burst, bit 3 = also on maps under 64 x 64; results are bit-identical
- *                         to the register-prefetch kernel; default 5 = measured best
+ *                         to the register-prefetch kernel; default 13 (round 6, same-call A/B: 20.13 -> 20.05 ms with bit 3)
  *   C3D_OPT_PW_WGRAD_V2 : 0 = c3d_pw_wgrad of bf16 dense rows on the first kernel (operand-split staging, 32-row tiles;
  *                         csrc/pw_wgrad.hip) instead of the flat-staged, transposing-read one (csrc/pw_wgrad_v2.hip, default 1);
  *                         same operand arithmetic, products summed in another order (f32 rounding apart); bit 1 SET = the stage

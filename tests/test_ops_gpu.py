@@ -756,7 +756,7 @@ def test_dw_bwd_ring_kernel_is_bit_identical_to_the_register_prefetch_kernel(B, 
             torch.cuda.synchronize()
             out[rv] = (t2, ds, dw)
     finally:
-        ops.set_option(ops.OPT_DW_RING, 5)
+        ops.set_option(ops.OPT_DW_RING, 13)
     assert torch.equal(out[0][0].view(torch.int16), out[ring][0].view(torch.int16)), "data gradient differs"
     assert torch.allclose(out[0][1], out[ring][1], rtol=1e-12, atol=0), "BatchNorm_a sums differ"
     scale = out[0][2].abs().max().item()
