@@ -20,7 +20,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from change3d_amd._lib import csrc_digest  # noqa: E402
 
 ENTRY = [  # kernel-name prefix -> C-ABI entry point (bench.py's kernel table key)
-    ("pw_gemm_kernel", "c3d_pw_gemm"), ("pw_wgrad_kernel", "c3d_pw_wgrad"), ("pw_wgrad_v2", "c3d_pw_wgrad"), ("pw_wgrad_reduce", "c3d_pw_wgrad"),
+    ("pw_gemm_kernel", "c3d_pw_gemm"), ("pw_cfwd_kernel", "c3d_pw_gemm"), ("pw_cdg_a_kernel", "c3d_pw_gemm"), ("pw_cdg_c_kernel", "c3d_pw_gemm"),
+    ("pw_wgrad_kernel", "c3d_pw_wgrad"), ("pw_wgrad_v2", "c3d_pw_wgrad"), ("pw_wgrad_reduce", "c3d_pw_wgrad"),
     ("dw_fwd", "c3d_dw333_fwd"), ("dw_bwd_fused", "c3d_dw333_bwd_fused"), ("dw_bwd_ring", "c3d_dw333_bwd_fused"),
     ("block_out_fwd", "c3d_block_out_fwd"), ("block_out_bwd", "c3d_block_out_bwd"),
     ("se_bn_bwd_coef", "c3d_se_bn_bwd_coef"), ("bn_se_finalize", "c3d_bn_se_finalize"),
