@@ -222,10 +222,10 @@ int make_plan(const c3d_stage_desc* d, Plan& P) {
   for (int r = 0; r < R + 1; ++r) ring_dx[r] = mx_dx ? cb.take(mx_dx) : SIZE_MAX;
   P.wgrad_ws = cb.take((size_t)wsf * 4);
   P.wgrad_ws2 = cb.take((size_t)wsf * 4);   // chained weight-gradient launches alternate between the two (c3d_pw_wgrad_args.chain)
-  // slot 0: the wave-private kernel's fused variant (kernel, then its reducer, on the main stream); slots 1..6: the cooperative
-  // kernels' partials, reduced on the side stream -- launch k uses slot 1 + k % 6: two launches per block, and the side stream
-  // lags at most two blocks (the lag rule of c3d_stage_bwd with <= 3 ring slots)
-  P.wgrad_ws_fused = wsf_fused ? cb.take((size_t)wsf_fused * 4 * 7) : SIZE_MAX;
+  // slot 0: the wave-private kernel's fused variant (kernel, then its reducer, on the main stream); slots 1..2n: one per
+  // cooperative data + weight gradient launch of a backward pass -- their partials are reduced behind ONE fork at the end of
+  // the pass (c3d_stage_bwd), not launch by launch
+  P.wgrad_ws_fused = wsf_fused ? cb.take((size_t)wsf_fused * 4 * (1 + 2 * (size_t)n)) : SIZE_MAX;
   P.wgrad_ws_fused_slot = (size_t)wsf_fused * 4;
   for (int i = 0; i < n; ++i) {
     const BlkGeom& G = P.g[i];
@@ -733,7 +733,9 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
   float* const wgws_ab[2] = {atT<float>(wb, P.wgrad_ws), atT<float>(wb, P.wgrad_ws2)};
   int wg_n = 0;   // weight-gradient launches of this call: launch k leaves its partials in workspace k & 1, launch k + 1 reduces them
   float* wgws_fused = atT<float>(wb, P.wgrad_ws_fused);
-  int cdg_n = 0;   // cooperative data + weight gradient launches of this call (workspace slot 1 + cdg_n % 6)
+  int cdg_n = 0;   // cooperative data + weight gradient launches of this call (workspace slot 1 + cdg_n)
+  struct RedJob { const float* ws; float* dw; int K, N, parts, sk, sn; };
+  std::vector<RedJob> red_jobs;   // their partials: reduced on the side stream behind one fork at the end of the pass
   c3d_detail_pw_wgrad_v2_drop();   // (nothing may be pending from a call that returned early)
   const bool wimg = use_pw_img(d);   // transposed weight images written by this step's c3d_stage_fwd (training mode)
   auto imgp = [&](size_t off) -> const void* { return wimg && off != SIZE_MAX ? at(ws, off) : nullptr; };
@@ -805,19 +807,14 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       if (consb) p.a.fin = fin_coef_consume(dsums_c, k.bn_c, (double)G.Mo, mr_c, true);
       p.a.epi_mode = C3D_EPI_SWISH_SE_BWD; p.a.e1 = b; p.a.epi_p = ss_b; p.a.epi_gate = gate; p.a.epi_q = mr_b;
       p.a.stats = nc3; p.a.rows_per_sample = rps; p.a.w_img = imgp(F.img_ct);
-      if (coop_wc && side_enabled() && bwd_ring() <= 3) {   // (the partials' reducer on the side stream: see conv_a below)
-        float* const wsk = wgws_fused + (size_t)(1 + cdg_n % 6) * (P.wgrad_ws_fused_slot / 4);
+      if (coop_wc && side_enabled()) {   // (the partials' reducer: deferred, see conv_a below)
+        float* const wsk = wgws_fused + (size_t)(1 + cdg_n) * (P.wgrad_ws_fused_slot / 4);
         p.a.wg_ws = wsk;
         c3d_cdg_defer_reduce = 1; c3d_cdg_parts = 0;
         const int rcl = pw_launch(p.a, st);
         c3d_cdg_defer_reduce = 0;
         RC(rcl);
-        const int parts = c3d_cdg_parts;
-        if (parts > 0) {
-          ++cdg_n;
-          const c3d_pw_args pa = p.a;
-          RC(side_run(st, [&](hipStream_t s2) { return c3d_detail_pw_wgrad_reduce(wsk, pa.wg_dw, pa.K, pa.N, parts, pa.w_sk, pa.w_sn, s2); }));
-        }
+        if (c3d_cdg_parts > 0) { ++cdg_n; red_jobs.push_back({wsk, p.a.wg_dw, p.a.K, p.a.N, c3d_cdg_parts, p.a.w_sk, p.a.w_sn}); }
       } else {
         RC(pw_launch(p.a, st));
       }
@@ -907,20 +904,18 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
       if (consb) p.a.fin = fin_coef_consume(dsums_a, k.bn_a, (double)G.M, mr_a, true);
       p.a.epi_mode = C3D_EPI_ADD; p.a.e1 = res; p.a.res_mode = res_mode; p.a.H = G.H; p.a.W = G.W;
       p.a.w_img = imgp(F.img_at);
-      if (coop_wa && side_enabled() && bwd_ring() <= 3) {
-        // the reducer of the cooperative kernel's partials runs on the side stream (5 us per launch off the data-gradient chain)
-        float* const wsk = wgws_fused + (size_t)(1 + cdg_n % 6) * (P.wgrad_ws_fused_slot / 4);
+      if (coop_wa && side_enabled()) {
+        // The cooperative kernel leaves its weight-gradient partials in a buffer of its own; ALL reducers of the pass are
+        // launched behind one fork at its end.  (Per launch -- on the side stream, six rotating buffers -- every fork was a
+        // barrier packet on the main queue: 11 us in front of every conv_c launch with the side queue otherwise idle,
+        // profiles/r06_trace_gaps.txt; on the main stream each reducer is 5 us of the data-gradient chain.)
+        float* const wsk = wgws_fused + (size_t)(1 + cdg_n) * (P.wgrad_ws_fused_slot / 4);
         p.a.wg_ws = wsk;
         c3d_cdg_defer_reduce = 1; c3d_cdg_parts = 0;
         const int rcl = pw_launch(p.a, st);
         c3d_cdg_defer_reduce = 0;
         RC(rcl);
-        const int parts = c3d_cdg_parts;
-        if (parts > 0) {
-          ++cdg_n;
-          const c3d_pw_args pa = p.a;
-          RC(side_run(st, [&](hipStream_t s2) { return c3d_detail_pw_wgrad_reduce(wsk, pa.wg_dw, pa.K, pa.N, parts, pa.w_sk, pa.w_sn, s2); }));
-        }
+        if (c3d_cdg_parts > 0) { ++cdg_n; red_jobs.push_back({wsk, p.a.wg_dw, p.a.K, p.a.N, c3d_cdg_parts, p.a.w_sk, p.a.w_sn}); }
       } else {
         RC(pw_launch(p.a, st));
       }
@@ -933,7 +928,11 @@ extern "C" int c3d_stage_bwd(const c3d_stage_desc* d, const void* x, const void*
     sums_done = sums_next;
   }
   // the last chained weight gradient's partials (its own reducer launch, on the stream it ran on)
-  if (wg_n) RC(side_run(st, [&](hipStream_t s2) { return c3d_pw_wgrad_flush(s2); }));
+  if (wg_n || !red_jobs.empty())
+    RC(side_run(st, [&](hipStream_t s2) {
+      for (const RedJob& j : red_jobs) RC(c3d_detail_pw_wgrad_reduce(j.ws, j.dw, j.K, j.N, j.parts, j.sk, j.sn, s2));
+      return wg_n ? c3d_pw_wgrad_flush(s2) : 0;
+    }));
   return 0;
 }
 

@@ -770,7 +770,7 @@ def test_folded_batchnorm_launches_are_bit_identical_end_to_end(flag):
                          "bufs": {n: b.cpu() for n, b in net.named_buffers()}})
     finally:
         ops.set_option(ops.OPT_PW_CFWD, 3)
-        ops.set_option(ops.OPT_PW_CDG, 1)
+        ops.set_option(ops.OPT_PW_CDG, 3)
     a, b = outs
     assert torch.equal(a["loss"], b["loss"]) and torch.isfinite(a["loss"])
     assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 400
@@ -847,7 +847,7 @@ def test_conv_c_forward_on_the_cooperative_kernel_end_to_end():
                          "bufs": {n: b.float().cpu() for n, b in net.named_buffers()}})
     finally:
         ops.set_option(ops.OPT_PW_CFWD, 3)
-        ops.set_option(ops.OPT_PW_CDG, 1)
+        ops.set_option(ops.OPT_PW_CDG, 3)
     a, b = outs
     assert torch.isfinite(b["loss"]) and abs(a["loss"].item() - b["loss"].item()) < 2e-3 * abs(a["loss"].item()), (a["loss"], b["loss"])
     assert (a["prob"] - b["prob"]).abs().max().item() < 2e-2

@@ -287,7 +287,7 @@ def test_cooperative_conv_a_data_and_weight_gradient(Ci, Cin, M, mask):
         dx0, dw0, s0 = run(0)
         dx1, dw1, s1 = run(1)
     finally:
-        ops.set_option(ops.OPT_PW_CDG, 1)
+        ops.set_option(ops.OPT_PW_CDG, 3)
     assert torch.isfinite(dx1.float()).all() and dx1.float().abs().max().item() > 0
     assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16)), f"{int((dx0.view(torch.int16) != dx1.view(torch.int16)).sum())} elements of dx differ"
     if mask:
