@@ -32,6 +32,19 @@
 
 thread_local int c3d_cdg_defer_reduce = 0, c3d_cdg_parts = 0;
 
+#ifdef C3D_CD_CLOCK
+// Debug build only (tools/r6/cdg_clock.py): s_memtime stamps of wave 0 per workgroup of the conv_c kernel -- [0] entry, [1]
+// prologue done (weights, coefficients, first rows in), [2] first tile converted, [3] tile loop done, [4] last weight-gradient
+// step + partials stored, [5] sums flushed
+__device__ unsigned long long c3d_cd_clk[1024][8];
+#define CDCLK(i) { if (threadIdx.x == 0) c3d_cd_clk[blockIdx.x & 1023][i] = __builtin_amdgcn_s_memtime(); }
+extern "C" int c3d_debug_cd_clock(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c3d_cd_clk), sizeof(c3d_cd_clk));
+}
+#else
+#define CDCLK(i)
+#endif
+
 namespace {
 
 constexpr int CD_THREADS = 512;
@@ -484,6 +497,7 @@ template <int KS, int NPW, int NQW, int K2>
 __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args a, const CcPlan L) {
   constexpr int NTW = 4;                                  // output tiles per wave (all three widths): 8 vectors x 8 row-lanes
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CDCLK(0)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Kp = a.Kp, Np = a.Np, Gq = Kp >> 3, MT = L.MT, KL = L.KL, QL = L.QL;
@@ -571,6 +585,7 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
   for (int i = tid; i < 2 * Np; i += CD_THREADS) { Ep[i] = a.epi_p[i]; Ep[2 * Np + i] = a.epi_q[i]; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  CDCLK(1)
 
   float s0[8], s1[8], s2[8];
 #pragma unroll
@@ -726,6 +741,7 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
   bf16_t* const bufQ1 = reinterpret_cast<bf16_t*>(smem + L.q_off + L.q_bytes);
   bf16_t* lastQ = bufQ0;
   if (t0 < t1) CC_CONVERT(t0, cP, 0)
+  CDCLK(2)
   // One iteration, the same for every tile: data gradient + epilogue of this tile, weight gradient of the tile before (the first
   // tile multiplies the zeroed buffers), conversion of the next (past the workgroup's last tile: rows the stream bounds answer
   // with zeros, written to a buffer nobody reads) -- straight-line code, no first / last copies.
@@ -754,6 +770,7 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
     if (tile + 1 < t1) CC_ITER(tile + 1, 1, bufQ1, bufQ0)
   }
 #undef CC_ITER
+  CDCLK(3)
   if (t0 < t1) {
     __syncthreads();
     CC_WGRAD(pP, lastQ)   // the last tile's
@@ -779,7 +796,9 @@ __global__ __launch_bounds__(CD_THREADS) void pw_cdg_c_kernel(const c3d_pw_args 
       }
     }
   }
+  CDCLK(4)
   if (cur_n >= 0) flush();
+  CDCLK(5)
 }
 
 template <int KS, int NPW, int NQW, int K2>
