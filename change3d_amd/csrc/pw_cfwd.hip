@@ -396,6 +396,9 @@ __attribute__((visibility("hidden"))) int c3d_detail_pw_cfwd(const c3d_pw_args* 
   L.KL = Kpad + 8;
   const int64_t tiles = (a.M + L.MT - 1) / L.MT;
   int64_t blocks = device_cus();
+  // the narrowest layers (K <= 64, N <= 64: under 128 registers and 80 KB of LDS) run TWO workgroups per CU, out of phase with
+  // each other: conv_c on the 128 x 128 maps 73.9 -> 59.7 us per launch (its byte floor: 50), conv_a there unchanged (at its floor)
+  if (KS <= 2 && ntn <= 4) blocks *= 2;
   if (blocks > (tiles + 1) / 2) blocks = (tiles + 1) / 2;
   if (blocks < 1) blocks = 1;
   const int tpw = (int)((tiles + blocks - 1) / blocks);
