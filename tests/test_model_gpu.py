@@ -872,6 +872,61 @@ def test_conv_c_forward_on_the_cooperative_kernel_end_to_end():
     assert cos > 0.99, cos
 
 
+def test_cooperative_data_and_weight_gradients_end_to_end():
+    """C3D_OPT_PW_CDG (csrc/pw_cdgrad.hip: conv_a / conv_c data gradients WITH their weight gradients on workgroup-cooperative
+    tiles, every stage width) against the wave-private kernels + separate weight-gradient launches, through a whole bf16 BCD train
+    step on conditioned weights (128 x 128: res2 / res3 / res4 all take the new kernels).  The forward pass is the same code:
+    loss and probabilities equal to the last bit.  The data gradients are bit-identical per launch (tests/test_pw_wg_gpu.py); the
+    BatchNorm-backward sums group their f32 partial sums differently, which flips isolated bf16 roundings of stored gradient
+    rows further down: parameter gradients agree to a median of 2e-3 (bound 1e-2; worst tensor 2e-2, bound 8e-2), flat-gradient
+    cosine > 0.9999; the weight gradients of the last res4 block (the first the backward pass reaches) agree to 1e-3."""
+    _need_gpu()
+    import contextlib
+    import io
+    from change3d_amd import ops, synthetic as synth
+    from change3d_amd.model.trainer import Trainer
+    from change3d_amd.model.utils import BCEDiceLoss
+    outs = []
+    try:
+        for opt in (0, 3):
+            ops.set_option(ops.OPT_PW_CDG, opt)
+            args = synth.make_args(size=128, act_dtype=torch.bfloat16)
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                net = Trainer(args)
+            net.load_state_dict(synth.synth_state_dict(net, seed=5, mask_margin=0.25, branch_gain=0.1))
+            net = net.to(DEV).train()
+            pre, post, tgt = (t.to(DEV) for t in synth.synth_batch(3, 128, seed=2))
+            prob = net.update_bcd(pre, post)
+            loss = BCEDiceLoss(prob, tgt)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append({"loss": loss.detach().cpu(), "prob": prob.detach().float().cpu(),
+                         "grads": {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None}})
+    finally:
+        ops.set_option(ops.OPT_PW_CDG, 3)
+    a, b = outs
+    assert torch.equal(a["loss"], b["loss"]) and torch.equal(a["prob"], b["prob"]), "the forward pass must not change"
+    assert a["grads"].keys() == b["grads"].keys() and len(a["grads"]) > 400
+    rels = {}
+    for n in a["grads"]:
+        assert torch.isfinite(b["grads"][n]).all(), n
+        d = (a["grads"][n] - b["grads"][n]).double()
+        rels[n] = (d.norm() / a["grads"][n].double().norm().clamp_min(1e-30)).item()
+    rs = sorted(rels.values())
+    print(f"  PW_CDG 0 vs 3: parameter-gradient rel-L2 median {rs[len(rs) // 2]:.1e}, 90 % {rs[len(rs) * 9 // 10]:.1e}, worst {rs[-1]:.1e}")
+    # measured: median 2.1e-3, 90 % 4.7e-3, worst 1.8e-2 (only the backward sums differ: far less decorrelation than a changed forward)
+    assert rs[len(rs) // 2] < 1e-2 and rs[len(rs) * 9 // 10] < 2.5e-2 and rs[-1] < 8e-2, (rs[len(rs) // 2], rs[len(rs) * 9 // 10], rs[-1])
+    fa = torch.cat([a["grads"][n].double().flatten() for n in sorted(a["grads"])])
+    fb = torch.cat([b["grads"][n].double().flatten() for n in sorted(b["grads"])])
+    cos = (fa @ fb / (fa.norm() * fb.norm())).item()
+    assert cos > 0.9999, cos
+    # the last res4 block is the first one the backward pass reaches: its gradients saw no flipped rounding yet
+    last = [n for n in rels if ".blocks.3." in n and ".res_blocks.24." in n and ("conv_a.weight" in n or "conv_c.weight" in n)]
+    assert last, [n for n in rels if ".blocks.3." in n][:5]
+    for n in last:
+        assert rels[n] < 1e-3, (n, rels[n])
+
+
 def test_block_output_backward_folded_into_conv_a_agrees_with_the_separate_launches_end_to_end():
     """C3D_OPT_MASK_IN_DGRAD = 3 (default: c3d_block_out_bwd of a block runs in the epilogue of the conv_a data gradient of the
     block above it -- mask and BatchNorm_c-backward sums, c3d_pw_args.add_sums / C3D_WG_MASKSUM) against = 1 (mask only where the
